@@ -1,0 +1,188 @@
+/* libvaecap C ABI -- MI355X (gfx950) kernels for the CVAE / AG-CVAE captioning trainer.
+ *
+ * The reference (yiyang92/vae_captioning) has NO native/FFI interface: its hot path is a
+ * TensorFlow-1 static graph.  Each entry point below therefore names the reference GRAPH
+ * CALL SITE (file:line under /root/reference) whose forward and/or tf.gradients-derived
+ * backward it replaces; INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; every function returns 0 on success, else a
+ *     hipError_t value or a VC_E* code (message: vc_last_error()).  No exceptions.
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued asynchronously on it.
+ *   - All tensor pointers are DEVICE pointers owned by the caller; the library never
+ *     allocates or frees caller-visible memory.  Scratch comes from caller workspaces.
+ *   - fp32 everywhere (tf.float32 graph); token ids / lengths are int32.
+ *   - Sequences are TIME-MAJOR [T, N, ...] (the reference feeds [N, T]; the transpose is
+ *     host-side index plumbing).
+ */
+#ifndef VAECAP_H
+#define VAECAP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VC_ABI_VERSION 1
+int vc_abi_version(void);
+const char* vc_last_error(void);
+/* 0 if a gfx950 device is usable from this process, else an error code. */
+int vc_device_check(int device);
+
+/* ------------------------------------------------------------------------------------
+ * GEMM  C[M,N] = op(A)[M,K] . op(B)[K,N] (+ bias[N]) ; flags below.   fp32 MFMA.
+ *   ta = 0: A stored [M,K] row-major (lda);  ta = 1: A stored [K,M] (computes A^T.B)
+ *   tb = 0: B stored [K,N] row-major (ldb);  tb = 1: B stored [N,K] (computes A.B^T)
+ * replaces tf.matmul / tf.layers.dense: main.py:94,108; vae_model/encoder.py:60-65,78-81,
+ * 94-97; vae_model/decoder.py:111,127-129; utils/image_embeddings.py:223,234 and their
+ * gradients (ops/optimizers.py:13,51).
+ * Small outputs with long K are split along K into `ws` (vc_gemm_workspace_bytes) and
+ * reduced in a fixed order (deterministic).
+ * ---------------------------------------------------------------------------------- */
+#define VC_GEMM_RELU 1
+#define VC_GEMM_ACCUMULATE 2
+size_t vc_gemm_workspace_bytes(int M, int N, int K);
+int vc_gemm_f32(void* stream, int ta, int tb, int M, int N, int K, const float* A, long lda, const float* B,
+                long ldb, float* C, long ldc, const float* bias, int flags, float* ws, size_t ws_bytes);
+
+/* ------------------------------------------------------------------------------------
+ * Embedding lookup and its gradient.   tf.nn.embedding_lookup, vae_model/encoder.py:31-36,
+ * vae_model/decoder.py:77-83 (pinned to /cpu:0 in the reference; on-device here).
+ *   gather      out[r, :] = table[ids[r], :]
+ *   scatter_add dtable[ids[r], :] += dX[r, :]      (IndexedSlices -> dense, TF-sem.)
+ *   mark_rows   touched[ids[i]] = 1                 (rows a sparse Momentum update touches)
+ * ---------------------------------------------------------------------------------- */
+int vc_embedding_gather_f32(void* stream, const float* table, const int32_t* ids, long rows, int E, int vocab, float* out);
+int vc_embedding_scatter_add_f32(void* stream, float* dtable, const int32_t* ids, long rows, int E, int vocab, const float* dX);
+int vc_mark_rows_f32(void* stream, float* touched, const int32_t* ids, long n, int vocab);
+
+/* ------------------------------------------------------------------------------------
+ * LSTM.  utils/rnn_model.py:23-51 (make_rnn_cell), stepped at vae_model/encoder.py:46-55 and
+ * vae_model/decoder.py:100-121.  W = [E+H, 4H] (rows 0..E-1 multiply x), gate order i,j,f,o,
+ * forget_bias 1.0 (TF-sem.).  lens_eff[n]: step t of row n is active iff t < lens_eff[n]
+ * (tf.nn.dynamic_rnn sequence_length semantics: state carried through when inactive).
+ * H must be a multiple of 32.
+ *   step_fwd: gact [N,4H] holds x.Wx+b on entry and the gate activations (i,j,f,o) on exit.
+ *   step_bwd: one step of back-propagation through time (see lstm.hip for the recurrences).
+ *   seq_fwd / seq_bwd: native loops over the T steps plus the batched input-projection and
+ *   weight-gradient GEMMs.  cs / hs are [T+1,N,H] with index 0 = initial state.
+ * ---------------------------------------------------------------------------------- */
+int vc_lstm_step_fwd_f32(void* stream, int N, int H, int t, const float* h_prev, const float* c_prev, const float* Wh,
+                         float* gact, const int32_t* lens_eff, float* c_out, float* h_out);
+int vc_lstm_step_bwd_f32(void* stream, int N, int H, int t, int first, const float* dG_next, const float* Wh,
+                         const int32_t* lens_eff, const float* dh_ext, float* dH_run, float* dC_run, const float* act,
+                         const float* c_prev, const float* c_cur, float* dG);
+size_t vc_lstm_seq_workspace_bytes(int T, int N, int E, int H);
+int vc_lstm_seq_fwd_f32(void* stream, int T, int N, int E, int H, const float* X, const float* W, const float* b,
+                        const int32_t* lens_eff, float* act, float* cs, float* hs, float* ws, size_t ws_bytes);
+int vc_lstm_seq_bwd_f32(void* stream, int T, int N, int E, int H, const float* X, const float* W, const int32_t* lens_eff,
+                        const float* act, const float* cs, const float* hs, const float* dhs_ext, float* dH_run,
+                        float* dC_run, float* dG, float* dX, float* dW, float* db, float* ws, size_t ws_bytes);
+
+/* ------------------------------------------------------------------------------------
+ * Masked sparse softmax cross-entropy, main.py:152-158.  In place: `logits` [rows, V] (ld)
+ * is overwritten by d(loss)/d(logits) = (softmax - onehot) * (label != 0) * gscale / den[0]
+ * when write_grad; row_loss[r] = (logsumexp - logit[label]) * (label != 0).
+ * den is a DEVICE scalar (number of non-PAD labels, global over data-parallel ranks).
+ * softmax_rows: gen-mode probabilities (vae_model/decoder.py:140,142).
+ * ---------------------------------------------------------------------------------- */
+int vc_softmax_xent_f32(void* stream, float* logits, const int32_t* labels, long rows, int V, long ld, const float* den,
+                        float gscale, float* row_loss, int write_grad);
+int vc_softmax_rows_f32(void* stream, const float* x, long rows, int V, long ld, float* y, long ldy);
+int vc_argmax_rows_f32(void* stream, const float* x, long rows, int cols, long ld, int32_t* out);
+
+/* ------------------------------------------------------------------------------------
+ * Latent variable.  vae_model/encoder.py:59-109, main.py:118-145.
+ *   latent_sample  z[s,n,l] = mean[n,l] + std[n,l]*eps[s,n,l]   (zs.Normal n_samples=S)
+ *   kl_rows        mode 0: Normal/GMM KL per row (main.py:120-124,131-135); mode 1: AG
+ *                  (main.py:140-145; mu_p = c_i.cluster_means [N,L])
+ *   latent_bwd     dmean, dstd (or dlogstd = dstd*std when out_logstd) from dz [S,N,L] plus
+ *                  ann[0]*kl_scale * dKL;  ann = device scalar (may be null = 1)
+ *   heads_mix_*    GMM pick (idx != NULL, encoder.py:87-88) / AG mixture (c_i, :105-107) over
+ *                  heads [N, 2*K*L] = [means | log-stds]
+ * ---------------------------------------------------------------------------------- */
+int vc_latent_sample_f32(void* stream, int S, int N, int L, const float* mean, const float* std_, const float* eps, float* z);
+int vc_kl_rows_f32(void* stream, int N, int L, int mode, const float* mean, const float* std_, const float* mu_p, float* row_kl);
+int vc_latent_bwd_f32(void* stream, int S, int N, int L, int mode, int out_logstd, const float* dz, const float* eps,
+                      const float* mean, const float* std_, const float* mu_p, const float* ann, float kl_scale,
+                      float* dmean, float* dstd);
+int vc_heads_mix_fwd_f32(void* stream, int N, int K, int L, const float* heads, const float* c_i, const int32_t* idx,
+                         float* mean, float* std_);
+int vc_heads_mix_bwd_f32(void* stream, int N, int K, int L, const float* heads, const float* c_i, const int32_t* idx,
+                         const float* dmean, const float* dstd, float* dheads);
+
+/* ------------------------------------------------------------------------------------
+ * Small data-movement ops.
+ *   colsum       out[c] (+)= sum_r x[r,c]                (bias gradients)
+ *   dropout      y = x*mask/keep                          (tf.nn.dropout, decoder.py:85-87, rnn_model.py:45-46)
+ *   relu_bwd     dx = dy*(y>0) [*mask/keep]               (ReluGrad [+ dropout grad], image_embeddings.py:224-237)
+ *   tile_rows    y[i*nc+j,:] = x[i,:]                     (main.py:84-89);  segment_sum_rows = its gradient
+ * ---------------------------------------------------------------------------------- */
+size_t vc_colsum_workspace_bytes(long rows, int cols);
+int vc_colsum_f32(void* stream, const float* x, long rows, int cols, long ld, float* out, int accumulate, float* ws, size_t ws_bytes);
+int vc_dropout_f32(void* stream, const float* x, const float* mask, float keep, long n, float* y);
+int vc_relu_bwd_f32(void* stream, const float* dy, const float* y, const float* mask, float keep, long n, float* dx);
+int vc_tile_rows_f32(void* stream, const float* x, long B, int nc, int E, float* y);
+int vc_segment_sum_rows_f32(void* stream, const float* y, long B, int nc, int E, float* x, int accumulate);
+int vc_exp_f32(void* stream, const float* x, long n, float* y);
+int vc_axpy_f32(void* stream, float a, const float* x, long n, float* y);
+int vc_reduce_sum_f32(void* stream, const float* x, long n, float scale, float* out, int accumulate);
+int vc_count_nonzero_i32(void* stream, const int32_t* x, long n, float* out);
+
+/* ------------------------------------------------------------------------------------
+ * Optimisers, ops/optimizers.py.
+ *   sumsq_partial + clip_finalize = tf.clip_by_global_norm (:15-16): partial must hold
+ *     vc_sumsq_blocks() floats per call; finalize sums n_partial of them in a fixed order and
+ *     writes out[0] = global norm, out[1] = clip * min(1/norm, 1/clip).
+ *   step_update: device-resident global_step, Adam lr_t, annealing coefficient
+ *     (main.py:163-170), staircase lr decay (:24-31).  scalars[0..4], see optim.hip.
+ *   adam / sgd / momentum: apply_gradients (:33-46, :68-81) over flat buffers; lr, scale are
+ *     DEVICE scalars (scale may be NULL = 1); l2 adds l2*p to the gradient (main.py:69-74).
+ * ---------------------------------------------------------------------------------- */
+int vc_sumsq_blocks(void);
+int vc_sumsq_partial_f32(void* stream, const float* x, long n, float* partial);
+int vc_clip_finalize_f32(void* stream, const float* partial, int n_partial, float clip, float* out_norm_scale);
+int vc_step_update(void* stream, int32_t* step, float* scalars, float lr, float cnn_lr, float beta1, float beta2,
+                   float ann_param, int ann_on, int decay_steps);
+int vc_adam_f32(void* stream, float* p, const float* g, float* m, float* v, long n, const float* lr_t, const float* scale,
+                float beta1, float beta2, float eps, float l2);
+int vc_sgd_f32(void* stream, float* p, const float* g, long n, const float* lr, const float* scale, float l2);
+int vc_momentum_f32(void* stream, float* p, const float* g, float* accum, long n, const float* lr, const float* scale,
+                    float momentum, float l2, const float* row_mask, int E);
+
+/* ------------------------------------------------------------------------------------
+ * Philox4x32-10 counter-based RNG (replaces TF's random_normal / dropout streams; the
+ * streams cannot match TF's, parity tests inject noise instead).  Element i comes from
+ * counter (i/4, offset) word i%4; `step` (device int, may be NULL) is added to the high
+ * offset word so graph replays draw fresh numbers.
+ * ---------------------------------------------------------------------------------- */
+int vc_philox_u32(void* stream, uint32_t* out, long n, uint64_t seed, uint64_t offset, const int32_t* step);
+int vc_philox_normal_f32(void* stream, float* out, long n, uint64_t seed, uint64_t offset, const int32_t* step);
+int vc_philox_bernoulli_f32(void* stream, float* out, long n, float keep, uint64_t seed, uint64_t offset, const int32_t* step);
+
+/* ------------------------------------------------------------------------------------
+ * VGG16 feature extractor, utils/image_embeddings.py:26-238.  NHWC activations, HWIO kernels,
+ * channel counts powers of two >= 4 (conv1_1: RGB zero-padded to 4 channels).
+ *   conv3x3_fwd    y = [relu](conv2d(x, w, stride 1, SAME) + bias)        (:40-44 ...)
+ *   conv3x3_dgrad  dx = conv2d_backprop_input(dy, w) [* (relu_src > 0)]
+ *   conv3x3_wgrad  dw (+)= conv2d_backprop_filter(x, dy)   (split-K, deterministic reduce)
+ *   maxpool2x2     tf.nn.max_pool 2x2/2 (:59-63 ...); bwd optionally fused with ReluGrad of x
+ *   vgg_preprocess images [B,H,W,3] (0..255 RGB) - mean -> NHWC4            (:31-34)
+ *   pad_dim        dst[o][c][i] = c < c_src ? src[o][c][i] : 0  (pad / strip a middle dim)
+ * ---------------------------------------------------------------------------------- */
+int vc_conv3x3_fwd_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const float* w,
+                       const float* bias, float* y, int relu);
+int vc_conv3x3_dgrad_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* dy, const float* w,
+                         const float* relu_src, float* dx);
+size_t vc_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+int vc_conv3x3_wgrad_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const float* dy, float* dw,
+                         int accumulate, float* ws, size_t ws_bytes);
+int vc_maxpool2x2_fwd_f32(void* stream, int B, int H, int W, int C, const float* x, float* y);
+int vc_maxpool2x2_bwd_f32(void* stream, int B, int H, int W, int C, const float* x, const float* dy, float* dx, int relu_grad);
+int vc_vgg_preprocess_f32(void* stream, const float* images, int B, int H, int W, float* out_nhwc4);
+int vc_pad_dim_f32(void* stream, const float* src, long outer, int c_src, int c_dst, int inner, float* dst);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,384 @@
+// VGG16 feature-extractor kernels (utils/image_embeddings.py:26-238) for gfx950:
+// 3x3 / stride 1 / SAME convolution as an implicit GEMM on the fp32 MFMA tile engine
+// (forward, data gradient, weight gradient), 2x2/2 max-pool forward/backward, input
+// preprocessing.  Layout: NHWC activations, HWIO kernels (the reference's TF layout).
+//
+//   forward : out[p, co]  = sum_{tap, ci} in[p + off(tap), ci] * W[tap, ci, co]      M = B*H*W, N = Cout, K = 9*Cin
+//   dgrad   : din[p, ci]  = sum_{tap, co} dout[p - off(tap), co] * W[tap, ci, co]    M = B*H*W, N = Cin,  K = 9*Cout
+//   wgrad   : dW[tap,ci,co] = sum_p in[p + off(tap), ci] * dout[p, co]               M = 9*Cin, N = Cout, K = B*H*W
+// The A operand is never materialised (no im2col): the tile loader gathers the shifted
+// NHWC rows directly (zero outside the image) into the LDS image, where the 9 taps of a
+// pixel tile are re-read from L1/L2.  Channel counts must be multiples of 4 (conv1_1's 3
+// input channels are zero-padded to 4 by the caller; vc_vgg_preprocess_f32 emits NHWC4).
+#include <type_traits>
+#include "gemm_core.h"
+#include "vaecap.h"
+
+namespace vc {
+
+struct ConvGeom {
+    int B, H, W, Cin, Cout;
+    int lc_in, lc_out;  // log2 of Cin / Cout (powers of two)
+    int HW;
+    long P;  // B*H*W
+};
+
+// ---- A loaders -------------------------------------------------------------------------
+// forward / dgrad: MK image, rows = pixels, k = tap*C + c over a [P, C] NHWC tensor, shifted by
+// sign * off(tap).
+struct LoadPixelsMK {
+    const float* x;
+    ConvGeom g;
+    int lc;    // log2(C) of the gathered tensor
+    int sign;  // +1 forward, -1 dgrad
+    __device__ __forceinline__ float4 load(int row, int k) const {
+        if (row >= g.P) return f4zero();
+        const int tap = k >> lc;
+        if (tap >= 9) return f4zero();
+        const int c = k & ((1 << lc) - 1);
+        const int dy = (tap / 3 - 1) * sign, dx = (tap % 3 - 1) * sign;
+        const int b = row / g.HW, rem = row - b * g.HW;
+        const int y = rem / g.W, xw = rem - y * g.W;
+        const int yy = y + dy, xx = xw + dx;
+        if ((unsigned)yy >= (unsigned)g.H || (unsigned)xx >= (unsigned)g.W) return f4zero();
+        return *reinterpret_cast<const float4*>(x + ((((long)b * g.H + yy) * g.W + xx) << lc) + c);
+    }
+};
+// wgrad: KM image, rows m = tap*Cin + ci (4 consecutive ci), k = pixel.
+struct LoadPixelsKM {
+    const float* x;
+    ConvGeom g;
+    __device__ __forceinline__ float4 load(int m, int k) const {
+        if (k >= g.P) return f4zero();
+        const int tap = m >> g.lc_in;
+        if (tap >= 9) return f4zero();
+        const int c = m & (g.Cin - 1);
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+        const int b = k / g.HW, rem = k - b * g.HW;
+        const int y = rem / g.W, xw = rem - y * g.W;
+        const int yy = y + dy, xx = xw + dx;
+        if ((unsigned)yy >= (unsigned)g.H || (unsigned)xx >= (unsigned)g.W) return f4zero();
+        return *reinterpret_cast<const float4*>(x + ((((long)b * g.H + yy) * g.W + xx) << g.lc_in) + c);
+    }
+};
+// dgrad B operand: MK image, rows n = ci, k = tap*Cout + co  ->  W[tap][ci][co]
+struct LoadWeightsT {
+    const float* w;
+    ConvGeom g;
+    __device__ __forceinline__ float4 load(int n, int k) const {
+        const int tap = k >> g.lc_out;
+        if (n >= g.Cin || tap >= 9) return f4zero();
+        const int co = k & (g.Cout - 1);
+        return *reinterpret_cast<const float4*>(w + (((long)tap * g.Cin + n) << g.lc_out) + co);
+    }
+};
+
+enum { CONV_FWD = 0, CONV_DGRAD = 1, CONV_WGRAD = 2 };
+
+struct ConvArgs {
+    ConvGeom g;
+    const float* a;      // fwd: x, dgrad: dy, wgrad: x
+    const float* b;      // fwd: w, dgrad: w,  wgrad: dy
+    float* out;          // fwd: y, dgrad: dx, wgrad: split-K workspace
+    const float* aux;    // fwd: bias, dgrad: relu source (x; may be null)
+    int relu;
+    int tiles_n, ntiles, kchunk;
+};
+
+template <class CFG, int KIND>
+__global__ __launch_bounds__(CFG::NT) void conv_kernel(ConvArgs c) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const ConvGeom& g = c.g;
+    const int id = xcd_remap(blockIdx.x, c.ntiles);
+    const int m0 = (id / c.tiles_n) * CFG::BM;
+    const int n0 = (id % c.tiles_n) * CFG::BN;
+    f32x16 acc[CFG::TM][CFG::TN];
+    acc_zero<CFG>(acc);
+    AccCoord<CFG> co;
+    if (KIND == CONV_FWD) {
+        LoadPixelsMK la{c.a, g, g.lc_in, 1};
+        LoadKM<true> lb{c.b, g.Cout, g.Cout, 9 * g.Cin};
+        mfma_mainloop<CFG, MODE_MK, MODE_KM>(acc, la, lb, m0, n0, 0, 9 * g.Cin, smem);
+#pragma unroll
+        for (int tn = 0; tn < CFG::TN; ++tn) {
+            const int col = n0 + co.col(tn);
+            if (col >= g.Cout) continue;
+            const float bv = c.aux ? c.aux[col] : 0.f;
+#pragma unroll
+            for (int tm = 0; tm < CFG::TM; ++tm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long row = m0 + co.row(tm, r);
+                    if (row >= g.P) continue;
+                    float v = acc[tm][tn][r] + bv;
+                    if (c.relu) v = fmaxf(v, 0.f);
+                    c.out[row * g.Cout + col] = v;
+                }
+        }
+    } else if (KIND == CONV_DGRAD) {
+        LoadPixelsMK la{c.a, g, g.lc_out, -1};
+        LoadWeightsT lb{c.b, g};
+        mfma_mainloop<CFG, MODE_MK, MODE_MK>(acc, la, lb, m0, n0, 0, 9 * g.Cout, smem);
+#pragma unroll
+        for (int tn = 0; tn < CFG::TN; ++tn) {
+            const int col = n0 + co.col(tn);
+            if (col >= g.Cin) continue;
+#pragma unroll
+            for (int tm = 0; tm < CFG::TM; ++tm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long row = m0 + co.row(tm, r);
+                    if (row >= g.P) continue;
+                    float v = acc[tm][tn][r];
+                    if (c.aux && !(c.aux[row * g.Cin + col] > 0.f)) v = 0.f;  // ReluGrad of the producing layer
+                    c.out[row * g.Cin + col] = v;
+                }
+        }
+    } else {
+        const int M = 9 * g.Cin;
+        const long kb = (long)blockIdx.y * c.kchunk;
+        const long ke = kb + c.kchunk < g.P ? kb + c.kchunk : g.P;
+        LoadPixelsKM la{c.a, g};
+        LoadKM<true> lb{c.b, g.Cout, g.Cout, (int)g.P};
+        mfma_mainloop<CFG, MODE_KM, MODE_KM>(acc, la, lb, m0, n0, (int)kb, (int)ke, smem);
+        float* out = c.out + (long)blockIdx.y * M * g.Cout;
+#pragma unroll
+        for (int tn = 0; tn < CFG::TN; ++tn) {
+            const int col = n0 + co.col(tn);
+            if (col >= g.Cout) continue;
+#pragma unroll
+            for (int tm = 0; tm < CFG::TM; ++tm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + co.row(tm, r);
+                    if (row >= M) continue;
+                    out[(long)row * g.Cout + col] = acc[tm][tn][r];
+                }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int splits, long MN,
+                                                           float* __restrict__ dw, int accumulate) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < MN; i += (long)gridDim.x * 256) {
+        float v = 0.f;
+        for (int z = 0; z < splits; ++z) v += ws[(long)z * MN + i];
+        dw[i] = accumulate ? dw[i] + v : v;
+    }
+}
+
+using ConvCfgWide = TileCfg<2, 2, 2, 2>;    // 128 x 128
+using ConvCfgNarrow = TileCfg<2, 1, 2, 2>;  // 128 x 64 (64-channel layers), 128 threads
+
+static int ilog2_exact(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return (1 << l) == v ? l : -1;
+}
+
+static int make_geom(ConvGeom& g, int B, int H, int W, int Cin, int Cout) {
+    g.B = B; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout;
+    g.lc_in = ilog2_exact(Cin);
+    g.lc_out = ilog2_exact(Cout);
+    g.HW = H * W;
+    g.P = (long)B * H * W;
+    if (g.lc_in < 2 || g.lc_out < 2) return 1;            // powers of two >= 4
+    if (g.P * (long)(Cin > Cout ? Cin : Cout) > 0x7fffffffffffL) return 1;
+    if (g.P > 0x7fffffff - 512) return 1;                  // pixel index is an int in the tile engine
+    return 0;
+}
+
+struct WgradPlan {
+    int splits, kchunk;
+};
+static WgradPlan plan_wgrad(const ConvGeom& g) {
+    const int bn = g.Cout <= 64 ? 64 : 128;
+    const long tiles = (long)cdiv(9 * g.Cin, 128) * cdiv(g.Cout, bn);
+    long splits = (1024 + tiles - 1) / tiles;
+    const long maxs = g.P / 512 > 0 ? g.P / 512 : 1;  // >= 16 K-tiles per split
+    if (splits > maxs) splits = maxs;
+    if (splits > 256) splits = 256;
+    if (splits < 1) splits = 1;
+    WgradPlan p;
+    p.kchunk = cdiv(cdiv(g.P, splits), 32) * 32;
+    p.splits = cdiv(g.P, p.kchunk);
+    return p;
+}
+
+template <int KIND>
+static void launch_conv(hipStream_t st, ConvArgs& c, int Mrows, int Ncols, int splits) {
+    if (Ncols <= 64) {
+        using C = ConvCfgNarrow;
+        c.tiles_n = cdiv(Ncols, C::BN);
+        c.ntiles = cdiv(Mrows, C::BM) * c.tiles_n;
+        hipLaunchKernelGGL((conv_kernel<C, KIND>), dim3(c.ntiles, splits), dim3(C::NT), C::SMEM_BYTES, st, c);
+    } else {
+        using C = ConvCfgWide;
+        c.tiles_n = cdiv(Ncols, C::BN);
+        c.ntiles = cdiv(Mrows, C::BM) * c.tiles_n;
+        hipLaunchKernelGGL((conv_kernel<C, KIND>), dim3(c.ntiles, splits), dim3(C::NT), C::SMEM_BYTES, st, c);
+    }
+}
+
+// ---- max-pool 2x2 / stride 2 (utils/image_embeddings.py:59-63 ...) ------------------------
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float4* __restrict__ x, int B, int H, int W, int C4,
+                                                          float4* __restrict__ y) {
+    const int Ho = H >> 1, Wo = W >> 1;
+    const long total = (long)B * Ho * Wo * C4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C4);
+        long p = i / C4;
+        const int xo = (int)(p % Wo);
+        p /= Wo;
+        const int yo = (int)(p % Ho);
+        const long b = p / Ho;
+        const long base = ((b * H + 2 * yo) * W + 2 * xo) * C4 + c;
+        const float4 a = x[base], b1 = x[base + C4], c1 = x[base + (long)W * C4], d = x[base + (long)W * C4 + C4];
+        float4 m;
+        m.x = fmaxf(fmaxf(a.x, b1.x), fmaxf(c1.x, d.x));
+        m.y = fmaxf(fmaxf(a.y, b1.y), fmaxf(c1.y, d.y));
+        m.z = fmaxf(fmaxf(a.z, b1.z), fmaxf(c1.z, d.z));
+        m.w = fmaxf(fmaxf(a.w, b1.w), fmaxf(c1.w, d.w));
+        y[i] = m;
+    }
+}
+
+// MaxPoolGrad (first maximum in (dy,dx) scan order wins; TF-sem.) fused with the ReluGrad of
+// the convolution that produced x:  dx = (x is the window's first max && x > 0) ? dy : 0
+__device__ __forceinline__ void route1(float a, float b, float c, float d, float g, int relu, float& oa, float& ob, float& oc,
+                                       float& od) {
+    const float m = fmaxf(fmaxf(a, b), fmaxf(c, d));
+    const int w = (a == m) ? 0 : (b == m) ? 1 : (c == m) ? 2 : 3;
+    const float v = (relu && !(m > 0.f)) ? 0.f : g;
+    oa = w == 0 ? v : 0.f; ob = w == 1 ? v : 0.f; oc = w == 2 ? v : 0.f; od = w == 3 ? v : 0.f;
+}
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float4* __restrict__ x, const float4* __restrict__ dy, int B,
+                                                          int H, int W, int C4, int relu, float4* __restrict__ dx) {
+    const int Ho = H >> 1, Wo = W >> 1;
+    const long total = (long)B * Ho * Wo * C4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C4);
+        long p = i / C4;
+        const int xo = (int)(p % Wo);
+        p /= Wo;
+        const int yo = (int)(p % Ho);
+        const long b = p / Ho;
+        const long base = ((b * H + 2 * yo) * W + 2 * xo) * C4 + c;
+        const long i1 = base + C4, i2 = base + (long)W * C4, i3 = i2 + C4;
+        const float4 a = x[base], b1 = x[i1], c1 = x[i2], d = x[i3], g = dy[i];
+        float4 oa, ob, oc, od;
+        route1(a.x, b1.x, c1.x, d.x, g.x, relu, oa.x, ob.x, oc.x, od.x);
+        route1(a.y, b1.y, c1.y, d.y, g.y, relu, oa.y, ob.y, oc.y, od.y);
+        route1(a.z, b1.z, c1.z, d.z, g.z, relu, oa.z, ob.z, oc.z, od.z);
+        route1(a.w, b1.w, c1.w, d.w, g.w, relu, oa.w, ob.w, oc.w, od.w);
+        dx[base] = oa; dx[i1] = ob; dx[i2] = oc; dx[i3] = od;
+    }
+}
+
+// images - mean_rgb (utils/image_embeddings.py:31-34), RGB -> NHWC4 (4th channel zero)
+__global__ __launch_bounds__(256) void preprocess_kernel(const float* __restrict__ img, long P, float4* __restrict__ out) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < P; i += (long)gridDim.x * 256)
+        out[i] = make_float4(img[i * 3] - 123.68f, img[i * 3 + 1] - 116.779f, img[i * 3 + 2] - 103.939f, 0.f);
+}
+
+// dst[o][c][i] = c < c_src ? src[o][c][i] : 0   (pad or truncate the middle dimension)
+__global__ __launch_bounds__(256) void pad_dim_kernel(const float* __restrict__ src, long outer, int c_src, int c_dst, int inner,
+                                                      float* __restrict__ dst) {
+    const long total = outer * c_dst * inner;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int in = (int)(i % inner);
+        const long t = i / inner;
+        const int c = (int)(t % c_dst);
+        const long o = t / c_dst;
+        dst[i] = c < c_src ? src[(o * c_src + c) * inner + in] : 0.f;
+    }
+}
+
+static inline int grid_for(long work_items, int per_block = 256, int cap = 4096) {
+    long b = (work_items + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (int)b;
+}
+
+}  // namespace vc
+
+using namespace vc;
+
+extern "C" int vc_conv3x3_fwd_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const float* w,
+                                  const float* bias, float* y, int relu) {
+    ConvArgs c;
+    VC_CHECK_ARG(x && w && y && B > 0 && H > 0 && W > 0, "bad argument");
+    if (make_geom(c.g, B, H, W, Cin, Cout)) return fail(VC_EINVAL, "%s: Cin/Cout must be powers of two >= 4", __func__);
+    c.a = x; c.b = w; c.out = y; c.aux = bias; c.relu = relu; c.kchunk = 0;
+    launch_conv<CONV_FWD>((hipStream_t)stream, c, (int)c.g.P, Cout, 1);
+    VC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vc_conv3x3_dgrad_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* dy, const float* w,
+                                    const float* relu_src, float* dx) {
+    ConvArgs c;
+    VC_CHECK_ARG(dy && w && dx && B > 0 && H > 0 && W > 0, "bad argument");
+    if (make_geom(c.g, B, H, W, Cin, Cout)) return fail(VC_EINVAL, "%s: Cin/Cout must be powers of two >= 4", __func__);
+    c.a = dy; c.b = w; c.out = dx; c.aux = relu_src; c.relu = 0; c.kchunk = 0;
+    launch_conv<CONV_DGRAD>((hipStream_t)stream, c, (int)c.g.P, Cin, 1);
+    VC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" size_t vc_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
+    ConvGeom g;
+    if (make_geom(g, B, H, W, Cin, Cout)) return 0;
+    WgradPlan p = plan_wgrad(g);
+    return (size_t)p.splits * 9 * Cin * Cout * sizeof(float);
+}
+
+extern "C" int vc_conv3x3_wgrad_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const float* dy,
+                                    float* dw, int accumulate, float* ws, size_t ws_bytes) {
+    ConvArgs c;
+    VC_CHECK_ARG(x && dy && dw && B > 0 && H > 0 && W > 0, "bad argument");
+    if (make_geom(c.g, B, H, W, Cin, Cout)) return fail(VC_EINVAL, "%s: Cin/Cout must be powers of two >= 4", __func__);
+    WgradPlan p = plan_wgrad(c.g);
+    const long MN = 9L * Cin * Cout;
+    if (!ws || ws_bytes < (size_t)p.splits * MN * sizeof(float))
+        return fail(VC_EWORKSPACE, "%s: workspace too small (need vc_conv3x3_wgrad_workspace_bytes)", __func__);
+    c.a = x; c.b = dy; c.out = ws; c.aux = nullptr; c.relu = 0; c.kchunk = p.kchunk;
+    launch_conv<CONV_WGRAD>((hipStream_t)stream, c, 9 * Cin, Cout, p.splits);
+    VC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(MN)), dim3(256), 0, (hipStream_t)stream, ws, p.splits, MN, dw, accumulate);
+    VC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vc_maxpool2x2_fwd_f32(void* stream, int B, int H, int W, int C, const float* x, float* y) {
+    VC_CHECK_ARG(x && y && B > 0 && H > 0 && W > 0 && C > 0 && H % 2 == 0 && W % 2 == 0 && C % 4 == 0, "even H/W, C % 4 == 0 required");
+    const long total = (long)B * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float4*)x, B, H, W, C / 4, (float4*)y);
+    VC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vc_maxpool2x2_bwd_f32(void* stream, int B, int H, int W, int C, const float* x, const float* dy, float* dx,
+                                     int relu_grad) {
+    VC_CHECK_ARG(x && dy && dx && B > 0 && H > 0 && W > 0 && C > 0 && H % 2 == 0 && W % 2 == 0 && C % 4 == 0, "even H/W, C % 4 == 0 required");
+    const long total = (long)B * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float4*)x, (const float4*)dy, B, H, W, C / 4, relu_grad, (float4*)dx);
+    VC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vc_vgg_preprocess_f32(void* stream, const float* images, int B, int H, int W, float* out_nhwc4) {
+    VC_CHECK_ARG(images && out_nhwc4 && B > 0 && H > 0 && W > 0, "bad argument");
+    const long P = (long)B * H * W;
+    hipLaunchKernelGGL(preprocess_kernel, dim3(grid_for(P)), dim3(256), 0, (hipStream_t)stream, images, P, (float4*)out_nhwc4);
+    VC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vc_pad_dim_f32(void* stream, const float* src, long outer, int c_src, int c_dst, int inner, float* dst) {
+    VC_CHECK_ARG(src && dst && outer > 0 && c_src > 0 && c_dst > 0 && inner > 0, "bad argument");
+    hipLaunchKernelGGL(pad_dim_kernel, dim3(grid_for(outer * c_dst * inner)), dim3(256), 0, (hipStream_t)stream, src, outer, c_src, c_dst, inner, dst);
+    VC_LAUNCH_CHECK();
+    return 0;
+}

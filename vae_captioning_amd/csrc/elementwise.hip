@@ -1,0 +1,308 @@
+// HBM-bound data-movement kernels: embedding gather / scatter-add, column sums (bias
+// gradients), dropout, ReLU backward, row tiling, reductions.  All are coalesced,
+// 16-B vectorised where the layout allows, and sized as grid-stride loops over <= 2048
+// workgroups (cdna_hip_programming.md guideline 11).
+#include "common.h"
+#include "vaecap.h"
+
+namespace vc {
+
+static inline int grid_for(long work_items, int per_block = 256, int cap = 2048) {
+    long b = (work_items + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (int)b;
+}
+
+// ---- embedding ---------------------------------------------------------------------
+// tf.nn.embedding_lookup, vae_model/encoder.py:31-36, vae_model/decoder.py:77-83.
+template <bool VEC>
+__global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ table, const int32_t* __restrict__ ids,
+                                                     long rows, int E, int vocab, float* __restrict__ out) {
+    if (VEC) {
+        const int E4 = E >> 2;
+        const long total = rows * E4;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+            const long r = i / E4;
+            const int e = (int)(i % E4);
+            int id = ids[r];
+            id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+            reinterpret_cast<float4*>(out)[i] = reinterpret_cast<const float4*>(table + (long)id * E)[e];
+        }
+    } else {
+        const long total = rows * E;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+            const long r = i / E;
+            int id = ids[r];
+            id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+            out[i] = table[(long)id * E + (i % E)];
+        }
+    }
+}
+
+// Gradient of the lookup = IndexedSlices scatter-add (TF-sem.).  fp32 hardware atomics:
+// the order in which duplicate tokens are summed is not fixed (sum is order-dependent at
+// the 1e-7 level only).
+__global__ __launch_bounds__(256) void scatter_add_kernel(float* __restrict__ dtable, const int32_t* __restrict__ ids,
+                                                          long rows, int E, int vocab, const float* __restrict__ dX) {
+    const long total = rows * E;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long r = i / E;
+        const int id = ids[r];
+        if (id < 0 || id >= vocab) continue;
+        const float v = dX[i];
+        if (v != 0.f) unsafeAtomicAdd(dtable + (long)id * E + (i % E), v);
+    }
+}
+
+__global__ __launch_bounds__(256) void mark_rows_kernel(float* __restrict__ touched, const int32_t* __restrict__ ids,
+                                                        long n, int vocab) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int id = ids[i];
+        if (id >= 0 && id < vocab) touched[id] = 1.f;
+    }
+}
+
+// ---- column sums (bias gradients): two deterministic stages --------------------------
+constexpr int COLSUM_CHUNKS = 64;
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, long rows, int cols, long ld,
+                                                             float* __restrict__ part) {
+    __shared__ float sh[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;  // 0..3
+    const long per = (rows + gridDim.y - 1) / gridDim.y;
+    const long r0 = (long)blockIdx.y * per;
+    const long r1 = r0 + per < rows ? r0 + per : rows;
+    float s = 0.f;
+    if (c < cols)
+        for (long r = r0 + rl; r < r1; r += 4) s += x[r * ld + c];
+    sh[rl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rl == 0 && c < cols) part[(long)blockIdx.y * cols + c] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int chunks, int cols,
+                                                           float* __restrict__ out, int accumulate) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (int k = 0; k < chunks; ++k) s += part[(long)k * cols + c];
+    out[c] = accumulate ? out[c] + s : s;
+}
+
+// ---- dropout / relu ------------------------------------------------------------------
+// tf.nn.dropout (TF-sem.): y = x * mask / keep.  vae_model/decoder.py:85-87,
+// utils/rnn_model.py:45-46, utils/image_embeddings.py:225-226,236-237.
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, const float* __restrict__ mask,
+                                                      float inv_keep, long n, float* __restrict__ y) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = x[i] * mask[i] * inv_keep;
+}
+// dx = dy * (y > 0) [* mask / keep]  -- ReluGrad (+ dropout backward)
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                       const float* __restrict__ mask, float inv_keep, long n,
+                                                       float* __restrict__ dx) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float v = y[i] > 0.f ? dy[i] : 0.f;
+        if (mask) v *= mask[i] * inv_keep;
+        dx[i] = v;
+    }
+}
+
+// ---- row tiling (main.py:84-89) and its gradient ---------------------------------------
+__global__ __launch_bounds__(256) void tile_rows_kernel(const float* __restrict__ x, long B, int nc, int E,
+                                                        float* __restrict__ y) {
+    const long total = B * nc * E;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long row = i / E;
+        y[i] = x[(row / nc) * E + (i % E)];
+    }
+}
+__global__ __launch_bounds__(256) void segment_sum_kernel(const float* __restrict__ y, long B, int nc, int E,
+                                                          float* __restrict__ x, int accumulate) {
+    const long total = B * E;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long b = i / E;
+        const int e = (int)(i % E);
+        float s = 0.f;
+        for (int j = 0; j < nc; ++j) s += y[(b * nc + j) * E + e];
+        x[i] = accumulate ? x[i] + s : s;
+    }
+}
+
+// ---- misc ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void exp_kernel(const float* __restrict__ x, long n, float* __restrict__ y) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = __expf(x[i]);
+}
+__global__ __launch_bounds__(256) void axpy_kernel(float a, const float* __restrict__ x, long n, float* __restrict__ y) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] += a * x[i];
+}
+
+// single-workgroup fixed-order sum: out = scale * sum(x) (+ out)
+__global__ __launch_bounds__(1024) void reduce_sum_kernel(const float* __restrict__ x, long n, float scale,
+                                                          float* __restrict__ out, int accumulate) {
+    __shared__ float sh[16];
+    float s = 0.f;
+    for (long i = threadIdx.x; i < n; i += 1024) s += x[i];
+    s = block_sum<1024>(s, sh);
+    if (threadIdx.x == 0) out[0] = accumulate ? out[0] + scale * s : scale * s;
+}
+__global__ __launch_bounds__(1024) void count_nonzero_kernel(const int32_t* __restrict__ x, long n, float* __restrict__ out) {
+    __shared__ float sh[16];
+    float s = 0.f;
+    for (long i = threadIdx.x; i < n; i += 1024) s += (x[i] != 0) ? 1.f : 0.f;
+    s = block_sum<1024>(s, sh);
+    if (threadIdx.x == 0) out[0] = s;
+}
+
+// argmax per row: first maximum (np.argmax tie rule), one workgroup per row.
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ x, int cols, long ld,
+                                                          int32_t* __restrict__ out) {
+    __shared__ float sv[256];
+    __shared__ int si[256];
+    const float* p = x + (long)blockIdx.x * ld;
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        const float v = p[c];
+        if (v > bv) { bv = v; bi = c; }
+    }
+    sv[threadIdx.x] = bv;
+    si[threadIdx.x] = bi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            const float v2 = sv[threadIdx.x + o];
+            const int i2 = si[threadIdx.x + o];
+            if (v2 > sv[threadIdx.x] || (v2 == sv[threadIdx.x] && i2 < si[threadIdx.x])) {
+                sv[threadIdx.x] = v2;
+                si[threadIdx.x] = i2;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = si[0];
+}
+
+}  // namespace vc
+
+using namespace vc;
+
+extern "C" int vc_embedding_gather_f32(void* stream, const float* table, const int32_t* ids, long rows, int E, int vocab,
+                                       float* out) {
+    VC_CHECK_ARG(table && ids && out && rows >= 0 && E > 0 && vocab > 0, "bad argument");
+    if (rows == 0) return 0;
+    const bool vec = (E % 4 == 0) && (((uintptr_t)table | (uintptr_t)out) & 15) == 0;
+    if (vec)
+        hipLaunchKernelGGL(gather_kernel<true>, dim3(grid_for(rows * (E / 4))), dim3(256), 0, (hipStream_t)stream, table, ids, rows, E, vocab, out);
+    else
+        hipLaunchKernelGGL(gather_kernel<false>, dim3(grid_for(rows * E)), dim3(256), 0, (hipStream_t)stream, table, ids, rows, E, vocab, out);
+    VC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vc_embedding_scatter_add_f32(void* stream, float* dtable, const int32_t* ids, long rows, int E, int vocab,
+                                            const float* dX) {
+    VC_CHECK_ARG(dtable && ids && dX && rows >= 0 && E > 0 && vocab > 0, "bad argument");
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(scatter_add_kernel, dim3(grid_for(rows * E)), dim3(256), 0, (hipStream_t)stream, dtable, ids, rows, E, vocab, dX);
+    VC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vc_mark_rows_f32(void* stream, float* touched, const int32_t* ids, long n, int vocab) {
+    VC_CHECK_ARG(touched && ids && n >= 0 && vocab > 0, "bad argument");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(mark_rows_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, touched, ids, n, vocab);
+    VC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" size_t vc_colsum_workspace_bytes(long rows, int cols) {
+    (void)rows;
+    return (size_t)COLSUM_CHUNKS * cols * sizeof(float);
+}
+
+extern "C" int vc_colsum_f32(void* stream, const float* x, long rows, int cols, long ld, float* out, int accumulate,
+                             float* ws, size_t ws_bytes) {
+    VC_CHECK_ARG(x && out && rows >= 0 && cols > 0 && ld >= cols, "bad argument");
+    int chunks = (int)((rows + 63) / 64);
+    if (chunks > COLSUM_CHUNKS) chunks = COLSUM_CHUNKS;
+    if (chunks < 1) chunks = 1;
+    if (!ws || ws_bytes < (size_t)chunks * cols * sizeof(float))
+        return fail(VC_EWORKSPACE, "%s: workspace too small (need vc_colsum_workspace_bytes)", __func__);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(cols, 64), chunks), dim3(256), 0, (hipStream_t)stream, x, rows, cols, ld, ws);
+    VC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(cols, 256)), dim3(256), 0, (hipStream_t)stream, ws, chunks, cols, out, accumulate);
+    VC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vc_dropout_f32(void* stream, const float* x, const float* mask, float keep, long n, float* y) {
+    VC_CHECK_ARG(x && mask && y && n >= 0 && keep > 0.f, "bad argument");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, mask, 1.0f / keep, n, y);
+    VC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vc_relu_bwd_f32(void* stream, const float* dy, const float* y, const float* mask, float keep, long n,
+                               float* dx) {
+    VC_CHECK_ARG(dy && y && dx && n >= 0 && keep > 0.f, "bad argument");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dy, y, mask, 1.0f / keep, n, dx);
+    VC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vc_tile_rows_f32(void* stream, const float* x, long B, int nc, int E, float* y) {
+    VC_CHECK_ARG(x && y && B >= 0 && nc > 0 && E > 0, "bad argument");
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(tile_rows_kernel, dim3(grid_for(B * nc * E)), dim3(256), 0, (hipStream_t)stream, x, B, nc, E, y);
+    VC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vc_segment_sum_rows_f32(void* stream, const float* y, long B, int nc, int E, float* x, int accumulate) {
+    VC_CHECK_ARG(x && y && B >= 0 && nc > 0 && E > 0, "bad argument");
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(segment_sum_kernel, dim3(grid_for(B * E)), dim3(256), 0, (hipStream_t)stream, y, B, nc, E, x, accumulate);
+    VC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vc_exp_f32(void* stream, const float* x, long n, float* y) {
+    VC_CHECK_ARG(x && y && n >= 0, "bad argument");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(exp_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, n, y);
+    VC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vc_axpy_f32(void* stream, float a, const float* x, long n, float* y) {
+    VC_CHECK_ARG(x && y && n >= 0, "bad argument");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, x, n, y);
+    VC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vc_reduce_sum_f32(void* stream, const float* x, long n, float scale, float* out, int accumulate) {
+    VC_CHECK_ARG(x && out && n >= 0, "bad argument");
+    hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, n, scale, out, accumulate);
+    VC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vc_count_nonzero_i32(void* stream, const int32_t* x, long n, float* out) {
+    VC_CHECK_ARG(x && out && n >= 0, "bad argument");
+    hipLaunchKernelGGL(count_nonzero_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, n, out);
+    VC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vc_argmax_rows_f32(void* stream, const float* x, long rows, int cols, long ld, int32_t* out) {
+    VC_CHECK_ARG(x && out && rows >= 0 && cols > 0 && ld >= cols, "bad argument");
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, cols, ld, out);
+    VC_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,252 @@
+// Fused LSTM time-step kernels (forward and backward-through-time) for gfx950.
+//
+// Reference: utils/rnn_model.py:23-51 builds MultiRNNCell[DropoutWrapper(LSTMCell(H))];
+// it is stepped at vae_model/encoder.py:46,48,49-55 and vae_model/decoder.py:100,102,113,
+// 116-121.  TF LSTMCell (TF-sem.): g = [x,h].W + b; i,j,f,o = split(g,4);
+// c' = sigmoid(f+1)*c + sigmoid(i)*tanh(j); h' = sigmoid(o)*tanh(c').
+//
+// MI355X design: the eight per-gate GEMMs of a step collapse into TWO MFMA GEMMs --
+//   (1) the input projection of ALL steps at once,  G = X[T*N,E].Wx + b  (vc_gemm_f32),
+//   (2) per step the recurrent  h[N,H].Wh[H,4H]  fused with the gate math in its epilogue.
+// In (2) a workgroup owns 32 hidden units x all four gates: its 128 tile columns are
+// {i,j,f,o} x 32 units, so the four accumulators of a lane hold the four gates of the same
+// (row, unit) and the gate nonlinearity, cell update, length mask and state write are pure
+// per-lane register math -- no LDS round trip, no second kernel.
+#include "gemm_core.h"
+#include "vaecap.h"
+
+namespace vc {
+
+// B operand of the forward step: Wh [H, 4H] row-major viewed as tile columns
+// c -> gate c/32, unit u0 + c%32.
+struct LoadWhGates {
+    const float* p;  // Wh
+    int H, u0;
+    __device__ __forceinline__ float4 load(int c, int k) const {
+        if (k >= H) return f4zero();
+        const int g = c >> 5, u = u0 + (c & 31);
+        return *reinterpret_cast<const float4*>(p + (long)k * 4 * H + g * H + u);
+    }
+};
+
+struct LstmFwdArgs {
+    const float* h_prev;  // [N,H]
+    const float* c_prev;  // [N,H]
+    const float* Wh;      // [H,4H]
+    float* gact;          // [N,4H] in: x-projection + bias; out: gate activations i,j,f,o
+    const int32_t* lens;  // [N] effective lengths
+    float* c_out;
+    float* h_out;
+    int N, H, t;
+};
+
+template <class CFG>
+__global__ __launch_bounds__(CFG::NT) void lstm_step_fwd_kernel(LstmFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int m0 = blockIdx.x * CFG::BM;
+    const int u0 = blockIdx.y * 32;
+    f32x16 acc[1][4];
+    acc_zero<CFG>(acc);
+    LoadMK<true> la{a.h_prev, a.H, a.N, a.H};
+    LoadWhGates lb{a.Wh, a.H, u0};
+    mfma_mainloop<CFG, MODE_MK, MODE_KM>(acc, la, lb, m0, 0, 0, a.H, smem);
+    AccCoord<CFG> co;
+    const int u = u0 + co.li;
+    const int H = a.H;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + co.row(0, r);
+        if (row >= a.N) continue;
+        float* g = a.gact + (long)row * 4 * H + u;
+        const float gi = acc[0][0][r] + g[0];
+        const float gj = acc[0][1][r] + g[H];
+        const float gf = acc[0][2][r] + g[2 * H];
+        const float go = acc[0][3][r] + g[3 * H];
+        const float i = sigmoidf_(gi), j = tanhf(gj), f = sigmoidf_(gf + 1.0f), o = sigmoidf_(go);
+        const long si = (long)row * H + u;
+        const float cp = a.c_prev[si];
+        const float c = f * cp + i * j;
+        const float h = o * tanhf(c);
+        g[0] = i; g[H] = j; g[2 * H] = f; g[3 * H] = o;
+        const bool active = a.t < a.lens[row];  // dynamic_rnn: state copied through past the length
+        a.c_out[si] = active ? c : cp;
+        a.h_out[si] = active ? h : a.h_prev[si];
+    }
+}
+
+struct LstmBwdArgs {
+    const float* dG_next;  // [N,4H] gate gradients of step t+1 (unused when first)
+    const float* Wh;       // [H,4H]
+    const int32_t* lens;
+    const float* dh_ext;   // [N,H] external gradient w.r.t. hs[t+1], may be null
+    float* dH_run;         // [N,H] in/out: total gradient w.r.t. hs[t+2] -> hs[t+1]
+    float* dC_run;         // [N,H] in/out: gradient w.r.t. cs[t+1] -> cs[t]
+    const float* act;      // [N,4H] gate activations of step t
+    const float* c_prev;   // cs[t]
+    const float* c_cur;    // cs[t+1]
+    float* dG;             // [N,4H] out: gate pre-activation gradients of step t
+    int N, H, t, first;
+};
+
+template <class CFG>
+__global__ __launch_bounds__(CFG::NT) void lstm_step_bwd_kernel(LstmBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int m0 = blockIdx.x * CFG::BM;
+    const int n0 = blockIdx.y * CFG::BN;
+    const int H = a.H;
+    f32x16 acc[CFG::TM][CFG::TN];
+    acc_zero<CFG>(acc);
+    if (!a.first) {
+        LoadMK<true> la{a.dG_next, 4L * H, a.N, 4 * H};
+        LoadMK<true> lb{a.Wh, 4L * H, H, 4 * H};  // (dG.Wh^T)[row,u] = sum_k dG[row,k] * Wh[u,k]
+        mfma_mainloop<CFG, MODE_MK, MODE_MK>(acc, la, lb, m0, n0, 0, 4 * H, smem);
+    }
+    AccCoord<CFG> co;
+#pragma unroll
+    for (int tn = 0; tn < CFG::TN; ++tn) {
+        const int u = n0 + co.col(tn);
+        if (u >= H) continue;
+#pragma unroll
+        for (int tm = 0; tm < CFG::TM; ++tm) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + co.row(tm, r);
+                if (row >= a.N) continue;
+                const long si = (long)row * H + u;
+                const int len = a.lens[row];
+                float dh = a.dH_run[si];
+                if (!a.first && (a.t + 1 < len)) dh = acc[tm][tn][r];  // step t+1 was active
+                if (a.dh_ext) dh += a.dh_ext[si];
+                a.dH_run[si] = dh;
+                const float* ac = a.act + (long)row * 4 * H + u;
+                float* dg = a.dG + (long)row * 4 * H + u;
+                if (a.t < len) {
+                    const float i = ac[0], j = ac[H], f = ac[2 * H], o = ac[3 * H];
+                    const float tc = tanhf(a.c_cur[si]);
+                    const float dct = a.dC_run[si] + dh * o * (1.f - tc * tc);
+                    dg[0] = dct * j * i * (1.f - i);
+                    dg[H] = dct * i * (1.f - j * j);
+                    dg[2 * H] = dct * a.c_prev[si] * f * (1.f - f);
+                    dg[3 * H] = dh * tc * o * (1.f - o);
+                    a.dC_run[si] = dct * f;
+                } else {
+                    dg[0] = 0.f; dg[H] = 0.f; dg[2 * H] = 0.f; dg[3 * H] = 0.f;
+                }
+            }
+        }
+    }
+}
+
+using FwdCfg128 = TileCfg<4, 1, 1, 4>;  // 128 rows x (4 gates x 32 units), 256 threads
+using FwdCfg64 = TileCfg<2, 1, 1, 4>;   //  64 rows,                       128 threads
+using BwdCfg = TileCfg<2, 2, 1, 1>;     // 64 x 64
+
+static int step_fwd(hipStream_t st, const LstmFwdArgs& a) {
+    if (a.N > 640) {
+        hipLaunchKernelGGL((lstm_step_fwd_kernel<FwdCfg128>), dim3(cdiv(a.N, 128), a.H / 32), dim3(FwdCfg128::NT),
+                           FwdCfg128::SMEM_BYTES, st, a);
+    } else {
+        hipLaunchKernelGGL((lstm_step_fwd_kernel<FwdCfg64>), dim3(cdiv(a.N, 64), a.H / 32), dim3(FwdCfg64::NT),
+                           FwdCfg64::SMEM_BYTES, st, a);
+    }
+    return launch_status("vc_lstm_step_fwd_f32");
+}
+
+static int step_bwd(hipStream_t st, const LstmBwdArgs& a) {
+    hipLaunchKernelGGL((lstm_step_bwd_kernel<BwdCfg>), dim3(cdiv(a.N, 64), cdiv(a.H, 64)), dim3(BwdCfg::NT),
+                       BwdCfg::SMEM_BYTES, st, a);
+    return launch_status("vc_lstm_step_bwd_f32");
+}
+
+static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+}  // namespace vc
+
+extern "C" int vc_lstm_step_fwd_f32(void* stream, int N, int H, int t, const float* h_prev, const float* c_prev,
+                                    const float* Wh, float* gact, const int32_t* lens_eff, float* c_out, float* h_out) {
+    using namespace vc;
+    VC_CHECK_ARG(N > 0 && H > 0 && H % 32 == 0, "H must be a positive multiple of 32");
+    VC_CHECK_ARG(h_prev && c_prev && Wh && gact && lens_eff && c_out && h_out, "null pointer");
+    VC_CHECK_ARG(aligned16(h_prev) && aligned16(Wh), "h_prev / Wh must be 16-byte aligned");
+    LstmFwdArgs a{h_prev, c_prev, Wh, gact, lens_eff, c_out, h_out, N, H, t};
+    return step_fwd((hipStream_t)stream, a);
+}
+
+extern "C" int vc_lstm_step_bwd_f32(void* stream, int N, int H, int t, int first, const float* dG_next, const float* Wh,
+                                    const int32_t* lens_eff, const float* dh_ext, float* dH_run, float* dC_run,
+                                    const float* act, const float* c_prev, const float* c_cur, float* dG) {
+    using namespace vc;
+    VC_CHECK_ARG(N > 0 && H > 0 && H % 32 == 0, "H must be a positive multiple of 32");
+    VC_CHECK_ARG(Wh && lens_eff && dH_run && dC_run && act && c_prev && c_cur && dG, "null pointer");
+    VC_CHECK_ARG(first || dG_next, "dG_next required unless first");
+    VC_CHECK_ARG(aligned16(Wh) && (first || aligned16(dG_next)), "Wh / dG_next must be 16-byte aligned");
+    LstmBwdArgs a{dG_next, Wh, lens_eff, dh_ext, dH_run, dC_run, act, c_prev, c_cur, dG, N, H, t, first};
+    return step_bwd((hipStream_t)stream, a);
+}
+
+extern "C" size_t vc_lstm_seq_workspace_bytes(int T, int N, int E, int H) {
+    size_t w = vc_gemm_workspace_bytes(E, 4 * H, T * N);
+    size_t w2 = vc_gemm_workspace_bytes(H, 4 * H, T * N);
+    size_t w3 = vc_gemm_workspace_bytes(T * N, E, 4 * H);
+    size_t w4 = vc_gemm_workspace_bytes(T * N, 4 * H, E);
+    size_t w5 = vc_colsum_workspace_bytes(T * N, 4 * H);
+    size_t m = w;
+    if (w2 > m) m = w2;
+    if (w3 > m) m = w3;
+    if (w4 > m) m = w4;
+    if (w5 > m) m = w5;
+    return m;
+}
+
+// Whole sequence forward: act = X.Wx + b for all T steps (one GEMM), then T fused steps.
+// cs[0], hs[0] must hold the initial state (zeros for the reference's zero_state).
+extern "C" int vc_lstm_seq_fwd_f32(void* stream, int T, int N, int E, int H, const float* X, const float* W,
+                                   const float* b, const int32_t* lens_eff, float* act, float* cs, float* hs, float* ws,
+                                   size_t ws_bytes) {
+    using namespace vc;
+    VC_CHECK_ARG(T > 0 && N > 0 && E > 0 && H > 0 && H % 32 == 0, "bad dimensions (H % 32 == 0 required)");
+    VC_CHECK_ARG(X && W && b && lens_eff && act && cs && hs, "null pointer");
+    const float* Wx = W;
+    const float* Wh = W + (long)E * 4 * H;
+    int rc = vc_gemm_f32(stream, 0, 0, T * N, 4 * H, E, X, E, Wx, 4 * H, act, 4 * H, b, 0, ws, ws_bytes);
+    if (rc) return rc;
+    const long NH = (long)N * H;
+    for (int t = 0; t < T; ++t) {
+        rc = vc_lstm_step_fwd_f32(stream, N, H, t, hs + t * NH, cs + t * NH, Wh, act + (long)t * N * 4 * H, lens_eff,
+                                  cs + (t + 1) * NH, hs + (t + 1) * NH);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+// Whole sequence backward.  dhs_ext: [T+1,N,H] external gradient w.r.t. every state hs[t]
+// (may be null); dH_run / dC_run: [N,H] scratch that must hold the gradient w.r.t. the
+// final state on entry (zeros, or the encoder's d h_T) and holds d(hs[1]), d(cs[0]) on exit.
+// Outputs: dG [T,N,4H], dX [T,N,E], dW [E+H,4H], db [4H].
+extern "C" int vc_lstm_seq_bwd_f32(void* stream, int T, int N, int E, int H, const float* X, const float* W,
+                                   const int32_t* lens_eff, const float* act, const float* cs, const float* hs,
+                                   const float* dhs_ext, float* dH_run, float* dC_run, float* dG, float* dX, float* dW,
+                                   float* db, float* ws, size_t ws_bytes) {
+    using namespace vc;
+    VC_CHECK_ARG(T > 0 && N > 0 && E > 0 && H > 0 && H % 32 == 0, "bad dimensions (H % 32 == 0 required)");
+    VC_CHECK_ARG(X && W && lens_eff && act && cs && hs && dH_run && dC_run && dG && dX && dW && db, "null pointer");
+    const float* Wx = W;
+    const float* Wh = W + (long)E * 4 * H;
+    const long NH = (long)N * H, NG = (long)N * 4 * H;
+    int rc;
+    for (int t = T - 1; t >= 0; --t) {
+        const int first = (t == T - 1);
+        rc = vc_lstm_step_bwd_f32(stream, N, H, t, first, first ? nullptr : dG + (t + 1) * NG, Wh, lens_eff,
+                                  dhs_ext ? dhs_ext + (t + 1) * NH : nullptr, dH_run, dC_run, act + t * NG, cs + t * NH,
+                                  cs + (t + 1) * NH, dG + t * NG);
+        if (rc) return rc;
+    }
+    // dWx = X^T.dG, dWh = hs[0:T]^T.dG, db = colsum(dG), dX = dG.Wx^T
+    rc = vc_gemm_f32(stream, 1, 0, E, 4 * H, T * N, X, E, dG, 4 * H, dW, 4 * H, nullptr, 0, ws, ws_bytes);
+    if (rc) return rc;
+    rc = vc_gemm_f32(stream, 1, 0, H, 4 * H, T * N, hs, H, dG, 4 * H, dW + (long)E * 4 * H, 4 * H, nullptr, 0, ws, ws_bytes);
+    if (rc) return rc;
+    rc = vc_colsum_f32(stream, dG, T * N, 4 * H, 4 * H, db, 0, ws, ws_bytes);
+    if (rc) return rc;
+    return vc_gemm_f32(stream, 0, 1, T * N, E, 4 * H, dG, 4 * H, Wx, 4 * H, dX, E, nullptr, 0, ws, ws_bytes);
+}
