@@ -17,3 +17,13 @@ def lib():
     """The C-ABI library (built in-tree by __graft_entry__.build())."""
     from vae_captioning_amd import abi
     return abi.load()
+
+
+@pytest.fixture(autouse=True)
+def _release_device_temporaries():
+    yield
+    try:
+        from tests import gpu_util
+    except Exception:
+        return
+    gpu_util.release()

@@ -9,11 +9,23 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# Tensors created by dev() stay alive until the end of the test: `P(dev(x))` hands a raw
+# pointer to the library, and a temporary freed before the next dev() call would have its
+# block recycled by the caching allocator (the next upload would overwrite it).
+_KEEP = []
+
+
 def dev(x, dtype=None):
     a = np.ascontiguousarray(x)
     if dtype is not None:
         a = a.astype(dtype)
-    return torch.from_numpy(a).cuda()
+    t = torch.from_numpy(a).cuda()
+    _KEEP.append(t)
+    return t
+
+
+def release():
+    del _KEEP[:]
 
 
 def zeros(*shape, dtype=torch.float32):
