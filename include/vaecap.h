@@ -110,6 +110,11 @@ int vc_heads_mix_fwd_f32(void* stream, int N, int K, int L, const float* heads, 
                          float* mean, float* std_);
 int vc_heads_mix_bwd_f32(void* stream, int N, int K, int L, const float* heads, const float* c_i, const int32_t* idx,
                          const float* dmean, const float* dstd, float* dheads);
+/* Step scalars, main.py:156-177: out4 = {rec_loss = ce_num/ce_den + reg_scale*reg_sumsq, mean KL =
+ * kl_sum*inv_n, lower_bound = rec + ann*KL/10, ann}; every pointer is a device scalar (reg_sumsq,
+ * kl_sum, ann may be NULL). */
+int vc_loss_finalize_f32(void* stream, const float* ce_num, const float* ce_den, const float* reg_sumsq, float reg_scale,
+                         const float* kl_sum, float inv_n, const float* ann, float* out4);
 
 /* ------------------------------------------------------------------------------------
  * Small data-movement ops.

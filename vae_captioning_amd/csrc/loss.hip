@@ -260,9 +260,33 @@ __global__ __launch_bounds__(256) void heads_mix_bwd_kernel(const float* __restr
     }
 }
 
+// Scalars of one step (main.py:156-177): out[0] rec_loss = ce_num/ce_den (+ reg), out[1] mean KL,
+// out[2] lower_bound = rec + ann*kld/10 (mean over rows for the AG vector loss, what main.py:247-251
+// prints), out[3] annealing coefficient.  All inputs are device scalars.
+__global__ void loss_finalize_kernel(const float* ce_num, const float* ce_den, const float* reg, float reg_scale,
+                                     const float* kl_sum, float inv_n, const float* ann, float* out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float rec = ce_num[0] / ce_den[0];
+    if (reg) rec += reg[0] * reg_scale;
+    const float a = ann ? ann[0] : 1.f;
+    const float kld = kl_sum ? kl_sum[0] * inv_n : 0.f;
+    out[0] = rec;
+    out[1] = kld;
+    out[2] = kl_sum ? rec + a * kld / 10.f : rec;
+    out[3] = a;
+}
+
 }  // namespace vc
 
 using namespace vc;
+
+extern "C" int vc_loss_finalize_f32(void* stream, const float* ce_num, const float* ce_den, const float* reg_sumsq,
+                                    float reg_scale, const float* kl_sum, float inv_n, const float* ann, float* out4) {
+    VC_CHECK_ARG(ce_num && ce_den && out4, "null pointer");
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ce_num, ce_den, reg_sumsq, reg_scale, kl_sum, inv_n, ann, out4);
+    VC_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int vc_softmax_xent_f32(void* stream, float* logits, const int32_t* labels, long rows, int V, long ld,
                                    const float* den, float gscale, float* row_loss, int write_grad) {

@@ -1,0 +1,513 @@
+"""Device-side training engine: the reference's one-`sess.run` training step
+(main.py:84-183, 241-244) executed as a sequence of libvaecap C-ABI calls on HIP
+streams.  torch is used for device memory, streams and torch.distributed only.
+
+Layout decisions (MI355X-first):
+  * every trainable tensor lives in ONE flat fp32 buffer per optimiser group (params,
+    grads, Adam m/v): one fused optimiser launch, one global-norm reduction and ONE
+    RCCL all-reduce over the gradient buffer per step;
+  * sequences are time-major [T, N, .]: the image / c_v / z "init chain" steps
+    (encoder.py:46-48, decoder.py:100-113) are just leading time steps of one
+    contiguous LSTM input buffer;
+  * the [S, N, L] sample buffer IS the [N, S*L] z_rnn input (quirk Q1) -- no copy;
+  * the 180 GMM/AG head layers are stored as one [H, 2*90*L] matrix (split only when
+    a reference-named checkpoint is exported).
+"""
+import numpy as np
+import torch
+
+from . import abi, spec
+from .abi import ptr as P
+
+K_CL = spec.NUM_CLUSTERS
+TAIL = 64  # floats appended to the gradient buffer: scalars that ride in the all-reduce
+T_DXSQ, T_CENUM, T_KLSUM = 0, 1, 2
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _round(n, m=64):
+    return (n + m - 1) // m * m
+
+
+class FlatStore(object):
+    """Named views over flat parameter / gradient / optimiser-slot buffers."""
+
+    def __init__(self, entries, device, tail=0, grad_backing=None):
+        self.entries = list(entries)
+        self.offsets = {}
+        off = 0
+        for name, shape in self.entries:
+            self.offsets[name] = (off, tuple(shape))
+            off += _round(int(np.prod(shape)))
+        self.n = off
+        self.tail = tail
+        self.device = device
+        self.p = torch.zeros(off, dtype=torch.float32, device=device)
+        self.g = grad_backing if grad_backing is not None else torch.zeros(off + tail, dtype=torch.float32, device=device)
+        assert self.g.numel() == off + tail
+        self.slots = {}
+
+    def slot(self, name):
+        if name not in self.slots:
+            self.slots[name] = torch.zeros(self.n, dtype=torch.float32, device=self.device)
+        return self.slots[name]
+
+    def _view(self, buf, name):
+        off, shape = self.offsets[name]
+        return buf[off:off + int(np.prod(shape))].view(shape)
+
+    def param(self, name):
+        return self._view(self.p, name)
+
+    def grad(self, name):
+        return self._view(self.g, name)
+
+    def offset(self, name):
+        return self.offsets[name][0]
+
+    def names(self):
+        return [n for n, _ in self.entries]
+
+
+def internal_caption_variables(p, vocab):
+    """spec.caption_variables with (a) the 360 head tensors fused into two and (b) the
+    embedding tables moved to the end (their dense gradients are excluded from the
+    global norm, quirk Q5, so the norm runs over a prefix)."""
+    ents = spec.caption_variables(p, vocab)
+    fused = []
+    heads_done = False
+    for name, shape in ents:
+        if "_ll_" in name:
+            if not heads_done:
+                He, L = p.encoder_hidden, p.latent_size
+                fused += [("encoder/heads/kernel", (He, 2 * K_CL * L)), ("encoder/heads/bias", (2 * K_CL * L,))]
+                heads_done = True
+            continue
+        fused.append((name, shape))
+    emb = [e for e in fused if e[0].endswith("embeddings")]
+    rest = [e for e in fused if not e[0].endswith("embeddings")]
+    return rest + emb
+
+
+class CaptionEngine(object):
+    """Caption side of the graph: imf_emb / cv_emb, encoder q(z|x,I), KL, decoder p(x|z,I),
+    masked CE, non_cnn_optimizer."""
+
+    def __init__(self, p, vocab, device="cuda", lib=None, grad_backing=None, world=1, rank=0, group=None, seed=0):
+        self.p = p
+        self.V = int(vocab)
+        self.lib = lib or abi.load()
+        self.dev = device
+        self.world, self.rank, self.group = world, rank, group
+        self.use_ci = spec.uses_ci(p)
+        self.feed_cv = bool(p.use_c_v) and self.use_ci
+        self.enc = not p.no_encoder
+        self.n_init_e = 1 + int(self.feed_cv)
+        self.n_init_d = 1 + int(self.feed_cv) + int(self.enc)
+        if p.encoder_hidden % 32 or p.decoder_hidden % 32:
+            raise ValueError("enc_hid / dec_hid must be multiples of 32 (MFMA gate tile)")
+        self.store = FlatStore(internal_caption_variables(p, self.V), device, tail=TAIL, grad_backing=grad_backing)
+        names = self.store.names()
+        emb = [n for n in names if n.endswith("embeddings")]
+        self.n_dense = self.store.offset(emb[0]) if emb else self.store.n
+        self.buf = {}
+        self.ws = None
+        self.ws_bytes = 0
+        i32 = dict(dtype=torch.int32, device=device)
+        f32 = dict(dtype=torch.float32, device=device)
+        self.step = torch.zeros(1, **i32)
+        self.scal = torch.zeros(8, **f32)     # vc_step_update outputs
+        self.red = torch.zeros(8, **f32)      # [0] ce_num, [1] ce_den, [2] kl_sum, [3] reg_sumsq
+        self.out = torch.zeros(4, **f32)      # rec_loss, kld, lower_bound, ann
+        self.ns = torch.zeros(2, **f32)       # global norm, clip scale
+        nb = self.lib.vc_sumsq_blocks()
+        self.nb = nb
+        self.part = torch.zeros(3 * nb + 4, **f32)
+        self.inject = False
+        self.seed = seed
+        self.reg_scale = 0.0
+        self.c_means = None
+        if self.enc and p.prior == "AG":
+            self.c_means = torch.from_numpy(init_clusters(K_CL, p.latent_size)).to(device)
+        self.ann_on = int((not p.fine_tune) and (not p.restore) and p.ann_param > 1)  # main.py:163-170
+        self.decay_steps = int(p.num_ex_per_epoch / (p.batch_size + 0.001) * p.num_epochs_per_decay)
+
+    # ---------------------------------------------------------------- parameters
+    def load_params(self, named):
+        """named: {reference variable name -> numpy array} (spec.caption_variables names)."""
+        p = self.p
+        for name in self.store.names():
+            if name == "encoder/heads/kernel":
+                ks = [named[spec.head_scope(p.prior, k) + "dense/kernel"] for k in range(K_CL)]
+                ls = [named[spec.head_scope(p.prior, k) + "dense_1/kernel"] for k in range(K_CL)]
+                arr = np.concatenate(ks + ls, axis=1)
+            elif name == "encoder/heads/bias":
+                ks = [named[spec.head_scope(p.prior, k) + "dense/bias"] for k in range(K_CL)]
+                ls = [named[spec.head_scope(p.prior, k) + "dense_1/bias"] for k in range(K_CL)]
+                arr = np.concatenate(ks + ls, axis=0)
+            else:
+                arr = named[name]
+            self.store.param(name).copy_(torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)))
+
+    def _export(self, getter):
+        p = self.p
+        out = {}
+        L = p.latent_size
+        for name in self.store.names():
+            a = getter(name).detach().cpu().numpy().copy()
+            if name == "encoder/heads/kernel":
+                for k in range(K_CL):
+                    out[spec.head_scope(p.prior, k) + "dense/kernel"] = a[:, k * L:(k + 1) * L].copy()
+                    out[spec.head_scope(p.prior, k) + "dense_1/kernel"] = a[:, (K_CL + k) * L:(K_CL + k + 1) * L].copy()
+            elif name == "encoder/heads/bias":
+                for k in range(K_CL):
+                    out[spec.head_scope(p.prior, k) + "dense/bias"] = a[k * L:(k + 1) * L].copy()
+                    out[spec.head_scope(p.prior, k) + "dense_1/bias"] = a[(K_CL + k) * L:(K_CL + k + 1) * L].copy()
+            else:
+                out[name] = a
+        return out
+
+    def state_dict(self):
+        torch.cuda.synchronize()
+        return self._export(self.store.param)
+
+    def grads_dict(self):
+        torch.cuda.synchronize()
+        return self._export(self.store.grad)
+
+    # ---------------------------------------------------------------- buffers
+    def _b(self, name, shape, dtype=torch.float32, zero=False):
+        t = self.buf.get(name)
+        shape = tuple(int(s) for s in shape)
+        if t is None or tuple(t.shape) != shape or t.dtype != dtype:
+            t = torch.zeros(shape, dtype=dtype, device=self.dev)
+            self.buf[name] = t
+        elif zero:
+            t.zero_()
+        return t
+
+    def _need_ws(self, nbytes):
+        if nbytes > self.ws_bytes:
+            nb = max(int(nbytes), 1 << 20)
+            self.ws = torch.empty(nb // 4 + 16, dtype=torch.float32, device=self.dev)
+            self.ws_bytes = self.ws.numel() * 4
+
+    def gemm(self, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias=None, flags=0):
+        self._need_ws(self.lib.vc_gemm_workspace_bytes(M, N, K))
+        self.lib.vc_gemm_f32(_stream(), ta, tb, M, N, K, P(A), lda, P(B), ldb, P(C), ldc, P(bias), flags, P(self.ws), self.ws_bytes)
+
+    def colsum(self, x, rows, cols, out, accumulate=0):
+        self._need_ws(self.lib.vc_colsum_workspace_bytes(rows, cols))
+        self.lib.vc_colsum_f32(_stream(), P(x), rows, cols, cols, P(out), accumulate, P(self.ws), self.ws_bytes)
+
+    def dense_bwd_w(self, x, rows, fin, fout, dy, wname, bname):
+        """dW = x^T.dy, db = colsum(dy) written straight into the flat gradient buffer."""
+        self.gemm(1, 0, fin, fout, rows, x, fin, dy, fout, self.store.grad(wname), fout)
+        self.colsum(dy, rows, fout, self.store.grad(bname))
+
+    # ---------------------------------------------------------------- inputs
+    def set_batch(self, batch, noise=None):
+        """Upload one batch (numpy, reference layout: cap_* are [N, T])."""
+        p = self.p
+        nc = p.num_captions if p.mode == "training" else 1
+        up = lambda name, a, dt: self._b(name, a.shape, dt).copy_(torch.from_numpy(np.ascontiguousarray(a)))
+        if "features" in batch:
+            up("features", batch["features"].astype(np.float32), torch.float32)
+        cap_dec = np.asarray(batch["cap_dec"], np.int32)
+        cap_enc = np.asarray(batch["cap_enc"], np.int32)
+        self.N, self.T = cap_dec.shape
+        self.B = self.N // nc
+        self.nc = nc
+        up("cap_dec_t", cap_dec.T, torch.int32)
+        up("cap_enc_t", cap_enc.T, torch.int32)
+        lens = np.asarray(batch["lengths"], np.int32)
+        up("lens_e", lens + self.n_init_e, torch.int32)
+        up("lens_d", lens + self.n_init_d, torch.int32)
+        if self.use_ci:
+            up("c_v", batch["c_v"].astype(np.float32), torch.float32)
+        self.inject = noise is not None
+        if noise is not None:
+            for k in ("eps", "drop_in", "drop_out"):
+                if k in noise:
+                    up(k, noise[k].astype(np.float32), torch.float32)
+            if "gmm_idx" in noise:
+                up("gmm_idx", np.asarray(noise["gmm_idx"], np.int32), torch.int32)
+        elif self.enc and p.prior == "GMM":
+            # encoder.py:72: tf.multinomial(c_i_ph, 1) -- the cluster vector used as LOGITS (Q15)
+            cv = batch["c_v"].astype(np.float64)
+            pr = np.exp(cv - cv.max(1, keepdims=True))
+            pr /= pr.sum(1, keepdims=True)
+            rs = np.random.default_rng(self.seed + int(self.step.item()))
+            idx = np.array([rs.choice(K_CL, p=pr[n]) for n in range(self.N)], np.int32)
+            up("gmm_idx", idx, torch.int32)
+
+    def _noise(self):
+        """Device-generated noise when none was injected (Philox, advanced by the step counter)."""
+        p, lib, st = self.p, self.lib, _stream()
+        S, N, L, T = p.gen_z_samples, self.N, p.latent_size, self.T
+        if self.enc:
+            eps = self._b("eps", (S, N, L))
+            lib.vc_philox_normal_f32(st, P(eps), eps.numel(), self.seed * 1000003 + self.rank, 1 << 32, P(self.step))
+        if p.dec_keep_rate < 1:
+            m = self._b("drop_in", (T, N, p.embed_size))
+            lib.vc_philox_bernoulli_f32(st, P(m), m.numel(), p.dec_keep_rate, self.seed * 1000003 + self.rank, 2 << 32, P(self.step))
+        if p.dec_lstm_drop < 1:
+            m = self._b("drop_out", (T, N, p.decoder_hidden))
+            lib.vc_philox_bernoulli_f32(st, P(m), m.numel(), p.dec_lstm_drop, self.seed * 1000003 + self.rank, 3 << 32, P(self.step))
+
+    # ---------------------------------------------------------------- forward
+    def forward(self, features=None, train=True):
+        """Forward pass + (train) in-place d(loss)/d(logits).  `features` [B, F] device tensor
+        (defaults to the uploaded precomputed features)."""
+        p, lib, st, S = self.p, self.lib, _stream(), self.store
+        N, T, B, nc = self.N, self.T, self.B, self.nc
+        E, He, Hd, L, Sm, V, F = p.embed_size, p.encoder_hidden, p.decoder_hidden, p.latent_size, p.gen_z_samples, self.V, p.cnn_feature_size
+        feats = features if features is not None else self.buf["features"]
+        self.feats = feats
+        if not self.inject:
+            self._noise()
+        if train:  # global_step / annealing / lr schedules advance only on optimiser steps
+            lib.vc_step_update(st, P(self.step), P(self.scal), p.learning_rate, p.cnn_lr, 0.8, 0.999, float(p.ann_param), self.ann_on, self.decay_steps)
+        ann = self.scal[1:2]
+        # imf_emb on the B image rows, then tile x nc (identical values to tiling first, main.py:84-94)
+        imf = self._b("imf", (B, E))
+        self.gemm(0, 0, B, E, F, feats, F, S.param("imf_emb/kernel"), E, imf, E, S.param("imf_emb/bias"))
+        Te, Td = T + self.n_init_e, T + self.n_init_d
+        Xd = self._b("Xd", (Td, N, E))
+        if nc > 1:
+            lib.vc_tile_rows_f32(st, P(imf), B, nc, E, P(Xd[0]))
+        else:
+            Xd[0].copy_(imf)
+        if self.use_ci:
+            cv = self.buf["c_v"]
+            if self.feed_cv:
+                self.gemm(0, 0, N, E, K_CL, cv, K_CL, S.param("cv_emb/kernel"), E, Xd[1], E, S.param("cv_emb/bias"))
+        kl_sum = None
+        if self.enc:
+            Xe = self._b("Xe", (Te, N, E))
+            Xe[:self.n_init_e].copy_(Xd[:self.n_init_e])
+            lib.vc_embedding_gather_f32(st, P(S.param("encoder/enc_embeddings")), P(self.buf["cap_enc_t"]), T * N, E, V, P(Xe[self.n_init_e]))
+            act_e, cs_e, hs_e = self._b("act_e", (Te, N, 4 * He)), self._b("cs_e", (Te + 1, N, He)), self._b("hs_e", (Te + 1, N, He))
+            self._need_ws(lib.vc_lstm_seq_workspace_bytes(Te, N, E, He))
+            cs_e[0].zero_(); hs_e[0].zero_()
+            lib.vc_lstm_seq_fwd_f32(st, Te, N, E, He, P(Xe), P(S.param(spec.ENC_CELL + "kernel")), P(S.param(spec.ENC_CELL + "bias")),
+                                    P(self.buf["lens_e"]), P(act_e), P(cs_e), P(hs_e), P(self.ws), self.ws_bytes)
+            hT = hs_e[Te]
+            mean, std = self._b("mean", (N, L)), self._b("std", (N, L))
+            if p.prior == "Normal":
+                logstd = self._b("logstd", (N, L))
+                self.gemm(0, 0, N, L, He, hT, He, S.param("encoder/dense/kernel"), L, mean, L, S.param("encoder/dense/bias"))
+                self.gemm(0, 0, N, L, He, hT, He, S.param("encoder/dense_1/kernel"), L, logstd, L, S.param("encoder/dense_1/bias"))
+                lib.vc_exp_f32(st, P(logstd), N * L, P(std))
+            else:
+                heads = self._b("heads", (N, 2 * K_CL * L))
+                self.gemm(0, 0, N, 2 * K_CL * L, He, hT, He, S.param("encoder/heads/kernel"), 2 * K_CL * L, heads, 2 * K_CL * L, S.param("encoder/heads/bias"))
+                gmm = p.prior == "GMM"
+                lib.vc_heads_mix_fwd_f32(st, N, K_CL, L, P(heads), None if gmm else P(cv), P(self.buf["gmm_idx"]) if gmm else None, P(mean), P(std))
+            mu_p = None
+            mode = 0
+            if p.prior == "AG":
+                mode = 1
+                mu_p = self._b("mu_p", (N, L))
+                self.gemm(0, 0, N, L, K_CL, cv, K_CL, self.c_means, L, mu_p, L)
+            z = self._b("z", (Sm, N, L))
+            lib.vc_latent_sample_f32(st, Sm, N, L, P(mean), P(std), P(self.buf["eps"]), P(z))
+            row_kl = self._b("row_kl", (N,))
+            lib.vc_kl_rows_f32(st, N, L, mode, P(mean), P(std), P(mu_p), P(row_kl))
+            lib.vc_reduce_sum_f32(st, P(row_kl), N, 1.0, self.red.data_ptr() + 8, 0)
+            kl_sum = self.red.data_ptr() + 8
+            # decoder.py:109-111: z viewed as [N, S*L] (Q1) -> z_rnn -> the z step of the init chain
+            zi = self.n_init_d - 1
+            self.gemm(0, 0, N, E, Sm * L, z, Sm * L, S.param("decoder/net/z_rnn/kernel"), E, Xd[zi], E, S.param("decoder/net/z_rnn/bias"))
+        xw = Xd[self.n_init_d]
+        lib.vc_embedding_gather_f32(st, P(S.param("decoder/net/dec_embeddings")), P(self.buf["cap_dec_t"]), T * N, E, V, P(xw))
+        if p.dec_keep_rate < 1:  # no train/eval switch in the reference (Q21)
+            lib.vc_dropout_f32(st, P(xw), P(self.buf["drop_in"]), p.dec_keep_rate, T * N * E, P(xw))
+        act_d, cs_d, hs_d = self._b("act_d", (Td, N, 4 * Hd)), self._b("cs_d", (Td + 1, N, Hd)), self._b("hs_d", (Td + 1, N, Hd))
+        self._need_ws(lib.vc_lstm_seq_workspace_bytes(Td, N, E, Hd))
+        cs_d[0].zero_(); hs_d[0].zero_()
+        lib.vc_lstm_seq_fwd_f32(st, Td, N, E, Hd, P(Xd), P(S.param(spec.DEC_CELL + "kernel")), P(S.param(spec.DEC_CELL + "bias")),
+                                P(self.buf["lens_d"]), P(act_d), P(cs_d), P(hs_d), P(self.ws), self.ws_bytes)
+        # outputs of the word steps.  (The reference zeroes outputs past the caption length; those rows
+        # have PAD labels, so neither the loss nor any gradient can see the difference.)
+        outs = hs_d[self.n_init_d + 1:]
+        if p.dec_lstm_drop < 1:
+            od = self._b("outs_drop", (T, N, Hd))
+            lib.vc_dropout_f32(st, P(outs), P(self.buf["drop_out"]), p.dec_lstm_drop, T * N * Hd, P(od))
+            outs = od
+        self.outs = outs
+        logits = self._b("logits", (T * N, V))
+        self.gemm(0, 0, T * N, V, Hd, outs, Hd, S.param("decoder/rnn_logits/kernel"), V, logits, V, S.param("decoder/rnn_logits/bias"))
+        labels = self.buf["cap_enc_t"]
+        den = self.red[1:2]
+        lib.vc_count_nonzero_i32(st, P(labels), T * N, P(den))
+        if self.world > 1:
+            torch.distributed.all_reduce(den, group=self.group)
+        vector_loss = self.enc and p.prior == "AG"  # Q3
+        Ng = N * self.world
+        gscale = float(Ng) if vector_loss else 1.0
+        row_loss = self._b("row_loss", (T * N,))
+        lib.vc_softmax_xent_f32(st, P(logits), P(labels), T * N, V, V, P(den), gscale, P(row_loss), 1 if train else 0)
+        lib.vc_reduce_sum_f32(st, P(row_loss), T * N, 1.0, P(self.red), 0)
+        self._finalize_losses(kl_sum, Ng, ann)
+        return self.out
+
+    def _finalize_losses(self, kl_sum, Ng, ann):
+        lib, st = self.lib, _stream()
+        if self.world > 1:
+            t = self.red[:3]
+            if kl_sum is None:
+                t[2] = 0
+            buf = torch.stack([t[0], t[2]])
+            torch.distributed.all_reduce(buf, group=self.group)
+            t[0], t[2] = buf[0], buf[1]
+        reg = self.red.data_ptr() + 12 if self.reg_scale else None
+        lib.vc_loss_finalize_f32(st, P(self.red), self.red.data_ptr() + 4, reg, float(self.reg_scale), kl_sum, 1.0 / Ng,
+                                 P(ann) if self.enc else None, P(self.out))
+
+    # ---------------------------------------------------------------- backward
+    def backward(self, want_dfeatures=False):
+        """Gradients of sum(lower_bound) w.r.t. every non-CNN variable, into store.g."""
+        p, lib, st, S = self.p, self.lib, _stream(), self.store
+        N, T, B, nc = self.N, self.T, self.B, self.nc
+        E, He, Hd, L, Sm, V, F = p.embed_size, p.encoder_hidden, p.decoder_hidden, p.latent_size, p.gen_z_samples, self.V, p.cnn_feature_size
+        Te, Td = T + self.n_init_e, T + self.n_init_d
+        nid = self.n_init_d
+        ann = self.scal[1:2]
+        dlogits = self.buf["logits"]
+        outs = self.outs
+        self.dense_bwd_w(outs, T * N, Hd, V, dlogits, "decoder/rnn_logits/kernel", "decoder/rnn_logits/bias")
+        dhs = self._b("dhs_d", (Td + 1, N, Hd))  # external gradient w.r.t. every decoder state; init steps stay 0
+        douts = dhs[nid + 1:]
+        self.gemm(0, 1, T * N, Hd, V, dlogits, V, S.param("decoder/rnn_logits/kernel"), V, douts, Hd)
+        if p.dec_lstm_drop < 1:
+            lib.vc_dropout_f32(st, P(douts), P(self.buf["drop_out"]), p.dec_lstm_drop, T * N * Hd, P(douts))
+        dH, dC = self._b("dH_d", (N, Hd), zero=True), self._b("dC_d", (N, Hd), zero=True)
+        dG, dXd = self._b("dG_d", (Td, N, 4 * Hd)), self._b("dXd", (Td, N, E))
+        lib.vc_lstm_seq_bwd_f32(st, Td, N, E, Hd, P(self.buf["Xd"]), P(S.param(spec.DEC_CELL + "kernel")), P(self.buf["lens_d"]),
+                                P(self.buf["act_d"]), P(self.buf["cs_d"]), P(self.buf["hs_d"]), P(dhs), P(dH), P(dC), P(dG), P(dXd),
+                                P(S.grad(spec.DEC_CELL + "kernel")), P(S.grad(spec.DEC_CELL + "bias")), P(self.ws), self.ws_bytes)
+        dxw = dXd[nid]
+        if p.dec_keep_rate < 1:
+            lib.vc_dropout_f32(st, P(dxw), P(self.buf["drop_in"]), p.dec_keep_rate, T * N * E, P(dxw))
+        gd = S.grad("decoder/net/dec_embeddings")
+        gd.zero_()
+        lib.vc_embedding_scatter_add_f32(st, P(gd), P(self.buf["cap_dec_t"]), T * N, E, V, P(dxw))
+        nb = self.nb
+        lib.vc_sumsq_partial_f32(st, P(dxw), T * N * E, self.part.data_ptr() + nb * 4)  # IndexedSlices.values (Q5)
+        d_imfv = dXd[0]       # [N, E] gradient w.r.t. images_fv (decoder part)
+        d_ci = dXd[1] if self.feed_cv else None
+        if self.enc:
+            zi = nid - 1
+            dz_dec = dXd[zi]
+            z = self.buf["z"]
+            self.dense_bwd_w(z, N, Sm * L, E, dz_dec, "decoder/net/z_rnn/kernel", "decoder/net/z_rnn/bias")
+            dz = self._b("dz", (Sm, N, L))
+            self.gemm(0, 1, N, Sm * L, E, dz_dec, E, S.param("decoder/net/z_rnn/kernel"), E, dz, Sm * L)
+            mean, std = self.buf["mean"], self.buf["std"]
+            dmean, dstd = self._b("dmean", (N, L)), self._b("dstd", (N, L))
+            Ng = N * self.world
+            hT = self.buf["hs_e"][Te]
+            dhT = self._b("dH_e", (N, He))
+            if p.prior == "Normal":
+                lib.vc_latent_bwd_f32(st, Sm, N, L, 0, 1, P(dz), P(self.buf["eps"]), P(mean), P(std), None, P(ann), 0.1 / Ng, P(dmean), P(dstd))
+                self.dense_bwd_w(hT, N, He, L, dmean, "encoder/dense/kernel", "encoder/dense/bias")
+                self.dense_bwd_w(hT, N, He, L, dstd, "encoder/dense_1/kernel", "encoder/dense_1/bias")
+                self.gemm(0, 1, N, He, L, dmean, L, S.param("encoder/dense/kernel"), L, dhT, He)
+                self.gemm(0, 1, N, He, L, dstd, L, S.param("encoder/dense_1/kernel"), L, dhT, He, None, 2)
+            else:
+                gmm = p.prior == "GMM"
+                if gmm:
+                    lib.vc_latent_bwd_f32(st, Sm, N, L, 0, 0, P(dz), P(self.buf["eps"]), P(mean), P(std), None, P(ann), 0.1 / Ng, P(dmean), P(dstd))
+                else:
+                    lib.vc_latent_bwd_f32(st, Sm, N, L, 1, 0, P(dz), P(self.buf["eps"]), P(mean), P(std), P(self.buf["mu_p"]), P(ann), 0.1, P(dmean), P(dstd))
+                heads = self.buf["heads"]
+                dheads = self._b("dheads", (N, 2 * K_CL * L))
+                lib.vc_heads_mix_bwd_f32(st, N, K_CL, L, P(heads), None if gmm else P(self.buf["c_v"]), P(self.buf["gmm_idx"]) if gmm else None,
+                                         P(dmean), P(dstd), P(dheads))
+                self.dense_bwd_w(hT, N, He, 2 * K_CL * L, dheads, "encoder/heads/kernel", "encoder/heads/bias")
+                self.gemm(0, 1, N, He, 2 * K_CL * L, dheads, 2 * K_CL * L, S.param("encoder/heads/kernel"), 2 * K_CL * L, dhT, He)
+            dC = self._b("dC_e", (N, He), zero=True)
+            dG, dXe = self._b("dG_e", (Te, N, 4 * He)), self._b("dXe", (Te, N, E))
+            lib.vc_lstm_seq_bwd_f32(st, Te, N, E, He, P(self.buf["Xe"]), P(S.param(spec.ENC_CELL + "kernel")), P(self.buf["lens_e"]),
+                                    P(self.buf["act_e"]), P(self.buf["cs_e"]), P(self.buf["hs_e"]), None, P(dhT), P(dC), P(dG), P(dXe),
+                                    P(S.grad(spec.ENC_CELL + "kernel")), P(S.grad(spec.ENC_CELL + "bias")), P(self.ws), self.ws_bytes)
+            lib.vc_axpy_f32(st, 1.0, P(dXe[0]), N * E, P(d_imfv))
+            if self.feed_cv:
+                lib.vc_axpy_f32(st, 1.0, P(dXe[1]), N * E, P(d_ci))
+            dxe = dXe[self.n_init_e]
+            ge = S.grad("encoder/enc_embeddings")
+            ge.zero_()
+            lib.vc_embedding_scatter_add_f32(st, P(ge), P(self.buf["cap_enc_t"]), T * N, E, V, P(dxe))
+            lib.vc_sumsq_partial_f32(st, P(dxe), T * N * E, self.part.data_ptr() + 2 * nb * 4)
+        else:
+            self.part[2 * nb:3 * nb].zero_()
+        dimf = self._b("dimf", (B, E))
+        if nc > 1:
+            lib.vc_segment_sum_rows_f32(st, P(d_imfv), B, nc, E, P(dimf), 0)
+        else:
+            dimf.copy_(d_imfv)
+        self.dense_bwd_w(self.feats, B, F, E, dimf, "imf_emb/kernel", "imf_emb/bias")
+        if self.use_ci:
+            if self.feed_cv:
+                self.dense_bwd_w(self.buf["c_v"], N, K_CL, E, d_ci, "cv_emb/kernel", "cv_emb/bias")
+            else:  # variable exists but is off the loss path (tf.gradients -> None)
+                S.grad("cv_emb/kernel").zero_()
+                S.grad("cv_emb/bias").zero_()
+        if want_dfeatures:
+            dfe = self._b("dfeatures", (B, F))
+            self.gemm(0, 1, B, F, E, dimf, E, S.param("imf_emb/kernel"), E, dfe, F)
+            return dfe
+        return None
+
+    # ---------------------------------------------------------------- optimiser
+    def pack_tail(self):
+        """Scalars that must be summed over data-parallel ranks ride in the gradient buffer's tail."""
+        lib, st, nb = self.lib, _stream(), self.nb
+        tail = self.store.g[self.store.n:]
+        lib.vc_reduce_sum_f32(st, self.part.data_ptr() + nb * 4, 2 * nb, 1.0, P(tail), 0)  # sum ||dX||^2 (both tables)
+
+    def apply_gradients(self):
+        """non_cnn_optimizer (ops/optimizers.py:3-47): global-norm clip 5.0 + Adam / SGD / Momentum."""
+        p, lib, st, S, nb = self.p, self.lib, _stream(), self.store, self.nb
+        lib.vc_sumsq_partial_f32(st, P(S.g), self.n_dense, P(self.part))
+        self.part[nb:nb + 1].copy_(S.g[S.n:S.n + 1])
+        lib.vc_clip_finalize_f32(st, P(self.part), nb + 1, float(p.lstm_clip_by_norm), P(self.ns))
+        scale = self.ns.data_ptr() + 4
+        if p.optimizer == "Adam":
+            lib.vc_adam_f32(st, P(S.p), P(S.g), P(S.slot("m")), P(S.slot("v")), S.n, P(self.scal), scale, 0.8, 0.999, 1e-8, 0.0)
+        elif p.optimizer == "SGD":
+            lib.vc_sgd_f32(st, P(S.p), P(S.g), S.n, self.scal.data_ptr() + 8, scale, 0.0)
+        else:
+            a = S.slot("a")
+            lr = self.scal.data_ptr() + 8
+            lib.vc_momentum_f32(st, P(S.p), P(S.g), P(a), self.n_dense, lr, scale, 0.9, 0.0, None, 0)
+            for name, ids in (("decoder/net/dec_embeddings", "cap_dec_t"), ("encoder/enc_embeddings", "cap_enc_t")):
+                if name not in S.offsets:
+                    continue
+                off, shape = S.offsets[name]
+                touched = self._b("touched_" + ids, (self.V,), zero=True)
+                lib.vc_mark_rows_f32(st, P(touched), P(self.buf[ids]), self.T * self.N, self.V)
+                n = shape[0] * shape[1]
+                lib.vc_momentum_f32(st, S.p.data_ptr() + off * 4, S.g.data_ptr() + off * 4, a.data_ptr() + off * 4, n, lr, scale, 0.9, 0.0,
+                                    P(touched), shape[1])
+
+    def losses(self):
+        """(kld, rec_loss, lower_bound, annealing) as Python floats -- the fetches of main.py:241-244."""
+        o = self.out.detach().cpu().numpy()
+        return float(o[1]), float(o[0]), float(o[2]), float(o[3])
+
+
+def init_clusters(num_clusters=90, latent_size=150, seed=42):
+    """Cluster means of the GMM / AG priors: utils/vae_utils.py:20-27 under the numpy global
+    seed 42 set by Batch_Generator.__init__ (utils/batch_gen.py:65-66): 90 draws of
+    2*random_sample((1, L)) - 1, each L2-normalised.  (Host-side, one-off.)"""
+    rs = np.random.RandomState(seed)
+    rows = []
+    for _ in range(num_clusters):
+        v = 2 * rs.random_sample((1, latent_size)) - 1
+        rows.append(v / np.sqrt(np.sum(v ** 2)))
+    return np.squeeze(np.stack(rows).astype(np.float32))
