@@ -1,0 +1,241 @@
+#!/usr/bin/env python
+"""Headline benchmark: captions/sec of one full training step (forward + backward +
+optimisers) of the CVAE captioning trainer on synthetic data resident in HBM.
+
+  python bench.py --gpus N --steps K --warmup W [--workload cfg4|cfg2|cfg3|cfg1]
+
+Workloads (BASELINE.json configs):
+  cfg4 (default, the configuration the metric is quoted on): Normal CVAE + --fine_tune,
+        224x224 images, VGG16 on device, 64 images (320 caption rows) PER GPU, T=20, V=10000
+        -> global batch 512 on 8 GPUs (weak scaling).
+  cfg2: Normal CVAE, precomputed 4096-d features, 256 images (1280 rows) per GPU.
+  cfg3: AG-CVAE with cluster vectors, 256 images per GPU.   cfg1: LSTM baseline, 32 images.
+A "step" = one pass of the whole hot path over one batch.  One process per GPU; for N > 1
+launch with torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the env).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
+PEAK_HBM_GBS = 8000.0
+
+WORKLOADS = {
+    "cfg1": dict(B=32, prior="Normal", no_encoder=True, use_c_v=False, fine_tune=False),
+    "cfg2": dict(B=256, prior="Normal", no_encoder=False, use_c_v=False, fine_tune=False),
+    "cfg3": dict(B=256, prior="AG", no_encoder=False, use_c_v=True, fine_tune=False),
+    "cfg4": dict(B=64, prior="Normal", no_encoder=False, use_c_v=False, fine_tune=True),
+}
+T_LEN, VOCAB = 20, 10000
+
+
+def make_params(w):
+    from vae_captioning_amd.utils.parameters import Parameters
+    p = Parameters()
+    p.prior, p.no_encoder, p.use_c_v, p.fine_tune = w["prior"], w["no_encoder"], w["use_c_v"], w["fine_tune"]
+    p.batch_size = w["B"]
+    p.vocab_size = VOCAB
+    return p
+
+
+def conv_flops_per_image():
+    """Algorithmic MACs of the 13 convolutions per image."""
+    from vae_captioning_amd import spec
+    H = 224
+    macs = {}
+    for name, ci, co in spec.VGG_CONV:
+        macs[name] = H * H * 9 * ci * co
+        if name in spec.VGG_POOL_AFTER:
+            H //= 2
+    return macs
+
+
+def cpu_baseline(workload, w, seed):
+    """Own CPU restatement (numpy oracle, NOT TF1 -- the reference cannot run here), timed on
+    the host cores on a bounded sample of the same workload.  Uses oracle/ as the thing timed
+    only for this reported baseline."""
+    from oracle import caption_model as cm, optim as oo, vgg as ov
+    from vae_captioning_amd import spec, synth
+    p = make_params(w)
+    rng = np.random.default_rng(seed)
+    Bc = {"cfg1": 32, "cfg2": 32, "cfg3": 16, "cfg4": 2}[workload]
+    nsteps = 2
+    P = spec.init_caption_params(p, VOCAB, seed=1)
+    batch = synth.make_batch(rng, Bc, p.num_captions, T_LEN, VOCAB, use_ci=spec.uses_ci(p), images=p.fine_tune)
+    noise = synth.make_noise(rng, Bc * p.num_captions, T_LEN, p)
+    if p.prior == "AG":
+        from oracle import decode
+        noise["c_means"] = decode.init_clusters(90, p.latent_size)
+    PV = spec.init_vgg_params(seed=2) if p.fine_tune else None
+    st, stv = {}, {}
+    t0 = time.perf_counter()
+    for s in range(nsteps):
+        if p.fine_tune:
+            d1 = (rng.random((Bc, 4096)) < 0.5).astype(np.float32)
+            d2 = (rng.random((Bc, 4096)) < 0.5).astype(np.float32)
+            fc2, cache = ov.forward(PV, batch["images"], d1, d2, keep=0.5)
+            batch["features"] = fc2
+        out = cm.forward_backward(P, batch, noise, p, global_step=s)
+        norm = oo.global_norm(out.grads, out.sparse)
+        oo.adam_step(P, out.grads, st, p.learning_rate, s + 1, scale=float(oo.clip_scale(norm, 5.0)))
+        if p.fine_tune:
+            GV = ov.backward(PV, cache, out.dfeatures)
+            oo.adam_step(PV, GV, stv, p.cnn_lr, s + 1, l2=p.weight_decay)
+    dt = time.perf_counter() - t0
+    try:
+        import threadpoolctl
+        nthreads = max([i.get("num_threads", 1) for i in threadpoolctl.threadpool_info()] + [1])
+    except Exception:
+        nthreads = os.cpu_count()
+    return dict(value=round(Bc * p.num_captions * nsteps / dt, 3), unit="captions/s", cores=int(nthreads), kind="port",
+                host_cpus=os.cpu_count(),
+                sample="%d steps of %s at %d images (%d caption rows)/step, numpy oracle (own CPU restatement, not TF1), %.1f s"
+                       % (nsteps, workload, Bc, Bc * p.num_captions, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cfg4", choices=sorted(WORKLOADS))
+    ap.add_argument("--graph", type=int, default=1, help="capture the step in a hipGraph (single GPU)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=1234)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from vae_captioning_amd import abi, spec, synth
+    from vae_captioning_amd.trainer import Trainer
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    torch.cuda.set_device(local)
+    lib = abi.load()  # raises if the HIP library is missing: no fallback
+    lib.vc_device_check(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    w = WORKLOADS[args.workload]
+    p = make_params(w)
+    rng = np.random.default_rng(args.seed + rank)
+    B = w["B"]
+    N = B * p.num_captions
+    tr = Trainer(p, VOCAB, device="cuda", lib=lib, world=world, rank=rank, seed=args.seed)
+    tr.load_state_dict({**spec.init_caption_params(p, VOCAB, seed=1), **(spec.init_vgg_params(seed=2) if p.fine_tune else {})})
+    batch = synth.make_batch(rng, B, p.num_captions, T_LEN, VOCAB, use_ci=spec.uses_ci(p), images=p.fine_tune)
+    tr.set_batch(batch)  # inputs resident in HBM before the timed region; noise is generated on device
+
+    use_graph = bool(args.graph) and world == 1
+    for _ in range(args.warmup):
+        tr._step()
+    if use_graph:
+        tr.capture(warmup=0)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tr.train_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    kld, rec, lb, ann = tr.losses()
+    assert np.isfinite(rec) and np.isfinite(lb), "non-finite loss"
+
+    # ---- roofline of the dominant kernel family, measured with HIP events on the launch stream
+    roof = measure_roofline(torch, tr, args.workload, B)
+    out = {
+        "metric": "captions/sec training (224x224, seq20, vocab~10k)",
+        "value": round(N * world * args.steps / dt, 2),
+        "unit": "captions/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1000 * dt / args.steps, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s: %s" % (args.workload, json.dumps(w, sort_keys=True)), "images_per_gpu": B,
+                   "captions_per_image": p.num_captions, "caption_rows_per_gpu": N, "global_caption_rows": N * world,
+                   "seq_len": T_LEN, "vocab": VOCAB, "gen_z_samples": p.gen_z_samples, "hipgraph": use_graph,
+                   "parallelism": "dp%d" % world},
+        "final_losses": {"rec_loss": round(rec, 5), "kld": round(kld, 5)},
+        "roofline": roof,
+    }
+    if rank == 0:
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.workload, w, args.seed)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def measure_roofline(torch, tr, workload, B):
+    """Dominant kernel family: the implicit-GEMM conv kernels (cfg4) or the logits-GEMM family
+    (caption-only).  achieved = algorithmic FLOPs of the launches / their summed HIP-event time."""
+    st = torch.cuda.current_stream()
+    reps = 5
+    if tr.vgg is not None:
+        macs = conv_flops_per_image()
+        fl = 2.0 * sum(macs.values()) * B * 3.0  # fwd + dgrad + wgrad (conv1_1 has no dgrad: counted below)
+        fl -= 2.0 * macs["conv1_1"] * B
+        vgg = tr.vgg
+        img = tr.images
+        fc2 = vgg.forward(img, tr.cap.step)
+        dfe = torch.zeros_like(fc2)
+        torch.cuda.synchronize()
+        # time conv forward+pool and conv backward sections with events on the launch stream
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        e[0].record(st)
+        for _ in range(reps):
+            vgg.forward(img, tr.cap.step)
+            vgg.backward(dfe)
+        e[1].record(st)
+        torch.cuda.synchronize()
+        ms = e[0].elapsed_time(e[1]) / reps
+        # the section also contains pool / fc / bias kernels (< 3 % of its FLOPs, HBM-bound); see DESIGN.md
+        ach = fl / (ms * 1e-3) / 1e12
+        return {"bound": "mfma", "kernel": "conv_kernel<*> (VGG16 fwd+dgrad+wgrad section)", "achieved": round(ach, 2),
+                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                "traffic": None, "section_ms": round(ms, 3)}
+    cap = tr.cap
+    p = cap.p
+    M, V, H = cap.T * cap.N, cap.V, p.decoder_hidden
+    outs, logits = cap.outs, cap.buf["logits"]
+    W, bia = cap.store.param("decoder/rnn_logits/kernel"), cap.store.param("decoder/rnn_logits/bias")
+    cap.gemm(0, 0, M, V, H, outs, H, W, V, logits, V, bia)
+    torch.cuda.synchronize()
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    e[0].record(st)
+    for _ in range(reps):
+        cap.gemm(0, 0, M, V, H, outs, H, W, V, logits, V, bia)
+    e[1].record(st)
+    torch.cuda.synchronize()
+    ms = e[0].elapsed_time(e[1]) / reps
+    fl = 2.0 * M * V * H
+    ach = fl / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "gemm_kernel<128x128,MK,KM> (logits [T*N,H]x[H,V])", "achieved": round(ach, 2),
+            "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "launch_ms": round(ms, 4)}
+
+
+if __name__ == "__main__":
+    main()

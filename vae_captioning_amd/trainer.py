@@ -1,0 +1,291 @@
+"""VGG16 engine + the training-step harness (counterpart of main.py:186-290's inner loop).
+
+Data parallelism (new work, the reference is single-GPU): one process per GPU,
+replicated parameters, the minibatch sharded by image; ONE RCCL all-reduce per step over
+the single flat gradient buffer (caption-side grads | reduction scalars | VGG grads),
+plus a 4-byte all-reduce of the non-PAD token count that the CE gradient scale needs
+before backward (main.py:156-157 divides by the GLOBAL count).
+"""
+import numpy as np
+import torch
+
+from . import abi, spec
+from .abi import ptr as P
+from .engine import TAIL, CaptionEngine, FlatStore, _stream, internal_caption_variables, _round
+
+
+class VggEngine(object):
+    """utils/image_embeddings.py:26-238 on device: 13 x (conv3x3 + bias + ReLU), 5 max-pools,
+    fc1 / fc2 (+ dropout), forward and backward, plus cnn_optimizer (ops/optimizers.py:49-82)."""
+
+    def __init__(self, p, device="cuda", lib=None, grad_backing=None, seed=0, rank=0):
+        self.p = p
+        self.lib = lib or abi.load()
+        self.dev = device
+        self.store = FlatStore(spec.vgg_variables(), device, tail=0, grad_backing=grad_backing)
+        self.buf = {}
+        self.ws = None
+        self.ws_bytes = 0
+        self.train = bool(p.fine_tune) and p.mode == "training"
+        self.keep = float(p.cnn_dropout) if self.train else 1.0  # main.py:67-73
+        self.wd = float(p.weight_decay) if self.train else 0.0
+        self.seed, self.rank = seed, rank
+        self.inject = False
+        self.part = torch.zeros(self.lib.vc_sumsq_blocks(), dtype=torch.float32, device=device)
+
+    def _b(self, name, shape, dtype=torch.float32):
+        t = self.buf.get(name)
+        shape = tuple(int(s) for s in shape)
+        if t is None or tuple(t.shape) != shape:
+            t = torch.zeros(shape, dtype=dtype, device=self.dev)
+            self.buf[name] = t
+        return t
+
+    def _need_ws(self, nbytes):
+        if nbytes > self.ws_bytes:
+            self.ws = torch.empty(max(int(nbytes), 1 << 20) // 4 + 16, dtype=torch.float32, device=self.dev)
+            self.ws_bytes = self.ws.numel() * 4
+
+    def gemm(self, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias=None, flags=0):
+        self._need_ws(self.lib.vc_gemm_workspace_bytes(M, N, K))
+        self.lib.vc_gemm_f32(_stream(), ta, tb, M, N, K, P(A), lda, P(B), ldb, P(C), ldc, P(bias), flags, P(self.ws), self.ws_bytes)
+
+    def colsum(self, x, rows, cols, out):
+        self._need_ws(self.lib.vc_colsum_workspace_bytes(rows, cols))
+        self.lib.vc_colsum_f32(_stream(), P(x), rows, cols, cols, P(out), 0, P(self.ws), self.ws_bytes)
+
+    def load_params(self, named):
+        for name in self.store.names():
+            self.store.param(name).copy_(torch.from_numpy(np.ascontiguousarray(named[name], dtype=np.float32)))
+
+    def load_weights(self, weight_file):
+        """utils/image_embeddings.py:240-246: first 30 alphabetically sorted npz arrays."""
+        w = np.load(weight_file)
+        keys = sorted(w.keys())
+        names = self.store.names()
+        for i, k in enumerate(keys):
+            if i == 30:
+                break
+            self.store.param(names[i]).copy_(torch.from_numpy(np.ascontiguousarray(w[k], dtype=np.float32)))
+
+    def state_dict(self):
+        torch.cuda.synchronize()
+        return {n: self.store.param(n).detach().cpu().numpy().copy() for n in self.store.names()}
+
+    def grads_dict(self):
+        torch.cuda.synchronize()
+        return {n: self.store.grad(n).detach().cpu().numpy().copy() for n in self.store.names()}
+
+    def set_masks(self, drop1, drop2):
+        self.inject = True
+        for k, a in (("drop1", drop1), ("drop2", drop2)):
+            self._b(k, a.shape).copy_(torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)))
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, images, step=None):
+        """images [B, 224, 224, 3] float32 RGB 0..255 on device -> fc2 [B, 4096]."""
+        lib, st, S = self.lib, _stream(), self.store
+        B, H, W = int(images.shape[0]), int(images.shape[1]), int(images.shape[2])
+        self.B = B
+        x = self._b("x0", (B, H, W, 4))
+        lib.vc_vgg_preprocess_f32(st, P(images), B, H, W, P(x))
+        w4 = self._b("w1_4", (3, 3, 4, 64))
+        lib.vc_pad_dim_f32(st, P(S.param("cnn/conv1_1/weights")), 9, 3, 4, 64, P(w4))
+        self.acts = []  # (layer name, input tensor, H, W, Cin_eff, Cout, weights used)
+        for name, ci, co in spec.VGG_CONV:
+            wn, bn = spec.vgg_var_names(name)
+            cie = 4 if ci == 3 else ci
+            w = w4 if ci == 3 else S.param(wn)
+            y = self._b("y_" + name, (B, H, W, co))
+            lib.vc_conv3x3_fwd_f32(st, B, H, W, cie, co, P(x), P(w), P(S.param(bn)), P(y), 1)
+            self.acts.append((name, x, H, W, cie, co, w))
+            x = y
+            if name in spec.VGG_POOL_AFTER:
+                yp = self._b("p_" + name, (B, H // 2, W // 2, co))
+                lib.vc_maxpool2x2_fwd_f32(st, B, H, W, co, P(x), P(yp))
+                self.acts.append(("P", x, H, W, co, co, None))
+                x = yp
+                H, W = H // 2, W // 2
+        flat = x  # [B, 7, 7, 512] NHWC == [B, 25088] (image_embeddings.py:222)
+        self.flat = flat
+        F1 = H * W * 512
+        fc1 = self._b("fc1", (B, 4096))
+        self.gemm(0, 0, B, 4096, F1, flat, F1, S.param("cnn/fc1/weights"), 4096, fc1, 4096, S.param("cnn/fc1/biases"), 1)
+        fc2 = self._b("fc2", (B, 4096))
+        if self.keep < 1:
+            if not self.inject:
+                for i, k in enumerate(("drop1", "drop2")):
+                    m = self._b(k, (B, 4096))
+                    lib.vc_philox_bernoulli_f32(st, P(m), m.numel(), self.keep, self.seed * 1000003 + self.rank, (8 + i) << 32, P(step))
+            fc1d = self._b("fc1d", (B, 4096))
+            lib.vc_dropout_f32(st, P(fc1), P(self.buf["drop1"]), self.keep, B * 4096, P(fc1d))
+        else:
+            fc1d = fc1
+        self.fc1d = fc1d
+        self.gemm(0, 0, B, 4096, 4096, fc1d, 4096, S.param("cnn/fc2/weights"), 4096, fc2, 4096, S.param("cnn/fc2/biases"), 1)
+        if self.keep < 1:
+            fc2d = self._b("fc2d", (B, 4096))
+            lib.vc_dropout_f32(st, P(fc2), P(self.buf["drop2"]), self.keep, B * 4096, P(fc2d))
+        else:
+            fc2d = fc2
+        return fc2d
+
+    def reg_sumsq(self, out_ptr):
+        """sum(w^2) over every cnn/* variable (main.py:69-74, Q9: biases included) -> device scalar."""
+        lib, st = self.lib, _stream()
+        lib.vc_sumsq_partial_f32(st, P(self.store.p), self.store.n, P(self.part))
+        lib.vc_reduce_sum_f32(st, P(self.part), self.part.numel(), 1.0, out_ptr, 0)
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, dfc2):
+        lib, st, S = self.lib, _stream(), self.store
+        B = self.B
+        m1 = P(self.buf["drop1"]) if self.keep < 1 else None
+        m2 = P(self.buf["drop2"]) if self.keep < 1 else None
+        d2 = self._b("d_fc2", (B, 4096))
+        lib.vc_relu_bwd_f32(st, P(dfc2), P(self.buf["fc2"]), m2, self.keep, B * 4096, P(d2))
+        self.gemm(1, 0, 4096, 4096, B, self.fc1d, 4096, d2, 4096, S.grad("cnn/fc2/weights"), 4096)
+        self.colsum(d2, B, 4096, S.grad("cnn/fc2/biases"))
+        d1 = self._b("d_fc1", (B, 4096))
+        self.gemm(0, 1, B, 4096, 4096, d2, 4096, S.param("cnn/fc2/weights"), 4096, d1, 4096)
+        lib.vc_relu_bwd_f32(st, P(d1), P(self.buf["fc1"]), m1, self.keep, B * 4096, P(d1))
+        F1 = self.flat.numel() // B
+        self.gemm(1, 0, F1, 4096, B, self.flat, F1, d1, 4096, S.grad("cnn/fc1/weights"), 4096)
+        self.colsum(d1, B, 4096, S.grad("cnn/fc1/biases"))
+        d = self._b("d_pool5", tuple(self.flat.shape))
+        self.gemm(0, 1, B, F1, 4096, d1, 4096, S.param("cnn/fc1/weights"), 4096, d, F1)
+        dw4 = self._b("dw1_4", (3, 3, 4, 64))
+        for li in range(len(self.acts) - 1, -1, -1):
+            name, x, H, W, ci, co, w = self.acts[li]
+            if name == "P":
+                dx = self._b("dx_%d" % li, (B, H, W, co))
+                lib.vc_maxpool2x2_bwd_f32(st, B, H, W, co, P(x), P(d), P(dx), 1)  # + ReluGrad of the conv that made x
+                d = dx
+                continue
+            wn, bn = spec.vgg_var_names(name)
+            self._need_ws(lib.vc_conv3x3_wgrad_workspace_bytes(B, H, W, ci, co))
+            if ci == 4:
+                lib.vc_conv3x3_wgrad_f32(st, B, H, W, ci, co, P(x), P(d), P(dw4), 0, P(self.ws), self.ws_bytes)
+                lib.vc_pad_dim_f32(st, P(dw4), 9, 4, 3, 64, P(S.grad(wn)))
+            else:
+                lib.vc_conv3x3_wgrad_f32(st, B, H, W, ci, co, P(x), P(d), P(S.grad(wn)), 0, P(self.ws), self.ws_bytes)
+            self.colsum(d, B * H * W, co, S.grad(bn))
+            if li > 0:
+                prev_is_pool = self.acts[li - 1][0] == "P"
+                dx = self._b("dx_%d" % li, (B, H, W, ci))
+                lib.vc_conv3x3_dgrad_f32(st, B, H, W, ci, co, P(d), P(w), None if prev_is_pool else P(x), P(dx))
+                d = dx
+
+    def apply_gradients(self, scal):
+        """cnn_optimizer: no clipping; Adam(cnn_lr, beta1=0.8) by default; the L2 regulariser's
+        gradient wd*w is folded into the update."""
+        p, lib, st, S = self.p, self.lib, _stream(), self.store
+        if p.cnn_optimizer == "Adam":
+            lib.vc_adam_f32(st, P(S.p), P(S.g), P(S.slot("m")), P(S.slot("v")), S.n, scal.data_ptr() + 12, None, 0.8, 0.999, 1e-8, self.wd)
+        elif p.cnn_optimizer == "SGD":
+            lib.vc_sgd_f32(st, P(S.p), P(S.g), S.n, scal.data_ptr() + 16, None, self.wd)
+        else:
+            lib.vc_momentum_f32(st, P(S.p), P(S.g), P(S.slot("a")), S.n, scal.data_ptr() + 16, None, 0.9, self.wd, None, 0)
+
+
+class Trainer(object):
+    """One training step = main.py:241-244's sess.run([kld, rec_loss, lower_bound, optimize,
+    optimize_cnn, annealing])."""
+
+    def __init__(self, p, vocab, device="cuda", lib=None, world=1, rank=0, group=None, seed=0):
+        self.p, self.lib = p, (lib or abi.load())
+        self.world, self.rank, self.group = world, rank, group
+        self.dev = device
+        n_cap = sum(_round(int(np.prod(s))) for _, s in internal_caption_variables(p, vocab)) + TAIL
+        self.fine = bool(p.fine_tune)
+        n_vgg = sum(_round(int(np.prod(s))) for _, s in spec.vgg_variables()) if self.fine else 0
+        self.gall = torch.zeros(n_cap + n_vgg, dtype=torch.float32, device=device)  # THE all-reduce buffer
+        self.cap = CaptionEngine(p, vocab, device, self.lib, grad_backing=self.gall[:n_cap], world=world, rank=rank, group=group, seed=seed)
+        self.vgg = None
+        if self.fine:
+            self.vgg = VggEngine(p, device, self.lib, grad_backing=self.gall[n_cap:], seed=seed, rank=rank)
+            if self.vgg.wd:
+                self.cap.reg_scale = self.vgg.wd / 2.0  # l2_regularizer(wd)(w) = wd * sum(w^2)/2
+        self.images = None
+        self.graph = None
+
+    def set_batch(self, batch, noise=None):
+        self.cap.set_batch(batch, noise)
+        if self.fine:
+            img = np.ascontiguousarray(batch["images"], dtype=np.float32)
+            if self.images is None or tuple(self.images.shape) != img.shape:
+                self.images = torch.zeros(img.shape, dtype=torch.float32, device=self.dev)
+            self.images.copy_(torch.from_numpy(img))
+            if noise is not None and "cnn_drop1" in noise:
+                self.vgg.set_masks(noise["cnn_drop1"], noise["cnn_drop2"])
+
+    def _step(self):
+        cap, vgg = self.cap, self.vgg
+        feats = None
+        if vgg is not None:
+            feats = vgg.forward(self.images, cap.step)
+            if vgg.wd:
+                vgg.reg_sumsq(cap.red.data_ptr() + 12)
+        cap.forward(feats)
+        dfe = cap.backward(want_dfeatures=vgg is not None)
+        if vgg is not None and vgg.train:
+            vgg.backward(dfe)
+        cap.pack_tail()
+        if self.world > 1:
+            torch.distributed.all_reduce(self.gall, group=self.group)  # the single gradient all-reduce
+        cap.apply_gradients()
+        if vgg is not None and vgg.train:
+            vgg.apply_gradients(cap.scal)
+
+    def train_step(self):
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self._step()
+
+    def capture(self, warmup=2):
+        """Capture the whole step into one hipGraph (removes ~300 launch latencies per step).
+        Requires fixed shapes and device-generated noise; collectives stay outside graphs."""
+        assert self.world == 1 and not self.cap.inject
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                self._step()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._step()
+        self.graph = g
+
+    def eval_rec_loss(self):
+        """validate() of main.py:262-284: rec_loss of the TRAINING graph (dropout active, z ~ q)."""
+        cap, vgg = self.cap, self.vgg
+        feats = vgg.forward(self.images, cap.step) if vgg is not None else None
+        cap.forward(feats, train=False)
+        return cap.losses()[1]
+
+    def losses(self):
+        return self.cap.losses()
+
+    # ------------------------------------------------------------------ checkpoints
+    def state_dict(self):
+        d = self.cap.state_dict()
+        if self.vgg is not None:
+            d.update(self.vgg.state_dict())
+        return d
+
+    def load_state_dict(self, d):
+        self.cap.load_params(d)
+        if self.vgg is not None:
+            self.vgg.load_params(d)
+
+    def save(self, path):
+        """Name-keyed tensor file with the reference's variable names (main.py:186-191).
+        Optimiser slots and global_step are not saved (Q11)."""
+        np.savez(path, **self.state_dict())
+
+    def restore(self, path):
+        with np.load(path) as z:
+            self.load_state_dict({k: z[k] for k in z.files})
