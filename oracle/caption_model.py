@@ -54,7 +54,7 @@ def _stack_heads(P, cfg):
     return Wm, bm, Ws, bs
 
 
-def forward_backward(P, batch, noise, cfg, global_step=0, reg_loss=0.0, want_grads=True):
+def forward_backward(P, batch, noise, cfg, global_step=0, reg_loss=0.0, want_grads=True, q1_groups=1, dp=None):
     """One training-step evaluation.
 
     batch: features [B, F] f32 (fc2 features, precomputed or from the VGG oracle)
@@ -64,6 +64,11 @@ def forward_backward(P, batch, noise, cfg, global_step=0, reg_loss=0.0, want_gra
            c_v      [N, 90] f32 (only when uses_ci)
     noise: eps [S, N, L]; gmm_idx [N] (GMM); drop_in [T, N, E] / drop_out
            [T, N, H] Bernoulli masks when the keep rates are < 1.
+    q1_groups: the Q1 reshape mixes rows inside each of `q1_groups` contiguous row groups
+           (1 = the reference; G = what G data-parallel towers of the reference graph compute).
+    dp:    None, or dict(ce_den=global non-PAD count, n_rows=global row count): evaluate ONE
+           data-parallel shard so that summing the returned gradients / ce_num / kl_sum over
+           shards gives the global-batch result (DESIGN.md section "data parallelism").
     returns SimpleNamespace(kld, rec_loss, lower_bound, ann, grads, sparse, dfeatures, aux)
     """
     dt = batch["features"].dtype
@@ -125,6 +130,8 @@ def forward_backward(P, batch, noise, cfg, global_step=0, reg_loss=0.0, want_gra
         # ---- KL, main.py:118-145 ----
         if cfg.prior in ("Normal", "GMM"):
             kld = ops.kl_normal_fwd(mean, std)
+            if dp is not None:  # this shard's share of the global batch mean
+                kld = kld * dt.type(N) / dt.type(dp["n_rows"])
         else:
             kld = ops.kl_ag_fwd(mean, std, ci, noise["c_means"])
 
@@ -134,7 +141,11 @@ def forward_backward(P, batch, noise, cfg, global_step=0, reg_loss=0.0, want_gra
     if feed_cv:
         xs.append(ci_emb[None])
     if not cfg.no_encoder:
-        zin = ops.q1_reshape(enc.z, L, S)  # decoder.py:109-110 (Q1)
+        if q1_groups == 1:
+            zin = ops.q1_reshape(enc.z, L, S)  # decoder.py:109-110 (Q1)
+        else:
+            ng = N // q1_groups
+            zin = np.concatenate([ops.q1_reshape(enc.z[:, g * ng:(g + 1) * ng], L, S) for g in range(q1_groups)], axis=0)
         z_dec = ops.dense_fwd(zin, P["decoder/net/z_rnn/kernel"], P["decoder/net/z_rnn/bias"])
         xs.append(z_dec[None])
     xw_d = ops.embedding_fwd(P["decoder/net/dec_embeddings"], cap_dec_t)
@@ -152,6 +163,9 @@ def forward_backward(P, batch, noise, cfg, global_step=0, reg_loss=0.0, want_gra
     logits = ops.dense_fwd(outs_r, P["decoder/rnn_logits/kernel"], P["decoder/rnn_logits/bias"])
     labels = cap_enc_t.reshape(-1)  # main.py:152 (time-major permutation of the same multiset)
     ce_loss, xc = ops.xent_masked_fwd(logits, labels)
+    if dp is not None:
+        xc["den"] = dt.type(dp["ce_den"])
+        ce_loss = xc["num"] / xc["den"]
     rec_loss = ce_loss + dt.type(reg_loss)  # main.py:159-160 (Q9)
     ann = dt.type(annealing(cfg, global_step))
     if cfg.no_encoder:
@@ -168,7 +182,8 @@ def forward_backward(P, batch, noise, cfg, global_step=0, reg_loss=0.0, want_gra
 
     # ================= backward of sum(lower_bound) (ops/optimizers.py:13) =======
     vector_loss = (not cfg.no_encoder) and cfg.prior == "AG"  # Q3
-    d_rec = dt.type(N) if vector_loss else dt.type(1)
+    n_rows = N if dp is None else dp["n_rows"]
+    d_rec = dt.type(n_rows) if vector_loss else dt.type(1)
     G = {}
     sparse = {}
     dlogits = ops.xent_masked_bwd(xc, d_rec)
@@ -199,13 +214,17 @@ def forward_backward(P, batch, noise, cfg, global_step=0, reg_loss=0.0, want_gra
     if not cfg.no_encoder:
         dzin, G["decoder/net/z_rnn/kernel"], G["decoder/net/z_rnn/bias"] = ops.dense_bwd(
             zin, P["decoder/net/z_rnn/kernel"], dz_dec)
-        dz = dzin.reshape(S, N, L)
+        if q1_groups == 1:
+            dz = dzin.reshape(S, N, L)
+        else:
+            ng = N // q1_groups
+            dz = np.concatenate([dzin[g * ng:(g + 1) * ng].reshape(S, ng, L) for g in range(q1_groups)], axis=1)
         dmean, dstd = ops.sample_z_bwd(dz, noise["eps"])
         if vector_loss:
             dk = np.full((N,), ann / dt.type(10), dt)
             km, ks = ops.kl_ag_bwd(enc.mean, enc.std, ci, noise["c_means"], dk)
         else:
-            km, ks = ops.kl_normal_bwd(enc.mean, enc.std, ann / dt.type(10))
+            km, ks = ops.kl_normal_bwd(enc.mean, enc.std, ann / dt.type(10) * dt.type(N) / dt.type(n_rows))
         dmean = dmean + km
         dstd = dstd + ks
         hT = enc.hT

@@ -1,0 +1,132 @@
+"""CPU, world_size 2, gloo: the data-parallel protocol of vae_captioning_amd/dp.py
+(shard by image, count all-reduce, ONE flat-gradient all-reduce with the reduction scalars in
+its tail, identical optimiser step on each replica).  The per-rank compute is the oracle
+(there is no GPU here); the expected result is the single-process oracle on the global batch
+with q1_groups = 2 (each rank mixes z samples inside its own shard, see dp.py)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _case(prior, use_c_v):
+    sys.path.insert(0, ROOT)
+    from oracle import caption_model as cm
+    from oracle import decode
+    from vae_captioning_amd import spec, synth
+    cfg = cm.default_cfg(embed_size=8, encoder_hidden=12, decoder_hidden=12, latent_size=6, gen_z_samples=3,
+                         num_captions=2, cnn_feature_size=20, vocab_size=31, prior=prior, use_c_v=use_c_v)
+    rng = np.random.default_rng(3)
+    P = {k: v.astype(np.float64) for k, v in spec.init_caption_params(cfg, 31, seed=4).items()}
+    batch = synth.make_batch(rng, 4, 2, 5, 31, use_ci=spec.uses_ci(cfg), variable_len=True, feature_size=20)
+    batch["features"] = batch["features"].astype(np.float64)
+    if "c_v" in batch:
+        batch["c_v"] = batch["c_v"].astype(np.float64)
+    noise = synth.make_noise(rng, 8, 5, cfg)
+    noise = {k: (v.astype(np.float64) if v.dtype.kind == "f" else v) for k, v in noise.items()}
+    if prior == "AG":
+        noise["c_means"] = decode.init_clusters(90, 6).astype(np.float64)
+    return cfg, P, batch, noise
+
+
+def _worker(rank, world, port, prior, use_c_v, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sys.path.insert(0, ROOT)
+        from oracle import caption_model as cm
+        from oracle import optim as oo
+        from vae_captioning_amd import dp
+        cfg, P, batch, noise = _case(prior, use_c_v)
+        nc = cfg.num_captions
+        n_glob = batch["cap_dec"].shape[0]
+        b = dp.shard_batch(batch, rank, world, nc)
+        n = dp.shard_noise(noise, rank, world, n_glob)
+        # (1) count all-reduce
+        den = torch.tensor([float((b["cap_enc"] != 0).sum())], dtype=torch.float64)
+        dist.all_reduce(den)
+        # (2) local forward/backward with the shard scales
+        out = cm.forward_backward(P, b, n, cfg, global_step=0, dp=dict(ce_den=float(den), n_rows=n_glob))
+        names = sorted(out.grads)
+        dx_sq = sum(float((v ** 2).sum()) for v in out.sparse.values())
+        kl_sum = float(np.sum(out.kld)) if prior == "AG" else float(out.kld)
+        flat = np.concatenate([out.grads[k].ravel() for k in names] + [np.array([dx_sq, float(out.ce_num), kl_sum])])
+        t = torch.from_numpy(flat)
+        # (3) the single gradient all-reduce
+        dist.all_reduce(t)
+        flat = t.numpy()
+        G, off = {}, 0
+        for k in names:
+            sz = out.grads[k].size
+            G[k] = flat[off:off + sz].reshape(out.grads[k].shape)
+            off += sz
+        dx_sq, ce_num, kl_sum = flat[off:off + 3]
+        # (4) clip + Adam on every replica
+        dense_sq = sum(float((G[k] ** 2).sum()) for k in names if k not in out.sparse)
+        norm = np.sqrt(dense_sq + dx_sq)
+        scale = 5.0 * min(1.0 / norm, 1.0 / 5.0)
+        P32 = {k: v.astype(np.float32) for k, v in P.items()}
+        oo.adam_step(P32, {k: G[k].astype(np.float32) for k in names}, {}, 5e-4, 1, scale=scale)
+        if rank == 0:
+            ret["G"] = {k: G[k].copy() for k in names}
+            ret["rec"] = ce_num / float(den)
+            ret["kl"] = kl_sum / (n_glob if prior == "AG" else 1.0)
+            ret["norm"] = norm
+            ret["P"] = P32
+        chk = torch.tensor([float(sum(v.astype(np.float64).sum() for v in P32.values()))], dtype=torch.float64)
+        both = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(both, chk)
+        assert all(float(x) == float(both[0]) for x in both), "replicas diverged"
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.parametrize("prior,use_c_v", [("Normal", False), ("AG", True), ("GMM", False)])
+def test_two_rank_step_equals_global_batch_oracle(prior, use_c_v):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), prior, use_c_v, ret), nprocs=2, join=True)
+    sys.path.insert(0, ROOT)
+    from oracle import caption_model as cm
+    from oracle import optim as oo
+    cfg, P, batch, noise = _case(prior, use_c_v)
+    ref = cm.forward_backward(P, batch, noise, cfg, global_step=0, q1_groups=2)
+    np.testing.assert_allclose(ret["rec"], float(ref.rec_loss), rtol=1e-12)
+    np.testing.assert_allclose(ret["kl"], float(np.mean(ref.kld)), rtol=1e-10)
+    for k, g in ref.grads.items():
+        np.testing.assert_allclose(ret["G"][k], g, rtol=1e-9, atol=1e-13, err_msg=k)
+    norm = float(oo.global_norm({k: v for k, v in ref.grads.items()}, ref.sparse))
+    np.testing.assert_allclose(ret["norm"], norm, rtol=1e-5)
+    # and it is NOT the single-GPU Q1 mix of the concatenated batch (documented difference)
+    one = cm.forward_backward(P, batch, noise, cfg, global_step=0, q1_groups=1)
+    assert abs(float(one.rec_loss) - float(ref.rec_loss)) > 0
+
+
+def test_shard_batch_keeps_an_images_rows_together():
+    from vae_captioning_amd import dp
+    B, nc = 6, 5
+    batch = dict(features=np.arange(B)[:, None].astype(np.float32), cap_dec=np.repeat(np.arange(B), nc)[:, None],
+                 cap_enc=np.repeat(np.arange(B), nc)[:, None], lengths=np.repeat(np.arange(B), nc))
+    for r in range(3):
+        s = dp.shard_batch(batch, r, 3, nc)
+        assert s["features"][:, 0].tolist() == [2 * r, 2 * r + 1]
+        assert s["lengths"].tolist() == [2 * r] * nc + [2 * r + 1] * nc
+    g, kn, ka, inv = dp.scales(320, 8, True)
+    assert g == 2560.0 and abs(kn - 0.1 / 2560) < 1e-12 and ka == 0.1 and inv == 1 / 2560
+    assert dp.scales(320, 8, False)[0] == 1.0

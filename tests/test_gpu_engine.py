@@ -157,3 +157,33 @@ def test_device_noise_runs_and_is_fresh_each_step(lib):
     assert not torch.equal(e1, eng.buf["eps"])
     assert all(np.isfinite(l1)) and all(np.isfinite(eng.losses()))
     assert abs(float(e1.mean())) < 0.1 and abs(float(e1.std()) - 1) < 0.1
+
+
+def test_collective_code_path_on_a_one_rank_rccl_group(lib):
+    """The data-parallel branches (count all-reduce, loss-scalar all-reduce, the single flat
+    gradient all-reduce over RCCL) executed on a 1-rank nccl group: results must equal the
+    collective-free step bit for bit (sum over one rank is the identity)."""
+    import os
+    import torch.distributed as dist
+    from vae_captioning_amd.trainer import Trainer
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        p = small_params(prior="Normal")
+        V, B, T = 203, 4, 6
+        P0, batch, noise = make_case(p, V, B, T, seed=13)
+        res = []
+        for force in (False, True):
+            tr = Trainer(p, V, lib=lib, force_collectives=force)
+            tr.load_state_dict(P0)
+            for _ in range(2):
+                tr.set_batch(batch, noise)
+                tr.train_step()
+            res.append((tr.losses(), tr.state_dict()))
+        assert res[0][0] == res[1][0]
+        for k in res[0][1]:  # every kernel is deterministic (no atomics on the training path)
+            np.testing.assert_array_equal(res[0][1][k], res[1][1][k])
+    finally:
+        dist.destroy_process_group()

@@ -129,6 +129,15 @@ def test_embedding_gather_scatter(lib):
     dt = zeros(V, E)
     lib.vc_embedding_scatter_add_f32(stream(), P(dt), P(dev(ids)), R, E, V, P(dev(dX)))
     assert_close(host(dt), O.embedding_bwd(V, ids, dX.astype(np.float64)), 1e-5, msg="scatter_add")
+    order = np.argsort(ids, kind="stable").astype(np.int32)
+    seg = np.concatenate([[0], np.cumsum(np.bincount(ids, minlength=V))]).astype(np.int32)
+    runs = []
+    for _ in range(2):
+        d2 = torch.full((V, E), 7.0, device="cuda")  # every row must be overwritten
+        lib.vc_embedding_grad_sorted_f32(stream(), P(d2), P(dev(order)), P(dev(seg)), E, V, P(dev(dX)))
+        runs.append(host(d2))
+    assert_close(runs[0], O.embedding_bwd(V, ids, dX.astype(np.float64)), 1e-6, msg="sorted embedding grad")
+    np.testing.assert_array_equal(runs[0], runs[1])  # deterministic
     tch = zeros(V)
     lib.vc_mark_rows_f32(stream(), P(tch), P(dev(ids)), R, V)
     ref = np.zeros(V, np.float32)

@@ -55,6 +55,23 @@ __global__ __launch_bounds__(256) void scatter_add_kernel(float* __restrict__ dt
     }
 }
 
+// Deterministic alternative: the caller supplies a stable argsort of the ids (`order`) and the
+// per-vocabulary-row segment starts; one wave owns one table row and sums its positions in
+// order (no atomics, no memset: absent rows are written as zeros).
+__global__ __launch_bounds__(256) void segment_grad_kernel(float* __restrict__ dtable, const int32_t* __restrict__ order,
+                                                           const int32_t* __restrict__ seg_start, int E, int vocab,
+                                                           const float* __restrict__ dX) {
+    const int lane = threadIdx.x & 63;
+    for (int v = blockIdx.x * 4 + (threadIdx.x >> 6); v < vocab; v += gridDim.x * 4) {
+        const int s0 = seg_start[v], s1 = seg_start[v + 1];
+        for (int e = lane; e < E; e += 64) {
+            float acc = 0.f;
+            for (int j = s0; j < s1; ++j) acc += dX[(long)order[j] * E + e];
+            dtable[(long)v * E + e] = acc;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void mark_rows_kernel(float* __restrict__ touched, const int32_t* __restrict__ ids,
                                                         long n, int vocab) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
@@ -64,21 +81,44 @@ __global__ __launch_bounds__(256) void mark_rows_kernel(float* __restrict__ touc
 }
 
 // ---- column sums (bias gradients): two deterministic stages --------------------------
-constexpr int COLSUM_CHUNKS = 64;
+// Stage 1: grid (cols/64, chunks); a workgroup owns 64 columns x one contiguous row chunk and
+// reads it as 16 row-lanes x 16 float4 lanes (256 B per row segment, fully coalesced).
+constexpr int COLSUM_MAX_CHUNKS = 1024;
+template <bool VEC>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, long rows, int cols, long ld,
                                                              float* __restrict__ part) {
-    __shared__ float sh[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int rl = threadIdx.x >> 6;  // 0..3
+    __shared__ float sh[16][65];
     const long per = (rows + gridDim.y - 1) / gridDim.y;
     const long r0 = (long)blockIdx.y * per;
     const long r1 = r0 + per < rows ? r0 + per : rows;
-    float s = 0.f;
-    if (c < cols)
-        for (long r = r0 + rl; r < r1; r += 4) s += x[r * ld + c];
-    sh[rl][threadIdx.x & 63] = s;
+    if (VEC) {
+        const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+        const int c = blockIdx.x * 64 + cl * 4;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < cols)
+            for (long r = r0 + rl; r < r1; r += 16) {
+                const float4 v = *reinterpret_cast<const float4*>(x + r * ld + c);
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+        sh[rl][cl * 4 + 0] = s.x; sh[rl][cl * 4 + 1] = s.y; sh[rl][cl * 4 + 2] = s.z; sh[rl][cl * 4 + 3] = s.w;
+    } else {
+        const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+        const int c = blockIdx.x * 64 + cl;
+        float s = 0.f;
+        if (c < cols)
+            for (long r = r0 + rl; r < r1; r += 4) s += x[r * ld + c];
+        sh[rl][cl] = s;
+        if (rl == 0)
+            for (int k = 4; k < 16; ++k) sh[k][cl] = 0.f;
+    }
     __syncthreads();
-    if (rl == 0 && c < cols) part[(long)blockIdx.y * cols + c] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+    if (threadIdx.x < 64) {
+        const int c = blockIdx.x * 64 + threadIdx.x;
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sh[k][threadIdx.x];
+        if (c < cols) part[(long)blockIdx.y * cols + c] = t;
+    }
 }
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int chunks, int cols,
                                                            float* __restrict__ out, int accumulate) {
@@ -208,6 +248,14 @@ extern "C" int vc_embedding_scatter_add_f32(void* stream, float* dtable, const i
     return 0;
 }
 
+extern "C" int vc_embedding_grad_sorted_f32(void* stream, float* dtable, const int32_t* order, const int32_t* seg_start,
+                                           int E, int vocab, const float* dX) {
+    VC_CHECK_ARG(dtable && order && seg_start && dX && E > 0 && vocab > 0, "bad argument");
+    hipLaunchKernelGGL(segment_grad_kernel, dim3(grid_for((long)vocab * 64)), dim3(256), 0, (hipStream_t)stream, dtable, order, seg_start, E, vocab, dX);
+    VC_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int vc_mark_rows_f32(void* stream, float* touched, const int32_t* ids, long n, int vocab) {
     VC_CHECK_ARG(touched && ids && n >= 0 && vocab > 0, "bad argument");
     if (n == 0) return 0;
@@ -216,20 +264,31 @@ extern "C" int vc_mark_rows_f32(void* stream, float* touched, const int32_t* ids
     return 0;
 }
 
+static int colsum_chunks(long rows, int cols) {
+    const int gx = cdiv(cols, 64);
+    long chunks = rows / 64;
+    const long cap = 2048 / gx > 1 ? 2048 / gx : 1;
+    if (chunks > cap) chunks = cap;
+    if (chunks > COLSUM_MAX_CHUNKS) chunks = COLSUM_MAX_CHUNKS;
+    if (chunks < 1) chunks = 1;
+    return (int)chunks;
+}
+
 extern "C" size_t vc_colsum_workspace_bytes(long rows, int cols) {
-    (void)rows;
-    return (size_t)COLSUM_CHUNKS * cols * sizeof(float);
+    return (size_t)colsum_chunks(rows, cols) * cols * sizeof(float);
 }
 
 extern "C" int vc_colsum_f32(void* stream, const float* x, long rows, int cols, long ld, float* out, int accumulate,
                              float* ws, size_t ws_bytes) {
     VC_CHECK_ARG(x && out && rows >= 0 && cols > 0 && ld >= cols, "bad argument");
-    int chunks = (int)((rows + 63) / 64);
-    if (chunks > COLSUM_CHUNKS) chunks = COLSUM_CHUNKS;
-    if (chunks < 1) chunks = 1;
+    const int chunks = colsum_chunks(rows, cols);
     if (!ws || ws_bytes < (size_t)chunks * cols * sizeof(float))
         return fail(VC_EWORKSPACE, "%s: workspace too small (need vc_colsum_workspace_bytes)", __func__);
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(cols, 64), chunks), dim3(256), 0, (hipStream_t)stream, x, rows, cols, ld, ws);
+    const bool vec = (cols % 4 == 0) && (ld % 4 == 0) && (((uintptr_t)x & 15) == 0);
+    if (vec)
+        hipLaunchKernelGGL(colsum_partial_kernel<true>, dim3(cdiv(cols, 64), chunks), dim3(256), 0, (hipStream_t)stream, x, rows, cols, ld, ws);
+    else
+        hipLaunchKernelGGL(colsum_partial_kernel<false>, dim3(cdiv(cols, 64), chunks), dim3(256), 0, (hipStream_t)stream, x, rows, cols, ld, ws);
     VC_LAUNCH_CHECK();
     hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(cols, 256)), dim3(256), 0, (hipStream_t)stream, ws, chunks, cols, out, accumulate);
     VC_LAUNCH_CHECK();

@@ -1,0 +1,60 @@
+"""Data-parallel protocol (new work: the reference is single-GPU).
+
+One process per GPU, replicated parameters, the minibatch sharded BY IMAGE (an image's nc
+caption rows, its cluster-vector rows and its noise slices stay together).  Per step:
+
+  1. all-reduce(sum) of ONE float: the number of non-PAD labels.  The CE loss divides by the
+     GLOBAL count (main.py:156-157), and the backward pass needs it as its scale.
+  2. every rank runs forward + backward on its shard with the scales of `scales()`, so that
+     the SUM over ranks of the local gradients is the gradient of the global-batch loss.
+  3. ONE all-reduce(sum) of the flat gradient buffer (caption grads | tail scalars | VGG
+     grads).  The tail carries sum ||dX||^2 of the embedding IndexedSlices values (the
+     un-deduplicated term of the global norm, quirk Q5); ce_num and kl_sum are reduced with
+     the count for reporting.
+  4. identical clip + optimiser step on every replica (parameter-only terms such as the L2
+     regulariser's gradient are applied once, inside the optimiser kernel).
+
+The one place the reference graph is not separable over rows is the Q1 reshape
+(vae_model/decoder.py:109-110), which mixes the z samples of different batch rows: here each
+rank mixes within its own shard -- exactly what G towers of the reference graph would do --
+so an N-GPU step equals the oracle run with q1_groups = N, not the single-GPU step on the
+concatenated batch.  (Reproducing the global mix needs an all-gather of mean/std and a
+reduce-scatter of their gradients, 1.5 MB each; listed as next work in DESIGN.md.)
+"""
+import numpy as np
+
+
+def shard_batch(batch, rank, world, nc):
+    """Rows of image i are i*nc .. i*nc+nc-1 (utils/caption_utils.py:4-25)."""
+    some = batch["features"] if "features" in batch else batch["images"]
+    B = some.shape[0]
+    assert B % world == 0, "global batch must divide evenly over ranks"
+    b0, b1 = rank * (B // world), (rank + 1) * (B // world)
+    out = {}
+    for k, v in batch.items():
+        if k in ("features", "images"):
+            out[k] = v[b0:b1]
+        else:
+            out[k] = v[b0 * nc:b1 * nc]
+    return out
+
+
+def shard_noise(noise, rank, world, n_rows_global):
+    n0, n1 = rank * (n_rows_global // world), (rank + 1) * (n_rows_global // world)
+    out = {}
+    for k, v in noise.items():
+        if k == "c_means":
+            out[k] = v
+        elif k in ("eps", "drop_in", "drop_out"):
+            out[k] = np.ascontiguousarray(v[:, n0:n1])
+        else:
+            out[k] = v[n0:n1]
+    return out
+
+
+def scales(n_local_rows, world, vector_loss):
+    """(gscale, kl_scale_normal, kl_scale_ag, inv_n) for a shard of n_local_rows rows.
+    gscale:  multiplies d(CE)/d(logits) (the AG vector loss differentiates N copies of rec_loss, Q3)
+    kl_scale_*: multiplies ann * dKL in vc_latent_bwd_f32;  inv_n: 1 / global row count."""
+    n_global = n_local_rows * world
+    return (float(n_global) if vector_loss else 1.0, 0.1 / n_global, 0.1, 1.0 / n_global)

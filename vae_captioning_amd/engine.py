@@ -16,7 +16,7 @@ Layout decisions (MI355X-first):
 import numpy as np
 import torch
 
-from . import abi, spec
+from . import abi, dp, spec
 from .abi import ptr as P
 
 K_CL = spec.NUM_CLUSTERS
@@ -96,8 +96,10 @@ class CaptionEngine(object):
     """Caption side of the graph: imf_emb / cv_emb, encoder q(z|x,I), KL, decoder p(x|z,I),
     masked CE, non_cnn_optimizer."""
 
-    def __init__(self, p, vocab, device="cuda", lib=None, grad_backing=None, world=1, rank=0, group=None, seed=0):
+    def __init__(self, p, vocab, device="cuda", lib=None, grad_backing=None, world=1, rank=0, group=None, seed=0,
+                 force_collectives=False):
         self.p = p
+        self.collectives = world > 1 or force_collectives
         self.V = int(vocab)
         self.lib = lib or abi.load()
         self.dev = device
@@ -223,6 +225,11 @@ class CaptionEngine(object):
         self.nc = nc
         up("cap_dec_t", cap_dec.T, torch.int32)
         up("cap_enc_t", cap_enc.T, torch.int32)
+        for key, ids in (("dec", cap_dec.T.reshape(-1)), ("enc", cap_enc.T.reshape(-1))):
+            # inverted index for the deterministic embedding gradient (vc_embedding_grad_sorted_f32)
+            ids = np.clip(ids, 0, self.V - 1)
+            up("order_" + key, np.argsort(ids, kind="stable").astype(np.int32), torch.int32)
+            up("seg_" + key, np.concatenate([[0], np.cumsum(np.bincount(ids, minlength=self.V))]).astype(np.int32), torch.int32)
         lens = np.asarray(batch["lengths"], np.int32)
         up("lens_e", lens + self.n_init_e, torch.int32)
         up("lens_d", lens + self.n_init_d, torch.int32)
@@ -344,11 +351,11 @@ class CaptionEngine(object):
         labels = self.buf["cap_enc_t"]
         den = self.red[1:2]
         lib.vc_count_nonzero_i32(st, P(labels), T * N, P(den))
-        if self.world > 1:
+        if self.collectives:
             torch.distributed.all_reduce(den, group=self.group)
         vector_loss = self.enc and p.prior == "AG"  # Q3
         Ng = N * self.world
-        gscale = float(Ng) if vector_loss else 1.0
+        gscale = dp.scales(N, self.world, vector_loss)[0]
         row_loss = self._b("row_loss", (T * N,))
         lib.vc_softmax_xent_f32(st, P(logits), P(labels), T * N, V, V, P(den), gscale, P(row_loss), 1 if train else 0)
         lib.vc_reduce_sum_f32(st, P(row_loss), T * N, 1.0, P(self.red), 0)
@@ -357,13 +364,14 @@ class CaptionEngine(object):
 
     def _finalize_losses(self, kl_sum, Ng, ann):
         lib, st = self.lib, _stream()
-        if self.world > 1:
-            t = self.red[:3]
-            if kl_sum is None:
-                t[2] = 0
-            buf = torch.stack([t[0], t[2]])
-            torch.distributed.all_reduce(buf, group=self.group)
-            t[0], t[2] = buf[0], buf[1]
+        if self.collectives:  # ce_num and kl_sum summed over ranks (reporting only)
+            r2 = self._b("red2", (2,), zero=True)
+            r2[0:1].copy_(self.red[0:1])
+            if kl_sum is not None:
+                r2[1:2].copy_(self.red[2:3])
+            torch.distributed.all_reduce(r2, group=self.group)
+            self.red[0:1].copy_(r2[0:1])
+            self.red[2:3].copy_(r2[1:2])
         reg = self.red.data_ptr() + 12 if self.reg_scale else None
         lib.vc_loss_finalize_f32(st, P(self.red), self.red.data_ptr() + 4, reg, float(self.reg_scale), kl_sum, 1.0 / Ng,
                                  P(ann) if self.enc else None, P(self.out))
@@ -393,9 +401,7 @@ class CaptionEngine(object):
         dxw = dXd[nid]
         if p.dec_keep_rate < 1:
             lib.vc_dropout_f32(st, P(dxw), P(self.buf["drop_in"]), p.dec_keep_rate, T * N * E, P(dxw))
-        gd = S.grad("decoder/net/dec_embeddings")
-        gd.zero_()
-        lib.vc_embedding_scatter_add_f32(st, P(gd), P(self.buf["cap_dec_t"]), T * N, E, V, P(dxw))
+        lib.vc_embedding_grad_sorted_f32(st, P(S.grad("decoder/net/dec_embeddings")), P(self.buf["order_dec"]), P(self.buf["seg_dec"]), E, V, P(dxw))
         nb = self.nb
         lib.vc_sumsq_partial_f32(st, P(dxw), T * N * E, self.part.data_ptr() + nb * 4)  # IndexedSlices.values (Q5)
         d_imfv = dXd[0]       # [N, E] gradient w.r.t. images_fv (decoder part)
@@ -409,11 +415,11 @@ class CaptionEngine(object):
             self.gemm(0, 1, N, Sm * L, E, dz_dec, E, S.param("decoder/net/z_rnn/kernel"), E, dz, Sm * L)
             mean, std = self.buf["mean"], self.buf["std"]
             dmean, dstd = self._b("dmean", (N, L)), self._b("dstd", (N, L))
-            Ng = N * self.world
+            _, kl_n, kl_ag, _ = dp.scales(N, self.world, p.prior == "AG")
             hT = self.buf["hs_e"][Te]
             dhT = self._b("dH_e", (N, He))
             if p.prior == "Normal":
-                lib.vc_latent_bwd_f32(st, Sm, N, L, 0, 1, P(dz), P(self.buf["eps"]), P(mean), P(std), None, P(ann), 0.1 / Ng, P(dmean), P(dstd))
+                lib.vc_latent_bwd_f32(st, Sm, N, L, 0, 1, P(dz), P(self.buf["eps"]), P(mean), P(std), None, P(ann), kl_n, P(dmean), P(dstd))
                 self.dense_bwd_w(hT, N, He, L, dmean, "encoder/dense/kernel", "encoder/dense/bias")
                 self.dense_bwd_w(hT, N, He, L, dstd, "encoder/dense_1/kernel", "encoder/dense_1/bias")
                 self.gemm(0, 1, N, He, L, dmean, L, S.param("encoder/dense/kernel"), L, dhT, He)
@@ -421,9 +427,9 @@ class CaptionEngine(object):
             else:
                 gmm = p.prior == "GMM"
                 if gmm:
-                    lib.vc_latent_bwd_f32(st, Sm, N, L, 0, 0, P(dz), P(self.buf["eps"]), P(mean), P(std), None, P(ann), 0.1 / Ng, P(dmean), P(dstd))
+                    lib.vc_latent_bwd_f32(st, Sm, N, L, 0, 0, P(dz), P(self.buf["eps"]), P(mean), P(std), None, P(ann), kl_n, P(dmean), P(dstd))
                 else:
-                    lib.vc_latent_bwd_f32(st, Sm, N, L, 1, 0, P(dz), P(self.buf["eps"]), P(mean), P(std), P(self.buf["mu_p"]), P(ann), 0.1, P(dmean), P(dstd))
+                    lib.vc_latent_bwd_f32(st, Sm, N, L, 1, 0, P(dz), P(self.buf["eps"]), P(mean), P(std), P(self.buf["mu_p"]), P(ann), kl_ag, P(dmean), P(dstd))
                 heads = self.buf["heads"]
                 dheads = self._b("dheads", (N, 2 * K_CL * L))
                 lib.vc_heads_mix_bwd_f32(st, N, K_CL, L, P(heads), None if gmm else P(self.buf["c_v"]), P(self.buf["gmm_idx"]) if gmm else None,
@@ -439,9 +445,7 @@ class CaptionEngine(object):
             if self.feed_cv:
                 lib.vc_axpy_f32(st, 1.0, P(dXe[1]), N * E, P(d_ci))
             dxe = dXe[self.n_init_e]
-            ge = S.grad("encoder/enc_embeddings")
-            ge.zero_()
-            lib.vc_embedding_scatter_add_f32(st, P(ge), P(self.buf["cap_enc_t"]), T * N, E, V, P(dxe))
+            lib.vc_embedding_grad_sorted_f32(st, P(S.grad("encoder/enc_embeddings")), P(self.buf["order_enc"]), P(self.buf["seg_enc"]), E, V, P(dxe))
             lib.vc_sumsq_partial_f32(st, P(dxe), T * N * E, self.part.data_ptr() + 2 * nb * 4)
         else:
             self.part[2 * nb:3 * nb].zero_()

@@ -192,15 +192,17 @@ class Trainer(object):
     """One training step = main.py:241-244's sess.run([kld, rec_loss, lower_bound, optimize,
     optimize_cnn, annealing])."""
 
-    def __init__(self, p, vocab, device="cuda", lib=None, world=1, rank=0, group=None, seed=0):
+    def __init__(self, p, vocab, device="cuda", lib=None, world=1, rank=0, group=None, seed=0, force_collectives=False):
         self.p, self.lib = p, (lib or abi.load())
+        self.collectives = world > 1 or force_collectives
         self.world, self.rank, self.group = world, rank, group
         self.dev = device
         n_cap = sum(_round(int(np.prod(s))) for _, s in internal_caption_variables(p, vocab)) + TAIL
         self.fine = bool(p.fine_tune)
         n_vgg = sum(_round(int(np.prod(s))) for _, s in spec.vgg_variables()) if self.fine else 0
         self.gall = torch.zeros(n_cap + n_vgg, dtype=torch.float32, device=device)  # THE all-reduce buffer
-        self.cap = CaptionEngine(p, vocab, device, self.lib, grad_backing=self.gall[:n_cap], world=world, rank=rank, group=group, seed=seed)
+        self.cap = CaptionEngine(p, vocab, device, self.lib, grad_backing=self.gall[:n_cap], world=world, rank=rank, group=group, seed=seed,
+                                 force_collectives=force_collectives)
         self.vgg = None
         if self.fine:
             self.vgg = VggEngine(p, device, self.lib, grad_backing=self.gall[n_cap:], seed=seed, rank=rank)
@@ -231,7 +233,7 @@ class Trainer(object):
         if vgg is not None and vgg.train:
             vgg.backward(dfe)
         cap.pack_tail()
-        if self.world > 1:
+        if self.collectives:
             torch.distributed.all_reduce(self.gall, group=self.group)  # the single gradient all-reduce
         cap.apply_gradients()
         if vgg is not None and vgg.train:
@@ -246,7 +248,7 @@ class Trainer(object):
     def capture(self, warmup=2):
         """Capture the whole step into one hipGraph (removes ~300 launch latencies per step).
         Requires fixed shapes and device-generated noise; collectives stay outside graphs."""
-        assert self.world == 1 and not self.cap.inject
+        assert not self.collectives and not self.cap.inject
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
