@@ -95,6 +95,10 @@ int vc_softmax_xent_f32(void* stream, float* logits, const int32_t* labels, long
                         float gscale, float* row_loss, int write_grad);
 int vc_softmax_rows_f32(void* stream, const float* x, long rows, int V, long ld, float* y, long ldy);
 int vc_argmax_rows_f32(void* stream, const float* x, long rows, int cols, long ld, int32_t* out);
+/* The first k entries of each row under a STABLE descending sort (ties -> lower index first): the
+ * candidate expansion of beam search, vae_model/decoder.py:273-276. */
+int vc_topk_rows_f32(void* stream, const float* x, long rows, int cols, long ld, int k, float* out_val, int32_t* out_idx);
+int vc_fill_f32(void* stream, float* x, long n, float value);
 
 /* ------------------------------------------------------------------------------------
  * Latent variable.  vae_model/encoder.py:59-109, main.py:118-145.

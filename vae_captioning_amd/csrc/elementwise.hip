@@ -222,9 +222,69 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restric
     if (threadIdx.x == 0) out[blockIdx.x] = si[0];
 }
 
+// top-k per row in (value descending, index ascending) order == the first k entries of a STABLE
+// sort on -p (vae_model/decoder.py:273-276).  k passes; pass j finds the best element strictly after
+// the (j-1)-th winner in that order, so the data are never modified.
+__global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict__ x, int cols, long ld, int k,
+                                                        float* __restrict__ out_val, int32_t* __restrict__ out_idx) {
+    __shared__ float sv[256];
+    __shared__ int si[256];
+    const float* p = x + (long)blockIdx.x * ld;
+    float lv = INFINITY;
+    int li = -1;
+    for (int j = 0; j < k; ++j) {
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int c = threadIdx.x; c < cols; c += 256) {
+            const float v = p[c];
+            const bool eligible = (v < lv) || (v == lv && c > li);
+            if (eligible && (v > bv || (v == bv && c < bi))) { bv = v; bi = c; }
+        }
+        sv[threadIdx.x] = bv;
+        si[threadIdx.x] = bi;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (threadIdx.x < o) {
+                const float v2 = sv[threadIdx.x + o];
+                const int i2 = si[threadIdx.x + o];
+                if (v2 > sv[threadIdx.x] || (v2 == sv[threadIdx.x] && i2 < si[threadIdx.x])) { sv[threadIdx.x] = v2; si[threadIdx.x] = i2; }
+            }
+            __syncthreads();
+        }
+        lv = sv[0];
+        li = si[0];
+        if (threadIdx.x == 0) {
+            out_val[(long)blockIdx.x * k + j] = lv;
+            out_idx[(long)blockIdx.x * k + j] = li;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ x, long n, float v) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) x[i] = v;
+}
+
 }  // namespace vc
 
 using namespace vc;
+
+extern "C" int vc_topk_rows_f32(void* stream, const float* x, long rows, int cols, long ld, int k, float* out_val,
+                                int32_t* out_idx) {
+    VC_CHECK_ARG(x && out_val && out_idx && rows >= 0 && cols > 0 && ld >= cols && k > 0 && k <= cols, "bad argument");
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(topk_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, cols, ld, k, out_val, out_idx);
+    VC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vc_fill_f32(void* stream, float* x, long n, float value) {
+    VC_CHECK_ARG(x && n >= 0, "bad argument");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, n, value);
+    VC_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int vc_embedding_gather_f32(void* stream, const float* table, const int32_t* ids, long rows, int E, int vocab,
                                        float* out) {

@@ -1,0 +1,209 @@
+"""Caption generation on device: batched greedy decoding and beam search
+(vae_model/decoder.py:145-320, ops/inference.py).
+
+The reference decodes ONE image and ONE beam per `sess.run` (batch 1, one Python<->runtime
+crossing per token per beam).  Here every round advances all images x all live beams in one
+batched LSTM step + logits GEMM + softmax + top-k on the GPU; only the O(beam) bookkeeping
+(TopN heaps, sentence lists, length-normalised scores) stays on the host, with the reference's
+exact semantics: stable top-`beam_size` expansion, p < 1e-12 skipped, score =
+logprob / len**0.7 for completed captions, `<BOS>` consumed twice (decoder.py:230-262).
+Per-image semantics of the z input are those of batch 1: row b of the z_rnn input is the S
+samples of image b (the Q1 reshape is the identity at N = 1).
+"""
+import numpy as np
+import torch
+
+from . import spec
+from .abi import ptr as P
+from .engine import K_CL, _stream
+from .utils.top_n import Beam, TopN
+
+# vae_model/decoder.py:56 -- category ids absent from MSCOCO (obj_vectors/category_index.pickle)
+UN_CLUSTERS = {0, 66, 68, 69, 71, 12, 45, 83, 26, 29, 30}
+
+
+class CaptionGenerator(object):
+    def __init__(self, engine):
+        self.e = engine
+        self.p = engine.p
+        self.lib = engine.lib
+        self.buf = {}
+
+    def _b(self, name, shape, dtype=torch.float32):
+        t = self.buf.get(name)
+        shape = tuple(int(s) for s in shape)
+        if t is None or tuple(t.shape) != shape or t.dtype != dtype:
+            t = torch.zeros(shape, dtype=dtype, device=self.e.dev)
+            self.buf[name] = t
+        return t
+
+    def _dev(self, a, dtype):
+        if isinstance(a, torch.Tensor):
+            return a.to(self.e.dev)
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).to(self.e.dev)
+
+    def prior_mean(self, c_v):
+        """decoder.py:42-71: zeros, or for the AG prior the mean of the image's cluster means
+        (empty cluster vector -> every used category id; ids beyond the 90-row matrix, quirk Q16,
+        are dropped)."""
+        p = self.p
+        B = c_v.shape[0] if c_v is not None else 0
+        if p.prior != "AG" or c_v is None:
+            return None
+        cm = self.e.c_means.cpu().numpy()
+        out = np.zeros((B, p.latent_size), np.float32)
+        for b in range(B):
+            idx = np.nonzero(c_v[b] > 0)[0]
+            if idx.size == 0:
+                idx = np.array([i for i in range(p.num_clusters + 1) if i not in UN_CLUSTERS and i < cm.shape[0]])
+            out[b] = cm[idx].mean(axis=0)
+        return out
+
+    # ------------------------------------------------------------------ init chain
+    def init_state(self, features, c_v=None, eps=None):
+        """State after image -> (c_v) -> z (decoder.py:96-114), batched over B images.
+        eps: [S, B, L] N(0,1) draws (generated on device when None)."""
+        e, p, lib, st, S = self.e, self.p, self.lib, _stream(), self.e.store
+        feats = self._dev(features, np.float32)
+        B = feats.shape[0]
+        E, Hd, L, Sm, F = p.embed_size, p.decoder_hidden, p.latent_size, p.gen_z_samples, p.cnn_feature_size
+        n_init = e.n_init_d
+        X = self._b("X", (n_init, B, E))
+        e.gemm(0, 0, B, E, F, feats, F, S.param("imf_emb/kernel"), E, X[0], E, S.param("imf_emb/bias"))
+        if e.feed_cv:
+            cv = self._dev(c_v, np.float32)
+            e.gemm(0, 0, B, E, K_CL, cv, K_CL, S.param("cv_emb/kernel"), E, X[1], E, S.param("cv_emb/bias"))
+        if e.enc:
+            z = self._b("z", (B, Sm, L))
+            if eps is None:
+                epsd = self._b("eps", (B, Sm, L))
+                lib.vc_philox_normal_f32(st, P(epsd), epsd.numel(), e.seed * 1000003 + 17, 5 << 32, P(e.step))
+            else:
+                epsd = self._dev(np.ascontiguousarray(np.transpose(np.asarray(eps, np.float32), (1, 0, 2))), np.float32)
+            mean = self._b("zmean", (B * Sm, L))
+            pm = self.prior_mean(np.asarray(c_v) if c_v is not None else None)
+            if pm is None:
+                mean.zero_()
+            else:
+                lib.vc_tile_rows_f32(st, P(self._dev(pm, np.float32)), B, Sm, L, P(mean))
+            std = self._b("zstd", (B * Sm, L))
+            lib.vc_fill_f32(st, P(std), std.numel(), float(p.std))
+            lib.vc_latent_sample_f32(st, 1, B * Sm, L, P(mean), P(std), P(epsd), P(z))  # decoder.py:72-74
+            e.gemm(0, 0, B, E, Sm * L, z, Sm * L, S.param("decoder/net/z_rnn/kernel"), E, X[n_init - 1], E, S.param("decoder/net/z_rnn/bias"))
+        act, cs, hs = self._b("act0", (n_init, B, 4 * Hd)), self._b("cs0", (n_init + 1, B, Hd)), self._b("hs0", (n_init + 1, B, Hd))
+        cs[0].zero_(); hs[0].zero_()
+        lens = torch.full((B,), n_init, dtype=torch.int32, device=e.dev)
+        e._need_ws(lib.vc_lstm_seq_workspace_bytes(n_init, B, E, Hd))
+        lib.vc_lstm_seq_fwd_f32(st, n_init, B, E, Hd, P(X), P(S.param(spec.DEC_CELL + "kernel")), P(S.param(spec.DEC_CELL + "bias")),
+                                P(lens), P(act), P(cs), P(hs), P(e.ws), e.ws_bytes)
+        return cs[n_init].clone(), hs[n_init].clone()
+
+    # ------------------------------------------------------------------ one decoder step
+    def step(self, tokens, c, h, want="probs"):
+        """Feed one token per row: returns (softmax probs [M, V], c', h')."""
+        e, p, lib, st, S = self.e, self.p, self.lib, _stream(), self.e.store
+        M = int(tokens.shape[0])
+        E, Hd, V = p.embed_size, p.decoder_hidden, e.V
+        x = torch.empty((M, E), dtype=torch.float32, device=e.dev)
+        lib.vc_embedding_gather_f32(st, P(S.param("decoder/net/dec_embeddings")), P(tokens), M, E, V, P(x))
+        W = S.param(spec.DEC_CELL + "kernel")
+        gact = torch.empty((M, 4 * Hd), dtype=torch.float32, device=e.dev)
+        e.gemm(0, 0, M, 4 * Hd, E, x, E, W, 4 * Hd, gact, 4 * Hd, S.param(spec.DEC_CELL + "bias"))
+        c2, h2 = torch.empty_like(c), torch.empty_like(h)
+        ones = torch.ones((M,), dtype=torch.int32, device=e.dev)
+        lib.vc_lstm_step_fwd_f32(st, M, Hd, 0, P(h), P(c), W.data_ptr() + E * 4 * Hd * 4, P(gact), P(ones), P(c2), P(h2))
+        logits = torch.empty((M, V), dtype=torch.float32, device=e.dev)
+        e.gemm(0, 0, M, V, Hd, h2, Hd, S.param("decoder/rnn_logits/kernel"), V, logits, V, S.param("decoder/rnn_logits/bias"))
+        if want == "logits":
+            return logits, c2, h2
+        probs = torch.empty_like(logits)
+        lib.vc_softmax_rows_f32(st, P(logits), M, V, V, P(probs), V)
+        return probs, c2, h2
+
+    # ------------------------------------------------------------------ greedy (online_inference)
+    def greedy(self, features, c_v=None, eps=None, bos=1, eos=2, max_len=None):
+        """decoder.py:145-201 with sample_gen='greedy' for a batch of images: returns the list
+        of generated token-id lists (each ends with <EOS> unless max_len was hit)."""
+        max_len = max_len or self.p.gen_max_len
+        c, h = self.init_state(features, c_v, eps)
+        B = c.shape[0]
+        tok = torch.full((B,), bos, dtype=torch.int32, device=self.e.dev)
+        out = [[] for _ in range(B)]
+        done = np.zeros(B, bool)
+        nxt = torch.empty((B,), dtype=torch.int32, device=self.e.dev)
+        for _ in range(max_len):
+            logits, c, h = self.step(tok, c, h, want="logits")  # argmax(softmax**(1/t)/sum) == argmax(logits)
+            self.lib.vc_argmax_rows_f32(_stream(), P(logits), B, self.e.V, self.e.V, P(nxt))
+            ids = nxt.cpu().numpy()
+            for b in range(B):
+                if not done[b]:
+                    out[b].append(int(ids[b]))
+                    if ids[b] == eos:
+                        done[b] = True
+            if done.all():
+                break
+            tok = nxt.clone()
+        return out
+
+    # ------------------------------------------------------------------ beam search
+    def beam_search(self, features, c_v=None, eps=None, bos=1, eos=2, beam_size=2, max_len=None, len_norm_f=0.7):
+        """decoder.py:203-320 for a batch of images.  Returns per image the list of
+        (sentence, score) of the kept beams in descending score order."""
+        lib, e = self.lib, self.e
+        max_len = max_len or self.p.gen_max_len
+        c, h = self.init_state(features, c_v, eps)
+        B, Hd, V = c.shape[0], self.p.decoder_hidden, e.V
+        tok = torch.full((B,), bos, dtype=torch.int32, device=e.dev)
+        _, c, h = self.step(tok, c, h, want="logits")  # :230-236 -- probabilities discarded, state kept
+        partial = [TopN(beam_size) for _ in range(B)]
+        complete = [TopN(beam_size) for _ in range(B)]
+        for b in range(B):
+            partial[b].push(Beam([bos], b, 0.0, 0.0))  # state = row index into the current (c, h)
+        alive = [True] * B
+        for _ in range(max_len - 1):
+            rows, owner, plist = [], [], []
+            for b in range(B):
+                if not alive[b]:
+                    continue
+                lst = partial[b].extract()
+                partial[b].reset()
+                for bm in lst:
+                    rows.append(bm.state)
+                    owner.append(b)
+                    plist.append(bm)
+            if not rows:
+                break
+            M = len(rows)
+            idx = torch.tensor(rows, dtype=torch.int32, device=e.dev)
+            cg, hg = torch.empty((M, Hd), device=e.dev), torch.empty((M, Hd), device=e.dev)
+            lib.vc_embedding_gather_f32(_stream(), P(c), P(idx), M, Hd, c.shape[0], P(cg))
+            lib.vc_embedding_gather_f32(_stream(), P(h), P(idx), M, Hd, h.shape[0], P(hg))
+            tok = torch.tensor([bm.sentence[-1] for bm in plist], dtype=torch.int32, device=e.dev)
+            probs, c, h = self.step(tok, cg, hg)
+            tv = torch.empty((M, beam_size), dtype=torch.float32, device=e.dev)
+            ti = torch.empty((M, beam_size), dtype=torch.int32, device=e.dev)
+            lib.vc_topk_rows_f32(_stream(), P(probs), M, V, V, beam_size, P(tv), P(ti))
+            tvh, tih = tv.cpu().numpy(), ti.cpu().numpy()
+            for i, bm in enumerate(plist):
+                b = owner[i]
+                for w, pw in zip(tih[i], tvh[i]):
+                    if pw < 1e-12:
+                        continue
+                    sentence = bm.sentence + [int(w)]
+                    logprob = bm.logprob + np.log(pw)
+                    score = logprob
+                    if w == eos:
+                        if len_norm_f > 0:
+                            score /= len(sentence) ** len_norm_f
+                        complete[b].push(Beam(sentence, i, logprob, score))
+                    else:
+                        partial[b].push(Beam(sentence, i, logprob, score))
+            for b in range(B):
+                if alive[b] and partial[b].size() == 0:
+                    alive[b] = False
+        res = []
+        for b in range(B):
+            top = complete[b] if complete[b].size() else partial[b]  # never mix complete and partial (:295-299)
+            beams = top.extract(sort=True)
+            res.append([(bm.sentence, float(bm.score)) for bm in beams])
+        return res
