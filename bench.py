@@ -107,7 +107,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg4", choices=sorted(WORKLOADS))
-    ap.add_argument("--graph", type=int, default=1, help="capture the step in a hipGraph (single GPU)")
+    ap.add_argument("--graph", type=int, default=0,
+                    help="1: replay the step from a captured hipGraph (single GPU).  Default 0: eager launches, so the "
+                         "dominant kernels can be bracketed by HIP events inside the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=1234)
     args = ap.parse_args()
@@ -138,11 +140,17 @@ def main():
     batch = synth.make_batch(rng, B, p.num_captions, T_LEN, VOCAB, use_ci=spec.uses_ci(p), images=p.fine_tune)
     tr.set_batch(batch)  # inputs resident in HBM before the timed region; noise is generated on device
 
+    from vae_captioning_amd.engine import KernelTimer
     use_graph = bool(args.graph) and world == 1
     for _ in range(args.warmup):
         tr._step()
+    timer = KernelTimer()
     if use_graph:
         tr.capture(warmup=0)
+    else:  # HIP-event pairs around the dominant kernel launches, live in the timed region
+        tr.cap.timer = timer
+        if tr.vgg is not None:
+            tr.vgg.timer = timer
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -162,8 +170,18 @@ def main():
     kld, rec, lb, ann = tr.losses()
     assert np.isfinite(rec) and np.isfinite(lb), "non-finite loss"
 
-    # ---- roofline of the dominant kernel family, measured with HIP events on the launch stream
-    roof = measure_roofline(torch, tr, args.workload, B)
+    # ---- roofline of the dominant kernel family from the HIP events of the timed region
+    instrumented_pass = False
+    if use_graph:  # events cannot be recorded inside a replayed graph: one extra eager, instrumented pass
+        instrumented_pass = True
+        tr.graph = None
+        tr.cap.timer = timer
+        if tr.vgg is not None:
+            tr.vgg.timer = timer
+        for _ in range(max(2, args.steps // 4)):
+            tr._step()
+    roof = roofline_from_timer(timer, tr.vgg is not None)
+    roof["instrumented_pass"] = instrumented_pass
     out = {
         "metric": "captions/sec training (224x224, seq20, vocab~10k)",
         "value": round(N * world * args.steps / dt, 2),
@@ -188,53 +206,21 @@ def main():
         dist.destroy_process_group()
 
 
-def measure_roofline(torch, tr, workload, B):
-    """Dominant kernel family: the implicit-GEMM conv kernels (cfg4) or the logits-GEMM family
-    (caption-only).  achieved = algorithmic FLOPs of the launches / their summed HIP-event time."""
-    st = torch.cuda.current_stream()
-    reps = 5
-    if tr.vgg is not None:
-        macs = conv_flops_per_image()
-        fl = 2.0 * sum(macs.values()) * B * 3.0  # fwd + dgrad + wgrad (conv1_1 has no dgrad: counted below)
-        fl -= 2.0 * macs["conv1_1"] * B
-        vgg = tr.vgg
-        img = tr.images
-        fc2 = vgg.forward(img, tr.cap.step)
-        dfe = torch.zeros_like(fc2)
-        torch.cuda.synchronize()
-        # time conv forward+pool and conv backward sections with events on the launch stream
-        e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-        e[0].record(st)
-        for _ in range(reps):
-            vgg.forward(img, tr.cap.step)
-            vgg.backward(dfe)
-        e[1].record(st)
-        torch.cuda.synchronize()
-        ms = e[0].elapsed_time(e[1]) / reps
-        # the section also contains pool / fc / bias kernels (< 3 % of its FLOPs, HBM-bound); see DESIGN.md
-        ach = fl / (ms * 1e-3) / 1e12
-        return {"bound": "mfma", "kernel": "conv_kernel<*> (VGG16 fwd+dgrad+wgrad section)", "achieved": round(ach, 2),
-                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-                "traffic": None, "section_ms": round(ms, 3)}
-    cap = tr.cap
-    p = cap.p
-    M, V, H = cap.T * cap.N, cap.V, p.decoder_hidden
-    outs, logits = cap.outs, cap.buf["logits"]
-    W, bia = cap.store.param("decoder/rnn_logits/kernel"), cap.store.param("decoder/rnn_logits/bias")
-    cap.gemm(0, 0, M, V, H, outs, H, W, V, logits, V, bia)
-    torch.cuda.synchronize()
-    e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-    e[0].record(st)
-    for _ in range(reps):
-        cap.gemm(0, 0, M, V, H, outs, H, W, V, logits, V, bia)
-    e[1].record(st)
-    torch.cuda.synchronize()
-    ms = e[0].elapsed_time(e[1]) / reps
-    fl = 2.0 * M * V * H
-    ach = fl / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "gemm_kernel<128x128,MK,KM> (logits [T*N,H]x[H,V])", "achieved": round(ach, 2),
-            "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-            "launch_ms": round(ms, 4)}
+def roofline_from_timer(timer, fine_tune):
+    """achieved = algorithmic FLOPs of the dominant kernel family's launches / their summed HIP-event
+    duration.  cfg4: the implicit-GEMM convolution kernels (forward, dgrad, wgrad; wgrad includes its
+    split-K reduce).  Caption-only workloads: the [T*N, H] x [H, V] logits GEMM."""
+    sm = timer.summary()
+    tags = ["conv_fwd", "conv_dgrad", "conv_wgrad"] if fine_tune else ["logits_gemm"]
+    fl = sum(sm[t]["flops"] for t in tags)
+    sec = sum(sm[t]["seconds"] for t in tags)
+    n = sum(sm[t]["launches"] for t in tags)
+    ach = fl / sec / 1e12
+    per = {t: dict(launches=sm[t]["launches"], avg_us=round(1e6 * sm[t]["seconds"] / sm[t]["launches"], 2),
+                   tflops=round(sm[t]["flops"] / sm[t]["seconds"] / 1e12, 2)) for t in tags}
+    return {"bound": "mfma", "kernel": "vc::conv_kernel<TileCfg,{fwd,dgrad,wgrad}>" if fine_tune else "vc::gemm_kernel<128x128,MK,KM> (logits)",
+            "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+            "traffic": None, "launches": n, "avg_launch_us": round(1e6 * sec / n, 2), "per_kernel": per}
 
 
 if __name__ == "__main__":

@@ -54,11 +54,12 @@ int vc_gemm_f32(void* stream, int ta, int tb, int M, int N, int K, const float* 
  * ---------------------------------------------------------------------------------- */
 int vc_embedding_gather_f32(void* stream, const float* table, const int32_t* ids, long rows, int E, int vocab, float* out);
 int vc_embedding_scatter_add_f32(void* stream, float* dtable, const int32_t* ids, long rows, int E, int vocab, const float* dX);
-/* Deterministic form of scatter_add: order = stable argsort of ids, seg_start[v]..seg_start[v+1] =
- * the slice of `order` whose id is v (vocab+1 entries).  Writes EVERY row of dtable (zeros for
- * absent tokens); duplicates are summed in position order, so repeated runs are bit-identical. */
+/* Deterministic form of scatter_add: out row v = sum of dX[order[j]] for j in seg_start[v] ..
+ * seg_start[v+1] (nrows+1 entries), summed in that order; order = stable argsort of the ids (NULL =
+ * identity).  Writes EVERY output row (zeros for empty segments), so repeated runs are
+ * bit-identical.  Hot tokens are handled by calling it twice (sub-segments, then partial rows). */
 int vc_embedding_grad_sorted_f32(void* stream, float* dtable, const int32_t* order, const int32_t* seg_start, int E,
-                                 int vocab, const float* dX);
+                                 int nrows, const float* dX);
 int vc_mark_rows_f32(void* stream, float* touched, const int32_t* ids, long n, int vocab);
 
 /* ------------------------------------------------------------------------------------

@@ -1,0 +1,161 @@
+#!/usr/bin/env python
+"""Training / inference driver with the command line of the reference's main.py
+(utils/parameters.py:75-132) on the MI355X-native hot path.
+
+    python main.py --gpu 0 --synthetic [--prior AG --c_v] [--fine_tune] [--mode inference]
+    python -m torch.distributed.run --nproc-per-node 8 main.py --synthetic --fine_tune   # data parallel
+
+The flow follows main.py:43-297 step for step, with the graph-building classes replaced by the
+eager facades of vae_captioning_amd (same names, same call order):
+    vgg16 -> imf_emb/cv_emb -> Encoder.q_net -> KL -> Decoder.px_z_fi -> masked CE ->
+    non_cnn_optimizer / cnn_optimizer -> print every 500 steps -> validate -> checkpoint per epoch.
+The MSCOCO data layer (utils/data.py, batch_gen.py) is out of scope; `--synthetic` feeds seeded
+batches with the same tensor contract (vae_captioning_amd/synth.py).
+"""
+import json
+import os
+import pickle
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from vae_captioning_amd import session, spec, synth  # noqa: E402
+from vae_captioning_amd.ops import optimizers  # noqa: E402
+from vae_captioning_amd.utils.parameters import Parameters  # noqa: E402
+from vae_captioning_amd.vae_model.decoder import Decoder  # noqa: E402
+from vae_captioning_amd.vae_model.encoder import Encoder  # noqa: E402
+
+
+class SyntheticDictionary(object):
+    """Stand-in for utils/captions.py's Dictionary: ids 0 = <PAD>, 1 = <BOS>, 2 = <EOS>."""
+
+    def __init__(self, vocab_size):
+        self.vocab_size = vocab_size
+        self.idx2word = {0: "<PAD>", synth.BOS: "<BOS>", synth.EOS: "<EOS>"}
+        for i in range(3, vocab_size):
+            self.idx2word[i] = "w%d" % i
+        self.word2idx = {w: i for i, w in self.idx2word.items()}
+
+
+class SyntheticBatches(object):
+    """next_batch() yields (images_or_features, (inputs, labels), lengths, c_v) already flattened to
+    N = B * num_captions rows -- the state after preprocess_captions (main.py:226-228)."""
+
+    def __init__(self, params, steps, seed, T=20):
+        self.p, self.steps, self.T = params, steps, T
+        self.rng = np.random.default_rng(seed)
+
+    def next_batch(self):
+        p = self.p
+        for _ in range(self.steps):
+            b = synth.make_batch(self.rng, p.batch_size, p.num_captions, self.T, p.vocab_size, use_ci=spec.uses_ci(p),
+                                 images=p.fine_tune, variable_len=True)
+            yield b
+
+
+def main(params):
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    if not params.synthetic:
+        raise SystemExit("the MSCOCO data layer is out of scope of this build: run with --synthetic")
+    cap_dict = SyntheticDictionary(params.vocab_size)
+    params.vocab_size = cap_dict.vocab_size  # main.py:92
+    from vae_captioning_amd.trainer import Trainer
+    tr = Trainer(params, params.vocab_size, world=world, rank=rank, seed=params.seed)
+    params._vc_trainer = tr  # the facades below share it (session.get)
+    tr.load_state_dict({**spec.init_caption_params(params, params.vocab_size, seed=params.seed),
+                        **(spec.init_vgg_params(seed=params.seed) if params.fine_tune else {})})
+    ckpt = "./checkpoints/%s.ckpt.npz" % params.checkpoint
+    if params.restore or params.mode == "inference":
+        if os.path.exists(ckpt):
+            print("Restoring from checkpoint")
+            tr.restore(ckpt)
+    steps_per_epoch = params.max_steps or (params.num_ex_per_epoch // params.batch_size + 1)  # main.py:217-221
+    say = print if rank == 0 else (lambda *a, **k: None)
+
+    if params.mode == "training":
+        cap = tr.cap
+        encoder = None if params.no_encoder else Encoder(None, None, None, params)
+        decoder = Decoder(None, None, None, params, cap_dict)
+        optimize, global_step, global_norm = optimizers.non_cnn_optimizer(None, params)
+        optimize_cnn = (lambda: 0.0)
+        if params.fine_tune:
+            optimize_cnn, _ = optimizers.cnn_optimizer(None, params)
+        for e in range(params.num_epochs):
+            data = SyntheticBatches(params, steps_per_epoch, params.seed + 17 * e + rank)
+            for batch in data.next_batch():
+                tr.set_batch(batch)
+                # ---- one sess.run([kld, rec_loss, lower_bound, optimize, optimize_cnn, annealing]) ----
+                feats = None
+                if tr.vgg is not None:
+                    feats = tr.vgg.forward(tr.images, cap.step)
+                    if tr.vgg.wd:
+                        tr.vgg.reg_sumsq(cap.red.data_ptr() + 12)
+                images_fv = cap.fw_prepare(feats)                       # main.py:84-108
+                if encoder is not None:
+                    encoder.images_fv = decoder.images_fv = images_fv
+                    qz, tm_list, tv_list = encoder.q_net()              # main.py:117
+                dec_model, x_logits, shpe, _ = decoder.px_z_fi({} if params.no_encoder else {"z": qz})  # main.py:146-150
+                cap.fw_loss(train=True)                                 # main.py:152-177
+                optimize()                                              # main.py:179
+                optimize_cnn()                                          # main.py:183
+                gs = int(global_step.item()) - 1
+                if gs % 500 == 0:
+                    kl, rl, lb, ann = tr.losses()
+                    say("Epoch: {} Iteration: {} VLB: {} Rec Loss: {}".format(e, gs, lb, rl))
+                    if not params.no_encoder:
+                        say("Annealing coefficient:{} KLD: {}".format(ann, kl))
+            kl, rl, lb, ann = tr.losses()
+            say("Epoch: {} Iteration: {} VLB: {} Rec Loss: {}".format(e, int(global_step.item()), lb, rl))
+            # validate(): rec_loss of the training graph on held-out batches (main.py:262-284)
+            val = []
+            for batch in SyntheticBatches(params, 4, params.seed + 99991 + rank).next_batch():
+                tr.set_batch(batch)
+                val.append(tr.eval_rec_loss())
+            say("Validation reconstruction loss: {}".format(np.mean(val)))
+            say("-----------------------------------------------")
+            if rank == 0:
+                os.makedirs("./checkpoints", exist_ok=True)
+                tr.save(ckpt)
+                say("Model saved in file: %s" % ckpt)
+    if params.mode == "inference":
+        # ops/inference.py:4-39: captions for the validation images -> ./val_{gen_name}.json
+        decoder = Decoder(None, None, None, params, cap_dict)
+        rng = np.random.default_rng(params.seed + 5)
+        captions_gen = []
+        for it in range(2):
+            b = synth.make_batch(rng, params.batch_size, 1, 20, params.vocab_size, use_ci=spec.uses_ci(params), images=params.fine_tune)
+            ids = ["synthetic_%06d" % (it * params.batch_size + i) for i in range(params.batch_size)]
+            pics = b["images"] if params.fine_tune else b["features"]
+            c_v = b.get("c_v")
+            if params.sample_gen == "beam_search":
+                sent = decoder.beam_search(None, ids, pics, None, c_v, beam_size=params.beam_size)
+            else:
+                sent, _ = decoder.online_inference(None, ids, pics, None, c_v=c_v)
+            captions_gen += sent
+        say("Generated {} captions".format(len(captions_gen)))
+        if rank == 0:
+            with open("./val_{}.json".format(params.gen_name), "w") as wj:
+                json.dump(captions_gen, wj)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    params = Parameters()
+    params.parse_args()
+    if params.save_params:
+        os.makedirs("./pickles", exist_ok=True)
+        fn = "./pickles/params_{}_{}_{}_{}.pickle".format(params.prior, params.no_encoder, params.checkpoint, params.use_c_v)
+        print("Saving params to: ", fn)
+        with open(fn, "wb") as wf:
+            pickle.dump(file=wf, obj={k: v for k, v in vars(params).items() if not k.startswith("_")})
+    main(params)

@@ -56,18 +56,33 @@ __global__ __launch_bounds__(256) void scatter_add_kernel(float* __restrict__ dt
 }
 
 // Deterministic alternative: the caller supplies a stable argsort of the ids (`order`) and the
-// per-vocabulary-row segment starts; one wave owns one table row and sums its positions in
-// order (no atomics, no memset: absent rows are written as zeros).
+// per-output-row segment starts; one wave owns one output row and sums its positions in order
+// (no atomics, no memset: rows with an empty segment are written as zeros).  order == NULL means
+// the identity (used for the second level of a two-level sum: hot tokens such as <PAD>/<BOS>/<EOS>
+// are first reduced in sub-segments of <= 32 positions, then the partial rows are summed).
+template <bool VEC>
 __global__ __launch_bounds__(256) void segment_grad_kernel(float* __restrict__ dtable, const int32_t* __restrict__ order,
-                                                           const int32_t* __restrict__ seg_start, int E, int vocab,
+                                                           const int32_t* __restrict__ seg_start, int E, int nrows,
                                                            const float* __restrict__ dX) {
     const int lane = threadIdx.x & 63;
-    for (int v = blockIdx.x * 4 + (threadIdx.x >> 6); v < vocab; v += gridDim.x * 4) {
+    for (int v = blockIdx.x * 4 + (threadIdx.x >> 6); v < nrows; v += gridDim.x * 4) {
         const int s0 = seg_start[v], s1 = seg_start[v + 1];
-        for (int e = lane; e < E; e += 64) {
-            float acc = 0.f;
-            for (int j = s0; j < s1; ++j) acc += dX[(long)order[j] * E + e];
-            dtable[(long)v * E + e] = acc;
+        if (VEC) {
+            for (int e = lane * 4; e < E; e += 256) {
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int j = s0; j < s1; ++j) {
+                    const long r = order ? order[j] : j;
+                    const float4 x = *reinterpret_cast<const float4*>(dX + r * E + e);
+                    acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+                }
+                *reinterpret_cast<float4*>(dtable + (long)v * E + e) = acc;
+            }
+        } else {
+            for (int e = lane; e < E; e += 64) {
+                float acc = 0.f;
+                for (int j = s0; j < s1; ++j) acc += dX[(long)(order ? order[j] : j) * E + e];
+                dtable[(long)v * E + e] = acc;
+            }
         }
     }
 }
@@ -120,13 +135,22 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
         if (c < cols) part[(long)blockIdx.y * cols + c] = t;
     }
 }
+// Stage 2: a workgroup owns 64 columns; 4 row-lanes each sum every 4th chunk partial, then the four
+// lane sums are combined in a fixed order.
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int chunks, int cols,
                                                            float* __restrict__ out, int accumulate) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= cols) return;
+    __shared__ float sh[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     float s = 0.f;
-    for (int k = 0; k < chunks; ++k) s += part[(long)k * cols + c];
-    out[c] = accumulate ? out[c] + s : s;
+    if (c < cols)
+        for (int k = rl; k < chunks; k += 4) s += part[(long)k * cols + c];
+    sh[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && c < cols) {
+        const float t = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
+        out[c] = accumulate ? out[c] + t : t;
+    }
 }
 
 // ---- dropout / relu ------------------------------------------------------------------
@@ -309,9 +333,13 @@ extern "C" int vc_embedding_scatter_add_f32(void* stream, float* dtable, const i
 }
 
 extern "C" int vc_embedding_grad_sorted_f32(void* stream, float* dtable, const int32_t* order, const int32_t* seg_start,
-                                           int E, int vocab, const float* dX) {
-    VC_CHECK_ARG(dtable && order && seg_start && dX && E > 0 && vocab > 0, "bad argument");
-    hipLaunchKernelGGL(segment_grad_kernel, dim3(grid_for((long)vocab * 64)), dim3(256), 0, (hipStream_t)stream, dtable, order, seg_start, E, vocab, dX);
+                                           int E, int nrows, const float* dX) {
+    VC_CHECK_ARG(dtable && seg_start && dX && E > 0 && nrows > 0, "bad argument");
+    const bool vec = (E % 4 == 0) && ((((uintptr_t)dtable | (uintptr_t)dX) & 15) == 0);
+    if (vec)
+        hipLaunchKernelGGL(segment_grad_kernel<true>, dim3(grid_for((long)nrows * 64, 256, 8192)), dim3(256), 0, (hipStream_t)stream, dtable, order, seg_start, E, nrows, dX);
+    else
+        hipLaunchKernelGGL(segment_grad_kernel<false>, dim3(grid_for((long)nrows * 64, 256, 8192)), dim3(256), 0, (hipStream_t)stream, dtable, order, seg_start, E, nrows, dX);
     VC_LAUNCH_CHECK();
     return 0;
 }
@@ -330,6 +358,7 @@ static int colsum_chunks(long rows, int cols) {
     const long cap = 2048 / gx > 1 ? 2048 / gx : 1;
     if (chunks > cap) chunks = cap;
     if (chunks > COLSUM_MAX_CHUNKS) chunks = COLSUM_MAX_CHUNKS;
+    if (gx < 8 && chunks > 256) chunks = 256;  // narrow matrices: keep the serial second stage short
     if (chunks < 1) chunks = 1;
     return (int)chunks;
 }
@@ -350,7 +379,7 @@ extern "C" int vc_colsum_f32(void* stream, const float* x, long rows, int cols, 
     else
         hipLaunchKernelGGL(colsum_partial_kernel<false>, dim3(cdiv(cols, 64), chunks), dim3(256), 0, (hipStream_t)stream, x, rows, cols, ld, ws);
     VC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(cols, 256)), dim3(256), 0, (hipStream_t)stream, ws, chunks, cols, out, accumulate);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(cols, 64)), dim3(256), 0, (hipStream_t)stream, ws, chunks, cols, out, accumulate);
     VC_LAUNCH_CHECK();
     return 0;
 }

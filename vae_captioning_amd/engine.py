@@ -32,6 +32,32 @@ def _round(n, m=64):
     return (n + m - 1) // m * m
 
 
+class KernelTimer(object):
+    """HIP-event pairs around selected kernel launches, recorded on the launch stream inside the
+    timed region of bench.py (roofline.achieved = algorithmic FLOPs / summed event time)."""
+
+    def __init__(self):
+        self.recs = []
+
+    def run(self, tag, flops, fn):
+        st = torch.cuda.current_stream()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        fn()
+        e1.record(st)
+        self.recs.append((tag, flops, e0, e1))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for tag, fl, e0, e1 in self.recs:
+            d = out.setdefault(tag, [0, 0.0, 0.0])
+            d[0] += 1
+            d[1] += fl
+            d[2] += e0.elapsed_time(e1) * 1e-3
+        return {k: dict(launches=v[0], flops=v[1], seconds=v[2]) for k, v in out.items()}
+
+
 class FlatStore(object):
     """Named views over flat parameter / gradient / optimiser-slot buffers."""
 
@@ -130,6 +156,7 @@ class CaptionEngine(object):
         self.part = torch.zeros(3 * nb + 4, **f32)
         self.inject = False
         self.seed = seed
+        self.timer = None
         self.reg_scale = 0.0
         self.c_means = None
         if self.enc and p.prior == "AG":
@@ -201,6 +228,12 @@ class CaptionEngine(object):
         self._need_ws(self.lib.vc_gemm_workspace_bytes(M, N, K))
         self.lib.vc_gemm_f32(_stream(), ta, tb, M, N, K, P(A), lda, P(B), ldb, P(C), ldc, P(bias), flags, P(self.ws), self.ws_bytes)
 
+    def _timed(self, tag, flops, fn):
+        if self.timer is not None:
+            self.timer.run(tag, flops, fn)
+        else:
+            fn()
+
     def colsum(self, x, rows, cols, out, accumulate=0):
         self._need_ws(self.lib.vc_colsum_workspace_bytes(rows, cols))
         self.lib.vc_colsum_f32(_stream(), P(x), rows, cols, cols, P(out), accumulate, P(self.ws), self.ws_bytes)
@@ -226,10 +259,10 @@ class CaptionEngine(object):
         up("cap_dec_t", cap_dec.T, torch.int32)
         up("cap_enc_t", cap_enc.T, torch.int32)
         for key, ids in (("dec", cap_dec.T.reshape(-1)), ("enc", cap_enc.T.reshape(-1))):
-            # inverted index for the deterministic embedding gradient (vc_embedding_grad_sorted_f32)
-            ids = np.clip(ids, 0, self.V - 1)
-            up("order_" + key, np.argsort(ids, kind="stable").astype(np.int32), torch.int32)
-            up("seg_" + key, np.concatenate([[0], np.cumsum(np.bincount(ids, minlength=self.V))]).astype(np.int32), torch.int32)
+            order, seg1, seg2 = embedding_grad_index(ids, self.V)
+            up("order_" + key, order, torch.int32)
+            up("seg1_" + key, seg1, torch.int32)
+            up("seg2_" + key, seg2, torch.int32)
         lens = np.asarray(batch["lengths"], np.int32)
         up("lens_e", lens + self.n_init_e, torch.int32)
         up("lens_d", lens + self.n_init_d, torch.int32)
@@ -268,10 +301,23 @@ class CaptionEngine(object):
     # ---------------------------------------------------------------- forward
     def forward(self, features=None, train=True):
         """Forward pass + (train) in-place d(loss)/d(logits).  `features` [B, F] device tensor
-        (defaults to the uploaded precomputed features)."""
+        (defaults to the uploaded precomputed features).  Stages (also callable one by one through
+        the Encoder / Decoder facades): fw_prepare -> fw_encode -> fw_decode -> fw_loss."""
+        self.fw_prepare(features, train)
+        if self.enc:
+            self.fw_encode()
+        self.fw_decode()
+        return self.fw_loss(train)
+
+    def _dims(self):
+        p = self.p
+        return (self.N, self.T, self.B, self.nc, p.embed_size, p.encoder_hidden, p.decoder_hidden, p.latent_size,
+                p.gen_z_samples, self.V, p.cnn_feature_size)
+
+    def fw_prepare(self, features=None, train=True):
+        """main.py:84-108: imf_emb (+ tile x nc), cv_emb; advances global_step / annealing when training."""
         p, lib, st, S = self.p, self.lib, _stream(), self.store
-        N, T, B, nc = self.N, self.T, self.B, self.nc
-        E, He, Hd, L, Sm, V, F = p.embed_size, p.encoder_hidden, p.decoder_hidden, p.latent_size, p.gen_z_samples, self.V, p.cnn_feature_size
+        N, T, B, nc, E, He, Hd, L, Sm, V, F = self._dims()
         feats = features if features is not None else self.buf["features"]
         self.feats = feats
         if not self.inject:
@@ -292,8 +338,17 @@ class CaptionEngine(object):
             cv = self.buf["c_v"]
             if self.feed_cv:
                 self.gemm(0, 0, N, E, K_CL, cv, K_CL, S.param("cv_emb/kernel"), E, Xd[1], E, S.param("cv_emb/bias"))
-        kl_sum = None
-        if self.enc:
+        self.kl_sum = None
+        return Xd[0]
+
+    def fw_encode(self):
+        """vae_model/encoder.py:24-110 + KL (main.py:118-145): returns z [S, N, L]."""
+        p, lib, st, S = self.p, self.lib, _stream(), self.store
+        N, T, B, nc, E, He, Hd, L, Sm, V, F = self._dims()
+        Te = T + self.n_init_e
+        Xd = self.buf["Xd"]
+        cv = self.buf.get("c_v")
+        if True:
             Xe = self._b("Xe", (Te, N, E))
             Xe[:self.n_init_e].copy_(Xd[:self.n_init_e])
             lib.vc_embedding_gather_f32(st, P(S.param("encoder/enc_embeddings")), P(self.buf["cap_enc_t"]), T * N, E, V, P(Xe[self.n_init_e]))
@@ -325,8 +380,18 @@ class CaptionEngine(object):
             row_kl = self._b("row_kl", (N,))
             lib.vc_kl_rows_f32(st, N, L, mode, P(mean), P(std), P(mu_p), P(row_kl))
             lib.vc_reduce_sum_f32(st, P(row_kl), N, 1.0, self.red.data_ptr() + 8, 0)
-            kl_sum = self.red.data_ptr() + 8
+            self.kl_sum = self.red.data_ptr() + 8
+        return z
+
+    def fw_decode(self):
+        """vae_model/decoder.py:34-129 (training mode): returns the logits buffer [T*N, V]."""
+        p, lib, st, S = self.p, self.lib, _stream(), self.store
+        N, T, B, nc, E, He, Hd, L, Sm, V, F = self._dims()
+        Td = T + self.n_init_d
+        Xd = self.buf["Xd"]
+        if self.enc:
             # decoder.py:109-111: z viewed as [N, S*L] (Q1) -> z_rnn -> the z step of the init chain
+            z = self.buf["z"]
             zi = self.n_init_d - 1
             self.gemm(0, 0, N, E, Sm * L, z, Sm * L, S.param("decoder/net/z_rnn/kernel"), E, Xd[zi], E, S.param("decoder/net/z_rnn/bias"))
         xw = Xd[self.n_init_d]
@@ -347,7 +412,17 @@ class CaptionEngine(object):
             outs = od
         self.outs = outs
         logits = self._b("logits", (T * N, V))
-        self.gemm(0, 0, T * N, V, Hd, outs, Hd, S.param("decoder/rnn_logits/kernel"), V, logits, V, S.param("decoder/rnn_logits/bias"))
+        self._timed("logits_gemm", 2.0 * T * N * V * Hd,
+                    lambda: self.gemm(0, 0, T * N, V, Hd, outs, Hd, S.param("decoder/rnn_logits/kernel"), V, logits, V, S.param("decoder/rnn_logits/bias")))
+        return logits
+
+    def fw_loss(self, train=True):
+        """main.py:152-177: masked CE (+ in-place gradient when train), loss scalars."""
+        p, lib, st = self.p, self.lib, _stream()
+        N, T, B, nc, E, He, Hd, L, Sm, V, F = self._dims()
+        logits = self.buf["logits"]
+        ann = self.scal[1:2]
+        kl_sum = self.kl_sum
         labels = self.buf["cap_enc_t"]
         den = self.red[1:2]
         lib.vc_count_nonzero_i32(st, P(labels), T * N, P(den))
@@ -401,7 +476,7 @@ class CaptionEngine(object):
         dxw = dXd[nid]
         if p.dec_keep_rate < 1:
             lib.vc_dropout_f32(st, P(dxw), P(self.buf["drop_in"]), p.dec_keep_rate, T * N * E, P(dxw))
-        lib.vc_embedding_grad_sorted_f32(st, P(S.grad("decoder/net/dec_embeddings")), P(self.buf["order_dec"]), P(self.buf["seg_dec"]), E, V, P(dxw))
+        self._embedding_grad("decoder/net/dec_embeddings", "dec", dxw)
         nb = self.nb
         lib.vc_sumsq_partial_f32(st, P(dxw), T * N * E, self.part.data_ptr() + nb * 4)  # IndexedSlices.values (Q5)
         d_imfv = dXd[0]       # [N, E] gradient w.r.t. images_fv (decoder part)
@@ -445,7 +520,7 @@ class CaptionEngine(object):
             if self.feed_cv:
                 lib.vc_axpy_f32(st, 1.0, P(dXe[1]), N * E, P(d_ci))
             dxe = dXe[self.n_init_e]
-            lib.vc_embedding_grad_sorted_f32(st, P(S.grad("encoder/enc_embeddings")), P(self.buf["order_enc"]), P(self.buf["seg_enc"]), E, V, P(dxe))
+            self._embedding_grad("encoder/enc_embeddings", "enc", dxe)
             lib.vc_sumsq_partial_f32(st, P(dxe), T * N * E, self.part.data_ptr() + 2 * nb * 4)
         else:
             self.part[2 * nb:3 * nb].zero_()
@@ -466,6 +541,16 @@ class CaptionEngine(object):
             self.gemm(0, 1, B, F, E, dimf, E, S.param("imf_emb/kernel"), E, dfe, F)
             return dfe
         return None
+
+    def _embedding_grad(self, name, key, dX):
+        """Dense [V, E] gradient of an embedding table from the per-position rows dX, deterministic,
+        two levels: sub-segments of <= 32 positions -> partial rows -> table rows."""
+        lib, st, E = self.lib, _stream(), self.p.embed_size
+        seg1, seg2 = self.buf["seg1_" + key], self.buf["seg2_" + key]
+        nsub = seg1.numel() - 1
+        part = self._b("embpart_" + key, (max(nsub, 1), E))
+        lib.vc_embedding_grad_sorted_f32(st, P(part), P(self.buf["order_" + key]), P(seg1), E, nsub, P(dX))
+        lib.vc_embedding_grad_sorted_f32(st, P(self.store.grad(name)), None, P(seg2), E, self.V, P(part))
 
     # ---------------------------------------------------------------- optimiser
     def pack_tail(self):
@@ -503,6 +588,25 @@ class CaptionEngine(object):
         """(kld, rec_loss, lower_bound, annealing) as Python floats -- the fetches of main.py:241-244."""
         o = self.out.detach().cpu().numpy()
         return float(o[1]), float(o[0]), float(o[2]), float(o[3])
+
+
+def embedding_grad_index(ids, vocab, chunk=32):
+    """Inverted index for the deterministic embedding gradient.  Returns
+    order [R]      stable argsort of the token ids,
+    seg1 [nsub+1]  boundaries (into `order`) of sub-segments of <= `chunk` positions, never
+                   crossing a token boundary,
+    seg2 [V+1]     for every vocabulary row the range of sub-segments that belong to it."""
+    ids = np.clip(np.asarray(ids, np.int64).reshape(-1), 0, vocab - 1)
+    order = np.argsort(ids, kind="stable").astype(np.int32)
+    counts = np.bincount(ids, minlength=vocab)
+    nsub_per = (counts + chunk - 1) // chunk
+    seg2 = np.concatenate([[0], np.cumsum(nsub_per)]).astype(np.int32)
+    starts = np.concatenate([[0], np.cumsum(counts)])[:-1]
+    rows = np.repeat(np.arange(vocab), nsub_per)
+    within = np.arange(rows.size) - np.repeat(seg2[:-1], nsub_per)
+    s1 = starts[rows] + within * chunk
+    seg1 = np.concatenate([s1, [ids.size]]).astype(np.int32)
+    return order, seg1, seg2
 
 
 def init_clusters(num_clusters=90, latent_size=150, seed=42):

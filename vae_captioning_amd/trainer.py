@@ -31,6 +31,7 @@ class VggEngine(object):
         self.wd = float(p.weight_decay) if self.train else 0.0
         self.seed, self.rank = seed, rank
         self.inject = False
+        self.timer = None
         self.part = torch.zeros(self.lib.vc_sumsq_blocks(), dtype=torch.float32, device=device)
 
     def _b(self, name, shape, dtype=torch.float32):
@@ -49,6 +50,12 @@ class VggEngine(object):
     def gemm(self, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias=None, flags=0):
         self._need_ws(self.lib.vc_gemm_workspace_bytes(M, N, K))
         self.lib.vc_gemm_f32(_stream(), ta, tb, M, N, K, P(A), lda, P(B), ldb, P(C), ldc, P(bias), flags, P(self.ws), self.ws_bytes)
+
+    def _timed(self, tag, flops, fn):
+        if self.timer is not None:
+            self.timer.run(tag, flops, fn)
+        else:
+            fn()
 
     def colsum(self, x, rows, cols, out):
         self._need_ws(self.lib.vc_colsum_workspace_bytes(rows, cols))
@@ -97,7 +104,8 @@ class VggEngine(object):
             cie = 4 if ci == 3 else ci
             w = w4 if ci == 3 else S.param(wn)
             y = self._b("y_" + name, (B, H, W, co))
-            lib.vc_conv3x3_fwd_f32(st, B, H, W, cie, co, P(x), P(w), P(S.param(bn)), P(y), 1)
+            self._timed("conv_fwd", 2.0 * B * H * W * 9 * ci * co,
+                        lambda x=x, w=w, y=y, H=H, W=W, cie=cie, co=co, bn=bn: lib.vc_conv3x3_fwd_f32(st, B, H, W, cie, co, P(x), P(w), P(S.param(bn)), P(y), 1))
             self.acts.append((name, x, H, W, cie, co, w))
             x = y
             if name in spec.VGG_POOL_AFTER:
@@ -164,16 +172,18 @@ class VggEngine(object):
                 continue
             wn, bn = spec.vgg_var_names(name)
             self._need_ws(lib.vc_conv3x3_wgrad_workspace_bytes(B, H, W, ci, co))
+            cr = 3 if ci == 4 else ci  # algorithmic channel count (conv1_1 is zero-padded 3 -> 4)
+            fl = 2.0 * B * H * W * 9 * cr * co
             if ci == 4:
-                lib.vc_conv3x3_wgrad_f32(st, B, H, W, ci, co, P(x), P(d), P(dw4), 0, P(self.ws), self.ws_bytes)
+                self._timed("conv_wgrad", fl, lambda x=x, d=d: lib.vc_conv3x3_wgrad_f32(st, B, H, W, ci, co, P(x), P(d), P(dw4), 0, P(self.ws), self.ws_bytes))
                 lib.vc_pad_dim_f32(st, P(dw4), 9, 4, 3, 64, P(S.grad(wn)))
             else:
-                lib.vc_conv3x3_wgrad_f32(st, B, H, W, ci, co, P(x), P(d), P(S.grad(wn)), 0, P(self.ws), self.ws_bytes)
+                self._timed("conv_wgrad", fl, lambda x=x, d=d, wn=wn: lib.vc_conv3x3_wgrad_f32(st, B, H, W, ci, co, P(x), P(d), P(S.grad(wn)), 0, P(self.ws), self.ws_bytes))
             self.colsum(d, B * H * W, co, S.grad(bn))
             if li > 0:
                 prev_is_pool = self.acts[li - 1][0] == "P"
                 dx = self._b("dx_%d" % li, (B, H, W, ci))
-                lib.vc_conv3x3_dgrad_f32(st, B, H, W, ci, co, P(d), P(w), None if prev_is_pool else P(x), P(dx))
+                self._timed("conv_dgrad", fl, lambda d=d, w=w, x=x, dx=dx: lib.vc_conv3x3_dgrad_f32(st, B, H, W, ci, co, P(d), P(w), None if prev_is_pool else P(x), P(dx)))
                 d = dx
 
     def apply_gradients(self, scal):
@@ -233,11 +243,14 @@ class Trainer(object):
         if vgg is not None and vgg.train:
             vgg.backward(dfe)
         cap.pack_tail()
-        if self.collectives:
-            torch.distributed.all_reduce(self.gall, group=self.group)  # the single gradient all-reduce
+        self.all_reduce_grads()
         cap.apply_gradients()
         if vgg is not None and vgg.train:
             vgg.apply_gradients(cap.scal)
+
+    def all_reduce_grads(self):
+        if self.collectives:
+            torch.distributed.all_reduce(self.gall, group=self.group)  # the single gradient all-reduce
 
     def train_step(self):
         if self.graph is not None:
