@@ -44,6 +44,9 @@ int vc_device_check(int device);
 size_t vc_gemm_workspace_bytes(int M, int N, int K);
 int vc_gemm_f32(void* stream, int ta, int tb, int M, int N, int K, const float* A, long lda, const float* B,
                 long ldb, float* C, long ldc, const float* bias, int flags, float* ws, size_t ws_bytes);
+/* Benchmark-only: the NN 128x128 kernel with main-loop stages ablated (bit 1: no global loads, 2: no
+ * LDS stores/barriers, 4: no LDS reads); output is meaningless for variant != 0.  tools/microbench.py. */
+int vc_debug_gemm_ablate_f32(void* stream, int variant, int M, int N, int K, const float* A, const float* B, float* C);
 
 /* ------------------------------------------------------------------------------------
  * Embedding lookup and its gradient.   tf.nn.embedding_lookup, vae_model/encoder.py:31-36,
@@ -78,6 +81,9 @@ int vc_lstm_step_fwd_f32(void* stream, int N, int H, int t, const float* h_prev,
 int vc_lstm_step_bwd_f32(void* stream, int N, int H, int t, int first, const float* dG_next, const float* Wh,
                          const int32_t* lens_eff, const float* dh_ext, float* dH_run, float* dC_run, const float* act,
                          const float* c_prev, const float* c_cur, float* dG);
+/* Sequence drivers: 1 (default) = recurrent GEMM via vc_gemm_f32 (split-K) + element-wise gate kernels,
+ * 0 = the fused step kernels.  Identical arithmetic; process-wide switch for A/B measurements. */
+int vc_lstm_set_mode(int split);
 size_t vc_lstm_seq_workspace_bytes(int T, int N, int E, int H);
 int vc_lstm_seq_fwd_f32(void* stream, int T, int N, int E, int H, const float* X, const float* W, const float* b,
                         const int32_t* lens_eff, float* act, float* cs, float* hs, float* ws, size_t ws_bytes);

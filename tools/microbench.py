@@ -1,0 +1,102 @@
+#!/usr/bin/env python
+"""Kernel microbenchmarks on one MI355X (HIP events, within-process interleaved rounds):
+   python tools/microbench.py gemm | ablate | conv | lstm"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vae_captioning_amd import abi  # noqa: E402
+from vae_captioning_amd.abi import ptr as P  # noqa: E402
+
+lib = abi.load()
+
+
+def st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def timeit(fn, reps=10, rounds=3):
+    fn()
+    torch.cuda.synchronize()
+    best = []
+    for _ in range(rounds):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        best.append(e0.elapsed_time(e1) / reps)
+    return float(np.median(best)), float(min(best))
+
+
+def rnd(*shape):
+    return torch.rand(*shape, device="cuda") * 2 - 1
+
+
+def gemm():
+    for (M, N, K) in [(4096, 4096, 4096), (8192, 8192, 8192), (25600, 10000, 512), (6400, 10000, 512), (28160, 2048, 256), (200704, 256, 2304)]:
+        A, B, C = rnd(M, K), rnd(K, N), torch.empty(M, N, device="cuda")
+        ws = torch.empty(max(lib.vc_gemm_workspace_bytes(M, N, K), 16) // 4 + 4, device="cuda")
+        med, mn = timeit(lambda: lib.vc_gemm_f32(st(), 0, 0, M, N, K, P(A), K, P(B), N, P(C), N, None, 0, P(ws), ws.numel() * 4))
+        print("gemm NN %6d x %6d x %6d: %8.3f ms  %6.1f TFLOP/s (best %.1f)" % (M, N, K, med, 2e-9 * M * N * K / med, 2e-9 * M * N * K / mn))
+
+
+def ablate(shapes=((4096, 4096, 4096), (8192, 8192, 8192), (25600, 10000, 512), (200704, 256, 2304), (12544, 512, 4608))):
+    names = {0: "full", 8: "double-buffered", 2: "no lds-store/barrier", 7: "mfma only"}
+    for (M, N, K) in shapes:
+        M, N = M // 128 * 128, N // 128 * 128
+        A, B, C = rnd(M, K), rnd(K, N), torch.empty(M, N, device="cuda")
+        ref = None
+        for v, nm in names.items():
+            med, mn = timeit(lambda: lib.vc_debug_gemm_ablate_f32(st(), v, M, N, K, P(A), P(B), P(C)))
+            chk = ""
+            if v == 0:
+                ref = C.clone()
+            elif v == 8:
+                chk = " maxdiff vs full %.3g" % float((C - ref).abs().max())
+            print("ablate %dx%dx%d %d %-22s %8.3f ms  %6.1f TFLOP/s%s" % (M, N, K, v, nm, med, 2e-9 * M * N * K / med, chk))
+
+
+def conv():
+    B = 64
+    for (name, H, ci, co) in [("1_2", 224, 64, 64), ("2_2", 112, 128, 128), ("3_2", 56, 256, 256), ("4_2", 28, 512, 512), ("5_2", 14, 512, 512)]:
+        x, w, bias = rnd(B, H, H, ci), rnd(3, 3, ci, co), rnd(co)
+        y, dx, dw = torch.empty(B, H, H, co, device="cuda"), torch.empty(B, H, H, ci, device="cuda"), torch.empty(3, 3, ci, co, device="cuda")
+        dy = rnd(B, H, H, co)
+        ws = torch.empty(lib.vc_conv3x3_wgrad_workspace_bytes(B, H, H, ci, co) // 4 + 4, device="cuda")
+        fl = 2e-9 * B * H * H * 9 * ci * co
+        for nm, fn in (("fwd", lambda: lib.vc_conv3x3_fwd_f32(st(), B, H, H, ci, co, P(x), P(w), P(bias), P(y), 1)),
+                       ("dgrad", lambda: lib.vc_conv3x3_dgrad_f32(st(), B, H, H, ci, co, P(dy), P(w), P(x), P(dx))),
+                       ("dgr-nomask", lambda: lib.vc_conv3x3_dgrad_f32(st(), B, H, H, ci, co, P(dy), P(w), None, P(dx))),
+                       ("wgrad", lambda: lib.vc_conv3x3_wgrad_f32(st(), B, H, H, ci, co, P(x), P(dy), P(dw), 0, P(ws), ws.numel() * 4))):
+            med, mn = timeit(fn, reps=5)
+            print("conv%s %-10s B=%d H=%3d %3d->%3d: %8.3f ms  %6.1f TFLOP/s" % (name, nm, B, H, ci, co, med, fl / med))
+
+
+def lstm():
+  for mode in (0, 1):
+    lib.vc_lstm_set_mode(mode)
+    print("lstm mode", mode, "(1 = gemm + gate kernels, 0 = fused step kernels)")
+    for N in (320, 1280):
+        H, E, T = 512, 256, 22
+        X, W, b = rnd(T, N, E), rnd(E + H, 4 * H) * 0.05, rnd(4 * H) * 0.1
+        lens = torch.full((N,), T, dtype=torch.int32, device="cuda")
+        act, cs, hs = torch.empty(T, N, 4 * H, device="cuda"), torch.zeros(T + 1, N, H, device="cuda"), torch.zeros(T + 1, N, H, device="cuda")
+        ws = torch.empty(lib.vc_lstm_seq_workspace_bytes(T, N, E, H) // 4 + 4, device="cuda")
+        med, _ = timeit(lambda: lib.vc_lstm_seq_fwd_f32(st(), T, N, E, H, P(X), P(W), P(b), P(lens), P(act), P(cs), P(hs), P(ws), ws.numel() * 4), reps=5)
+        fl = 2e-9 * T * N * (E + H) * 4 * H
+        print("lstm fwd seq N=%4d T=%d: %8.3f ms (%.1f us/step) %6.1f TFLOP/s" % (N, T, med, 1e3 * med / T, fl / med))
+        dhs = rnd(T + 1, N, H) * 0.1
+        dH, dC, dG = torch.zeros(N, H, device="cuda"), torch.zeros(N, H, device="cuda"), torch.empty(T, N, 4 * H, device="cuda")
+        dX, dW, db = torch.empty(T, N, E, device="cuda"), torch.empty(E + H, 4 * H, device="cuda"), torch.empty(4 * H, device="cuda")
+        med, _ = timeit(lambda: lib.vc_lstm_seq_bwd_f32(st(), T, N, E, H, P(X), P(W), P(lens), P(act), P(cs), P(hs), P(dhs), P(dH), P(dC), P(dG), P(dX), P(dW), P(db), P(ws), ws.numel() * 4), reps=5)
+        print("lstm bwd seq N=%4d T=%d: %8.3f ms (%.1f us/step) %6.1f TFLOP/s" % (N, T, med, 1e3 * med / T, 2 * fl / med))
+
+
+if __name__ == "__main__":
+    for a in sys.argv[1:] or ["gemm", "ablate", "conv", "lstm"]:
+        globals()[a]()

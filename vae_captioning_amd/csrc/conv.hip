@@ -23,53 +23,88 @@ struct ConvGeom {
     long P;  // B*H*W
 };
 
-// ---- A loaders -------------------------------------------------------------------------
-// forward / dgrad: MK image, rows = pixels, k = tap*C + c over a [P, C] NHWC tensor, shifted by
-// sign * off(tap).
+// ---- gathering loaders (slot protocol of gemm_core.h) ------------------------------------
+// forward / dgrad A operand: MK image, rows = pixels, k = tap*C + c over a [P, C] NHWC tensor,
+// shifted by sign * off(tap).  The pixel decode (two divisions) happens once per slot.
 struct LoadPixelsMK {
     const float* x;
     ConvGeom g;
     int lc;    // log2(C) of the gathered tensor
     int sign;  // +1 forward, -1 dgrad
-    __device__ __forceinline__ float4 load(int row, int k) const {
-        if (row >= g.P) return f4zero();
+    const float* pb[MAXNV];
+    int py[MAXNV], px[MAXNV], ko[MAXNV];
+    __device__ __forceinline__ void init(int u, int row, int kofs) {
+        ko[u] = kofs;
+        if (row >= g.P) { pb[u] = nullptr; py[u] = px[u] = 0; return; }
+        const int b = row / g.HW, rem = row - b * g.HW;
+        py[u] = rem / g.W;
+        px[u] = rem - py[u] * g.W;
+        pb[u] = x + ((long)row << lc);
+    }
+    __device__ __forceinline__ float4 load(int u, int k0) const {
+        const int k = k0 + ko[u];
         const int tap = k >> lc;
-        if (tap >= 9) return f4zero();
+        if (!pb[u] || tap >= 9) return f4zero();
         const int c = k & ((1 << lc) - 1);
         const int dy = (tap / 3 - 1) * sign, dx = (tap % 3 - 1) * sign;
-        const int b = row / g.HW, rem = row - b * g.HW;
-        const int y = rem / g.W, xw = rem - y * g.W;
-        const int yy = y + dy, xx = xw + dx;
-        if ((unsigned)yy >= (unsigned)g.H || (unsigned)xx >= (unsigned)g.W) return f4zero();
-        return *reinterpret_cast<const float4*>(x + ((((long)b * g.H + yy) * g.W + xx) << lc) + c);
+        if ((unsigned)(py[u] + dy) >= (unsigned)g.H || (unsigned)(px[u] + dx) >= (unsigned)g.W) return f4zero();
+        return *reinterpret_cast<const float4*>(pb[u] + (long)((dy * g.W + dx) << lc) + c);
     }
 };
-// wgrad: KM image, rows m = tap*Cin + ci (4 consecutive ci), k = pixel.
+// wgrad A operand: KM image, rows m = tap*Cin + ci (4 consecutive ci), k = pixel.  The tap of a slot is
+// fixed; the pixel -> (y, x) decode per K-tile uses a float reciprocal with a +-1 correction (exact
+// for pixel indices < 2^24; larger tensors take the integer-division path).
+__device__ __forceinline__ int fastdiv(int n, int d, float inv) {
+    int q = (int)((float)n * inv);
+    const int r = n - q * d;
+    q += (r >= d) - (r < 0);
+    return q;
+}
 struct LoadPixelsKM {
     const float* x;
     ConvGeom g;
-    __device__ __forceinline__ float4 load(int m, int k) const {
-        if (k >= g.P) return f4zero();
+    float invW, invH;
+    const float* pb[MAXNV];   // x + shift(tap)*Cin + ci  (add pixel*Cin)
+    int dy[MAXNV], dx[MAXNV], ko[MAXNV];
+    __device__ __forceinline__ void init(int u, int m, int kofs) {
+        ko[u] = kofs;
         const int tap = m >> g.lc_in;
-        if (tap >= 9) return f4zero();
-        const int c = m & (g.Cin - 1);
-        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-        const int b = k / g.HW, rem = k - b * g.HW;
-        const int y = rem / g.W, xw = rem - y * g.W;
-        const int yy = y + dy, xx = xw + dx;
-        if ((unsigned)yy >= (unsigned)g.H || (unsigned)xx >= (unsigned)g.W) return f4zero();
-        return *reinterpret_cast<const float4*>(x + ((((long)b * g.H + yy) * g.W + xx) << g.lc_in) + c);
+        if (tap >= 9) { pb[u] = nullptr; dy[u] = dx[u] = 0; return; }
+        dy[u] = tap / 3 - 1;
+        dx[u] = tap % 3 - 1;
+        pb[u] = x + (long)((dy[u] * g.W + dx[u]) << g.lc_in) + (m & (g.Cin - 1));
+    }
+    __device__ __forceinline__ float4 load(int u, int k0) const {
+        const int p = k0 + ko[u];
+        if (!pb[u] || p >= g.P) return f4zero();
+        int rowi, yy;
+        if (g.P < (1 << 24)) {
+            rowi = fastdiv(p, g.W, invW);
+            yy = rowi - fastdiv(rowi, g.H, invH) * g.H;
+        } else {
+            rowi = p / g.W;
+            yy = rowi % g.H;
+        }
+        const int xx = p - rowi * g.W;
+        if ((unsigned)(yy + dy[u]) >= (unsigned)g.H || (unsigned)(xx + dx[u]) >= (unsigned)g.W) return f4zero();
+        return *reinterpret_cast<const float4*>(pb[u] + ((long)p << g.lc_in));
     }
 };
 // dgrad B operand: MK image, rows n = ci, k = tap*Cout + co  ->  W[tap][ci][co]
 struct LoadWeightsT {
     const float* w;
     ConvGeom g;
-    __device__ __forceinline__ float4 load(int n, int k) const {
+    const float* q[MAXNV];
+    int ko[MAXNV];
+    __device__ __forceinline__ void init(int u, int n, int kofs) {
+        q[u] = n < g.Cin ? w + ((long)n << g.lc_out) : nullptr;
+        ko[u] = kofs;
+    }
+    __device__ __forceinline__ float4 load(int u, int k0) const {
+        const int k = k0 + ko[u];
         const int tap = k >> g.lc_out;
-        if (n >= g.Cin || tap >= 9) return f4zero();
-        const int co = k & (g.Cout - 1);
-        return *reinterpret_cast<const float4*>(w + (((long)tap * g.Cin + n) << g.lc_out) + co);
+        if (!q[u] || tap >= 9) return f4zero();
+        return *reinterpret_cast<const float4*>(q[u] + (((long)tap * g.Cin) << g.lc_out) + (k & (g.Cout - 1)));
     }
 };
 
@@ -94,67 +129,57 @@ __global__ __launch_bounds__(CFG::NT) void conv_kernel(ConvArgs c) {
     const int n0 = (id % c.tiles_n) * CFG::BN;
     f32x16 acc[CFG::TM][CFG::TN];
     acc_zero<CFG>(acc);
-    AccCoord<CFG> co;
     if (KIND == CONV_FWD) {
-        LoadPixelsMK la{c.a, g, g.lc_in, 1};
-        LoadKM<true> lb{c.b, g.Cout, g.Cout, 9 * g.Cin};
+        LoadPixelsMK la;
+        la.x = c.a; la.g = g; la.lc = g.lc_in; la.sign = 1;
+        LoadKM<true> lb;
+        lb.p = c.b; lb.ld = g.Cout; lb.R = g.Cout; lb.K = 9 * g.Cin;
         mfma_mainloop<CFG, MODE_MK, MODE_KM>(acc, la, lb, m0, n0, 0, 9 * g.Cin, smem);
-#pragma unroll
-        for (int tn = 0; tn < CFG::TN; ++tn) {
-            const int col = n0 + co.col(tn);
-            if (col >= g.Cout) continue;
-            const float bv = c.aux ? c.aux[col] : 0.f;
-#pragma unroll
-            for (int tm = 0; tm < CFG::TM; ++tm)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const long row = m0 + co.row(tm, r);
-                    if (row >= g.P) continue;
-                    float v = acc[tm][tn][r] + bv;
-                    if (c.relu) v = fmaxf(v, 0.f);
-                    c.out[row * g.Cout + col] = v;
-                }
-        }
+        epilogue_rows<CFG>(acc, smem, [&](int r, int cc, float4 v) {
+            const long row = m0 + r;
+            const int col = n0 + cc;
+            if (row >= g.P || col >= g.Cout) return;  // Cout % 4 == 0: whole quads
+            if (c.aux) {
+                const float4 bv = *reinterpret_cast<const float4*>(c.aux + col);
+                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+            }
+            if (c.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *reinterpret_cast<float4*>(c.out + row * g.Cout + col) = v;
+        });
     } else if (KIND == CONV_DGRAD) {
-        LoadPixelsMK la{c.a, g, g.lc_out, -1};
-        LoadWeightsT lb{c.b, g};
+        LoadPixelsMK la;
+        la.x = c.a; la.g = g; la.lc = g.lc_out; la.sign = -1;
+        LoadWeightsT lb;
+        lb.w = c.b; lb.g = g;
         mfma_mainloop<CFG, MODE_MK, MODE_MK>(acc, la, lb, m0, n0, 0, 9 * g.Cout, smem);
-#pragma unroll
-        for (int tn = 0; tn < CFG::TN; ++tn) {
-            const int col = n0 + co.col(tn);
-            if (col >= g.Cin) continue;
-#pragma unroll
-            for (int tm = 0; tm < CFG::TM; ++tm)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const long row = m0 + co.row(tm, r);
-                    if (row >= g.P) continue;
-                    float v = acc[tm][tn][r];
-                    if (c.aux && !(c.aux[row * g.Cin + col] > 0.f)) v = 0.f;  // ReluGrad of the producing layer
-                    c.out[row * g.Cin + col] = v;
-                }
-        }
+        epilogue_rows<CFG>(acc, smem, [&](int r, int cc, float4 v) {
+            const long row = m0 + r;
+            const int col = n0 + cc;
+            if (row >= g.P || col >= g.Cin) return;
+            if (c.aux) {  // ReluGrad of the layer that produced this convolution's input
+                const float4 m = *reinterpret_cast<const float4*>(c.aux + row * g.Cin + col);
+                if (!(m.x > 0.f)) v.x = 0.f;
+                if (!(m.y > 0.f)) v.y = 0.f;
+                if (!(m.z > 0.f)) v.z = 0.f;
+                if (!(m.w > 0.f)) v.w = 0.f;
+            }
+            *reinterpret_cast<float4*>(c.out + row * g.Cin + col) = v;
+        });
     } else {
         const int M = 9 * g.Cin;
         const long kb = (long)blockIdx.y * c.kchunk;
         const long ke = kb + c.kchunk < g.P ? kb + c.kchunk : g.P;
-        LoadPixelsKM la{c.a, g};
-        LoadKM<true> lb{c.b, g.Cout, g.Cout, (int)g.P};
+        LoadPixelsKM la;
+        la.x = c.a; la.g = g; la.invW = 1.0f / (float)g.W; la.invH = 1.0f / (float)g.H;
+        LoadKM<true> lb;
+        lb.p = c.b; lb.ld = g.Cout; lb.R = g.Cout; lb.K = (int)g.P;
         mfma_mainloop<CFG, MODE_KM, MODE_KM>(acc, la, lb, m0, n0, (int)kb, (int)ke, smem);
         float* out = c.out + (long)blockIdx.y * M * g.Cout;
-#pragma unroll
-        for (int tn = 0; tn < CFG::TN; ++tn) {
-            const int col = n0 + co.col(tn);
-            if (col >= g.Cout) continue;
-#pragma unroll
-            for (int tm = 0; tm < CFG::TM; ++tm)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + co.row(tm, r);
-                    if (row >= M) continue;
-                    out[(long)row * g.Cout + col] = acc[tm][tn][r];
-                }
-        }
+        epilogue_rows<CFG>(acc, smem, [&](int r, int cc, float4 v) {
+            const int row = m0 + r, col = n0 + cc;
+            if (row >= M || col >= g.Cout) return;
+            *reinterpret_cast<float4*>(out + (long)row * g.Cout + col) = v;
+        });
     }
 }
 
@@ -168,7 +193,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 using ConvCfgWide = TileCfg<2, 2, 2, 2>;    // 128 x 128
-using ConvCfgNarrow = TileCfg<2, 1, 2, 2>;  // 128 x 64 (64-channel layers), 128 threads
+using ConvCfgNarrow = TileCfg<4, 1, 2, 2>;  // 256 x 64 (64-channel layers), 256 threads
 
 static int ilog2_exact(int v) {
     int l = 0;
@@ -193,7 +218,7 @@ struct WgradPlan {
 };
 static WgradPlan plan_wgrad(const ConvGeom& g) {
     const int bn = g.Cout <= 64 ? 64 : 128;
-    const long tiles = (long)cdiv(9 * g.Cin, 128) * cdiv(g.Cout, bn);
+    const long tiles = (long)cdiv(9 * g.Cin, g.Cout <= 64 ? 256 : 128) * cdiv(g.Cout, bn);
     long splits = (1024 + tiles - 1) / tiles;
     const long maxs = g.P / 512 > 0 ? g.P / 512 : 1;  // >= 16 K-tiles per split
     if (splits > maxs) splits = maxs;

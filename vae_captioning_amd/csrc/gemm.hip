@@ -22,7 +22,7 @@ struct GemmArgs {
     int flags;
 };
 
-template <class CFG, int AM, int BMD, bool VEC>
+template <class CFG, int AM, int BMD, bool VEC, int ABL = 0>
 __global__ __launch_bounds__(CFG::NT) void gemm_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int id = xcd_remap(blockIdx.x, g.ntiles);
@@ -32,34 +32,50 @@ __global__ __launch_bounds__(CFG::NT) void gemm_kernel(GemmArgs g) {
     const int ke = min(g.K, kb + g.kchunk);
     f32x16 acc[CFG::TM][CFG::TN];
     acc_zero<CFG>(acc);
-    typename std::conditional<AM == MODE_MK, LoadMK<VEC>, LoadKM<VEC>>::type la{g.A, g.lda, g.M, g.K};
-    typename std::conditional<BMD == MODE_MK, LoadMK<VEC>, LoadKM<VEC>>::type lb{g.B, g.ldb, g.N, g.K};
-    mfma_mainloop<CFG, AM, BMD>(acc, la, lb, m0, n0, kb, ke, smem);
-    AccCoord<CFG> co;
+    typename std::conditional<AM == MODE_MK, LoadMK<VEC>, LoadKM<VEC>>::type la;
+    la.p = g.A; la.ld = g.lda; la.R = g.M; la.K = g.K;
+    typename std::conditional<BMD == MODE_MK, LoadMK<VEC>, LoadKM<VEC>>::type lb;
+    lb.p = g.B; lb.ld = g.ldb; lb.R = g.N; lb.K = g.K;
+    if (ABL == 8) mfma_mainloop_db<CFG, AM, BMD>(acc, la, lb, m0, n0, kb, ke, smem);
+    else mfma_mainloop<CFG, AM, BMD, decltype(la), decltype(lb), ABL>(acc, la, lb, m0, n0, kb, ke, smem);
     const bool split = g.splits > 1;
     float* out = split ? g.ws + (long)blockIdx.y * g.M * g.N : g.C;
     const long ldo = split ? g.N : g.ldc;
-#pragma unroll
-    for (int tn = 0; tn < CFG::TN; ++tn) {
-        const int col = n0 + co.col(tn);
-        if (col >= g.N) continue;
-        const float bv = (!split && g.bias) ? g.bias[col] : 0.f;
-#pragma unroll
-        for (int tm = 0; tm < CFG::TM; ++tm) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + co.row(tm, r);
-                if (row >= g.M) continue;
-                float v = acc[tm][tn][r] + bv;
-                float* p = out + (long)row * ldo + col;
-                if (!split) {
-                    if (g.flags & VC_GEMM_ACCUMULATE) v += *p;
-                    if (g.flags & VC_GEMM_RELU) v = fmaxf(v, 0.f);
-                }
-                *p = v;
+    const bool vec_out = ((ldo & 3) == 0) && ((((uintptr_t)out) & 15) == 0);
+    epilogue_rows<CFG>(acc, smem, [&](int r, int c, float4 v) {
+        const int row = m0 + r, col = n0 + c;
+        if (row >= g.M || col >= g.N) return;
+        float* p = out + (long)row * ldo + col;
+        const bool full = vec_out && col + 3 < g.N;
+        if (!split) {
+            if (g.bias) {
+                v.x += g.bias[col];
+                if (col + 1 < g.N) v.y += g.bias[col + 1];
+                if (col + 2 < g.N) v.z += g.bias[col + 2];
+                if (col + 3 < g.N) v.w += g.bias[col + 3];
             }
+            if (g.flags & VC_GEMM_ACCUMULATE) {
+                if (full) {
+                    const float4 o = *reinterpret_cast<const float4*>(p);
+                    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                } else {
+                    v.x += p[0];
+                    if (col + 1 < g.N) v.y += p[1];
+                    if (col + 2 < g.N) v.z += p[2];
+                    if (col + 3 < g.N) v.w += p[3];
+                }
+            }
+            if (g.flags & VC_GEMM_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         }
-    }
+        if (full) {
+            *reinterpret_cast<float4*>(p) = v;
+        } else {
+            p[0] = v.x;
+            if (col + 1 < g.N) p[1] = v.y;
+            if (col + 2 < g.N) p[2] = v.z;
+            if (col + 3 < g.N) p[3] = v.w;
+        }
+    });
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, long MN, int N,
@@ -86,7 +102,7 @@ struct GemmPlan {
 static GemmPlan plan_gemm(int M, int N, int K) {
     GemmPlan p;
     const long t128 = (long)cdiv(M, 128) * cdiv(N, 128);
-    p.big = t128 >= 160;
+    p.big = t128 >= 384;  // 128x128 tiles only when they still give >= 1.5 workgroups per CU
     const int b = p.big ? 128 : 64;
     p.tiles_m = cdiv(M, b);
     p.tiles_n = cdiv(N, b);
@@ -164,5 +180,28 @@ extern "C" int vc_gemm_f32(void* stream, int ta, int tb, int M, int N, int K, co
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws, p.splits, MN, N, C, ldc, bias, flags);
         VC_LAUNCH_CHECK();
     }
+    return 0;
+}
+
+// Benchmark-only entry (tools/microbench.py): the NN 128x128 kernel with parts of its main loop
+// ablated (results are then meaningless); variant 0 == vc_gemm_f32's kernel for aligned NN operands.
+extern "C" int vc_debug_gemm_ablate_f32(void* stream, int variant, int M, int N, int K, const float* A, const float* B, float* C) {
+    using namespace vc;
+    VC_CHECK_ARG(A && B && C && M % 128 == 0 && N % 128 == 0 && K % 32 == 0, "debug entry: multiples of 128/128/32 only");
+    GemmArgs g;
+    g.A = A; g.B = B; g.C = C; g.bias = nullptr; g.ws = nullptr;
+    g.lda = K; g.ldb = N; g.ldc = N; g.M = M; g.N = N; g.K = K;
+    g.tiles_n = N / 128; g.ntiles = (M / 128) * (N / 128); g.kchunk = K; g.splits = 1; g.flags = 0;
+    dim3 grid(g.ntiles, 1);
+    hipStream_t st = (hipStream_t)stream;
+#define VC_ABL(V) case V: hipLaunchKernelGGL((gemm_kernel<Cfg128, MODE_MK, MODE_KM, true, V>), grid, dim3(Cfg128::NT), Cfg128::SMEM_BYTES, st, g); break;
+    if (variant == 8) {
+        hipLaunchKernelGGL((gemm_kernel<Cfg128, MODE_MK, MODE_KM, true, 8>), grid, dim3(Cfg128::NT), 2 * Cfg128::SMEM_BYTES, st, g);
+        VC_LAUNCH_CHECK();
+        return 0;
+    }
+    switch (variant) { VC_ABL(0) VC_ABL(1) VC_ABL(2) VC_ABL(3) VC_ABL(4) VC_ABL(6) VC_ABL(7) default: return fail(VC_EINVAL, "%s: unknown variant", __func__); }
+#undef VC_ABL
+    VC_LAUNCH_CHECK();
     return 0;
 }

@@ -36,28 +36,38 @@ struct TileCfg {
 };
 
 // ---------------------------------------------------------------------------
-// Plain global-memory operand loaders.  load(r, k): 4 consecutive elements
-//   MK: rows r, K-contiguous:   elements (r, k..k+3)      address p[r*ld + k]
-//   KM: rows k, R-contiguous:   elements (r..r+3, k)      address p[k*ld + r]
+// Operand loaders.  A thread owns NV "slots" of an operand tile; slot u always covers the same
+// tile row and the same K offset, so everything that does not depend on the K-tile is computed
+// ONCE in init() and kept in registers (u is a compile-time index after unrolling):
+//   init(u, row, kofs)   row = global row of the slot, kofs = its K offset inside a tile
+//   load(u, k0)          4 consecutive elements for the K-tile starting at k0 (zero outside)
+// MK: operand stored K-contiguous (the 4 elements run along K): address p[row*ld + k]
+// KM: operand stored row-contiguous (the 4 elements run along rows): address p[k*ld + row]
 // VEC = pointer 16-B aligned, ld % 4 == 0, extent-along-vector % 4 == 0.
 // ---------------------------------------------------------------------------
+constexpr int MAXNV = 8;
+
 template <bool VEC>
 struct LoadMK {
     const float* p;
     long ld;
     int R, K;
-    __device__ __forceinline__ float4 load(int r, int k) const {
-        if (r >= R) return f4zero();
-        const float* q = p + (long)r * ld + k;
-        if (VEC) {
-            if (k >= K) return f4zero();
-            return *reinterpret_cast<const float4*>(q);
-        }
+    const float* q[MAXNV];
+    int ko[MAXNV];
+    __device__ __forceinline__ void init(int u, int row, int kofs) {
+        q[u] = row < R ? p + (long)row * ld + kofs : nullptr;
+        ko[u] = kofs;
+    }
+    __device__ __forceinline__ float4 load(int u, int k0) const {
+        const int k = k0 + ko[u];
+        if (!q[u] || k >= K) return f4zero();
+        const float* s = q[u] + k0;
+        if (VEC) return *reinterpret_cast<const float4*>(s);
         float4 v;
-        v.x = (k + 0 < K) ? q[0] : 0.f;
-        v.y = (k + 1 < K) ? q[1] : 0.f;
-        v.z = (k + 2 < K) ? q[2] : 0.f;
-        v.w = (k + 3 < K) ? q[3] : 0.f;
+        v.x = s[0];
+        v.y = (k + 1 < K) ? s[1] : 0.f;
+        v.z = (k + 2 < K) ? s[2] : 0.f;
+        v.w = (k + 3 < K) ? s[3] : 0.f;
         return v;
     }
 };
@@ -67,18 +77,23 @@ struct LoadKM {
     const float* p;
     long ld;
     int R, K;
-    __device__ __forceinline__ float4 load(int r, int k) const {
-        if (k >= K) return f4zero();
-        const float* q = p + (long)k * ld + r;
-        if (VEC) {
-            if (r >= R) return f4zero();
-            return *reinterpret_cast<const float4*>(q);
-        }
+    const float* q[MAXNV];
+    int ko[MAXNV], rr[MAXNV];
+    __device__ __forceinline__ void init(int u, int row, int kofs) {
+        q[u] = row < R ? p + (long)kofs * ld + row : nullptr;
+        ko[u] = kofs;
+        rr[u] = row;
+    }
+    __device__ __forceinline__ float4 load(int u, int k0) const {
+        if (!q[u] || k0 + ko[u] >= K) return f4zero();
+        const float* s = q[u] + (long)k0 * ld;
+        if (VEC) return *reinterpret_cast<const float4*>(s);
+        const int r = rr[u];
         float4 v;
-        v.x = (r + 0 < R) ? q[0] : 0.f;
-        v.y = (r + 1 < R) ? q[1] : 0.f;
-        v.z = (r + 2 < R) ? q[2] : 0.f;
-        v.w = (r + 3 < R) ? q[3] : 0.f;
+        v.x = s[0];
+        v.y = (r + 1 < R) ? s[1] : 0.f;
+        v.z = (r + 2 < R) ? s[2] : 0.f;
+        v.w = (r + 3 < R) ? s[3] : 0.f;
         return v;
     }
 };
@@ -102,8 +117,10 @@ struct Stage {
 // The main loop.  acc[TM][TN] accumulates  sum_k A(m0+.., k) * B(n0+.., k)  for
 // k in [k_begin, k_end)  (k_begin % 32 == 0).
 // ---------------------------------------------------------------------------
-template <class CFG, int AMODE, int BMODE, class ALoader, class BLoader>
-__device__ __forceinline__ void mfma_mainloop(f32x16 (&acc)[CFG::TM][CFG::TN], const ALoader& A, const BLoader& B,
+// ABL (ablation bits, debugging/benchmark only, see tools/microbench.py): 1 = no global loads after
+// the prologue, 2 = no LDS stores / barriers, 4 = no LDS fragment reads.  ABL = 0 is the product path.
+template <class CFG, int AMODE, int BMODE, class ALoader, class BLoader, int ABL = 0>
+__device__ __forceinline__ void mfma_mainloop(f32x16 (&acc)[CFG::TM][CFG::TN], ALoader A, BLoader B,
                                               int m0, int n0, int k_begin, int k_end, float* smem) {
     constexpr int TM = CFG::TM, TN = CFG::TN, BM = CFG::BM, BN = CFG::BN, NT = CFG::NT;
     using SA = Stage<BM, NT, AMODE>;
@@ -115,30 +132,124 @@ __device__ __forceinline__ void mfma_mainloop(f32x16 (&acc)[CFG::TM][CFG::TN], c
     const int wm = wave / CFG::WN, wn = wave % CFG::WN;
     const int li = lane & 31, lh = lane >> 5;
 
+    static_assert(SA::NV <= MAXNV && SB::NV <= MAXNV, "too many slots per thread");
     float4 ra[SA::NV], rb[SB::NV];
+#pragma unroll
+    for (int u = 0; u < SA::NV; ++u) A.init(u, m0 + SA::row(tid + u * NT), SA::kof(tid + u * NT));
+#pragma unroll
+    for (int u = 0; u < SB::NV; ++u) B.init(u, n0 + SB::row(tid + u * NT), SB::kof(tid + u * NT));
     auto gload = [&](int k0) {
 #pragma unroll
-        for (int u = 0; u < SA::NV; ++u) {
-            const int f = tid + u * NT;
-            ra[u] = A.load(m0 + SA::row(f), k0 + SA::kof(f));
-        }
+        for (int u = 0; u < SA::NV; ++u) ra[u] = A.load(u, k0);
 #pragma unroll
-        for (int u = 0; u < SB::NV; ++u) {
-            const int f = tid + u * NT;
-            rb[u] = B.load(n0 + SB::row(f), k0 + SB::kof(f));
-        }
+        for (int u = 0; u < SB::NV; ++u) rb[u] = B.load(u, k0);
     };
     if (k_begin < k_end) gload(k_begin);
+    float a[TM][8], b[TN][8];
+    if (ABL & 4) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) a[tm][s] = ra[0].x + s + tm;
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) b[tn][s] = rb[0].y + s - tn;
+        }
+    }
     for (int k0 = k_begin; k0 < k_end; k0 += 32) {
-        __syncthreads();
+        if (!(ABL & 2) || k0 == k_begin) {
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < SA::NV; ++u) *reinterpret_cast<float4*>(&As[SA::lds(tid + u * NT)]) = ra[u];
+#pragma unroll
+            for (int u = 0; u < SB::NV; ++u) *reinterpret_cast<float4*>(&Bs[SB::lds(tid + u * NT)]) = rb[u];
+            __syncthreads();
+        }
+        if (!(ABL & 1) && k0 + 32 < k_end) gload(k0 + 32);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {  // two chunks of 8 MFMA k-steps
+            if (!(ABL & 4))
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const int r = (wm * TM + tm) * 32 + li;
+                if (AMODE == MODE_MK) {
+                    const float4 v0 = *reinterpret_cast<const float4*>(&As[r * 36 + lh * 16 + c * 8]);
+                    const float4 v1 = *reinterpret_cast<const float4*>(&As[r * 36 + lh * 16 + c * 8 + 4]);
+                    a[tm][0] = v0.x; a[tm][1] = v0.y; a[tm][2] = v0.z; a[tm][3] = v0.w;
+                    a[tm][4] = v1.x; a[tm][5] = v1.y; a[tm][6] = v1.z; a[tm][7] = v1.w;
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) a[tm][s] = As[(lh * 16 + c * 8 + s) * (BM + 4) + r];
+                }
+            }
+            if (!(ABL & 4))
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const int r = (wn * TN + tn) * 32 + li;
+                if (BMODE == MODE_MK) {
+                    const float4 v0 = *reinterpret_cast<const float4*>(&Bs[r * 36 + lh * 16 + c * 8]);
+                    const float4 v1 = *reinterpret_cast<const float4*>(&Bs[r * 36 + lh * 16 + c * 8 + 4]);
+                    b[tn][0] = v0.x; b[tn][1] = v0.y; b[tn][2] = v0.z; b[tn][3] = v0.w;
+                    b[tn][4] = v1.x; b[tn][5] = v1.y; b[tn][6] = v1.z; b[tn][7] = v1.w;
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) b[tn][s] = Bs[(lh * 16 + c * 8 + s) * (BN + 4) + r];
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][s], b[tn][s], acc[tm][tn], 0, 0, 0);
+        }
+    }
+}
+
+// Double-buffered variant: ONE barrier per K-tile.  Tile t is consumed from LDS buffer t&1 while the
+// global loads of tile t+1 are in flight; they are written to the other buffer after the MFMAs.
+// (A wave can only reach the store of iteration t after every wave passed the barrier of iteration
+// t-1, i.e. finished reading that buffer in iteration t-1.)  Needs 2 * CFG::SMEM_BYTES of LDS.
+template <class CFG, int AMODE, int BMODE, class ALoader, class BLoader>
+__device__ __forceinline__ void mfma_mainloop_db(f32x16 (&acc)[CFG::TM][CFG::TN], ALoader A, BLoader B,
+                                                 int m0, int n0, int k_begin, int k_end, float* smem) {
+    constexpr int TM = CFG::TM, TN = CFG::TN, BM = CFG::BM, BN = CFG::BN, NT = CFG::NT;
+    constexpr int BUF = CFG::A_FLOATS + CFG::B_FLOATS;
+    using SA = Stage<BM, NT, AMODE>;
+    using SB = Stage<BN, NT, BMODE>;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / CFG::WN, wn = wave % CFG::WN;
+    const int li = lane & 31, lh = lane >> 5;
+    float4 ra[SA::NV], rb[SB::NV];
+#pragma unroll
+    for (int u = 0; u < SA::NV; ++u) A.init(u, m0 + SA::row(tid + u * NT), SA::kof(tid + u * NT));
+#pragma unroll
+    for (int u = 0; u < SB::NV; ++u) B.init(u, n0 + SB::row(tid + u * NT), SB::kof(tid + u * NT));
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < SA::NV; ++u) ra[u] = A.load(u, k0);
+#pragma unroll
+        for (int u = 0; u < SB::NV; ++u) rb[u] = B.load(u, k0);
+    };
+    auto sstore = [&](float* As, float* Bs) {
 #pragma unroll
         for (int u = 0; u < SA::NV; ++u) *reinterpret_cast<float4*>(&As[SA::lds(tid + u * NT)]) = ra[u];
 #pragma unroll
         for (int u = 0; u < SB::NV; ++u) *reinterpret_cast<float4*>(&Bs[SB::lds(tid + u * NT)]) = rb[u];
-        __syncthreads();
-        if (k0 + 32 < k_end) gload(k0 + 32);
+    };
+    if (k_begin >= k_end) return;
+    gload(k_begin);
+    sstore(smem, smem + CFG::A_FLOATS);
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = k_begin; k0 < k_end; k0 += 32) {
+        const bool more = k0 + 32 < k_end;
+        if (more) gload(k0 + 32);
+        const float* As = smem + cur * BUF;
+        const float* Bs = As + CFG::A_FLOATS;
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {  // two chunks of 8 MFMA k-steps
+        for (int c = 0; c < 2; ++c) {
             float a[TM][8], b[TN][8];
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) {
@@ -174,6 +285,12 @@ __device__ __forceinline__ void mfma_mainloop(f32x16 (&acc)[CFG::TM][CFG::TN], c
                     for (int tn = 0; tn < TN; ++tn)
                         acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][s], b[tn][s], acc[tm][tn], 0, 0, 0);
         }
+        if (more) {
+            float* An = smem + (cur ^ 1) * BUF;
+            sstore(An, An + CFG::A_FLOATS);
+        }
+        __syncthreads();
+        cur ^= 1;
     }
 }
 
@@ -203,6 +320,43 @@ struct AccCoord {
     }
     __device__ __forceinline__ int col(int tn) const { return (wn * CFG::TN + tn) * 32 + li; }
 };
+
+// ---------------------------------------------------------------------------
+// Row-vectorised epilogue.  The MFMA accumulator layout gives a lane ONE column and 16 scattered
+// rows, i.e. 4-byte global accesses in 128-B row segments.  Here every wave transposes its tiles
+// through a private LDS strip so that a lane owns 4 CONSECUTIVE columns: 16-B global accesses,
+// TN*128 contiguous bytes per row, 4x fewer memory instructions (cf. cdna_hip_programming.md T21).
+// f(row, col, v): row / col relative to the workgroup tile, col % 4 == 0, v = 4 consecutive columns.
+// Must be called by all threads (contains __syncthreads); smem is reused (>= WM*WN*32*(TN*32+4) floats).
+// ---------------------------------------------------------------------------
+template <class CFG, class F>
+__device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[CFG::TM][CFG::TN], float* smem, F f) {
+    constexpr int TM = CFG::TM, TN = CFG::TN;
+    constexpr int LD = TN * 32 + 4;        // floats per staged row (16-B aligned, rows 4 banks apart)
+    constexpr int QPR = TN * 8;            // float4 per row
+    constexpr int RPP = 64 / QPR;          // rows per pass
+    static_assert(CFG::WM * CFG::WN * 32 * LD <= CFG::A_FLOATS + CFG::B_FLOATS, "epilogue strip does not fit the tile LDS");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / CFG::WN, wn = wave % CFG::WN;
+    const int li = lane & 31, lh = lane >> 5;
+    float* T = smem + wave * 32 * LD;
+    __syncthreads();  // every wave is done reading the operand tiles
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * lh) * LD + tn * 32 + li] = acc[tm][tn][r];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 32 / RPP; ++j) {
+            const int row = j * RPP + lane / QPR, cq = lane % QPR;
+            const float4 v = *reinterpret_cast<const float4*>(&T[row * LD + cq * 4]);
+            f((wm * TM + tm) * 32 + row, wn * TN * 32 + cq * 4, v);
+        }
+        __syncthreads();
+    }
+}
 
 // XCD-aware remap of a linear workgroup id (cdna_hip_programming.md T1, bijective form):
 // consecutive logical ids land on the same XCD so neighbouring tiles share its L2.

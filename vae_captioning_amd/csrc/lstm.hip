@@ -22,10 +22,15 @@ namespace vc {
 struct LoadWhGates {
     const float* p;  // Wh
     int H, u0;
-    __device__ __forceinline__ float4 load(int c, int k) const {
-        if (k >= H) return f4zero();
-        const int g = c >> 5, u = u0 + (c & 31);
-        return *reinterpret_cast<const float4*>(p + (long)k * 4 * H + g * H + u);
+    const float* q[MAXNV];
+    int ko[MAXNV];
+    __device__ __forceinline__ void init(int u, int c, int kofs) {
+        q[u] = p + (long)kofs * 4 * H + (c >> 5) * H + u0 + (c & 31);
+        ko[u] = kofs;
+    }
+    __device__ __forceinline__ float4 load(int u, int k0) const {
+        if (k0 + ko[u] >= H) return f4zero();
+        return *reinterpret_cast<const float4*>(q[u] + (long)k0 * 4 * H);
     }
 };
 
@@ -47,8 +52,10 @@ __global__ __launch_bounds__(CFG::NT) void lstm_step_fwd_kernel(LstmFwdArgs a) {
     const int u0 = blockIdx.y * 32;
     f32x16 acc[1][4];
     acc_zero<CFG>(acc);
-    LoadMK<true> la{a.h_prev, a.H, a.N, a.H};
-    LoadWhGates lb{a.Wh, a.H, u0};
+    LoadMK<true> la;
+    la.p = a.h_prev; la.ld = a.H; la.R = a.N; la.K = a.H;
+    LoadWhGates lb;
+    lb.p = a.Wh; lb.H = a.H; lb.u0 = u0;
     mfma_mainloop<CFG, MODE_MK, MODE_KM>(acc, la, lb, m0, 0, 0, a.H, smem);
     AccCoord<CFG> co;
     const int u = u0 + co.li;
@@ -97,8 +104,9 @@ __global__ __launch_bounds__(CFG::NT) void lstm_step_bwd_kernel(LstmBwdArgs a) {
     f32x16 acc[CFG::TM][CFG::TN];
     acc_zero<CFG>(acc);
     if (!a.first) {
-        LoadMK<true> la{a.dG_next, 4L * H, a.N, 4 * H};
-        LoadMK<true> lb{a.Wh, 4L * H, H, 4 * H};  // (dG.Wh^T)[row,u] = sum_k dG[row,k] * Wh[u,k]
+        LoadMK<true> la, lb;  // (dG.Wh^T)[row,u] = sum_k dG[row,k] * Wh[u,k]
+        la.p = a.dG_next; la.ld = 4L * H; la.R = a.N; la.K = 4 * H;
+        lb.p = a.Wh; lb.ld = 4L * H; lb.R = H; lb.K = 4 * H;
         mfma_mainloop<CFG, MODE_MK, MODE_MK>(acc, la, lb, m0, n0, 0, 4 * H, smem);
     }
     AccCoord<CFG> co;
@@ -136,6 +144,59 @@ __global__ __launch_bounds__(CFG::NT) void lstm_step_bwd_kernel(LstmBwdArgs a) {
         }
     }
 }
+
+// ---- split form: the recurrent GEMM through vc_gemm_f32 (64x64 tiles + split-K fill the chip even
+// at N = 320 rows, where the fused kernel above has only 50 workgroups) followed by these
+// element-wise gate kernels.  Same arithmetic, same buffers; chosen by the sequence drivers.
+__global__ __launch_bounds__(256) void lstm_gates_fwd_kernel(float* __restrict__ gact, const float* __restrict__ c_prev,
+                                                             const float* __restrict__ h_prev, const int32_t* __restrict__ lens,
+                                                             float* __restrict__ c_out, float* __restrict__ h_out, int N, int H, int t) {
+    const long total = (long)N * H;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int row = (int)(i / H), u = (int)(i % H);
+        float* g = gact + (long)row * 4 * H + u;
+        const float ig = sigmoidf_(g[0]), jg = tanhf(g[H]), fg = sigmoidf_(g[2 * H] + 1.0f), og = sigmoidf_(g[3 * H]);
+        const float cp = c_prev[i];
+        const float c = fg * cp + ig * jg;
+        const float h = og * tanhf(c);
+        g[0] = ig; g[H] = jg; g[2 * H] = fg; g[3 * H] = og;
+        const bool active = t < lens[row];
+        c_out[i] = active ? c : cp;
+        h_out[i] = active ? h : h_prev[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void lstm_gates_bwd_kernel(const float* __restrict__ rec, const int32_t* __restrict__ lens,
+                                                             const float* __restrict__ dh_ext, float* __restrict__ dH_run,
+                                                             float* __restrict__ dC_run, const float* __restrict__ act,
+                                                             const float* __restrict__ c_prev, const float* __restrict__ c_cur,
+                                                             float* __restrict__ dG, int N, int H, int t, int first) {
+    const long total = (long)N * H;
+    for (long si = (long)blockIdx.x * 256 + threadIdx.x; si < total; si += (long)gridDim.x * 256) {
+        const int row = (int)(si / H), u = (int)(si % H);
+        const int len = lens[row];
+        float dh = dH_run[si];
+        if (!first && (t + 1 < len)) dh = rec[si];
+        if (dh_ext) dh += dh_ext[si];
+        dH_run[si] = dh;
+        const float* ac = act + (long)row * 4 * H + u;
+        float* dg = dG + (long)row * 4 * H + u;
+        if (t < len) {
+            const float i = ac[0], j = ac[H], f = ac[2 * H], o = ac[3 * H];
+            const float tc = tanhf(c_cur[si]);
+            const float dct = dC_run[si] + dh * o * (1.f - tc * tc);
+            dg[0] = dct * j * i * (1.f - i);
+            dg[H] = dct * i * (1.f - j * j);
+            dg[2 * H] = dct * c_prev[si] * f * (1.f - f);
+            dg[3 * H] = dh * tc * o * (1.f - o);
+            dC_run[si] = dct * f;
+        } else {
+            dg[0] = 0.f; dg[H] = 0.f; dg[2 * H] = 0.f; dg[3 * H] = 0.f;
+        }
+    }
+}
+
+static int g_lstm_split = 1;  // 1: GEMM + gate kernels (default), 0: fused step kernels
 
 using FwdCfg128 = TileCfg<4, 1, 1, 4>;  // 128 rows x (4 gates x 32 units), 256 threads
 using FwdCfg64 = TileCfg<2, 1, 1, 4>;   //  64 rows,                       128 threads
@@ -184,8 +245,17 @@ extern "C" int vc_lstm_step_bwd_f32(void* stream, int N, int H, int t, int first
     return step_bwd((hipStream_t)stream, a);
 }
 
+extern "C" int vc_lstm_set_mode(int split) {
+    vc::g_lstm_split = split ? 1 : 0;
+    return 0;
+}
+
 extern "C" size_t vc_lstm_seq_workspace_bytes(int T, int N, int E, int H) {
     size_t w = vc_gemm_workspace_bytes(E, 4 * H, T * N);
+    size_t w6 = vc_gemm_workspace_bytes(N, 4 * H, H);
+    size_t w7 = vc_gemm_workspace_bytes(N, H, 4 * H);
+    if (w6 > w) w = w6;
+    if (w7 > w) w = w7;
     size_t w2 = vc_gemm_workspace_bytes(H, 4 * H, T * N);
     size_t w3 = vc_gemm_workspace_bytes(T * N, E, 4 * H);
     size_t w4 = vc_gemm_workspace_bytes(T * N, 4 * H, E);
@@ -211,9 +281,18 @@ extern "C" int vc_lstm_seq_fwd_f32(void* stream, int T, int N, int E, int H, con
     int rc = vc_gemm_f32(stream, 0, 0, T * N, 4 * H, E, X, E, Wx, 4 * H, act, 4 * H, b, 0, ws, ws_bytes);
     if (rc) return rc;
     const long NH = (long)N * H;
+    const int eg = (int)((NH + 255) / 256) < 2048 ? (int)((NH + 255) / 256) : 2048;
     for (int t = 0; t < T; ++t) {
-        rc = vc_lstm_step_fwd_f32(stream, N, H, t, hs + t * NH, cs + t * NH, Wh, act + (long)t * N * 4 * H, lens_eff,
-                                  cs + (t + 1) * NH, hs + (t + 1) * NH);
+        float* g = act + (long)t * N * 4 * H;
+        if (g_lstm_split) {
+            rc = vc_gemm_f32(stream, 0, 0, N, 4 * H, H, hs + t * NH, H, Wh, 4 * H, g, 4 * H, nullptr, VC_GEMM_ACCUMULATE, ws, ws_bytes);
+            if (rc) return rc;
+            hipLaunchKernelGGL(lstm_gates_fwd_kernel, dim3(eg), dim3(256), 0, (hipStream_t)stream, g, cs + t * NH, hs + t * NH, lens_eff,
+                               cs + (t + 1) * NH, hs + (t + 1) * NH, N, H, t);
+            rc = launch_status(__func__);
+        } else {
+            rc = vc_lstm_step_fwd_f32(stream, N, H, t, hs + t * NH, cs + t * NH, Wh, g, lens_eff, cs + (t + 1) * NH, hs + (t + 1) * NH);
+        }
         if (rc) return rc;
     }
     return 0;
@@ -234,11 +313,24 @@ extern "C" int vc_lstm_seq_bwd_f32(void* stream, int T, int N, int E, int H, con
     const float* Wh = W + (long)E * 4 * H;
     const long NH = (long)N * H, NG = (long)N * 4 * H;
     int rc;
+    const int eg = (int)((NH + 255) / 256) < 2048 ? (int)((NH + 255) / 256) : 2048;
+    // split form scratch: the recurrent product dG[t+1].Wh^T lives in dX (free until the final GEMM)
+    float* rec = dX;
     for (int t = T - 1; t >= 0; --t) {
         const int first = (t == T - 1);
-        rc = vc_lstm_step_bwd_f32(stream, N, H, t, first, first ? nullptr : dG + (t + 1) * NG, Wh, lens_eff,
-                                  dhs_ext ? dhs_ext + (t + 1) * NH : nullptr, dH_run, dC_run, act + t * NG, cs + t * NH,
-                                  cs + (t + 1) * NH, dG + t * NG);
+        const float* ext = dhs_ext ? dhs_ext + (t + 1) * NH : nullptr;
+        if (g_lstm_split && (long)T * N * E >= NH) {
+            if (!first) {
+                rc = vc_gemm_f32(stream, 0, 1, N, H, 4 * H, dG + (t + 1) * NG, 4 * H, Wh, 4 * H, rec, H, nullptr, 0, ws, ws_bytes);
+                if (rc) return rc;
+            }
+            hipLaunchKernelGGL(lstm_gates_bwd_kernel, dim3(eg), dim3(256), 0, (hipStream_t)stream, rec, lens_eff, ext, dH_run, dC_run,
+                               act + t * NG, cs + t * NH, cs + (t + 1) * NH, dG + t * NG, N, H, t, first);
+            rc = launch_status(__func__);
+        } else {
+            rc = vc_lstm_step_bwd_f32(stream, N, H, t, first, first ? nullptr : dG + (t + 1) * NG, Wh, lens_eff, ext, dH_run, dC_run,
+                                      act + t * NG, cs + t * NH, cs + (t + 1) * NH, dG + t * NG);
+        }
         if (rc) return rc;
     }
     // dWx = X^T.dG, dWh = hs[0:T]^T.dG, db = colsum(dG), dX = dG.Wx^T
