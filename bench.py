@@ -66,7 +66,7 @@ def cpu_baseline(workload, w, seed):
     from vae_captioning_amd import spec, synth
     p = make_params(w)
     rng = np.random.default_rng(seed)
-    Bc = {"cfg1": 32, "cfg2": 32, "cfg3": 16, "cfg4": 2}[workload]
+    Bc = {"cfg1": 64, "cfg2": 64, "cfg3": 32, "cfg4": 4}[workload]
     nsteps = 2
     P = spec.init_caption_params(p, VOCAB, seed=1)
     batch = synth.make_batch(rng, Bc, p.num_captions, T_LEN, VOCAB, use_ci=spec.uses_ci(p), images=p.fine_tune)
@@ -182,6 +182,13 @@ def main():
             tr._step()
     roof = roofline_from_timer(timer, tr.vgg is not None)
     roof["instrumented_pass"] = instrumented_pass
+    # HBM-side bytes per launch of the same kernels, from the rocprofv3 --pmc passes of this command
+    # (profiles/, FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); cannot be collected from inside the process.
+    tj = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
+    if os.path.exists(tj):
+        t = json.load(open(tj))
+        roof["traffic"] = t.get("bytes_per_launch")
+        roof["traffic_source"] = t.get("source")
     out = {
         "metric": "captions/sec training (224x224, seq20, vocab~10k)",
         "value": round(N * world * args.steps / dt, 2),

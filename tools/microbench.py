@@ -45,6 +45,17 @@ def gemm():
         print("gemm NN %6d x %6d x %6d: %8.3f ms  %6.1f TFLOP/s (best %.1f)" % (M, N, K, med, 2e-9 * M * N * K / med, 2e-9 * M * N * K / mn))
 
 
+def gemmt():
+    """transposed-operand forms at conv-wgrad-like and dense-backward shapes"""
+    for (ta, tb, M, N, K) in [(0, 0, 8192, 8192, 8192), (0, 1, 8192, 8192, 8192), (1, 0, 8192, 8192, 8192), (1, 1, 8192, 8192, 8192), (0, 0, 2304, 256, 200704), (1, 0, 2304, 256, 200704), (0, 1, 200704, 256, 2304), (1, 0, 512, 10000, 25600), (0, 1, 25600, 512, 10000)]:
+        A = rnd(K, M) if ta else rnd(M, K)
+        B = rnd(N, K) if tb else rnd(K, N)
+        C = torch.empty(M, N, device="cuda")
+        ws = torch.empty(max(lib.vc_gemm_workspace_bytes(M, N, K), 16) // 4 + 4, device="cuda")
+        med, mn = timeit(lambda: lib.vc_gemm_f32(st(), ta, tb, M, N, K, P(A), M if ta else K, P(B), K if tb else N, P(C), N, None, 0, P(ws), ws.numel() * 4), reps=5)
+        print("gemm ta=%d tb=%d %6d x %6d x %6d: %8.3f ms  %6.1f TFLOP/s" % (ta, tb, M, N, K, med, 2e-9 * M * N * K / med))
+
+
 def ablate(shapes=((4096, 4096, 4096), (8192, 8192, 8192), (25600, 10000, 512), (200704, 256, 2304), (12544, 512, 4608))):
     names = {0: "full", 8: "double-buffered", 2: "no lds-store/barrier", 7: "mfma only"}
     for (M, N, K) in shapes:
