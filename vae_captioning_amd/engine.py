@@ -126,6 +126,9 @@ class CaptionEngine(object):
                  force_collectives=False):
         self.p = p
         self.collectives = world > 1 or force_collectives
+        # sum-all-reduce used by the data-parallel branches; replaceable so that a single process can
+        # emulate N ranks in tests (default: RCCL through torch.distributed)
+        self.reduce_fn = lambda t: torch.distributed.all_reduce(t, group=self.group)
         self.V = int(vocab)
         self.lib = lib or abi.load()
         self.dev = device
@@ -348,39 +351,38 @@ class CaptionEngine(object):
         Te = T + self.n_init_e
         Xd = self.buf["Xd"]
         cv = self.buf.get("c_v")
-        if True:
-            Xe = self._b("Xe", (Te, N, E))
-            Xe[:self.n_init_e].copy_(Xd[:self.n_init_e])
-            lib.vc_embedding_gather_f32(st, P(S.param("encoder/enc_embeddings")), P(self.buf["cap_enc_t"]), T * N, E, V, P(Xe[self.n_init_e]))
-            act_e, cs_e, hs_e = self._b("act_e", (Te, N, 4 * He)), self._b("cs_e", (Te + 1, N, He)), self._b("hs_e", (Te + 1, N, He))
-            self._need_ws(lib.vc_lstm_seq_workspace_bytes(Te, N, E, He))
-            cs_e[0].zero_(); hs_e[0].zero_()
-            lib.vc_lstm_seq_fwd_f32(st, Te, N, E, He, P(Xe), P(S.param(spec.ENC_CELL + "kernel")), P(S.param(spec.ENC_CELL + "bias")),
-                                    P(self.buf["lens_e"]), P(act_e), P(cs_e), P(hs_e), P(self.ws), self.ws_bytes)
-            hT = hs_e[Te]
-            mean, std = self._b("mean", (N, L)), self._b("std", (N, L))
-            if p.prior == "Normal":
-                logstd = self._b("logstd", (N, L))
-                self.gemm(0, 0, N, L, He, hT, He, S.param("encoder/dense/kernel"), L, mean, L, S.param("encoder/dense/bias"))
-                self.gemm(0, 0, N, L, He, hT, He, S.param("encoder/dense_1/kernel"), L, logstd, L, S.param("encoder/dense_1/bias"))
-                lib.vc_exp_f32(st, P(logstd), N * L, P(std))
-            else:
-                heads = self._b("heads", (N, 2 * K_CL * L))
-                self.gemm(0, 0, N, 2 * K_CL * L, He, hT, He, S.param("encoder/heads/kernel"), 2 * K_CL * L, heads, 2 * K_CL * L, S.param("encoder/heads/bias"))
-                gmm = p.prior == "GMM"
-                lib.vc_heads_mix_fwd_f32(st, N, K_CL, L, P(heads), None if gmm else P(cv), P(self.buf["gmm_idx"]) if gmm else None, P(mean), P(std))
-            mu_p = None
-            mode = 0
-            if p.prior == "AG":
-                mode = 1
-                mu_p = self._b("mu_p", (N, L))
-                self.gemm(0, 0, N, L, K_CL, cv, K_CL, self.c_means, L, mu_p, L)
-            z = self._b("z", (Sm, N, L))
-            lib.vc_latent_sample_f32(st, Sm, N, L, P(mean), P(std), P(self.buf["eps"]), P(z))
-            row_kl = self._b("row_kl", (N,))
-            lib.vc_kl_rows_f32(st, N, L, mode, P(mean), P(std), P(mu_p), P(row_kl))
-            lib.vc_reduce_sum_f32(st, P(row_kl), N, 1.0, self.red.data_ptr() + 8, 0)
-            self.kl_sum = self.red.data_ptr() + 8
+        Xe = self._b("Xe", (Te, N, E))
+        Xe[:self.n_init_e].copy_(Xd[:self.n_init_e])
+        lib.vc_embedding_gather_f32(st, P(S.param("encoder/enc_embeddings")), P(self.buf["cap_enc_t"]), T * N, E, V, P(Xe[self.n_init_e]))
+        act_e, cs_e, hs_e = self._b("act_e", (Te, N, 4 * He)), self._b("cs_e", (Te + 1, N, He)), self._b("hs_e", (Te + 1, N, He))
+        self._need_ws(lib.vc_lstm_seq_workspace_bytes(Te, N, E, He))
+        cs_e[0].zero_(); hs_e[0].zero_()
+        lib.vc_lstm_seq_fwd_f32(st, Te, N, E, He, P(Xe), P(S.param(spec.ENC_CELL + "kernel")), P(S.param(spec.ENC_CELL + "bias")),
+                                P(self.buf["lens_e"]), P(act_e), P(cs_e), P(hs_e), P(self.ws), self.ws_bytes)
+        hT = hs_e[Te]
+        mean, std = self._b("mean", (N, L)), self._b("std", (N, L))
+        if p.prior == "Normal":
+            logstd = self._b("logstd", (N, L))
+            self.gemm(0, 0, N, L, He, hT, He, S.param("encoder/dense/kernel"), L, mean, L, S.param("encoder/dense/bias"))
+            self.gemm(0, 0, N, L, He, hT, He, S.param("encoder/dense_1/kernel"), L, logstd, L, S.param("encoder/dense_1/bias"))
+            lib.vc_exp_f32(st, P(logstd), N * L, P(std))
+        else:
+            heads = self._b("heads", (N, 2 * K_CL * L))
+            self.gemm(0, 0, N, 2 * K_CL * L, He, hT, He, S.param("encoder/heads/kernel"), 2 * K_CL * L, heads, 2 * K_CL * L, S.param("encoder/heads/bias"))
+            gmm = p.prior == "GMM"
+            lib.vc_heads_mix_fwd_f32(st, N, K_CL, L, P(heads), None if gmm else P(cv), P(self.buf["gmm_idx"]) if gmm else None, P(mean), P(std))
+        mu_p = None
+        mode = 0
+        if p.prior == "AG":
+            mode = 1
+            mu_p = self._b("mu_p", (N, L))
+            self.gemm(0, 0, N, L, K_CL, cv, K_CL, self.c_means, L, mu_p, L)
+        z = self._b("z", (Sm, N, L))
+        lib.vc_latent_sample_f32(st, Sm, N, L, P(mean), P(std), P(self.buf["eps"]), P(z))
+        row_kl = self._b("row_kl", (N,))
+        lib.vc_kl_rows_f32(st, N, L, mode, P(mean), P(std), P(mu_p), P(row_kl))
+        lib.vc_reduce_sum_f32(st, P(row_kl), N, 1.0, self.red.data_ptr() + 8, 0)
+        self.kl_sum = self.red.data_ptr() + 8
         return z
 
     def fw_decode(self):
@@ -427,7 +429,7 @@ class CaptionEngine(object):
         den = self.red[1:2]
         lib.vc_count_nonzero_i32(st, P(labels), T * N, P(den))
         if self.collectives:
-            torch.distributed.all_reduce(den, group=self.group)
+            self.reduce_fn(den)
         vector_loss = self.enc and p.prior == "AG"  # Q3
         Ng = N * self.world
         gscale = dp.scales(N, self.world, vector_loss)[0]
@@ -444,7 +446,7 @@ class CaptionEngine(object):
             r2[0:1].copy_(self.red[0:1])
             if kl_sum is not None:
                 r2[1:2].copy_(self.red[2:3])
-            torch.distributed.all_reduce(r2, group=self.group)
+            self.reduce_fn(r2)
             self.red[0:1].copy_(r2[0:1])
             self.red[2:3].copy_(r2[1:2])
         reg = self.red.data_ptr() + 12 if self.reg_scale else None

@@ -250,7 +250,7 @@ class Trainer(object):
 
     def all_reduce_grads(self):
         if self.collectives:
-            torch.distributed.all_reduce(self.gall, group=self.group)  # the single gradient all-reduce
+            self.cap.reduce_fn(self.gall)  # the single gradient all-reduce (RCCL over xGMI)
 
     def train_step(self):
         if self.graph is not None:
