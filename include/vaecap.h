@@ -118,6 +118,14 @@ int vc_fill_f32(void* stream, float* x, long n, float value);
  *                  heads [N, 2*K*L] = [means | log-stds]
  * ---------------------------------------------------------------------------------- */
 int vc_latent_sample_f32(void* stream, int S, int N, int L, const float* mean, const float* std_, const float* eps, float* z);
+/* Data-parallel forms (the Q1 reshape mixes rows of the GLOBAL batch): this rank's z_rnn rows are the
+ * flat range q in [q0, q0+nq) of the global [S, Ng, L] sample tensor, q = s*Ng + n; mean_g / std_g are the
+ * all-gathered [Ng, L] statistics; sums_mixed returns the [Ng, L] partial sums to reduce-scatter.
+ * vc_latent_bwd_f32 with S = 0 then adds the KL gradient to sums already stored in dmean / dstd. */
+int vc_latent_sample_mixed_f32(void* stream, int Ng, int L, long q0, long nq, const float* mean_g, const float* std_g,
+                               const float* eps, float* z);
+int vc_latent_sums_mixed_f32(void* stream, int Ng, int L, long q0, long nq, const float* dz, const float* eps,
+                             float* dmean_part, float* dstd_part);
 int vc_kl_rows_f32(void* stream, int N, int L, int mode, const float* mean, const float* std_, const float* mu_p, float* row_kl);
 int vc_latent_bwd_f32(void* stream, int S, int N, int L, int mode, int out_logstd, const float* dz, const float* eps,
                       const float* mean, const float* std_, const float* mu_p, const float* ann, float kl_scale,

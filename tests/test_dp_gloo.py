@@ -130,3 +130,20 @@ def test_shard_batch_keeps_an_images_rows_together():
     g, kn, ka, inv = dp.scales(320, 8, True)
     assert g == 2560.0 and abs(kn - 0.1 / 2560) < 1e-12 and ka == 0.1 and inv == 1 / 2560
     assert dp.scales(320, 8, False)[0] == 1.0
+
+
+def test_global_q1_noise_slices_tile_the_global_sample_tensor():
+    """q1_mode='global': rank r owns the flat range [r*Nl*S, (r+1)*Nl*S) of q = s*Ng + n, i.e. exactly the
+    rows r*Nl .. (r+1)*Nl of the reference's [Ng, S*L] reshape (vae_model/decoder.py:109-110)."""
+    from oracle import ops
+    from vae_captioning_amd import dp
+    S, Ng, L, world = 5, 12, 3, 4
+    eps = np.random.default_rng(0).standard_normal((S, Ng, L)).astype(np.float32)
+    zin = ops.q1_reshape(eps, L, S)  # [Ng, S*L]
+    nl = Ng // world
+    for r in range(world):
+        e = dp.shard_noise({"eps": eps}, r, world, Ng, "global")["eps"]
+        assert e.shape == (S, nl, L)
+        np.testing.assert_array_equal(e.reshape(nl, S * L), zin[r * nl:(r + 1) * nl])
+        t = dp.shard_noise({"eps": eps}, r, world, Ng, "tower")["eps"]
+        np.testing.assert_array_equal(t, eps[:, r * nl:(r + 1) * nl])

@@ -21,52 +21,91 @@ from vae_captioning_amd.utils.parameters import Parameters
 pytestmark = pytest.mark.gpu
 
 
-def test_two_emulated_ranks_equal_oracle_q1_groups_2(lib):
+class FakeGroup(object):
+    """In-process stand-in for a 2-rank RCCL group: the engine's collective hooks of both emulated ranks
+    (one Python thread each) meet at a barrier and exchange through a shared dict."""
+
+    def __init__(self, world):
+        import threading
+        self.world = world
+        self.bar = threading.Barrier(world)
+        self.slot = {}
+
+    def hooks(self, rank):
+        def exchange(t):
+            self.slot[rank] = t.clone()
+            self.bar.wait()
+            parts = [self.slot[r] for r in range(self.world)]
+            self.bar.wait()
+            return parts
+
+        def reduce_fn(t):
+            t.copy_(sum(exchange(t)))
+
+        def gather_fn(out, inp):
+            out.copy_(torch.cat(exchange(inp), 0).view_as(out))
+
+        def rscatter_fn(out, inp):
+            n = out.shape[0]
+            out.copy_(sum(p[rank * n:(rank + 1) * n] for p in exchange(inp)))
+        return reduce_fn, gather_fn, rscatter_fn
+
+
+@pytest.mark.parametrize("q1_mode,prior", [("tower", "Normal"), ("global", "Normal"), ("global", "AG")])
+def test_two_emulated_ranks_equal_the_global_batch_oracle(lib, q1_mode, prior):
+    """world = 2 code path of the Trainer (count all-reduce, mean/std all-gather, gradient
+    reduce-scatter, the single flat-gradient all-reduce, clip + Adam on both replicas) with the
+    collectives replaced by in-process exchanges; expected = the oracle on the whole batch with the
+    reference's own Q1 mix (q1_mode='global') or the per-tower mix (q1_groups = 2)."""
+    import threading
     p = Parameters()
     p.embed_size, p.encoder_hidden, p.decoder_hidden = 32, 64, 64
     p.latent_size, p.gen_z_samples, p.cnn_feature_size = 12, 5, 40
-    p.num_captions, p.batch_size = 3, 4
+    p.num_captions, p.batch_size, p.prior, p.use_c_v = 3, 4, prior, prior == "AG"
+    p.lstm_clip_by_norm = 0.05
     V, B, T, world = 150, 4, 6, 2
     rng = np.random.default_rng(3)
     P0 = spec.init_caption_params(p, V, seed=5)
-    batch = synth.make_batch(rng, B, p.num_captions, T, V, variable_len=True, feature_size=p.cnn_feature_size)
+    batch = synth.make_batch(rng, B, p.num_captions, T, V, use_ci=spec.uses_ci(p), variable_len=True, feature_size=p.cnn_feature_size)
     noise = synth.make_noise(rng, B * p.num_captions, T, p)
     f64 = lambda d: {k: (v.astype(np.float64) if v.dtype.kind == "f" else v) for k, v in d.items()}
-    ref = cm.forward_backward(f64(P0), f64(batch), f64(noise), p, q1_groups=world)
-    den_all = float((batch["cap_enc"] != 0).sum())
-    engines, grads, tails = [], [], []
-    for r in range(world):
-        b = dp.shard_batch(batch, r, world, p.num_captions)
-        n = dp.shard_noise(noise, r, world, B * p.num_captions)
-        e = CaptionEngine(p, V, lib=lib, world=world, rank=r)
-        other_den = den_all - float((b["cap_enc"] != 0).sum())
+    n64 = f64(noise)
+    if prior == "AG":
+        from oracle import decode
+        n64["c_means"] = decode.init_clusters(90, p.latent_size).astype(np.float64)
+    ref = cm.forward_backward(f64(P0), f64(batch), n64, p, q1_groups=world if q1_mode == "tower" else 1)
+    fg = FakeGroup(world)
+    trs, errs = [None] * world, []
 
-        def fake_reduce(t, other=other_den, eng=e):
-            if t.numel() == 1:
-                t += other           # the count all-reduce
-            # loss scalars are summed below from both engines
-        e.reduce_fn = fake_reduce
-        e.load_params(P0)
-        e.set_batch(b, n)
-        e.forward()
-        e.backward()
-        e.pack_tail()
-        engines.append(e)
-        grads.append(e.store.g.clone())
-    gsum = grads[0] + grads[1]           # what the single all-reduce delivers to every rank
-    for e in engines:
-        e.store.g.copy_(gsum)
-    G = engines[0].grads_dict()
+    def run(r):
+        try:
+            torch.cuda.set_device(0)
+            tr = Trainer(p, V, lib=lib, world=world, rank=r)
+            tr.cap.q1_mode = q1_mode
+            tr.cap.reduce_fn, tr.cap.gather_fn, tr.cap.rscatter_fn = fg.hooks(r)
+            tr.load_state_dict(P0)
+            tr.set_batch(dp.shard_batch(batch, r, world, p.num_captions), dp.shard_noise(noise, r, world, B * p.num_captions, q1_mode))
+            tr.train_step()
+            trs[r] = tr
+        except Exception as ex:  # pragma: no cover
+            errs.append(ex)
+            fg.bar.abort()
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    G = trs[0].cap.grads_dict()  # the all-reduced gradient, identical on both replicas
     for k, g in ref.grads.items():
         assert np.abs(G[k] - g).max() <= 2e-4 * (np.abs(g).max() + 1e-12), k
-    # clip norm from the all-reduced buffer (tail carries sum ||dX||^2 of both shards)
-    engines[0].apply_gradients()
+    assert torch.equal(trs[0].gall, trs[1].gall)
     norm = float(oo.global_norm({k: v.astype(np.float32) for k, v in ref.grads.items()}, {k: v.astype(np.float32) for k, v in ref.sparse.items()}))
-    assert abs(float(engines[0].ns[0].item()) - norm) <= 3e-4 * norm
-    ce_num = sum(float(e.red[0].item()) for e in engines)
-    assert abs(ce_num / den_all - float(ref.rec_loss)) <= 2e-4 * float(ref.rec_loss)
-    kl = sum(float(e.red[2].item()) for e in engines) / (B * p.num_captions)
-    assert abs(kl - float(ref.kld)) <= 2e-4 * abs(float(ref.kld)) + 1e-7
+    assert abs(float(trs[0].cap.ns[0].item()) - norm) <= 3e-4 * norm and norm > p.lstm_clip_by_norm
+    kld, rec, lb, _ = trs[1].losses()
+    assert abs(rec - float(ref.rec_loss)) <= 2e-4 * float(ref.rec_loss)
+    assert abs(kld - float(np.mean(ref.kld))) <= 2e-4 * abs(float(np.mean(ref.kld))) + 1e-7
+    a, b = trs[0].state_dict(), trs[1].state_dict()
+    for k in a:  # replicas stay bit-identical after the optimiser step
+        np.testing.assert_array_equal(a[k], b[k])
 
 
 def _cfg2_engine(lib, seed=0, **kw):

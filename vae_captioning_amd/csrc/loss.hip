@@ -145,6 +145,41 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ m
     }
 }
 
+// Data-parallel form of the sample (quirk Q1 under sharding, see dp.py): the z_rnn input rows of this
+// rank are the flat range q in [q0, q0+nq) of the GLOBAL [S, Ng, L] sample tensor, q = s*Ng + n.
+//   z[(q-q0), l] = mean_g[q % Ng, l] + std_g[q % Ng, l] * eps[(q-q0), l]
+// With Ng = N, q0 = 0, nq = S*N it is exactly sample_kernel.
+__global__ __launch_bounds__(256) void sample_mixed_kernel(const float* __restrict__ mean_g, const float* __restrict__ std_g,
+                                                           const float* __restrict__ eps, int Ng, int L, long q0, long total,
+                                                           float* __restrict__ z) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long q = q0 + i / L;
+        const long j = (q % Ng) * L + i % L;
+        z[i] = mean_g[j] + std_g[j] * eps[i];
+    }
+}
+// ... and of its gradient: per global row n, the sums over this rank's q == n (mod Ng):
+//   dmean_part[n,l] = sum dz[(q-q0), l],   dstd_part[n,l] = sum dz[(q-q0), l] * eps[(q-q0), l]
+// (rows that do not occur get zeros); the partials are then reduce-scattered over the ranks.
+__global__ __launch_bounds__(256) void latent_sums_mixed_kernel(const float* __restrict__ dz, const float* __restrict__ eps,
+                                                                int Ng, int L, long q0, long nq, float* __restrict__ dmean,
+                                                                float* __restrict__ dstd) {
+    const long NL = (long)Ng * L;
+    for (long j = (long)blockIdx.x * 256 + threadIdx.x; j < NL; j += (long)gridDim.x * 256) {
+        const long n = j / L;
+        const int l = (int)(j % L);
+        long q = q0 + ((n - q0 % Ng) % Ng + Ng) % Ng;  // first q >= q0 with q % Ng == n
+        float dm = 0.f, ds = 0.f;
+        for (; q < q0 + nq; q += Ng) {
+            const float g = dz[(q - q0) * L + l];
+            dm += g;
+            ds += g * eps[(q - q0) * L + l];
+        }
+        dmean[j] = dm;
+        dstd[j] = ds;
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // KL per row.  mode 0 (Normal / GMM, main.py:120-124,131-135):
 //     -0.5 * sum_l (1 + log(std^2 + 1e-5) - mean^2 - std^2)
@@ -186,7 +221,8 @@ __global__ __launch_bounds__(256) void latent_bwd_kernel(const float* __restrict
                                                          float* __restrict__ dmean, float* __restrict__ dstd) {
     const float w = (ann ? ann[0] : 1.f) * kl_scale;
     for (long j = (long)blockIdx.x * 256 + threadIdx.x; j < NL; j += (long)gridDim.x * 256) {
-        float dm = 0.f, ds = 0.f;
+        // S == 0: dmean / dstd already hold the sums over the samples (vc_latent_sums_mixed_f32)
+        float dm = S ? 0.f : dmean[j], ds = S ? 0.f : dstd[j];
         for (int s = 0; s < S; ++s) {
             const float g = dz[(long)s * NL + j];
             dm += g;
@@ -324,6 +360,23 @@ extern "C" int vc_latent_sample_f32(void* stream, int S, int N, int L, const flo
     return 0;
 }
 
+extern "C" int vc_latent_sample_mixed_f32(void* stream, int Ng, int L, long q0, long nq, const float* mean_g,
+                                          const float* std_g, const float* eps, float* z) {
+    VC_CHECK_ARG(mean_g && std_g && eps && z && Ng > 0 && L > 0 && q0 >= 0 && nq > 0, "bad argument");
+    const long total = nq * L;
+    hipLaunchKernelGGL(sample_mixed_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, mean_g, std_g, eps, Ng, L, q0, total, z);
+    VC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vc_latent_sums_mixed_f32(void* stream, int Ng, int L, long q0, long nq, const float* dz, const float* eps,
+                                        float* dmean_part, float* dstd_part) {
+    VC_CHECK_ARG(dz && eps && dmean_part && dstd_part && Ng > 0 && L > 0 && q0 >= 0 && nq > 0, "bad argument");
+    hipLaunchKernelGGL(latent_sums_mixed_kernel, dim3(grid_for((long)Ng * L)), dim3(256), 0, (hipStream_t)stream, dz, eps, Ng, L, q0, nq, dmean_part, dstd_part);
+    VC_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int vc_kl_rows_f32(void* stream, int N, int L, int mode, const float* mean, const float* std_,
                               const float* mu_p, float* row_kl) {
     VC_CHECK_ARG(mean && std_ && row_kl && N > 0 && L > 0 && (mode == 0 || (mode == 1 && mu_p)), "bad argument");
@@ -335,7 +388,7 @@ extern "C" int vc_kl_rows_f32(void* stream, int N, int L, int mode, const float*
 extern "C" int vc_latent_bwd_f32(void* stream, int S, int N, int L, int mode, int out_logstd, const float* dz,
                                  const float* eps, const float* mean, const float* std_, const float* mu_p,
                                  const float* ann, float kl_scale, float* dmean, float* dstd) {
-    VC_CHECK_ARG(dz && eps && mean && std_ && dmean && dstd && S > 0 && N > 0 && L > 0, "bad argument");
+    VC_CHECK_ARG(mean && std_ && dmean && dstd && S >= 0 && (S == 0 || (dz && eps)) && N > 0 && L > 0, "bad argument");
     VC_CHECK_ARG(mode == 0 || (mode == 1 && mu_p), "mu_p required for the AG prior");
     const long NL = (long)N * L;
     hipLaunchKernelGGL(latent_bwd_kernel, dim3(grid_for(NL)), dim3(256), 0, (hipStream_t)stream, dz, eps, mean, std_, mu_p, ann,

@@ -15,11 +15,13 @@ caption rows, its cluster-vector rows and its noise slices stay together).  Per 
      regulariser's gradient are applied once, inside the optimiser kernel).
 
 The one place the reference graph is not separable over rows is the Q1 reshape
-(vae_model/decoder.py:109-110), which mixes the z samples of different batch rows: here each
-rank mixes within its own shard -- exactly what G towers of the reference graph would do --
-so an N-GPU step equals the oracle run with q1_groups = N, not the single-GPU step on the
-concatenated batch.  (Reproducing the global mix needs an all-gather of mean/std and a
-reduce-scatter of their gradients, 1.5 MB each; listed as next work in DESIGN.md.)
+(vae_model/decoder.py:109-110), which mixes the z samples of different batch rows.  Default
+(q1_mode="global"): bit-for-bit the single-GPU semantics on the concatenated batch -- the per-row
+mean/std [N, L] are all-gathered (2 x 1.5 MB at 2560 rows), each rank samples the flat range
+q in [rank*Nl*S, (rank+1)*Nl*S) of the global [S, Ng, L] tensor (q = s*Ng + n) that forms its own
+z_rnn rows, and the [Ng, L] partial gradient sums are reduce-scattered back to the owning ranks.
+q1_mode="tower" mixes inside each rank's shard instead (what N towers of the reference graph
+would compute; equals the oracle with q1_groups = N) and needs no extra exchange.
 """
 import numpy as np
 
@@ -39,12 +41,19 @@ def shard_batch(batch, rank, world, nc):
     return out
 
 
-def shard_noise(noise, rank, world, n_rows_global):
-    n0, n1 = rank * (n_rows_global // world), (rank + 1) * (n_rows_global // world)
+def shard_noise(noise, rank, world, n_rows_global, q1_mode="tower"):
+    """Slices of the injected noise that belong to one rank.  eps [S, Ng, L]: "tower" takes the rank's
+    rows of every sample; "global" takes the flat range q in [rank*Nl*S, (rank+1)*Nl*S) of q = s*Ng + n
+    (the samples that land in this rank's z_rnn rows under the global Q1 reshape)."""
+    nl = n_rows_global // world
+    n0, n1 = rank * nl, (rank + 1) * nl
     out = {}
     for k, v in noise.items():
         if k == "c_means":
             out[k] = v
+        elif k == "eps" and q1_mode == "global":
+            S, Ng, L = v.shape
+            out[k] = np.ascontiguousarray(v.reshape(S * Ng, L)[rank * nl * S:(rank + 1) * nl * S]).reshape(S, nl, L)
         elif k in ("eps", "drop_in", "drop_out"):
             out[k] = np.ascontiguousarray(v[:, n0:n1])
         else:

@@ -123,12 +123,18 @@ class CaptionEngine(object):
     masked CE, non_cnn_optimizer."""
 
     def __init__(self, p, vocab, device="cuda", lib=None, grad_backing=None, world=1, rank=0, group=None, seed=0,
-                 force_collectives=False):
+                 force_collectives=False, q1_mode="global"):
         self.p = p
         self.collectives = world > 1 or force_collectives
         # sum-all-reduce used by the data-parallel branches; replaceable so that a single process can
         # emulate N ranks in tests (default: RCCL through torch.distributed)
         self.reduce_fn = lambda t: torch.distributed.all_reduce(t, group=self.group)
+        self.gather_fn = lambda out, inp: torch.distributed.all_gather_into_tensor(out, inp, group=self.group)
+        self.rscatter_fn = lambda out, inp: torch.distributed.reduce_scatter_tensor(out, inp, group=self.group)
+        # "global": the Q1 reshape mixes z samples over the GLOBAL batch exactly as a single-GPU run on the
+        # concatenated batch would (all-gather of mean/std, reduce-scatter of their gradients, 1.5 MB each);
+        # "tower": every rank mixes inside its own shard (what N towers of the reference graph compute).
+        self.q1_mode = q1_mode
         self.V = int(vocab)
         self.lib = lib or abi.load()
         self.dev = device
@@ -346,6 +352,11 @@ class CaptionEngine(object):
 
     def fw_encode(self):
         """vae_model/encoder.py:24-110 + KL (main.py:118-145): returns z [S, N, L]."""
+        self.fw_encode_stats()
+        return self.fw_encode_sample()
+
+    def fw_encode_stats(self):
+        """First half of q_net: embedding gather, init chain, length-masked LSTM, heads -> mean, std."""
         p, lib, st, S = self.p, self.lib, _stream(), self.store
         N, T, B, nc, E, He, Hd, L, Sm, V, F = self._dims()
         Te = T + self.n_init_e
@@ -371,6 +382,16 @@ class CaptionEngine(object):
             self.gemm(0, 0, N, 2 * K_CL * L, He, hT, He, S.param("encoder/heads/kernel"), 2 * K_CL * L, heads, 2 * K_CL * L, S.param("encoder/heads/bias"))
             gmm = p.prior == "GMM"
             lib.vc_heads_mix_fwd_f32(st, N, K_CL, L, P(heads), None if gmm else P(cv), P(self.buf["gmm_idx"]) if gmm else None, P(mean), P(std))
+        return mean, std
+
+    def _q1_global(self):
+        return self.collectives and self.q1_mode == "global" and self.world > 1
+
+    def fw_encode_sample(self):
+        """Second half of q_net: reparameterised sample (+ the data-parallel exchange of mean/std) and KL."""
+        p, lib, st = self.p, self.lib, _stream()
+        N, T, B, nc, E, He, Hd, L, Sm, V, F = self._dims()
+        mean, std, cv = self.buf["mean"], self.buf["std"], self.buf.get("c_v")
         mu_p = None
         mode = 0
         if p.prior == "AG":
@@ -378,7 +399,15 @@ class CaptionEngine(object):
             mu_p = self._b("mu_p", (N, L))
             self.gemm(0, 0, N, L, K_CL, cv, K_CL, self.c_means, L, mu_p, L)
         z = self._b("z", (Sm, N, L))
-        lib.vc_latent_sample_f32(st, Sm, N, L, P(mean), P(std), P(self.buf["eps"]), P(z))
+        if self._q1_global():
+            Ng = N * self.world
+            mg, sg = self._b("mean_g", (Ng, L)), self._b("std_g", (Ng, L))
+            self.gather_fn(mg, mean)
+            self.gather_fn(sg, std)
+            # this rank's z_rnn rows = flat range [rank*N*S, (rank+1)*N*S) of the global [S, Ng, L] tensor
+            lib.vc_latent_sample_mixed_f32(st, Ng, L, self.rank * N * Sm, N * Sm, P(mg), P(sg), P(self.buf["eps"]), P(z))
+        else:
+            lib.vc_latent_sample_f32(st, Sm, N, L, P(mean), P(std), P(self.buf["eps"]), P(z))
         row_kl = self._b("row_kl", (N,))
         lib.vc_kl_rows_f32(st, N, L, mode, P(mean), P(std), P(mu_p), P(row_kl))
         lib.vc_reduce_sum_f32(st, P(row_kl), N, 1.0, self.red.data_ptr() + 8, 0)
@@ -492,11 +521,19 @@ class CaptionEngine(object):
             self.gemm(0, 1, N, Sm * L, E, dz_dec, E, S.param("decoder/net/z_rnn/kernel"), E, dz, Sm * L)
             mean, std = self.buf["mean"], self.buf["std"]
             dmean, dstd = self._b("dmean", (N, L)), self._b("dstd", (N, L))
+            Sb = Sm
+            if self._q1_global():  # partial sums over this rank's q range for EVERY global row, then reduce-scatter
+                Ng = N * self.world
+                pm, ps = self._b("dmean_g", (Ng, L)), self._b("dstd_g", (Ng, L))
+                lib.vc_latent_sums_mixed_f32(st, Ng, L, self.rank * N * Sm, N * Sm, P(dz), P(self.buf["eps"]), P(pm), P(ps))
+                self.rscatter_fn(dmean, pm)
+                self.rscatter_fn(dstd, ps)
+                Sb = 0
             _, kl_n, kl_ag, _ = dp.scales(N, self.world, p.prior == "AG")
             hT = self.buf["hs_e"][Te]
             dhT = self._b("dH_e", (N, He))
             if p.prior == "Normal":
-                lib.vc_latent_bwd_f32(st, Sm, N, L, 0, 1, P(dz), P(self.buf["eps"]), P(mean), P(std), None, P(ann), kl_n, P(dmean), P(dstd))
+                lib.vc_latent_bwd_f32(st, Sb, N, L, 0, 1, P(dz), P(self.buf["eps"]), P(mean), P(std), None, P(ann), kl_n, P(dmean), P(dstd))
                 self.dense_bwd_w(hT, N, He, L, dmean, "encoder/dense/kernel", "encoder/dense/bias")
                 self.dense_bwd_w(hT, N, He, L, dstd, "encoder/dense_1/kernel", "encoder/dense_1/bias")
                 self.gemm(0, 1, N, He, L, dmean, L, S.param("encoder/dense/kernel"), L, dhT, He)
@@ -504,9 +541,9 @@ class CaptionEngine(object):
             else:
                 gmm = p.prior == "GMM"
                 if gmm:
-                    lib.vc_latent_bwd_f32(st, Sm, N, L, 0, 0, P(dz), P(self.buf["eps"]), P(mean), P(std), None, P(ann), kl_n, P(dmean), P(dstd))
+                    lib.vc_latent_bwd_f32(st, Sb, N, L, 0, 0, P(dz), P(self.buf["eps"]), P(mean), P(std), None, P(ann), kl_n, P(dmean), P(dstd))
                 else:
-                    lib.vc_latent_bwd_f32(st, Sm, N, L, 1, 0, P(dz), P(self.buf["eps"]), P(mean), P(std), P(self.buf["mu_p"]), P(ann), kl_ag, P(dmean), P(dstd))
+                    lib.vc_latent_bwd_f32(st, Sb, N, L, 1, 0, P(dz), P(self.buf["eps"]), P(mean), P(std), P(self.buf["mu_p"]), P(ann), kl_ag, P(dmean), P(dstd))
                 heads = self.buf["heads"]
                 dheads = self._b("dheads", (N, 2 * K_CL * L))
                 lib.vc_heads_mix_bwd_f32(st, N, K_CL, L, P(heads), None if gmm else P(self.buf["c_v"]), P(self.buf["gmm_idx"]) if gmm else None,
