@@ -101,19 +101,34 @@ struct GemmPlan {
 
 static GemmPlan plan_gemm(int M, int N, int K) {
     GemmPlan p;
+    // Measured on MI355X (tools/microbench.py): 128x128 tiles win when there are >= 1.5 per CU, and for
+    // small outputs with a deep K (weight gradients) when K is split into chunks of >= 512 so that every
+    // CU gets 2-3 of them; in between (e.g. 512 x 10000 x 25600) 64x64 tiles with ~5 workgroups per CU
+    // beat 128x128 with a ragged 2.5 per CU.
     const long t128 = (long)cdiv(M, 128) * cdiv(N, 128);
-    p.big = t128 >= 384;  // 128x128 tiles only when they still give >= 1.5 workgroups per CU
+    long sa = 1;
+    if (t128 <= 128) {
+        sa = (640 + t128 - 1) / t128;
+        const long maxs = K / 512;
+        if (sa > maxs) sa = maxs;
+        if (sa > 64) sa = 64;
+        if (sa < 1) sa = 1;
+    }
+    p.big = t128 >= 384 || (t128 <= 128 && t128 * sa >= 256);
     const int b = p.big ? 128 : 64;
     p.tiles_m = cdiv(M, b);
     p.tiles_n = cdiv(N, b);
     const long tiles = (long)p.tiles_m * p.tiles_n;
-    int splits = 1;
-    if (tiles < 192) {
-        splits = (int)((512 + tiles - 1) / tiles);
-        const int maxs = K / 256;  // keep >= 8 K-tiles per split
-        if (splits > maxs) splits = maxs;
-        if (splits > 64) splits = 64;
-        if (splits < 1) splits = 1;
+    int splits = (int)sa;
+    if (!p.big) {
+        splits = 1;
+        if (tiles < 192) {
+            splits = (int)((512 + tiles - 1) / tiles);
+            const int maxs = K / 256;  // keep >= 8 K-tiles per split
+            if (splits > maxs) splits = maxs;
+            if (splits > 64) splits = 64;
+            if (splits < 1) splits = 1;
+        }
     }
     int kchunk = cdiv(cdiv(K, splits), 32) * 32;
     if (kchunk < 32) kchunk = 32;
