@@ -123,12 +123,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    # one process per GPU.  (VC_DIST_BACKEND=gloo lets two ranks share ONE GPU: used only by the
+    # single-GPU test of the N > 1 code path, tests/test_gpu_cli.py.)
+    backend = os.environ.get("VC_DIST_BACKEND", "nccl")
+    local = local % torch.cuda.device_count() if backend != "nccl" else local
     torch.cuda.set_device(local)
     lib = abi.load()  # raises if the HIP library is missing: no fallback
     lib.vc_device_check(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     w = WORKLOADS[args.workload]
     p = make_params(w)

@@ -106,3 +106,31 @@ def test_main_cli_training_then_inference(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     caps = json.load(open(tmp_path / "val_t1.json"))
     assert len(caps) == 8 and set(caps[0]) == {"image_id", "caption"}
+
+
+def test_bench_two_ranks_through_torchrun_on_one_gpu(tmp_path):
+    """The driver launches bench.py for N > 1 as `python -m torch.distributed.run --nproc-per-node N ...`.
+    Only one GPU is available to the tests, so two ranks share it over gloo (VC_DIST_BACKEND); this
+    exercises rank/env handling, the count / mean-std / gradient collectives, the max-over-ranks
+    timing and the single JSON line on rank 0."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, PYTHONPATH=ROOT, VC_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--workload", "cfg1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=tmp_path, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["config"]["global_caption_rows"] == 2 * d["config"]["caption_rows_per_gpu"]
+    assert d["value"] > 0 and d["scaling"] == "weak" and d["roofline"]["achieved"] > 0
+    cmd[cmd.index("cfg1")] = "cfg2"  # encoder present: exercises the all-gather / reduce-scatter of the global Q1 mix
+    r = subprocess.run(cmd, cwd=tmp_path, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and np.isfinite(d["final_losses"]["rec_loss"]) and np.isfinite(d["final_losses"]["kld"])

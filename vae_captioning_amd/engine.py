@@ -130,7 +130,7 @@ class CaptionEngine(object):
         # emulate N ranks in tests (default: RCCL through torch.distributed)
         self.reduce_fn = lambda t: torch.distributed.all_reduce(t, group=self.group)
         self.gather_fn = lambda out, inp: torch.distributed.all_gather_into_tensor(out, inp, group=self.group)
-        self.rscatter_fn = lambda out, inp: torch.distributed.reduce_scatter_tensor(out, inp, group=self.group)
+        self.rscatter_fn = self._reduce_scatter
         # "global": the Q1 reshape mixes z samples over the GLOBAL batch exactly as a single-GPU run on the
         # concatenated batch would (all-gather of mean/std, reduce-scatter of their gradients, 1.5 MB each);
         # "tower": every rank mixes inside its own shard (what N towers of the reference graph compute).
@@ -172,6 +172,16 @@ class CaptionEngine(object):
             self.c_means = torch.from_numpy(init_clusters(K_CL, p.latent_size)).to(device)
         self.ann_on = int((not p.fine_tune) and (not p.restore) and p.ann_param > 1)  # main.py:163-170
         self.decay_steps = int(p.num_ex_per_epoch / (p.batch_size + 0.001) * p.num_epochs_per_decay)
+
+    def _reduce_scatter(self, out, inp):
+        """sum-reduce-scatter of inp [world*n, L] into out [n, L] (RCCL; backends without the primitive,
+        i.e. gloo in the 2-process single-GPU test, fall back to all-reduce + slice)."""
+        if torch.distributed.get_backend(self.group) == "nccl":
+            torch.distributed.reduce_scatter_tensor(out, inp, group=self.group)
+        else:
+            torch.distributed.all_reduce(inp, group=self.group)
+            n = out.shape[0]
+            out.copy_(inp[self.rank * n:(self.rank + 1) * n])
 
     # ---------------------------------------------------------------- parameters
     def load_params(self, named):
