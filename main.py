@@ -64,9 +64,24 @@ def main(params):
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     if world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world)
-    if not params.synthetic:
-        raise SystemExit("the MSCOCO data layer is out of scope of this build: run with --synthetic")
-    cap_dict = SyntheticDictionary(params.vocab_size)
+    real = None
+    if params.captions_json and params.features_pickle:
+        # precomputed-feature path of the reference's data layer (utils/data.py + utils/batch_gen.py)
+        from vae_captioning_amd.utils.batch_gen import BatchGenerator
+        from vae_captioning_amd.utils.captions import Captions, Dictionary
+        caps = Captions(params.captions_json)
+        cap_dict = Dictionary(caps.captions, params.keep_words)
+        with open(params.features_pickle, "rb") as rf:
+            feats = pickle.load(rf)
+        cvs = None
+        if params.cluster_pickle:
+            with open(params.cluster_pickle, "rb") as rf:
+                cvs = pickle.load(rf)
+        real = BatchGenerator(caps.index_captions(cap_dict.word2idx), feats, params.batch_size, cvs, seed=params.seed + rank)
+    elif params.synthetic:
+        cap_dict = SyntheticDictionary(params.vocab_size)
+    else:
+        raise SystemExit("give --synthetic, or --captions_json + --features_pickle (image/HDF5 loading is out of scope)")
     params.vocab_size = cap_dict.vocab_size  # main.py:92
     from vae_captioning_amd.trainer import Trainer
     tr = Trainer(params, params.vocab_size, world=world, rank=rank, seed=params.seed)
@@ -90,8 +105,13 @@ def main(params):
         if params.fine_tune:
             optimize_cnn, _ = optimizers.cnn_optimizer(None, params)
         for e in range(params.num_epochs):
-            data = SyntheticBatches(params, steps_per_epoch, params.seed + 17 * e + rank)
-            for batch in data.next_batch():
+            if real is not None:
+                it = real.next_batch(use_obj_vectors=spec.uses_ci(params), num_captions=params.num_captions)
+            else:
+                it = SyntheticBatches(params, steps_per_epoch, params.seed + 17 * e + rank).next_batch()
+            for batch in it:
+                if batch["features"].shape[0] != params.batch_size:
+                    continue  # ragged last batch: shapes are static on device
                 tr.set_batch(batch)
                 # ---- one sess.run([kld, rec_loss, lower_bound, optimize, optimize_cnn, annealing]) ----
                 feats = None

@@ -72,6 +72,9 @@ class Parameters(object):
     synthetic = False     # train on seeded synthetic batches (no MSCOCO needed)
     seed = 1234
     max_steps = 0         # 0 = reference stop rule (main.py:217-221)
+    captions_json = None
+    features_pickle = None
+    cluster_pickle = None
 
     def build_parser(self):
         p = argparse.ArgumentParser(description="CVAE / AG-CVAE captioning trainer (MI355X)")
@@ -107,6 +110,9 @@ class Parameters(object):
         a("--vocab", default=10000, help="vocabulary size for --synthetic")
         a("--seed", default=self.seed)
         a("--max_steps", default=self.max_steps)
+        a("--captions_json", default=None, help="COCO captions json (real-data path; with --features_pickle)")
+        a("--features_pickle", default=None, help="pickle {file_name: fc2 feature [1,4096]} (reference format)")
+        a("--cluster_pickle", default=None, help="pickle {file_name: 91-vector} (reference ./obj_vectors/c_v.pickle)")
         return p
 
     def parse_args(self, argv=None):
@@ -139,6 +145,7 @@ class Parameters(object):
         self.synthetic = args.synthetic
         self.seed = int(args.seed)
         self.max_steps = int(args.max_steps)
+        self.captions_json, self.features_pickle, self.cluster_pickle = args.captions_json, args.features_pickle, args.cluster_pickle
         if self.synthetic:
             self.vocab_size = int(args.vocab)
         self.hdf5_file = self.coco_dir + self.hdf5_file.split("/")[-1]
