@@ -33,6 +33,8 @@ WORKLOADS = {
     "cfg2": dict(B=256, prior="Normal", no_encoder=False, use_c_v=False, fine_tune=False),
     "cfg3": dict(B=256, prior="AG", no_encoder=False, use_c_v=True, fine_tune=False),
     "cfg4": dict(B=64, prior="Normal", no_encoder=False, use_c_v=False, fine_tune=True),
+    # generation (not a training step): GMM prior, beam width 5, 10 z samples, 128 images per batch
+    "cfg5": dict(B=128, prior="GMM", no_encoder=False, use_c_v=False, fine_tune=False, generate=True, beam=5, z=10),
 }
 T_LEN, VOCAB = 20, 10000
 
@@ -43,6 +45,8 @@ def make_params(w):
     p.prior, p.no_encoder, p.use_c_v, p.fine_tune = w["prior"], w["no_encoder"], w["use_c_v"], w["fine_tune"]
     p.batch_size = w["B"]
     p.vocab_size = VOCAB
+    if w.get("generate"):
+        p.mode, p.gen_z_samples, p.beam_size = "inference", w["z"], w["beam"]
     return p
 
 
@@ -139,6 +143,8 @@ def main():
 
     w = WORKLOADS[args.workload]
     p = make_params(w)
+    if w.get("generate"):
+        return bench_generation(args, torch, dist, lib, w, p, world, rank)
     rng = np.random.default_rng(args.seed + rank)
     B = w["B"]
     N = B * p.num_captions
@@ -214,6 +220,53 @@ def main():
     if rank == 0:
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, w, args.seed)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def bench_generation(args, torch, dist, lib, w, p, world, rank):
+    """cfg5: beam-search caption generation throughput (captions = images per second); replicas only --
+    images are independent, no collective."""
+    from vae_captioning_amd import spec, synth
+    from vae_captioning_amd.engine import CaptionEngine, KernelTimer
+    from vae_captioning_amd.generate import CaptionGenerator
+    rng = np.random.default_rng(args.seed + rank)
+    eng = CaptionEngine(p, VOCAB, lib=lib, seed=args.seed)
+    eng.load_params(spec.init_caption_params(p, VOCAB, seed=1))
+    gen = CaptionGenerator(eng)
+    B = w["B"]
+    feats = torch.from_numpy(np.maximum(rng.standard_normal((B, 4096), dtype=np.float32), 0)).cuda()
+    cv = np.zeros((B, 90), np.float32)
+    run = lambda: gen.beam_search(feats, cv, None, synth.BOS, synth.EOS, beam_size=w["beam"], max_len=p.gen_max_len)
+    for _ in range(args.warmup):
+        run()
+    eng.timer = KernelTimer()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = run()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    roof = roofline_from_timer(eng.timer, False)
+    roof["instrumented_pass"] = False
+    out = {"metric": "captions/sec generated (beam search)", "value": round(B * world * args.steps / dt, 2), "unit": "captions/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * dt / args.steps, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "cfg5: %s" % json.dumps(w, sort_keys=True), "images_per_gpu": B, "beam_size": w["beam"],
+                      "gen_z_samples": w["z"], "gen_max_len": p.gen_max_len, "vocab": VOCAB, "parallelism": "replicas%d" % world,
+                      "mean_caption_len": round(float(np.mean([len(r[0][0]) for r in res])), 2)},
+           "roofline": roof}
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
