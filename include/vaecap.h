@@ -106,6 +106,12 @@ int vc_argmax_rows_f32(void* stream, const float* x, long rows, int cols, long l
  * candidate expansion of beam search, vae_model/decoder.py:273-276. */
 int vc_topk_rows_f32(void* stream, const float* x, long rows, int cols, long ld, int k, float* out_val, int32_t* out_idx);
 int vc_fill_f32(void* stream, float* x, long n, float value);
+/* tf.multinomial(logits / temperature, 1) (vae_model/decoder.py:137-138) by inverse CDF with injected
+ * uniforms u[rows] in [0,1): out[r] = first index whose cumulative softmax exceeds u[r]. */
+int vc_multinomial_rows_f32(void* stream, const float* logits, long rows, int V, long ld, float temperature,
+                            const float* u, int32_t* out);
+/* Uniform [0,1) floats from the Philox stream (same counter convention as the other vc_philox_* calls). */
+int vc_philox_uniform_f32(void* stream, float* out, long n, uint64_t seed, uint64_t offset, const int32_t* step);
 
 /* ------------------------------------------------------------------------------------
  * Latent variable.  vae_model/encoder.py:59-109, main.py:118-145.

@@ -14,8 +14,12 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def lib():
-    """The C-ABI library (built in-tree by __graft_entry__.build())."""
+    """The C-ABI library (built in-tree by __graft_entry__.build(); built here if the snapshot lacks it --
+    abi.load() itself never builds or falls back, it raises when the library is missing)."""
     from vae_captioning_amd import abi
+    if not os.path.exists(abi.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
     return abi.load()
 
 

@@ -133,6 +133,44 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     for (int c = threadIdx.x; c < V; c += 256) q[c] = __expf(p[c] - mx) * inv;
 }
 
+// Categorical sample per row from logits / temperature (tf.multinomial, vae_model/decoder.py:137-138) by
+// inverse CDF with an INJECTED uniform u[row] in [0,1): index = first i with cumsum(softmax)[i] > u.
+// (TF draws with its own Gumbel/Philox stream, which cannot be matched; the distribution is the same.)
+__global__ __launch_bounds__(256) void multinomial_rows_kernel(const float* __restrict__ logits, int V, long ld, float inv_temp,
+                                                               const float* __restrict__ u, int32_t* __restrict__ out) {
+    __shared__ float sh[4];
+    __shared__ float part[256];
+    const float* p = logits + (long)blockIdx.x * ld;
+    float mx = -INFINITY;
+    for (int c = threadIdx.x; c < V; c += 256) mx = fmaxf(mx, p[c] * inv_temp);
+    mx = block_max<256>(mx, sh);
+    // contiguous chunk per thread so that the scan order is the index order
+    const int per = (V + 255) / 256;
+    const int c0 = threadIdx.x * per, c1 = min(V, c0 + per);
+    float s = 0.f;
+    for (int c = c0; c < c1; ++c) s += __expf(p[c] * inv_temp - mx);
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float tot = 0.f;
+        for (int i = 0; i < 256; ++i) tot += part[i];
+        const float target = u[blockIdx.x] * tot;
+        float run = 0.f;
+        int t = 0;
+        for (; t < 255; ++t) {
+            if (run + part[t] > target) break;
+            run += part[t];
+        }
+        int idx = min(V - 1, t * per);
+        for (int c = t * per; c < min(V, (t + 1) * per); ++c) {
+            run += __expf(p[c] * inv_temp - mx);
+            idx = c;
+            if (run > target) break;
+        }
+        out[blockIdx.x] = idx;
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // z[s,n,l] = mean[n,l] + std[n,l] * eps[s,n,l]   (zs.Normal, n_samples=S; encoder.py:108-109)
 // ---------------------------------------------------------------------------------------
@@ -347,6 +385,15 @@ extern "C" int vc_softmax_rows_f32(void* stream, const float* x, long rows, int 
     VC_CHECK_ARG(x && y && rows >= 0 && V > 0 && ld >= V && ldy >= V, "bad argument");
     if (rows == 0) return 0;
     hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, V, ld, y, ldy);
+    VC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vc_multinomial_rows_f32(void* stream, const float* logits, long rows, int V, long ld, float temperature,
+                                       const float* u, int32_t* out) {
+    VC_CHECK_ARG(logits && u && out && rows >= 0 && V > 0 && ld >= V && temperature > 0.f, "bad argument");
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(multinomial_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, logits, V, ld, 1.0f / temperature, u, out);
     VC_LAUNCH_CHECK();
     return 0;
 }

@@ -139,7 +139,7 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
 }
 
-// mode 0: raw uint32; 1: N(0,1) via Box-Muller; 2: Bernoulli(keep) as 0/1 floats
+// mode 0: raw uint32; 1: N(0,1) via Box-Muller; 2: Bernoulli(keep) as 0/1 floats; 3: uniform [0,1)
 // `step` (nullable, device): added to the high counter word so that a captured graph draws a
 // fresh stream every replay without any host-side argument change.
 __global__ __launch_bounds__(256) void philox_kernel(void* __restrict__ out, long n, uint64_t seed, uint64_t offset, int mode,
@@ -165,6 +165,9 @@ __global__ __launch_bounds__(256) void philox_kernel(void* __restrict__ out, lon
         } else if (mode == 2) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) f[j] = ((float)r[j] * 2.3283064365386963e-10f < keep) ? 1.f : 0.f;
+        } else if (mode == 3) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) f[j] = (float)(r[j] >> 8) * 5.9604644775390625e-08f;  // 24 bits -> [0, 1)
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -246,6 +249,10 @@ extern "C" int vc_philox_u32(void* stream, uint32_t* out, long n, uint64_t seed,
 extern "C" int vc_philox_normal_f32(void* stream, float* out, long n, uint64_t seed, uint64_t offset, const int32_t* step) {
     VC_CHECK_ARG(out && n >= 0, "bad argument");
     return philox_launch(stream, out, n, seed, offset, 1, 0.f, step);
+}
+extern "C" int vc_philox_uniform_f32(void* stream, float* out, long n, uint64_t seed, uint64_t offset, const int32_t* step) {
+    VC_CHECK_ARG(out && n >= 0, "bad argument");
+    return philox_launch(stream, out, n, seed, offset, 3, 0.f, step);
 }
 extern "C" int vc_philox_bernoulli_f32(void* stream, float* out, long n, float keep, uint64_t seed, uint64_t offset,
                                        const int32_t* step) {

@@ -146,6 +146,34 @@ class CaptionGenerator(object):
             tok = nxt.clone()
         return out
 
+    def sample(self, features, c_v=None, eps=None, bos=1, eos=2, max_len=None, uniforms=None):
+        """decoder.py:145-201 with sample_gen='sample': tokens drawn from softmax(logits / temperature)
+        (tf.multinomial).  uniforms [max_len, B] in [0,1) may be injected; otherwise Philox."""
+        max_len = max_len or self.p.gen_max_len
+        c, h = self.init_state(features, c_v, eps)
+        B = c.shape[0]
+        tok = torch.full((B,), bos, dtype=torch.int32, device=self.e.dev)
+        out = [[] for _ in range(B)]
+        done = np.zeros(B, bool)
+        nxt = torch.empty((B,), dtype=torch.int32, device=self.e.dev)
+        u = torch.empty((B,), dtype=torch.float32, device=self.e.dev)
+        for it in range(max_len):
+            logits, c, h = self.step(tok, c, h, want="logits")
+            if uniforms is not None:
+                u.copy_(torch.from_numpy(np.ascontiguousarray(uniforms[it], dtype=np.float32)))
+            else:
+                self.lib.vc_philox_uniform_f32(_stream(), P(u), B, self.e.seed * 1000003 + 29, (16 + it) << 32, P(self.e.step))
+            self.lib.vc_multinomial_rows_f32(_stream(), P(logits), B, self.e.V, self.e.V, float(self.p.temperature), P(u), P(nxt))
+            ids = nxt.cpu().numpy()
+            for b in range(B):
+                if not done[b]:
+                    out[b].append(int(ids[b]))
+                    done[b] = ids[b] == eos
+            if done.all():
+                break
+            tok = nxt.clone()
+        return out
+
     # ------------------------------------------------------------------ beam search
     def beam_search(self, features, c_v=None, eps=None, bos=1, eos=2, beam_size=2, max_len=None, len_norm_f=0.7):
         """decoder.py:203-320 for a batch of images.  Returns per image the list of

@@ -53,9 +53,10 @@ class Decoder(object):
         d = self.data_dict
         bos, eos = d.word2idx["<BOS>"], d.word2idx[stop_word]
         use_cv = c_v if (spec.uses_ci(self.params) and c_v is not None and len(c_v)) else None
-        if self.params.sample_gen == "sample":
-            raise NotImplementedError("sample_gen='sample' (tf.multinomial stream) is not reproducible; use greedy or beam_search")
-        raw = self._gen().greedy(self._features(in_pictures), use_cv, None, bos, eos, self.params.gen_max_len)
+        if self.params.sample_gen == "sample":  # tf.multinomial(logits / temperature): same distribution, own Philox stream
+            raw = self._gen().sample(self._features(in_pictures), use_cv, None, bos, eos, self.params.gen_max_len)
+        else:
+            raw = self._gen().greedy(self._features(in_pictures), use_cv, None, bos, eos, self.params.gen_max_len)
         cap_list = []
         for pid, toks in zip(picture_ids, raw):
             words = [d.idx2word[t] for t in toks if t not in (bos, eos)]
