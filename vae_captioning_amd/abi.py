@@ -90,6 +90,9 @@ def load(path=None):
     if _LIB is not None and path is None:
         return _LIB
     p = path or LIB_PATH
+    # PyTorch-ROCm bundles its own libamdhip64; load it FIRST so that libvaecap binds to the same HIP
+    # runtime (two runtimes in one process each enumerate the GPU and the second one sees no device).
+    import torch  # noqa: F401
     if not os.path.exists(p):
         raise VaecapError("libvaecap.so not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(there is no CPU fallback)" % p)
