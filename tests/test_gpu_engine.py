@@ -159,6 +159,36 @@ def test_device_noise_runs_and_is_fresh_each_step(lib):
     assert abs(float(e1.mean())) < 0.1 and abs(float(e1.std()) - 1) < 0.1
 
 
+def test_bucketed_async_allreduce_equals_single_allreduce_on_rccl(lib):
+    """Fine-tune step on a 1-rank nccl group: the three overlapped all-reduce pieces (caption | fc | conv)
+    give bit-identical parameters to the single blocking all-reduce and to the collective-free step."""
+    import os
+    import torch.distributed as dist
+    from vae_captioning_amd.trainer import Trainer
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29534")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        p = Parameters()
+        p.fine_tune, p.batch_size, p.num_captions, p.gen_z_samples = True, 2, 2, 4
+        V = 300
+        rng = np.random.default_rng(4)
+        batch = synth.make_batch(rng, 2, 2, 5, V, images=True, variable_len=True)
+        P0 = {**spec.init_caption_params(p, V, seed=1), **spec.init_vgg_params(seed=3)}
+        res = []
+        for force, buckets in ((False, False), (True, False), (True, True)):
+            tr = Trainer(p, V, lib=lib, force_collectives=force, seed=5)
+            tr.buckets = buckets
+            tr.load_state_dict(P0)
+            tr.set_batch(batch)
+            tr.train_step()
+            res.append((tr.losses(), tr.gall.clone()))
+        assert res[0][0] == res[1][0] == res[2][0]
+        assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][1], res[2][1])
+    finally:
+        dist.destroy_process_group()
+
+
 def test_collective_code_path_on_a_one_rank_rccl_group(lib):
     """The data-parallel branches (count all-reduce, loss-scalar all-reduce, the single flat
     gradient all-reduce over RCCL) executed on a 1-rank nccl group: results must equal the

@@ -83,6 +83,7 @@ def test_two_emulated_ranks_equal_the_global_batch_oracle(lib, q1_mode, prior):
             tr = Trainer(p, V, lib=lib, world=world, rank=r)
             tr.cap.q1_mode = q1_mode
             tr.cap.reduce_fn, tr.cap.gather_fn, tr.cap.rscatter_fn = fg.hooks(r)
+            tr.cap._fake_collectives = True
             tr.load_state_dict(P0)
             tr.set_batch(dp.shard_batch(batch, r, world, p.num_captions), dp.shard_noise(noise, r, world, B * p.num_captions, q1_mode))
             tr.train_step()

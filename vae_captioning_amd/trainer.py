@@ -145,7 +145,9 @@ class VggEngine(object):
         lib.vc_reduce_sum_f32(st, P(self.part), self.part.numel(), 1.0, out_ptr, 0)
 
     # ------------------------------------------------------------------ backward
-    def backward(self, dfc2):
+    def backward(self, dfc2, after_fc=None):
+        """after_fc: optional callback invoked as soon as the fc1 / fc2 gradients (89 % of the VGG
+        gradient bytes) are final, so their all-reduce can overlap the convolution backward."""
         lib, st, S = self.lib, _stream(), self.store
         B = self.B
         m1 = P(self.buf["drop1"]) if self.keep < 1 else None
@@ -162,6 +164,8 @@ class VggEngine(object):
         self.colsum(d1, B, 4096, S.grad("cnn/fc1/biases"))
         d = self._b("d_pool5", tuple(self.flat.shape))
         self.gemm(0, 1, B, F1, 4096, d1, 4096, S.param("cnn/fc1/weights"), 4096, d, F1)
+        if after_fc is not None:
+            after_fc()
         dw4 = self._b("dw1_4", (3, 3, 4, 64))
         for li in range(len(self.acts) - 1, -1, -1):
             name, x, H, W, ci, co, w = self.acts[li]
@@ -220,6 +224,14 @@ class Trainer(object):
                 self.cap.reg_scale = self.vgg.wd / 2.0  # l2_regularizer(wd)(w) = wd * sum(w^2)/2
         self.images = None
         self.graph = None
+        self.n_cap = n_cap
+        # Data-parallel gradient exchange.  Logically ONE sum-all-reduce of `gall` per step; with VGG
+        # fine-tuning it is issued as three asynchronous pieces in the order the gradients become final
+        # (caption side | fc1+fc2 | convolutions) so that RCCL overlaps the convolution backward
+        # (VC_DP_BUCKETS=0 forces the single blocking call).
+        import os
+        self.buckets = os.environ.get("VC_DP_BUCKETS", "1") != "0"
+        self.off_fc = n_cap + self.vgg.store.offset("cnn/fc1/weights") if self.vgg is not None else None
 
     def set_batch(self, batch, noise=None):
         self.cap.set_batch(batch, noise)
@@ -240,13 +252,26 @@ class Trainer(object):
                 vgg.reg_sumsq(cap.red.data_ptr() + 12)
         cap.forward(feats)
         dfe = cap.backward(want_dfeatures=vgg is not None)
-        if vgg is not None and vgg.train:
-            vgg.backward(dfe)
         cap.pack_tail()
-        self.all_reduce_grads()
+        if self.collectives and self.buckets and vgg is not None and vgg.train and self.reduce_async_fn is not None:
+            pending = [self.reduce_async_fn(self.gall[:self.n_cap])]
+            vgg.backward(dfe, after_fc=lambda: pending.append(self.reduce_async_fn(self.gall[self.off_fc:])))
+            pending.append(self.reduce_async_fn(self.gall[self.n_cap:self.off_fc]))
+            for h in pending:
+                h.wait()
+        else:
+            if vgg is not None and vgg.train:
+                vgg.backward(dfe)
+            self.all_reduce_grads()
         cap.apply_gradients()
         if vgg is not None and vgg.train:
             vgg.apply_gradients(cap.scal)
+
+    @property
+    def reduce_async_fn(self):
+        if getattr(self.cap, "_fake_collectives", False):
+            return None
+        return lambda t: torch.distributed.all_reduce(t, group=self.group, async_op=True)
 
     def all_reduce_grads(self):
         if self.collectives:
