@@ -200,7 +200,8 @@ int vc_philox_bernoulli_f32(void* stream, float* out, long n, float keep, uint64
  * channel counts powers of two >= 4 (conv1_1: RGB zero-padded to 4 channels).
  *   conv3x3_fwd    y = [relu](conv2d(x, w, stride 1, SAME) + bias)        (:40-44 ...)
  *   conv3x3_dgrad  dx = conv2d_backprop_input(dy, w) [* (relu_src > 0)]
- *   conv3x3_wgrad  dw (+)= conv2d_backprop_filter(x, dy)   (split-K, deterministic reduce)
+ *   conv3x3_wgrad  dw (+)= conv2d_backprop_filter(x, dy)   (split-K, deterministic reduce); db != NULL also
+ *                  returns the bias gradient db (+)= sum_pixels dy, summed from the dy tiles already staged in LDS
  *   maxpool2x2     tf.nn.max_pool 2x2/2 (:59-63 ...); bwd optionally fused with ReluGrad of x
  *   vgg_preprocess images [B,H,W,3] (0..255 RGB) - mean -> NHWC4            (:31-34)
  *   pad_dim        dst[o][c][i] = c < c_src ? src[o][c][i] : 0  (pad / strip a middle dim)
@@ -211,7 +212,7 @@ int vc_conv3x3_dgrad_f32(void* stream, int B, int H, int W, int Cin, int Cout, c
                          const float* relu_src, float* dx);
 size_t vc_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
 int vc_conv3x3_wgrad_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const float* dy, float* dw,
-                         int accumulate, float* ws, size_t ws_bytes);
+                         float* db, int accumulate, float* ws, size_t ws_bytes);
 int vc_maxpool2x2_fwd_f32(void* stream, int B, int H, int W, int C, const float* x, float* y);
 int vc_maxpool2x2_bwd_f32(void* stream, int B, int H, int W, int C, const float* x, const float* dy, float* dx, int relu_grad);
 int vc_vgg_preprocess_f32(void* stream, const float* images, int B, int H, int W, float* out_nhwc4);

@@ -430,12 +430,16 @@ def test_conv3x3_fwd_dgrad_wgrad(lib, case):
     assert_close(host(dx), dxref, 2e-6 * np.sqrt(9 * Co) + 1e-6, msg="conv dgrad")
     dw = zeros(3, 3, Ci, Co)
     ws = empty_bytes(lib.vc_conv3x3_wgrad_workspace_bytes(B, H, W, Ci, Co))
-    lib.vc_conv3x3_wgrad_f32(stream(), B, H, W, Ci, Co, P(tx), P(tdy), P(dw), 0, P(ws), ws.numel() * 4)
-    assert_close(host(dw), dwref, 2e-6 * np.sqrt(B * H * W) + 1e-6, msg="conv wgrad")
     db = zeros(Co)
+    lib.vc_conv3x3_wgrad_f32(stream(), B, H, W, Ci, Co, P(tx), P(tdy), P(dw), P(db), 0, P(ws), ws.numel() * 4)
+    assert_close(host(dw), dwref, 2e-6 * np.sqrt(B * H * W) + 1e-6, msg="conv wgrad")
+    assert_close(host(db), dbref, 1e-5, msg="conv bias grad (fused into wgrad)")
+    lib.vc_conv3x3_wgrad_f32(stream(), B, H, W, Ci, Co, P(tx), P(tdy), P(dw), None, 1, P(ws), ws.numel() * 4)
+    assert_close(host(dw), 2 * dwref, 2e-6 * np.sqrt(B * H * W) + 1e-6, msg="conv wgrad accumulate, no bias")
+    db2 = zeros(Co)
     ws2 = empty_bytes(lib.vc_colsum_workspace_bytes(B * H * W, Co))
-    lib.vc_colsum_f32(stream(), P(tdy), B * H * W, Co, Co, P(db), 0, P(ws2), ws2.numel() * 4)
-    assert_close(host(db), dbref, 1e-5, msg="conv bias grad")
+    lib.vc_colsum_f32(stream(), P(tdy), B * H * W, Co, Co, P(db2), 0, P(ws2), ws2.numel() * 4)
+    assert_close(host(db2), dbref, 1e-5, msg="colsum")
 
 
 def test_maxpool_and_preprocess(lib):

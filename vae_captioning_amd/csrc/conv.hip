@@ -118,6 +118,24 @@ struct ConvArgs {
     const float* aux;    // fwd: bias, dgrad: relu source (x; may be null)
     int relu;
     int tiles_n, ntiles, kchunk;
+    float* bias_ws;      // wgrad: [splits, Cout] partial column sums of dy (bias gradient), or null
+};
+
+// Column sums of the dy tile staged in LDS (KM image Bs[k][BN+4]); thread t owns column t % BN and the
+// k rows [part*PER, part*PER + PER), part = t / BN.
+template <class CFG>
+struct ColsumHook {
+    float* acc;
+    bool on;
+    __device__ __forceinline__ void operator()(const float*, const float* Bs) const {
+        if (!on) return;
+        constexpr int PARTS = CFG::NT / CFG::BN, PER = 32 / PARTS;
+        const int col = threadIdx.x % CFG::BN, part = threadIdx.x / CFG::BN;
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) s += Bs[(part * PER + k) * (CFG::BN + 4) + col];
+        *acc += s;
+    }
 };
 
 template <class CFG, int KIND>
@@ -173,7 +191,22 @@ __global__ __launch_bounds__(CFG::NT) void conv_kernel(ConvArgs c) {
         la.x = c.a; la.g = g; la.invW = 1.0f / (float)g.W; la.invH = 1.0f / (float)g.H;
         LoadKM<true> lb;
         lb.p = c.b; lb.ld = g.Cout; lb.R = g.Cout; lb.K = (int)g.P;
-        mfma_mainloop<CFG, MODE_KM, MODE_KM>(acc, la, lb, m0, n0, (int)kb, (int)ke, smem);
+        float csum = 0.f;
+        const bool do_bias = c.bias_ws != nullptr && m0 == 0;  // one m-tile per (n-tile, split) sums dy's columns
+        ColsumHook<CFG> hook{&csum, do_bias};
+        mfma_mainloop<CFG, MODE_KM, MODE_KM, LoadPixelsKM, LoadKM<true>, 0, ColsumHook<CFG>>(acc, la, lb, m0, n0, (int)kb, (int)ke, smem, hook);
+        if (do_bias) {  // combine the NT/BN partial sums of each column (fixed order) and store the split's partial
+            constexpr int PARTS = CFG::NT / CFG::BN;
+            __syncthreads();
+            smem[threadIdx.x] = csum;
+            __syncthreads();
+            if (threadIdx.x < CFG::BN && n0 + (int)threadIdx.x < g.Cout) {
+                float t = 0.f;
+#pragma unroll
+                for (int q = 0; q < PARTS; ++q) t += smem[q * CFG::BN + threadIdx.x];
+                c.bias_ws[(long)blockIdx.y * g.Cout + n0 + threadIdx.x] = t;
+            }
+        }
         float* out = c.out + (long)blockIdx.y * M * g.Cout;
         epilogue_rows<CFG>(acc, smem, [&](int r, int cc, float4 v) {
             const int row = m0 + r, col = n0 + cc;
@@ -342,7 +375,7 @@ extern "C" int vc_conv3x3_fwd_f32(void* stream, int B, int H, int W, int Cin, in
     ConvArgs c;
     VC_CHECK_ARG(x && w && y && B > 0 && H > 0 && W > 0, "bad argument");
     if (make_geom(c.g, B, H, W, Cin, Cout)) return fail(VC_EINVAL, "%s: Cin/Cout must be powers of two >= 4", __func__);
-    c.a = x; c.b = w; c.out = y; c.aux = bias; c.relu = relu; c.kchunk = 0;
+    c.a = x; c.b = w; c.out = y; c.aux = bias; c.relu = relu; c.kchunk = 0; c.bias_ws = nullptr;
     launch_conv<CONV_FWD>((hipStream_t)stream, c, (int)c.g.P, Cout, 1);
     VC_LAUNCH_CHECK();
     return 0;
@@ -353,7 +386,7 @@ extern "C" int vc_conv3x3_dgrad_f32(void* stream, int B, int H, int W, int Cin, 
     ConvArgs c;
     VC_CHECK_ARG(dy && w && dx && B > 0 && H > 0 && W > 0, "bad argument");
     if (make_geom(c.g, B, H, W, Cin, Cout)) return fail(VC_EINVAL, "%s: Cin/Cout must be powers of two >= 4", __func__);
-    c.a = dy; c.b = w; c.out = dx; c.aux = relu_src; c.relu = 0; c.kchunk = 0;
+    c.a = dy; c.b = w; c.out = dx; c.aux = relu_src; c.relu = 0; c.kchunk = 0; c.bias_ws = nullptr;
     launch_conv<CONV_DGRAD>((hipStream_t)stream, c, (int)c.g.P, Cin, 1);
     VC_LAUNCH_CHECK();
     return 0;
@@ -363,23 +396,28 @@ extern "C" size_t vc_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin,
     ConvGeom g;
     if (make_geom(g, B, H, W, Cin, Cout)) return 0;
     WgradPlan p = plan_wgrad(g);
-    return (size_t)p.splits * 9 * Cin * Cout * sizeof(float);
+    return (size_t)p.splits * (9L * Cin * Cout + Cout) * sizeof(float);
 }
 
 extern "C" int vc_conv3x3_wgrad_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const float* dy,
-                                    float* dw, int accumulate, float* ws, size_t ws_bytes) {
+                                    float* dw, float* db, int accumulate, float* ws, size_t ws_bytes) {
     ConvArgs c;
     VC_CHECK_ARG(x && dy && dw && B > 0 && H > 0 && W > 0, "bad argument");
     if (make_geom(c.g, B, H, W, Cin, Cout)) return fail(VC_EINVAL, "%s: Cin/Cout must be powers of two >= 4", __func__);
     WgradPlan p = plan_wgrad(c.g);
     const long MN = 9L * Cin * Cout;
-    if (!ws || ws_bytes < (size_t)p.splits * MN * sizeof(float))
+    if (!ws || ws_bytes < (size_t)p.splits * (MN + Cout) * sizeof(float))
         return fail(VC_EWORKSPACE, "%s: workspace too small (need vc_conv3x3_wgrad_workspace_bytes)", __func__);
     c.a = x; c.b = dy; c.out = ws; c.aux = nullptr; c.relu = 0; c.kchunk = p.kchunk;
+    c.bias_ws = db ? ws + (size_t)p.splits * MN : nullptr;
     launch_conv<CONV_WGRAD>((hipStream_t)stream, c, 9 * Cin, Cout, p.splits);
     VC_LAUNCH_CHECK();
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(MN)), dim3(256), 0, (hipStream_t)stream, ws, p.splits, MN, dw, accumulate);
     VC_LAUNCH_CHECK();
+    if (db) {
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(Cout)), dim3(256), 0, (hipStream_t)stream, c.bias_ws, p.splits, (long)Cout, db, accumulate);
+        VC_LAUNCH_CHECK();
+    }
     return 0;
 }
 

@@ -119,9 +119,15 @@ struct Stage {
 // ---------------------------------------------------------------------------
 // ABL (ablation bits, debugging/benchmark only, see tools/microbench.py): 1 = no global loads after
 // the prologue, 2 = no LDS stores / barriers, 4 = no LDS fragment reads.  ABL = 0 is the product path.
-template <class CFG, int AMODE, int BMODE, class ALoader, class BLoader, int ABL = 0>
+// Hook: called by every thread once per K-tile right after the tile became visible in LDS (As, Bs);
+// lets a kernel fold an extra reduction over a staged operand into the loop (conv wgrad: bias gradient).
+struct NoTileHook {
+    __device__ __forceinline__ void operator()(const float*, const float*) const {}
+};
+
+template <class CFG, int AMODE, int BMODE, class ALoader, class BLoader, int ABL = 0, class Hook = NoTileHook>
 __device__ __forceinline__ void mfma_mainloop(f32x16 (&acc)[CFG::TM][CFG::TN], ALoader A, BLoader B,
-                                              int m0, int n0, int k_begin, int k_end, float* smem) {
+                                              int m0, int n0, int k_begin, int k_end, float* smem, Hook hook = Hook()) {
     constexpr int TM = CFG::TM, TN = CFG::TN, BM = CFG::BM, BN = CFG::BN, NT = CFG::NT;
     using SA = Stage<BM, NT, AMODE>;
     using SB = Stage<BN, NT, BMODE>;
@@ -165,6 +171,7 @@ __device__ __forceinline__ void mfma_mainloop(f32x16 (&acc)[CFG::TM][CFG::TN], A
             __syncthreads();
         }
         if (!(ABL & 1) && k0 + 32 < k_end) gload(k0 + 32);
+        hook(As, Bs);
 #pragma unroll
         for (int c = 0; c < 2; ++c) {  // two chunks of 8 MFMA k-steps
             if (!(ABL & 4))

@@ -179,11 +179,10 @@ class VggEngine(object):
             cr = 3 if ci == 4 else ci  # algorithmic channel count (conv1_1 is zero-padded 3 -> 4)
             fl = 2.0 * B * H * W * 9 * cr * co
             if ci == 4:
-                self._timed("conv_wgrad", fl, lambda x=x, d=d: lib.vc_conv3x3_wgrad_f32(st, B, H, W, ci, co, P(x), P(d), P(dw4), 0, P(self.ws), self.ws_bytes))
+                self._timed("conv_wgrad", fl, lambda x=x, d=d, bn=bn: lib.vc_conv3x3_wgrad_f32(st, B, H, W, ci, co, P(x), P(d), P(dw4), P(S.grad(bn)), 0, P(self.ws), self.ws_bytes))
                 lib.vc_pad_dim_f32(st, P(dw4), 9, 4, 3, 64, P(S.grad(wn)))
             else:
-                self._timed("conv_wgrad", fl, lambda x=x, d=d, wn=wn: lib.vc_conv3x3_wgrad_f32(st, B, H, W, ci, co, P(x), P(d), P(S.grad(wn)), 0, P(self.ws), self.ws_bytes))
-            self.colsum(d, B * H * W, co, S.grad(bn))
+                self._timed("conv_wgrad", fl, lambda x=x, d=d, wn=wn, bn=bn: lib.vc_conv3x3_wgrad_f32(st, B, H, W, ci, co, P(x), P(d), P(S.grad(wn)), P(S.grad(bn)), 0, P(self.ws), self.ws_bytes))
             if li > 0:
                 prev_is_pool = self.acts[li - 1][0] == "P"
                 dx = self._b("dx_%d" % li, (B, H, W, ci))
