@@ -33,29 +33,52 @@ def _round(n, m=64):
 
 
 class KernelTimer(object):
-    """HIP-event pairs around selected kernel launches, recorded on the launch stream inside the
-    timed region of bench.py (roofline.achieved = algorithmic FLOPs / summed event time)."""
+    """HIP-event pairs around selected kernel launches, recorded on the stream each launch goes to,
+    inside the timed region of bench.py.  Kernels of one family may overlap (weight- and data-gradient
+    convolutions run on two streams), so busy time is the UNION of their [start, end] intervals:
+    roofline.achieved = algorithmic FLOPs / union time."""
 
     def __init__(self):
         self.recs = []
+        self.base = None
 
     def run(self, tag, flops, fn):
         st = torch.cuda.current_stream()
+        if self.base is None:
+            self.base = torch.cuda.Event(enable_timing=True)
+            self.base.record(st)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(st)
         fn()
         e1.record(st)
         self.recs.append((tag, flops, e0, e1))
 
-    def summary(self):
+    @staticmethod
+    def _union(iv):
+        tot, end = 0.0, -1.0
+        for a, b in sorted(iv):
+            if b <= end:
+                continue
+            tot += b - max(a, end)
+            end = b
+        return tot
+
+    def summary(self, family=None):
+        """{tag: launches, flops, seconds (sum of own durations)}; with `family` (list of tags) also
+        returns the union busy time of the family under key '__union__'."""
         torch.cuda.synchronize()
-        out = {}
+        out, iv = {}, []
         for tag, fl, e0, e1 in self.recs:
-            d = out.setdefault(tag, [0, 0.0, 0.0])
-            d[0] += 1
-            d[1] += fl
-            d[2] += e0.elapsed_time(e1) * 1e-3
-        return {k: dict(launches=v[0], flops=v[1], seconds=v[2]) for k, v in out.items()}
+            t0, t1 = self.base.elapsed_time(e0) * 1e-3, self.base.elapsed_time(e1) * 1e-3
+            d = out.setdefault(tag, dict(launches=0, flops=0.0, seconds=0.0))
+            d["launches"] += 1
+            d["flops"] += fl
+            d["seconds"] += t1 - t0
+            if family and tag in family:
+                iv.append((t0, t1))
+        if family:
+            out["__union__"] = self._union(iv)
+        return out
 
 
 class FlatStore(object):

@@ -32,6 +32,11 @@ class VggEngine(object):
         self.seed, self.rank = seed, rank
         self.inject = False
         self.timer = None
+        # the weight gradient of layer l and the data-gradient chain (layer l, then l-1 ...) are independent:
+        # wgrads run on a side stream so that the tail of one kernel (the last partial round of workgroups)
+        # is filled by the other instead of idling the chip
+        import os
+        self.side = torch.cuda.Stream() if os.environ.get("VC_VGG_STREAMS", "2") != "1" else None
         self.part = torch.zeros(self.lib.vc_sumsq_blocks(), dtype=torch.float32, device=device)
 
     def _b(self, name, shape, dtype=torch.float32):
@@ -167,6 +172,9 @@ class VggEngine(object):
         if after_fc is not None:
             after_fc()
         dw4 = self._b("dw1_4", (3, 3, 4, 64))
+        self._need_ws(max(lib.vc_conv3x3_wgrad_workspace_bytes(B, a[2], a[3], a[4], a[5]) for a in self.acts if a[0] != "P"))
+        main = torch.cuda.current_stream()
+        side = self.side
         for li in range(len(self.acts) - 1, -1, -1):
             name, x, H, W, ci, co, w = self.acts[li]
             if name == "P":
@@ -175,19 +183,29 @@ class VggEngine(object):
                 d = dx
                 continue
             wn, bn = spec.vgg_var_names(name)
-            self._need_ws(lib.vc_conv3x3_wgrad_workspace_bytes(B, H, W, ci, co))
             cr = 3 if ci == 4 else ci  # algorithmic channel count (conv1_1 is zero-padded 3 -> 4)
             fl = 2.0 * B * H * W * 9 * cr * co
-            if ci == 4:
-                self._timed("conv_wgrad", fl, lambda x=x, d=d, bn=bn: lib.vc_conv3x3_wgrad_f32(st, B, H, W, ci, co, P(x), P(d), P(dw4), P(S.grad(bn)), 0, P(self.ws), self.ws_bytes))
-                lib.vc_pad_dim_f32(st, P(dw4), 9, 4, 3, 64, P(S.grad(wn)))
+
+            def wgrad(x=x, d=d, wn=wn, bn=bn, ci=ci, co=co, H=H, W=W, fl=fl):
+                sw = _stream()
+                if ci == 4:
+                    self._timed("conv_wgrad", fl, lambda: lib.vc_conv3x3_wgrad_f32(sw, B, H, W, ci, co, P(x), P(d), P(dw4), P(S.grad(bn)), 0, P(self.ws), self.ws_bytes))
+                    lib.vc_pad_dim_f32(sw, P(dw4), 9, 4, 3, 64, P(S.grad(wn)))
+                else:
+                    self._timed("conv_wgrad", fl, lambda: lib.vc_conv3x3_wgrad_f32(sw, B, H, W, ci, co, P(x), P(d), P(S.grad(wn)), P(S.grad(bn)), 0, P(self.ws), self.ws_bytes))
+            if side is not None:
+                side.wait_stream(main)  # d (this layer's pre-activation gradient) is final on the main stream
+                with torch.cuda.stream(side):
+                    wgrad()
             else:
-                self._timed("conv_wgrad", fl, lambda x=x, d=d, wn=wn, bn=bn: lib.vc_conv3x3_wgrad_f32(st, B, H, W, ci, co, P(x), P(d), P(S.grad(wn)), P(S.grad(bn)), 0, P(self.ws), self.ws_bytes))
+                wgrad()
             if li > 0:
                 prev_is_pool = self.acts[li - 1][0] == "P"
                 dx = self._b("dx_%d" % li, (B, H, W, ci))
                 self._timed("conv_dgrad", fl, lambda d=d, w=w, x=x, dx=dx: lib.vc_conv3x3_dgrad_f32(st, B, H, W, ci, co, P(d), P(w), None if prev_is_pool else P(x), P(dx)))
                 d = dx
+        if side is not None:
+            main.wait_stream(side)
 
     def apply_gradients(self, scal):
         """cnn_optimizer: no clipping; Adam(cnn_lr, beta1=0.8) by default; the L2 regulariser's
