@@ -36,7 +36,9 @@ class VggEngine(object):
         # wgrads run on a side stream so that the tail of one kernel (the last partial round of workgroups)
         # is filled by the other instead of idling the chip
         import os
-        self.side = torch.cuda.Stream() if os.environ.get("VC_VGG_STREAMS", "2") != "1" else None
+        nstreams = int(os.environ.get("VC_VGG_STREAMS", "3"))
+        self.side = torch.cuda.Stream() if nstreams >= 2 else None
+        self.side2 = torch.cuda.Stream() if nstreams >= 3 else None
         self.part = torch.zeros(self.lib.vc_sumsq_blocks(), dtype=torch.float32, device=device)
 
     def _b(self, name, shape, dtype=torch.float32):
@@ -45,6 +47,12 @@ class VggEngine(object):
         if t is None or tuple(t.shape) != shape:
             t = torch.zeros(shape, dtype=dtype, device=self.dev)
             self.buf[name] = t
+            # the zero-fill is enqueued on the current stream: the side streams must not touch the new
+            # buffer before it has run (first step only; buffers persist afterwards)
+            cur = torch.cuda.current_stream()
+            for s in (self.side, self.side2):
+                if s is not None and s != cur:
+                    s.wait_stream(cur)
         return t
 
     def _need_ws(self, nbytes):
@@ -104,21 +112,36 @@ class VggEngine(object):
         w4 = self._b("w1_4", (3, 3, 4, 64))
         lib.vc_pad_dim_f32(st, P(S.param("cnn/conv1_1/weights")), 9, 3, 4, 64, P(w4))
         self.acts = []  # (layer name, input tensor, H, W, Cin_eff, Cout, weights used)
+        # The conv / pool chain of one image is independent of every other image: with two streams the
+        # batch is pushed through as two half-batch chains so that the tail of each kernel (its last partial
+        # round of workgroups) overlaps the other chain's kernels.  Halves are contiguous NHWC slices.
+        main = torch.cuda.current_stream()
+        side = self.side if (self.side is not None and B % 2 == 0 and B >= 2) else None
+        halves = [(0, B // 2, main), (B // 2, B // 2, side)] if side is not None else [(0, B, main)]
+        if side is not None:
+            side.wait_stream(main)
         for name, ci, co in spec.VGG_CONV:
             wn, bn = spec.vgg_var_names(name)
             cie = 4 if ci == 3 else ci
             w = w4 if ci == 3 else S.param(wn)
             y = self._b("y_" + name, (B, H, W, co))
-            self._timed("conv_fwd", 2.0 * B * H * W * 9 * ci * co,
-                        lambda x=x, w=w, y=y, H=H, W=W, cie=cie, co=co, bn=bn: lib.vc_conv3x3_fwd_f32(st, B, H, W, cie, co, P(x), P(w), P(S.param(bn)), P(y), 1))
+            pooled = name in spec.VGG_POOL_AFTER
+            yp = self._b("p_" + name, (B, H // 2, W // 2, co)) if pooled else None
+            for b0, nb, strm in halves:
+                with torch.cuda.stream(strm):
+                    sh = _stream()
+                    self._timed("conv_fwd", 2.0 * nb * H * W * 9 * ci * co,
+                                lambda: lib.vc_conv3x3_fwd_f32(sh, nb, H, W, cie, co, P(x[b0:]), P(w), P(S.param(bn)), P(y[b0:]), 1))
+                    if pooled:
+                        lib.vc_maxpool2x2_fwd_f32(sh, nb, H, W, co, P(y[b0:]), P(yp[b0:]))
             self.acts.append((name, x, H, W, cie, co, w))
             x = y
-            if name in spec.VGG_POOL_AFTER:
-                yp = self._b("p_" + name, (B, H // 2, W // 2, co))
-                lib.vc_maxpool2x2_fwd_f32(st, B, H, W, co, P(x), P(yp))
+            if pooled:
                 self.acts.append(("P", x, H, W, co, co, None))
                 x = yp
                 H, W = H // 2, W // 2
+        if side is not None:
+            main.wait_stream(side)
         flat = x  # [B, 7, 7, 512] NHWC == [B, 25088] (image_embeddings.py:222)
         self.flat = flat
         F1 = H * W * 512
@@ -174,12 +197,21 @@ class VggEngine(object):
         dw4 = self._b("dw1_4", (3, 3, 4, 64))
         self._need_ws(max(lib.vc_conv3x3_wgrad_workspace_bytes(B, a[2], a[3], a[4], a[5]) for a in self.acts if a[0] != "P"))
         main = torch.cuda.current_stream()
-        side = self.side
+        side, side2 = self.side, self.side2
+        # streams: with 3, the data-gradient chain runs as two half-batch chains (main, side) and every
+        # weight gradient (full batch) on side2; with 2, one full-batch chain (main) + weight gradients (side)
+        split = side2 is not None and B % 2 == 0
+        wst = side2 if split else side
+        halves = [(0, B // 2, main), (B // 2, B // 2, side)] if split else [(0, B, main)]
+        if split:
+            side.wait_stream(main)
         for li in range(len(self.acts) - 1, -1, -1):
             name, x, H, W, ci, co, w = self.acts[li]
             if name == "P":
                 dx = self._b("dx_%d" % li, (B, H, W, co))
-                lib.vc_maxpool2x2_bwd_f32(st, B, H, W, co, P(x), P(d), P(dx), 1)  # + ReluGrad of the conv that made x
+                for b0, nb, strm in halves:
+                    with torch.cuda.stream(strm):  # + ReluGrad of the conv that made x
+                        lib.vc_maxpool2x2_bwd_f32(_stream(), nb, H, W, co, P(x[b0:]), P(d[b0:]), P(dx[b0:]), 1)
                 d = dx
                 continue
             wn, bn = spec.vgg_var_names(name)
@@ -193,19 +225,27 @@ class VggEngine(object):
                     lib.vc_pad_dim_f32(sw, P(dw4), 9, 4, 3, 64, P(S.grad(wn)))
                 else:
                     self._timed("conv_wgrad", fl, lambda: lib.vc_conv3x3_wgrad_f32(sw, B, H, W, ci, co, P(x), P(d), P(S.grad(wn)), P(S.grad(bn)), 0, P(self.ws), self.ws_bytes))
-            if side is not None:
-                side.wait_stream(main)  # d (this layer's pre-activation gradient) is final on the main stream
-                with torch.cuda.stream(side):
+            if wst is not None:
+                wst.wait_stream(main)  # d (this layer's pre-activation gradient) is final on the chain stream(s)
+                if split:
+                    wst.wait_stream(side)
+                with torch.cuda.stream(wst):
                     wgrad()
             else:
                 wgrad()
             if li > 0:
                 prev_is_pool = self.acts[li - 1][0] == "P"
                 dx = self._b("dx_%d" % li, (B, H, W, ci))
-                self._timed("conv_dgrad", fl, lambda d=d, w=w, x=x, dx=dx: lib.vc_conv3x3_dgrad_f32(st, B, H, W, ci, co, P(d), P(w), None if prev_is_pool else P(x), P(dx)))
+                for b0, nb, strm in halves:
+                    with torch.cuda.stream(strm):
+                        sh = _stream()
+                        self._timed("conv_dgrad", fl * nb / B, lambda: lib.vc_conv3x3_dgrad_f32(
+                            sh, nb, H, W, ci, co, P(d[b0:]), P(w), None if prev_is_pool else P(x[b0:]), P(dx[b0:])))
                 d = dx
-        if side is not None:
+        if split:
             main.wait_stream(side)
+        if wst is not None:
+            main.wait_stream(wst)
 
     def apply_gradients(self, scal):
         """cnn_optimizer: no clipping; Adam(cnn_lr, beta1=0.8) by default; the L2 regulariser's
