@@ -200,7 +200,8 @@ def main():
     tj = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
     if os.path.exists(tj):
         t = json.load(open(tj))
-        roof["traffic"] = t.get("bytes_per_launch")
+        # PMC bytes are per STEP (the launch count per step depends on VC_VGG_STREAMS: half-batch launches)
+        roof["traffic"] = round(t["bytes_per_step"] * (max(2, args.steps // 4) if instrumented_pass else args.steps) / roof["launches"]) if "bytes_per_step" in t else t.get("bytes_per_launch")
         roof["traffic_source"] = t.get("source")
     out = {
         "metric": "captions/sec training (224x224, seq20, vocab~10k)",
@@ -287,7 +288,11 @@ def roofline_from_timer(timer, fine_tune):
                    tflops=round(sm[t]["flops"] / sm[t]["seconds"] / 1e12, 2)) for t in tags}
     return {"bound": "mfma", "kernel": "vc::conv_kernel<TileCfg,{fwd,dgrad,wgrad}>" if fine_tune else "vc::gemm_kernel<128x128,MK,KM> (logits)",
             "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-            "traffic": None, "launches": n, "avg_launch_us": round(1e6 * sec / n, 2), "per_kernel": per}
+            "traffic": None, "launches": n, "avg_launch_us": round(1e6 * sec / n, 2), "per_kernel": per,
+            "streams": int(os.environ.get("VC_VGG_STREAMS", "3")) if fine_tune else 1,
+            "note": "achieved = algorithmic FLOPs of the family / UNION of its launch intervals (HIP events on each launch's own stream); "
+                    "per_kernel.avg_us are per-launch durations and agree with rocprofv3's averages -- with >1 stream the launches share "
+                    "the chip, so per-launch TFLOP/s is not the family rate (VC_VGG_STREAMS=1 gives the serial figures, profiles/README.md)"}
 
 
 if __name__ == "__main__":

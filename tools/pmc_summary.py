@@ -25,7 +25,7 @@ def main(root):
     data = defaultdict(lambda: defaultdict(float))
     calls = defaultdict(int)
     dur = defaultdict(float)
-    for f in glob.glob(os.path.join(root, "*", "*counter_collection.csv")):
+    for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
         seen = set()
         for r in csv.DictReader(open(f)):
             fam = family(r["Kernel_Name"])
