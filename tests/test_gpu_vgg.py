@@ -126,3 +126,42 @@ def test_fine_tune_step_matches_oracle(lib):
     for n in ("cnn/conv3_2/weights", "cnn/fc2/weights", "cnn/conv1_1/biases"):
         upd = np.abs(PVn[n] - PV[n]).max()
         assert rel_l2(new[n] - PV[n], PVn[n] - PV[n]) < 2e-2, (n, rel_l2(new[n] - PV[n], PVn[n] - PV[n]), upd)
+
+
+def test_half_batch_chains_on_three_streams(lib, monkeypatch):
+    """B = 2: the default three-stream schedule (two half-batch conv/pool chains + weight gradients on a
+    third stream, trainer.VggEngine) vs the fp64 oracle forward, vs the oracle backward on the device's
+    forward decisions, and BIT-identical to the serial one-stream schedule (two steps: the first allocates)."""
+    p = Parameters()
+    p.fine_tune = True
+    rng = np.random.default_rng(12)
+    PV = spec.init_vgg_params(seed=4)
+    B = 2
+    img = rng.integers(0, 256, size=(B, 224, 224, 3)).astype(np.float32)
+    d1 = (rng.random((B, 4096)) < 0.5).astype(np.float32)
+    d2 = (rng.random((B, 4096)) < 0.5).astype(np.float32)
+    dfc2 = rng.normal(size=(B, 4096)).astype(np.float32)
+    P64 = {k: v.astype(np.float64) for k, v in PV.items()}
+    fc2_ref, cache = ov.forward(P64, img.astype(np.float64), d1.astype(np.float64), d2.astype(np.float64), keep=0.5)
+    res = {}
+    for ns in ("3", "1"):
+        monkeypatch.setenv("VC_VGG_STREAMS", ns)
+        eng = VggEngine(p, lib=lib)
+        assert (eng.side2 is not None) == (ns == "3")
+        eng.load_params(PV)
+        eng.set_masks(d1, d2)
+        for _ in range(2):
+            fc2 = eng.forward(torch.from_numpy(img).cuda())
+            eng.backward(torch.from_numpy(dfc2).cuda())
+        torch.cuda.synchronize()
+        res[ns] = (fc2.clone(), eng.store.g.clone())
+        if ns == "3":
+            assert rel_l2(fc2.cpu().numpy(), fc2_ref) < 2e-5
+            for name, x, y in [c for c in cache["conv"] if c[0] != "P"]:
+                assert rel_l2(eng.buf["y_" + name].cpu().numpy(), y) < 2e-5, name
+            G = eng.grads_dict()
+            Gdev = ov.backward(P64, device_cache(eng, P64, 0.5), dfc2.astype(np.float64))
+            for n, ref in Gdev.items():
+                assert rel_l2(G[n], ref) < 1e-4, (n, rel_l2(G[n], ref))
+    assert torch.equal(res["3"][0], res["1"][0])
+    assert torch.equal(res["3"][1], res["1"][1])
