@@ -218,6 +218,14 @@ int vc_maxpool2x2_bwd_f32(void* stream, int B, int H, int W, int C, const float*
 int vc_vgg_preprocess_f32(void* stream, const float* images, int B, int H, int W, float* out_nhwc4);
 int vc_pad_dim_f32(void* stream, const float* src, long outer, int c_src, int c_dst, int inner, float* dst);
 
+/* ------------------------------------------------------------------------------------
+ * Host-side helper (the only entry point that takes HOST pointers): CRC-32C (Castagnoli) of a byte
+ * range, continuing from *crc_inout (start with 0).  Used by the TensorFlow V2 checkpoint
+ * ("tensor bundle") reader / writer for the per-tensor and per-block checksums
+ * (main.py:189-190,286-288 tf.train.Saver; gen_caption.py:113-115 saver.restore).
+ * ---------------------------------------------------------------------------------- */
+int vc_host_crc32c(const void* data, size_t nbytes, uint32_t* crc_inout);
+
 #ifdef __cplusplus
 }
 #endif

@@ -71,6 +71,9 @@ def main(params):
         from vae_captioning_amd.utils.captions import Captions, Dictionary
         caps = Captions(params.captions_json)
         cap_dict = Dictionary(caps.captions, params.keep_words)
+        os.makedirs("./pickles", exist_ok=True)  # utils/captions.py:122-125: the vocabulary source gen_caption.py reloads
+        with open("./pickles/capt_vocab.pickle", "wb") as wf:
+            pickle.dump(file=wf, obj=caps.captions)
         with open(params.features_pickle, "rb") as rf:
             feats = pickle.load(rf)
         cvs = None
@@ -88,9 +91,11 @@ def main(params):
     params._vc_trainer = tr  # the facades below share it (session.get)
     tr.load_state_dict({**spec.init_caption_params(params, params.vocab_size, seed=params.seed),
                         **(spec.init_vgg_params(seed=params.seed) if params.fine_tune else {})})
-    ckpt = "./checkpoints/%s.ckpt.npz" % params.checkpoint
+    # saver.save(sess, "./checkpoints/{}.ckpt") (main.py:286-288): TF V2 checkpoint files by default,
+    # --ckpt_format npz for a name-keyed numpy archive
+    ckpt = "./checkpoints/%s.ckpt" % params.checkpoint + (".npz" if params.ckpt_format == "npz" else "")
     if params.restore or params.mode == "inference":
-        if os.path.exists(ckpt):
+        if os.path.exists(ckpt if params.ckpt_format == "npz" else ckpt + ".index"):
             print("Restoring from checkpoint")
             tr.restore(ckpt)
     steps_per_epoch = params.max_steps or (params.num_ex_per_epoch // params.batch_size + 1)  # main.py:217-221

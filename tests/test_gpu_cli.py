@@ -98,8 +98,12 @@ def test_main_cli_training_then_inference(tmp_path):
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "Validation reconstruction loss" in r.stdout and "Model saved in file" in r.stdout
-    z = np.load(tmp_path / "checkpoints" / "clitest.ckpt.npz")
-    assert "encoder/ag_ll_89/dense_1/kernel" in z.files and z["decoder/rnn_logits/kernel"].shape == (64, 300)
+    # saver.save writes TF V2 checkpoint files (main.py:286-288)
+    from vae_captioning_amd import tf_bundle
+    assert sorted(os.listdir(tmp_path / "checkpoints")) == ["checkpoint", "clitest.ckpt.data-00000-of-00001", "clitest.ckpt.index"]
+    assert tf_bundle.latest_checkpoint(str(tmp_path / "checkpoints")) == str(tmp_path / "checkpoints" / "clitest.ckpt")
+    z = tf_bundle.read_bundle(str(tmp_path / "checkpoints" / "clitest.ckpt"))
+    assert "encoder/ag_ll_89/dense_1/kernel" in z and z["decoder/rnn_logits/kernel"].shape == (64, 300)
     assert z["decoder/net/z_rnn/kernel"].shape == (4 * 10, 32)
     r = subprocess.run(base + ["--mode", "inference", "--sample_gen", "greedy", "--prior", "AG", "--c_v", "--gen_name", "t1"],
                        cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
@@ -134,3 +138,60 @@ def test_bench_two_ranks_through_torchrun_on_one_gpu(tmp_path):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert d["n_gpus"] == 2 and np.isfinite(d["final_losses"]["rec_loss"]) and np.isfinite(d["final_losses"]["kld"])
+
+
+def test_gen_caption_cli_single_image(tmp_path, lib):
+    """gen_caption.py (:134-165): params pickle + vocabulary pickle + TF-format checkpoint + an image file ->
+    caption.  LSTM baseline (--no_encoder: deterministic); the token ids must equal the oracle's greedy decode
+    of the features the device VGG16 extracts from the same resized image."""
+    import pickle
+    from PIL import Image
+    from oracle import decode as od
+    from vae_captioning_amd import tf_bundle
+    from vae_captioning_amd.trainer import VggEngine
+    from vae_captioning_amd.utils.captions import Dictionary
+    from vae_captioning_amd.utils.image_utils import keras_load_img
+    rng = np.random.default_rng(21)
+    words = ["w%02d" % i for i in range(25)]
+    caps = {"img%d.jpg" % i: [["<BOS>"] + [words[j] for j in rng.integers(0, 25, size=6)] + ["<EOS>"] for _ in range(5)] for i in range(12)}
+    d = Dictionary(caps, 3)
+    V = d.vocab_size
+    p = Parameters()
+    p.embed_size, p.decoder_hidden, p.encoder_hidden, p.latent_size, p.gen_z_samples = 32, 64, 64, 10, 4
+    p.no_encoder, p.gen_max_len = True, 9
+    PC = spec.init_caption_params(p, V, seed=3)
+    for k in PC:
+        PC[k] = (PC[k] * 3).astype(np.float32)
+    PV = spec.init_vgg_params(seed=4)
+    os.makedirs(tmp_path / "checkpoints")
+    os.makedirs(tmp_path / "pickles")
+    ck = str(tmp_path / "checkpoints" / "gc.ckpt")
+    tf_bundle.write_bundle(ck, {**PC, **PV})
+    with open(tmp_path / "pickles" / "params.pickle", "wb") as f:
+        pickle.dump(dict(embed_size=32, decoder_hidden=64, encoder_hidden=64, latent_size=10, gen_z_samples=4, no_encoder=True,
+                         gen_max_len=9, keep_words=3, use_c_v=False, prior="Normal"), f)
+    with open(tmp_path / "pickles" / "capt_vocab.pickle", "wb") as f:
+        pickle.dump(caps, f)
+    img = rng.integers(0, 256, size=(200, 300, 3), dtype=np.uint8)
+    Image.fromarray(img).save(tmp_path / "pic.png")
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    cmd = [sys.executable, os.path.join(ROOT, "gen_caption.py"), "--img_path", str(tmp_path / "pic.png"), "--checkpoint", ck,
+           "--params_path", str(tmp_path / "pickles" / "params.pickle"), "--vocab_path", str(tmp_path / "pickles" / "capt_vocab.pickle"),
+           "--gpu", "0"]
+    r = subprocess.run(cmd, cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    caption = r.stdout.strip().splitlines()[-1]
+    # expected: device features of the same NEAREST-resized image -> oracle greedy decode
+    x, _ = keras_load_img(str(tmp_path / "pic.png"))
+    assert x.shape == (1, 224, 224, 3) and x.dtype == np.float32
+    pv = Parameters()
+    pv.mode = "inference"
+    vgg = VggEngine(pv, lib=lib)
+    vgg.load_params(PV)
+    feats = vgg.forward(torch.from_numpy(x).cuda()).cpu().numpy().astype(np.float64)
+    P64 = {k: v.astype(np.float64) for k, v in PC.items()}
+    ref = od.greedy(P64, p, feats[0], None, None, d.word2idx["<BOS>"], d.word2idx["<EOS>"], c_means=None, max_len=9)
+    want = " ".join(d.idx2word[t] for t in ref if t not in (d.word2idx["<BOS>"], d.word2idx["<EOS>"]))
+    assert len(ref) > 0 and caption == want, (caption, want)
+    r = subprocess.run(cmd + ["--gen_method", "beam_search", "--beam_size", "3"], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and len(r.stdout.strip().splitlines()[-1]) > 0, r.stdout + r.stderr

@@ -1,0 +1,105 @@
+"""TF V2 checkpoint (tensor bundle) reader / writer: known answers of the format's primitives and
+write -> read round trips (vae_captioning_amd/tf_bundle.py; main.py:186-191,286-288 tf.train.Saver).
+TensorFlow itself is absent, so files are not cross-checked against a TF-written checkpoint."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from vae_captioning_amd import tf_bundle as tb
+
+
+def test_crc32c_known_answers_and_native_path():
+    # RFC 3720 B.4 / the canonical check value
+    assert tb.crc32c(b"123456789") == 0xE3069283
+    assert tb.crc32c(bytes(32)) == 0x8A9136AA
+    assert tb.crc32c(b"\xff" * 32) == 0x62A8AB43
+    assert tb.crc32c(bytes(range(32))) == 0x46DD794E
+    assert tb.crc32c(bytes(range(31, -1, -1))) == 0x113FDB5C
+    rng = np.random.default_rng(0)
+    big = rng.integers(0, 256, size=100003, dtype=np.uint8)
+    native = tb.crc32c(big)                      # >= 4096 bytes: libvaecap's vc_host_crc32c
+    assert native == tb._crc32c_py(big.tobytes())
+    # continuation: crc(a + b) == crc(b, crc(a)), through both paths
+    assert tb.crc32c(big[5000:], tb.crc32c(big[:5000])) == native
+    assert tb.crc32c(big[:100].tobytes() + big[100:].tobytes()) == native
+    for v in (0, 1, 0xE3069283, 0xFFFFFFFF):
+        assert tb.unmask_crc(tb.mask_crc(v)) == v
+    assert tb.mask_crc(0) == 0xA282EAD8
+
+
+def test_varint_and_proto_bytes():
+    assert tb.varint(0) == b"\x00" and tb.varint(127) == b"\x7f" and tb.varint(300) == b"\xac\x02"
+    assert tb.read_varint(b"\xac\x02\x05", 0) == (300, 2)
+    assert tb.encode_header(1) == bytes.fromhex("08011a020801")
+    assert tb.decode_header(tb.encode_header(1)) == dict(num_shards=1, endianness=0, producer=1)
+    e = tb.encode_entry(1, (3, 2), 0, 0, 24, 0x12345678)
+    #      dtype=1    shape{dim{3} dim{2}}          size=24  crc fixed32
+    assert e == bytes.fromhex("0801" "1208" "12020803" "12020802" "2818" "35" "78563412")
+    d = tb.decode_entry(e)
+    assert (d["dtype"], d["shape"], d["offset"], d["size"], d["crc32c"]) == (1, [3, 2], 0, 24, 0x12345678)
+    d = tb.decode_entry(tb.encode_entry(3, (), 0, 1 << 33, 4, 7))
+    assert d["shape"] == [] and d["offset"] == 1 << 33 and d["dtype"] == 3
+    assert tb.decode_entry(tb.encode_entry(1, (0, 5), 0, 8, 0, 0))["shape"] == [0, 5]
+
+
+def test_table_multi_block_round_trip_and_footer():
+    items = [(("key/%05d/suffix" % i).encode(), os.urandom(1 + i % 40)) for i in range(2000)]
+    buf = tb.build_table(items, block_size=4096)
+    assert buf[-8:] == bytes.fromhex("57fb808b247547db")          # kTableMagicNumber, little-endian
+    assert tb.parse_table(buf) == items
+    one = tb.build_table(items[:3])
+    assert tb.parse_table(one) == items[:3]
+    # first entry of a block is stored whole; the second shares the common prefix
+    k0, v0 = items[0]
+    assert one.startswith(b"\x00" + tb.varint(len(k0)) + tb.varint(len(v0)) + k0 + v0)
+    bad = bytearray(buf)
+    bad[10] ^= 1
+    with pytest.raises(ValueError):
+        tb.parse_table(bytes(bad))
+    with pytest.raises(ValueError):
+        tb.build_table([(b"b", b""), (b"a", b"")])
+    assert tb._shortest_separator(b"abc1", b"abc5") == b"abc2" and tb._shortest_separator(b"abc", b"abd") == b"abc"
+    assert tb._short_successor(b"\xff\xffa") == b"\xff\xffb"
+
+
+def test_bundle_round_trip(tmp_path):
+    rng = np.random.default_rng(1)
+    tensors = {
+        "decoder/rnn_logits/kernel": rng.normal(size=(512, 77)).astype(np.float32),
+        "decoder/rnn_logits/bias": rng.normal(size=(77,)).astype(np.float32),
+        "cnn/conv1_1/weights": rng.normal(size=(3, 3, 3, 64)).astype(np.float32),
+        "global_step": np.array(1234, dtype=np.int32),
+        "encoder/enc_embeddings": rng.normal(size=(100, 256)).astype(np.float32),
+        "lengths": np.arange(7, dtype=np.int64),
+        "empty": np.zeros((0, 4), np.float32),
+    }
+    prefix = str(tmp_path / "last_run.ckpt")
+    tb.write_bundle(prefix, tensors)
+    assert sorted(os.listdir(tmp_path)) == ["checkpoint", "last_run.ckpt.data-00000-of-00001", "last_run.ckpt.index"]
+    assert os.path.getsize(prefix + ".data-00000-of-00001") == sum(a.nbytes for a in tensors.values())
+    assert tb.latest_checkpoint(str(tmp_path)) == prefix
+    header, entries = tb.list_bundle(prefix)
+    assert header == dict(num_shards=1, endianness=0, producer=1)
+    # tensors lie back to back in key order
+    off = 0
+    for n in sorted(tensors, key=lambda s: s.encode()):
+        assert entries[n]["offset"] == off and entries[n]["shape"] == list(tensors[n].shape)
+        off += tensors[n].nbytes
+    got = tb.read_bundle(prefix)
+    assert set(got) == set(tensors)
+    for n, a in tensors.items():
+        assert got[n].dtype == a.dtype and got[n].shape == a.shape and np.array_equal(got[n], a)
+    assert list(tb.read_bundle(prefix, names=["global_step"])) == ["global_step"]
+    with pytest.raises(KeyError):
+        tb.read_bundle(prefix, names=["nope"])
+    # a flipped data byte is caught by the per-tensor checksum
+    with open(prefix + ".data-00000-of-00001", "r+b") as f:
+        f.seek(entries["encoder/enc_embeddings"]["offset"] + 5)
+        b = f.read(1)
+        f.seek(-1, 1)
+        f.write(bytes([b[0] ^ 0x40]))
+    with pytest.raises(ValueError):
+        tb.read_bundle(prefix, names=["encoder/enc_embeddings"])
+    assert np.array_equal(tb.read_bundle(prefix, names=["lengths"])["lengths"], tensors["lengths"])

@@ -108,6 +108,24 @@ def lstm():
         print("lstm bwd seq N=%4d T=%d: %8.3f ms (%.1f us/step) %6.1f TFLOP/s" % (N, T, med, 1e3 * med / T, 2 * fl / med))
 
 
+def fc():
+    """the six VGG fc GEMMs of a 64-image step (weight-bandwidth bound: fc1 = 411 MB, fc2 = 67 MB) + caption-side skinny shapes"""
+    Bn = 64
+    shapes = [("fc1 fwd", 0, 0, Bn, 4096, 25088), ("fc1 dgrad", 0, 1, Bn, 25088, 4096), ("fc1 wgrad", 1, 0, 25088, 4096, Bn),
+              ("fc2 fwd", 0, 0, Bn, 4096, 4096), ("fc2 dgrad", 0, 1, Bn, 4096, 4096), ("fc2 wgrad", 1, 0, 4096, 4096, Bn),
+              ("imf_emb fwd", 0, 0, Bn, 256, 4096), ("imf_emb wgrad", 1, 0, 4096, 256, Bn), ("z_rnn fwd", 0, 0, 320, 256, 15000),
+              ("z_rnn wgrad", 1, 0, 15000, 256, 320), ("z_rnn dgrad", 0, 1, 320, 15000, 256)]
+    for name, ta, tb, M, N, K in shapes:
+        A = rnd(K, M) if ta else rnd(M, K)
+        B = rnd(N, K) if tb else rnd(K, N)
+        C = torch.empty(M, N, device="cuda")
+        ws = torch.empty(max(lib.vc_gemm_workspace_bytes(M, N, K), 16) // 4 + 4, device="cuda")
+        med, mn = timeit(lambda: lib.vc_gemm_f32(st(), ta, tb, M, N, K, P(A), M if ta else K, P(B), K if tb else N, P(C), N, None, 0, P(ws), ws.numel() * 4), reps=5)
+        byts = 4.0 * (M * K + K * N + M * N)
+        print("%-14s ta=%d tb=%d %6d x %6d x %6d: %8.3f ms  %6.1f TFLOP/s  %6.2f TB/s (operands once)  ws %.1f MB" % (
+            name, ta, tb, M, N, K, med, 2e-9 * M * N * K / med, byts / med / 1e9, ws.numel() * 4 / 1e6))
+
+
 if __name__ == "__main__":
     for a in sys.argv[1:] or ["gemm", "ablate", "conv", "lstm"]:
         globals()[a]()

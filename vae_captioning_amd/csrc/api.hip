@@ -25,3 +25,39 @@ extern "C" int vc_device_check(int device) {
         return vc::fail(vc::VC_EINVAL, "%s: device is not gfx950 (MI355X): %s", __func__, (long)0) ;
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// CRC-32C (polynomial 0x1EDC6F41, reflected 0x82F63B78), slicing-by-8, host only.
+namespace vc {
+struct Crc32cTables {
+    uint32_t t[8][256];
+    Crc32cTables() {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : (c >> 1);
+            t[0][i] = c;
+        }
+        for (uint32_t i = 0; i < 256; ++i)
+            for (int s = 1; s < 8; ++s) t[s][i] = (t[s - 1][i] >> 8) ^ t[0][t[s - 1][i] & 0xff];
+    }
+};
+}  // namespace vc
+
+extern "C" int vc_host_crc32c(const void* data, size_t nbytes, uint32_t* crc_inout) {
+    VC_CHECK_ARG(crc_inout && (data || nbytes == 0), "null pointer");
+    static const vc::Crc32cTables T;
+    const unsigned char* p = (const unsigned char*)data;
+    uint32_t c = ~*crc_inout;
+    while (nbytes && ((uintptr_t)p & 7)) { c = (c >> 8) ^ T.t[0][(c ^ *p++) & 0xff]; --nbytes; }
+    while (nbytes >= 8) {
+        uint64_t w;
+        memcpy(&w, p, 8);
+        w ^= c;
+        c = T.t[7][w & 0xff] ^ T.t[6][(w >> 8) & 0xff] ^ T.t[5][(w >> 16) & 0xff] ^ T.t[4][(w >> 24) & 0xff] ^
+            T.t[3][(w >> 32) & 0xff] ^ T.t[2][(w >> 40) & 0xff] ^ T.t[1][(w >> 48) & 0xff] ^ T.t[0][(w >> 56) & 0xff];
+        p += 8; nbytes -= 8;
+    }
+    while (nbytes--) c = (c >> 8) ^ T.t[0][(c ^ *p++) & 0xff];
+    *crc_inout = ~c;
+    return 0;
+}

@@ -221,7 +221,10 @@ class CaptionEngine(object):
                 arr = np.concatenate(ks + ls, axis=0)
             else:
                 arr = named[name]
-            self.store.param(name).copy_(torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)))
+            dst = self.store.param(name)
+            if tuple(np.shape(arr)) != tuple(dst.shape):
+                raise ValueError("%s: checkpoint shape %s, model shape %s" % (name, tuple(np.shape(arr)), tuple(dst.shape)))
+            dst.copy_(torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)))
 
     def _export(self, getter):
         p = self.p

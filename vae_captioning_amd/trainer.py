@@ -76,7 +76,10 @@ class VggEngine(object):
 
     def load_params(self, named):
         for name in self.store.names():
-            self.store.param(name).copy_(torch.from_numpy(np.ascontiguousarray(named[name], dtype=np.float32)))
+            dst = self.store.param(name)
+            if tuple(np.shape(named[name])) != tuple(dst.shape):
+                raise ValueError("%s: checkpoint shape %s, model shape %s" % (name, tuple(np.shape(named[name])), tuple(dst.shape)))
+            dst.copy_(torch.from_numpy(np.ascontiguousarray(named[name], dtype=np.float32)))
 
     def load_weights(self, weight_file):
         """utils/image_embeddings.py:240-246: first 30 alphabetically sorted npz arrays."""
@@ -379,10 +382,21 @@ class Trainer(object):
             self.vgg.load_params(d)
 
     def save(self, path):
-        """Name-keyed tensor file with the reference's variable names (main.py:186-191).
-        Optimiser slots and global_step are not saved (Q11)."""
-        np.savez(path, **self.state_dict())
+        """saver.save (main.py:286-288): the trainable variables under the reference's names
+        (main.py:186-191; optimiser slots and global_step are not in its var list, Q11).
+        `path` ending in .npz -> a name-keyed numpy archive; anything else is a TensorFlow V2 checkpoint
+        prefix (<path>.index + <path>.data-00000-of-00001 + `checkpoint`, tf_bundle.py)."""
+        if path.endswith(".npz"):
+            np.savez(path, **self.state_dict())
+        else:
+            from . import tf_bundle
+            tf_bundle.write_bundle(path, self.state_dict())
 
     def restore(self, path):
-        with np.load(path) as z:
-            self.load_state_dict({k: z[k] for k in z.files})
+        """saver.restore (main.py:201-204, gen_caption.py:113-115): every variable of this model must be present."""
+        if path.endswith(".npz"):
+            with np.load(path) as z:
+                self.load_state_dict({k: z[k] for k in z.files})
+        else:
+            from . import tf_bundle
+            self.load_state_dict(tf_bundle.read_bundle(path))

@@ -75,6 +75,7 @@ class Parameters(object):
     captions_json = None
     features_pickle = None
     cluster_pickle = None
+    ckpt_format = "tf"    # "tf": TensorFlow V2 checkpoint files (what tf.train.Saver writes); "npz": numpy archive
 
     def build_parser(self):
         p = argparse.ArgumentParser(description="CVAE / AG-CVAE captioning trainer (MI355X)")
@@ -112,6 +113,7 @@ class Parameters(object):
         a("--max_steps", default=self.max_steps)
         a("--captions_json", default=None, help="COCO captions json (real-data path; with --features_pickle)")
         a("--features_pickle", default=None, help="pickle {file_name: fc2 feature [1,4096]} (reference format)")
+        a("--ckpt_format", default=self.ckpt_format, choices=["tf", "npz"], help="checkpoint file format")
         a("--cluster_pickle", default=None, help="pickle {file_name: 91-vector} (reference ./obj_vectors/c_v.pickle)")
         return p
 
@@ -146,6 +148,7 @@ class Parameters(object):
         self.seed = int(args.seed)
         self.max_steps = int(args.max_steps)
         self.captions_json, self.features_pickle, self.cluster_pickle = args.captions_json, args.features_pickle, args.cluster_pickle
+        self.ckpt_format = args.ckpt_format
         if self.synthetic:
             self.vocab_size = int(args.vocab)
         self.hdf5_file = self.coco_dir + self.hdf5_file.split("/")[-1]
