@@ -176,9 +176,12 @@ class VggEngine(object):
         lib.vc_reduce_sum_f32(st, P(self.part), self.part.numel(), 1.0, out_ptr, 0)
 
     # ------------------------------------------------------------------ backward
-    def backward(self, dfc2, after_fc=None):
+    def backward(self, dfc2, after_fc=None, after_layer=None):
         """after_fc: optional callback invoked as soon as the fc1 / fc2 gradients (89 % of the VGG
-        gradient bytes) are final, so their all-reduce can overlap the convolution backward."""
+        gradient bytes) are final, so their all-reduce can overlap the convolution backward.
+        after_layer: optional (conv layer name, callback): invoked on the weight-gradient stream right after
+        that layer's weight gradient has been enqueued (every gradient of that layer and of the layers
+        above it is then final in stream order)."""
         lib, st, S = self.lib, _stream(), self.store
         B = self.B
         m1 = P(self.buf["drop1"]) if self.keep < 1 else None
@@ -234,8 +237,12 @@ class VggEngine(object):
                     wst.wait_stream(side)
                 with torch.cuda.stream(wst):
                     wgrad()
+                    if after_layer is not None and after_layer[0] == name:
+                        after_layer[1]()
             else:
                 wgrad()
+                if after_layer is not None and after_layer[0] == name:
+                    after_layer[1]()
             if li > 0:
                 prev_is_pool = self.acts[li - 1][0] == "P"
                 dx = self._b("dx_%d" % li, (B, H, W, ci))
@@ -286,12 +293,14 @@ class Trainer(object):
         self.graph = None
         self.n_cap = n_cap
         # Data-parallel gradient exchange.  Logically ONE sum-all-reduce of `gall` per step; with VGG
-        # fine-tuning it is issued as three asynchronous pieces in the order the gradients become final
-        # (caption side | fc1+fc2 | convolutions) so that RCCL overlaps the convolution backward
+        # fine-tuning it is issued as four asynchronous pieces in the order the gradients become final
+        # (caption side | fc1+fc2, 478 MB | conv3_1..conv5_3, 58 MB | conv1_1..conv2_2, 1 MB) so that RCCL
+        # overlaps the convolution backward and only the last megabyte is exposed
         # (VC_DP_BUCKETS=0 forces the single blocking call).
         import os
         self.buckets = os.environ.get("VC_DP_BUCKETS", "1") != "0"
         self.off_fc = n_cap + self.vgg.store.offset("cnn/fc1/weights") if self.vgg is not None else None
+        self.off_c3 = n_cap + self.vgg.store.offset("cnn/conv3_1/weights") if self.vgg is not None else None
 
     def set_batch(self, batch, noise=None):
         self.cap.set_batch(batch, noise)
@@ -315,8 +324,9 @@ class Trainer(object):
         cap.pack_tail()
         if self.collectives and self.buckets and vgg is not None and vgg.train and self.reduce_async_fn is not None:
             pending = [self.reduce_async_fn(self.gall[:self.n_cap])]
-            vgg.backward(dfe, after_fc=lambda: pending.append(self.reduce_async_fn(self.gall[self.off_fc:])))
-            pending.append(self.reduce_async_fn(self.gall[self.n_cap:self.off_fc]))
+            vgg.backward(dfe, after_fc=lambda: pending.append(self.reduce_async_fn(self.gall[self.off_fc:])),
+                         after_layer=("conv3_1", lambda: pending.append(self.reduce_async_fn(self.gall[self.off_c3:self.off_fc]))))
+            pending.append(self.reduce_async_fn(self.gall[self.n_cap:self.off_c3]))
             for h in pending:
                 h.wait()
         else:
