@@ -405,7 +405,7 @@ def test_philox_bit_exact_and_moments(lib):
 
 # ----------------------------------------------------------------------------- VGG kernels
 CONV_CASES = [(2, 8, 6, 4, 8), (1, 14, 14, 64, 128), (2, 12, 10, 64, 64), (1, 7, 7, 512, 512), (3, 16, 16, 4, 64),
-              (1, 28, 28, 128, 256)]
+              (1, 28, 28, 128, 256), (1, 10, 10, 64, 256)]
 
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))

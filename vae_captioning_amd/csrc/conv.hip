@@ -123,14 +123,17 @@ struct ConvArgs {
 
 // Column sums of the dy tile staged in LDS (KM image Bs[k][BN+4]); thread t owns column t % BN and the
 // k rows [part*PER, part*PER + PER), part = t / BN.
+constexpr int colsum_parts(int groups) { return groups >= 32 ? 32 : groups >= 16 ? 16 : groups >= 8 ? 8 : groups >= 4 ? 4 : groups >= 2 ? 2 : 1; }
+
 template <class CFG>
 struct ColsumHook {
     float* acc;
     bool on;
     __device__ __forceinline__ void operator()(const float*, const float* Bs) const {
         if (!on) return;
-        constexpr int PARTS = CFG::NT / CFG::BN, PER = 32 / PARTS;
+        constexpr int PARTS = colsum_parts(CFG::NT / CFG::BN), PER = 32 / PARTS;
         const int col = threadIdx.x % CFG::BN, part = threadIdx.x / CFG::BN;
+        if (part >= PARTS) return;  // thread counts that are 3 x BN: the third group idles
         float s = 0.f;
 #pragma unroll
         for (int k = 0; k < PER; ++k) s += Bs[(part * PER + k) * (CFG::BN + 4) + col];
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(CFG::NT) void conv_kernel(ConvArgs c) {
         ColsumHook<CFG> hook{&csum, do_bias};
         mfma_mainloop<CFG, MODE_KM, MODE_KM, LoadPixelsKM, LoadKM<true>, 0, ColsumHook<CFG>>(acc, la, lb, m0, n0, (int)kb, (int)ke, smem, hook);
         if (do_bias) {  // combine the NT/BN partial sums of each column (fixed order) and store the split's partial
-            constexpr int PARTS = CFG::NT / CFG::BN;
+            constexpr int PARTS = colsum_parts(CFG::NT / CFG::BN);
             __syncthreads();
             smem[threadIdx.x] = csum;
             __syncthreads();
@@ -249,12 +252,17 @@ static int make_geom(ConvGeom& g, int B, int H, int W, int Cin, int Cout) {
 struct WgradPlan {
     int splits, kchunk;
 };
-static int wgrad_bm(int Cin, int Cout) { return 9 * Cin <= 64 ? 64 : (Cout <= 64 ? 256 : 128); }
+// 9*64 = 576 rows = 3 x 192 exactly: the 64-input-channel layers (conv1_2, conv2_1) get 192-row tiles
+// (256- / 128-row tiles would compute 768 / 640 rows: 25 % / 10 % of the MFMAs wasted)
+static int wgrad_bm(int Cin, int Cout) { return 9 * Cin <= 64 ? 64 : (Cin == 64 ? 192 : (Cout <= 64 ? 256 : 128)); }
 static int wgrad_bn(int Cin, int Cout) { return Cout <= 64 ? 64 : 128; }
 
 static WgradPlan plan_wgrad(const ConvGeom& g) {
     const long tiles = (long)cdiv(9 * g.Cin, wgrad_bm(g.Cin, g.Cout)) * cdiv(g.Cout, wgrad_bn(g.Cin, g.Cout));
-    long splits = (1024 + tiles - 1) / tiles;
+    // Cin == 64 (192-row tiles): exactly one round of resident workgroups -- the 192 x 64 kernel (152 VGPRs) runs
+    // 3 per CU = 768, the 192 x 128 kernel (212 VGPRs) 2 per CU = 512; measured 94 / 103 TFLOP/s on conv1_2 /
+    // conv2_1 (256- / 128-row tiles: 79 / 84)
+    long splits = g.Cin == 64 ? (g.Cout <= 64 ? 768 : 512) / tiles : (1024 + tiles - 1) / tiles;
     const long maxs = g.P / 512 > 0 ? g.P / 512 : 1;  // >= 16 K-tiles per split
     if (splits > maxs) splits = maxs;
     if (splits > 256) splits = 256;
@@ -266,6 +274,8 @@ static WgradPlan plan_wgrad(const ConvGeom& g) {
 }
 
 using ConvCfgSmall = TileCfg<2, 2, 1, 1>;    //  64 x  64: conv1_1's weight gradient (M = 9*4 rows)
+using ConvCfgW192n = TileCfg<2, 2, 3, 1>;    // 192 x  64, waves 96 x 32: conv1_2's weight gradient (576 x 64)
+using ConvCfgW192w = TileCfg<2, 2, 3, 2>;    // 192 x 128, waves 96 x 64: conv2_1's weight gradient (576 x 128)
 
 template <class C, int KIND>
 static void launch_cfg(hipStream_t st, ConvArgs& c, int Mrows, int Ncols, int splits) {
@@ -278,6 +288,9 @@ template <int KIND>
 static void launch_conv(hipStream_t st, ConvArgs& c, int Mrows, int Ncols, int splits) {
     if (KIND == CONV_WGRAD && Mrows <= 64) {
         launch_cfg<ConvCfgSmall, KIND>(st, c, Mrows, Ncols, splits);
+    } else if (KIND == CONV_WGRAD && Mrows == 576) {
+        if (Ncols <= 64) launch_cfg<ConvCfgW192n, KIND>(st, c, Mrows, Ncols, splits);
+        else launch_cfg<ConvCfgW192w, KIND>(st, c, Mrows, Ncols, splits);
     } else if (Ncols <= 64) {
         launch_cfg<ConvCfgNarrow, KIND>(st, c, Mrows, Ncols, splits);
     } else {  // (halving the tile for the few-tile conv5 layers was measured slower: 0.70 vs 0.62 ms)

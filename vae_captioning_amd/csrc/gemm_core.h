@@ -32,7 +32,9 @@ struct TileCfg {
     static constexpr int NT = WM * WN * 64;
     static constexpr int A_FLOATS = BM * 36;  // >= 32*(BM+4)
     static constexpr int B_FLOATS = BN * 36;
-    static constexpr int SMEM_BYTES = (A_FLOATS + B_FLOATS) * 4;
+    static constexpr int EPI_FLOATS = WM * WN * 32 * (TN * 32 + 4);  // epilogue_rows' per-wave transpose strips
+    static constexpr int SMEM_FLOATS = A_FLOATS + B_FLOATS > EPI_FLOATS ? A_FLOATS + B_FLOATS : EPI_FLOATS;
+    static constexpr int SMEM_BYTES = SMEM_FLOATS * 4;
 };
 
 // ---------------------------------------------------------------------------
@@ -103,8 +105,11 @@ struct LoadKM {
 // ---------------------------------------------------------------------------
 template <int ROWS, int NT, int MODE>
 struct Stage {
-    static constexpr int NV = ROWS * 8 / NT;  // float4 per thread per K-tile
-    static_assert(ROWS * 8 % NT == 0, "tile/threads mismatch");
+    static constexpr int NV = (ROWS * 8 + NT - 1) / NT;  // float4 per thread per K-tile
+    // thread counts that do not divide the tile (192 / 384 threads on a 64 / 128-row operand): the last
+    // slot exists only for the first ROWS*8 - (NV-1)*NT threads
+    static constexpr bool RAGGED = (ROWS * 8) % NT != 0;
+    static __device__ __forceinline__ bool has(int f) { return !RAGGED || f < ROWS * 8; }
     // MK: slot f -> row f/8, k-quad f%8.   KM: slot f -> k-row f/(ROWS/4), row-quad f%(ROWS/4)
     static __device__ __forceinline__ int row(int f) { return MODE == MODE_MK ? (f >> 3) : ((f % (ROWS / 4)) * 4); }
     static __device__ __forceinline__ int kof(int f) { return MODE == MODE_MK ? ((f & 7) * 4) : (f / (ROWS / 4)); }
@@ -141,14 +146,18 @@ __device__ __forceinline__ void mfma_mainloop(f32x16 (&acc)[CFG::TM][CFG::TN], A
     static_assert(SA::NV <= MAXNV && SB::NV <= MAXNV, "too many slots per thread");
     float4 ra[SA::NV], rb[SB::NV];
 #pragma unroll
-    for (int u = 0; u < SA::NV; ++u) A.init(u, m0 + SA::row(tid + u * NT), SA::kof(tid + u * NT));
+    for (int u = 0; u < SA::NV; ++u)
+        if (SA::has(tid + u * NT)) A.init(u, m0 + SA::row(tid + u * NT), SA::kof(tid + u * NT));
 #pragma unroll
-    for (int u = 0; u < SB::NV; ++u) B.init(u, n0 + SB::row(tid + u * NT), SB::kof(tid + u * NT));
+    for (int u = 0; u < SB::NV; ++u)
+        if (SB::has(tid + u * NT)) B.init(u, n0 + SB::row(tid + u * NT), SB::kof(tid + u * NT));
     auto gload = [&](int k0) {
 #pragma unroll
-        for (int u = 0; u < SA::NV; ++u) ra[u] = A.load(u, k0);
+        for (int u = 0; u < SA::NV; ++u)
+            if (SA::has(tid + u * NT)) ra[u] = A.load(u, k0);
 #pragma unroll
-        for (int u = 0; u < SB::NV; ++u) rb[u] = B.load(u, k0);
+        for (int u = 0; u < SB::NV; ++u)
+            if (SB::has(tid + u * NT)) rb[u] = B.load(u, k0);
     };
     if (k_begin < k_end) gload(k_begin);
     float a[TM][8], b[TN][8];
@@ -165,9 +174,11 @@ __device__ __forceinline__ void mfma_mainloop(f32x16 (&acc)[CFG::TM][CFG::TN], A
         if (!(ABL & 2) || k0 == k_begin) {
             __syncthreads();
 #pragma unroll
-            for (int u = 0; u < SA::NV; ++u) *reinterpret_cast<float4*>(&As[SA::lds(tid + u * NT)]) = ra[u];
+            for (int u = 0; u < SA::NV; ++u)
+                if (SA::has(tid + u * NT)) *reinterpret_cast<float4*>(&As[SA::lds(tid + u * NT)]) = ra[u];
 #pragma unroll
-            for (int u = 0; u < SB::NV; ++u) *reinterpret_cast<float4*>(&Bs[SB::lds(tid + u * NT)]) = rb[u];
+            for (int u = 0; u < SB::NV; ++u)
+                if (SB::has(tid + u * NT)) *reinterpret_cast<float4*>(&Bs[SB::lds(tid + u * NT)]) = rb[u];
             __syncthreads();
         }
         if (!(ABL & 1) && k0 + 32 < k_end) gload(k0 + 32);
@@ -224,6 +235,7 @@ __device__ __forceinline__ void mfma_mainloop_db(f32x16 (&acc)[CFG::TM][CFG::TN]
     constexpr int BUF = CFG::A_FLOATS + CFG::B_FLOATS;
     using SA = Stage<BM, NT, AMODE>;
     using SB = Stage<BN, NT, BMODE>;
+    static_assert(!SA::RAGGED && !SB::RAGGED, "double-buffered variant: thread count must divide the tiles");
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / CFG::WN, wn = wave % CFG::WN;
@@ -342,7 +354,7 @@ __device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[CFG::TM][CFG::TN], f
     constexpr int LD = TN * 32 + 4;        // floats per staged row (16-B aligned, rows 4 banks apart)
     constexpr int QPR = TN * 8;            // float4 per row
     constexpr int RPP = 64 / QPR;          // rows per pass
-    static_assert(CFG::WM * CFG::WN * 32 * LD <= CFG::A_FLOATS + CFG::B_FLOATS, "epilogue strip does not fit the tile LDS");
+    static_assert(CFG::WM * CFG::WN * 32 * LD <= CFG::SMEM_FLOATS, "epilogue strip does not fit the tile LDS");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / CFG::WN, wn = wave % CFG::WN;
     const int li = lane & 31, lh = lane >> 5;
