@@ -74,3 +74,123 @@ def test_generator_feeds_trainer_layout():
     assert b["cap_dec"].shape[0] == 4 and b["c_v"].shape == (4, 90) and b["c_v"][0, 0] == 1.0  # column 0 dropped (main.py:236)
     one = list(BatchGenerator(idx, feats, 3, seed=2).next_batch(num_captions=1))[0]
     assert one["cap_dec"].shape[0] == 3 and (one["lengths"] > 0).all()
+
+
+# ------------------------------------------------------------------------------------------------
+# Batch_Generator / Data / preprocess.py over a miniature MSCOCO tree (utils/batch_gen.py, utils/data.py)
+# ------------------------------------------------------------------------------------------------
+import os
+import pickle
+import subprocess
+import sys
+
+import pytest
+
+from vae_captioning_amd.utils.batch_gen import Batch_Generator, feed_dict
+from vae_captioning_amd.utils.image_utils import load_image
+from vae_captioning_amd.utils.parameters import Parameters
+
+from . import coco_fixture
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture()
+def coco(tmp_path, monkeypatch):
+    root = coco_fixture.build(tmp_path / "coco")
+    monkeypatch.chdir(tmp_path)  # ./pickles, ./obj_vectors are relative to the working directory, as in the reference
+    return root
+
+
+def _caps(root, split, word2idx=None):
+    c = Captions(root + "annotations/captions_%s2014.json" % split)
+    if word2idx is not None:
+        c.index_captions(word2idx)
+    return c
+
+
+def test_batch_generator_feature_path(coco):
+    tr = _caps(coco, "train")
+    d = Dictionary(tr.captions, 1)
+    tr.index_captions(d.word2idx)
+    feats = {fn: np.full((1, 4096), i, np.float32) for i, fn in enumerate(sorted(tr.captions))}
+    cv = {fn: np.arange(91, dtype=np.float64) + i for i, fn in enumerate(sorted(tr.captions))}
+    g = Batch_Generator(coco + "images/train2014/", coco + "annotations/captions_train2014.json", tr, 4, feature_dict=feats,
+                        cluster_vectors=cv)
+    items = list(g.next_batch(use_obj_vectors=True, num_captions=5))
+    assert [it[0].shape for it in items] == [(4, 4096), (2, 4096)]                  # ragged last batch is yielded
+    images, (ins, lab), lens, cl_v = items[0]
+    assert ins.shape == lab.shape and ins.ndim == 3 and ins.shape[:2] == (4, 5) and lens.shape == (4, 5) and cl_v.shape == (4, 91)
+    bos, eos = d.word2idx["<BOS>"], d.word2idx["<EOS>"]
+    assert np.all(ins[:, :, 0] == bos)
+    for b in range(4):
+        for k in range(5):
+            L = int(lens[b, k])
+            assert lab[b, k, L - 1] == eos and np.all(lab[b, k, L:] == 0) and np.array_equal(ins[b, k, 1:L], lab[b, k, :L - 1])
+    fd = feed_dict(images, (ins, lab), lens, cl_v, 5, False)
+    assert fd["cap_dec"].shape == (20, ins.shape[2]) and fd["c_v"].shape == (20, 90) and fd["features"].shape == (4, 4096)
+    assert np.array_equal(fd["c_v"][0], fd["c_v"][4]) and fd["c_v"][0, 0] == cl_v[0, 1]   # repeated per caption, column 0 dropped
+    one = next(iter(g.next_batch(num_captions=1)))
+    assert one[1][0].ndim == 2 and one[2].shape == (4,) and len(one[3]) == 0          # random single caption: squeezed, no c_v
+    # validation / test generators
+    val = _caps(coco, "val", d.word2idx)
+    vfe = {fn: np.zeros((1, 4096), np.float32) for fn in val.captions}
+    gv = Batch_Generator(coco + "images/val2014/", coco + "annotations/captions_val2014.json", val, 3, feature_dict=vfe, get_image_ids=True)
+    out = list(gv.next_val_batch(get_image_ids=True))
+    assert [len(o[3]) for o in out] == [3, 1] and sorted(sum((o[3] for o in out), [])) == sorted(val.filename_to_imid.values())
+    gt = Batch_Generator(coco + "images/test2014/", train_cap_json=coco + "annotations/image_info_test2014.json", batch_size=2,
+                         feature_dict={os.path.basename(p): np.zeros((1, 4096), np.float32) for p in os.listdir(coco + "images/test2014/")},
+                         get_image_ids=True, get_test_ids=True)
+    images, ids, cl = next(iter(gt.next_test_batch()))
+    assert images.shape == (2, 4096) and len(ids) == 2 and len(cl) == 0
+    # train + part of val
+    g.repartiton(val, vfe, gen_val_cap=1)
+    assert len(g._iterable) == 6 + 3 and len(g.unused_cap_in) == 1
+    seen = sum(len(it[0]) for it in g.next_batch(num_captions=5))
+    assert seen == 9
+
+
+def test_image_paths_and_preprocessed_array(coco):
+    tr = _caps(coco, "train")
+    d = Dictionary(tr.captions, 1)
+    tr.index_captions(d.word2idx)
+    tdir = coco + "images/train2014/"
+    g = Batch_Generator(tdir, None, tr, 3)                                            # no features, no array: decode files
+    images, _, _, _ = next(iter(g.next_val_batch()))
+    names = sorted(os.listdir(tdir))
+    assert images.shape == (3, 224, 224, 3) and images.dtype == np.uint8
+    assert np.array_equal(images[1], load_image(tdir + names[1]))
+    # preprocess.py: one array + name -> row map; the generator then reads rows in increasing index order
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "preprocess.py"), "--coco_dir", coco.rstrip("/"), "--output_h5", "train_val.hdf5"],
+                       capture_output=True, text=True, env=dict(os.environ, PYTHONPATH=ROOT))
+    assert r.returncode == 0, r.stdout + r.stderr
+    arr = np.load("train_val.npy", mmap_mode="r")
+    itoi = pickle.load(open("pickles/itoi.pickle", "rb"))
+    assert arr.shape == (10, 224, 224, 3) and len(itoi) == 10 and np.array_equal(arr[itoi[names[2]]], load_image(tdir + names[2]))
+    g2 = Batch_Generator(tdir, None, tr, 4, use_hdf5=True, hdf5_file="train_val.hdf5")   # resolves to the .npy next to it
+    assert g2.use_hdf5
+    for images, _, _, _ in g2.next_batch(num_captions=5):
+        assert images.dtype == np.uint8 and images.shape[1:] == (224, 224, 3)
+    g3 = Batch_Generator(tdir, None, tr, 4, use_hdf5=True, hdf5_file="missing.hdf5")
+    assert not g3.use_hdf5
+
+
+def test_data_class_builds_vocabulary_and_generators(coco):
+    from vae_captioning_amd.utils.data import Data
+    p = Parameters()
+    p.coco_dir, p.keep_words, p.use_hdf5 = coco, 1, False
+    data = Data(p)
+    assert data.num_examples == 6 and data.dictionary.word2idx["<PAD>"] == 0 and "<UNK>" in data.dictionary.word2idx
+    with pytest.raises(ValueError):
+        Data(p, repartiton=True)
+    with pytest.raises(ValueError):
+        Data(p, extract_features=True)
+    gen = data.load_train_data_generator(2, fine_tune=True)
+    images, (ins, lab), lens, cv = next(iter(gen.next_batch(num_captions=5)))
+    assert images.shape == (2, 224, 224, 3) and ins.shape[:2] == (2, 5)
+    fd = feed_dict(images, (ins, lab), lens, cv, 5, True)
+    assert fd["images"].dtype == np.float32 and fd["images"].shape == (2, 224, 224, 3) and "c_v" not in fd
+    vg = data.get_valid_data(2, pretrained=False)
+    assert len(list(vg.next_val_batch(get_image_ids=True))) == 2
+    tg = data.get_test_data(2, pretrained=False)
+    assert len(next(iter(tg.next_test_batch()))[1]) == 2

@@ -195,3 +195,50 @@ def test_gen_caption_cli_single_image(tmp_path, lib):
     assert len(ref) > 0 and caption == want, (caption, want)
     r = subprocess.run(cmd + ["--gen_method", "beam_search", "--beam_size", "3"], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and len(r.stdout.strip().splitlines()[-1]) > 0, r.stdout + r.stderr
+
+
+def test_coco_directory_training_and_inference(tmp_path, lib):
+    """The reference's own data path (main.py:23-41, utils/data.py, ops/inference.py) on a miniature MSCOCO tree:
+    batched VGG16 feature extraction into ./pickles/*.pickle, training from the generators, val / test json."""
+    import pickle
+    from . import coco_fixture
+    from vae_captioning_amd.trainer import VggEngine
+    from vae_captioning_amd.utils.image_utils import load_image
+    coco = coco_fixture.build(tmp_path / "coco")
+    os.makedirs(tmp_path / "utils")
+    PV = coco_fixture.vgg_weight_file(str(tmp_path / "utils" / "vgg16_weights.npz"))
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    base = [sys.executable, os.path.join(ROOT, "main.py"), "--coco_dir", coco, "--bs", "2", "--embed_dim", "32", "--enc_hid", "64",
+            "--dec_hid", "64", "--latent", "10", "--gen_z_samples", "4", "--gpu", "0", "--checkpoint", "cocotest"]
+    r = subprocess.run(base + ["--epochs", "1", "--max_steps", "3"], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Extracting features" in r.stdout and "Validation reconstruction loss" in r.stdout
+    assert sorted(os.listdir(tmp_path / "pickles")) == ["capt_vocab.pickle", "test2014.pickle", "train2014.pickle", "val2014.pickle"]
+    feats = pickle.load(open(tmp_path / "pickles" / "train2014.pickle", "rb"))
+    assert len(feats) == 6 and all(v.shape == (1, 4096) and v.dtype == np.float32 for v in feats.values())
+    # the pickled features are the device VGG16's fc2 of the cv2-style resized images, whatever the batching
+    pv = Parameters()
+    pv.mode = "inference"
+    vgg = VggEngine(pv, lib=lib)
+    vgg.load_params(PV)
+    name = sorted(feats)[3]
+    img = load_image(coco + "images/train2014/" + name).astype(np.float32)[None]
+    one = vgg.forward(torch.from_numpy(img).cuda()).cpu().numpy()
+    np.testing.assert_allclose(feats[name], one, rtol=1e-4, atol=1e-4)
+    # second run loads the cached pickles; inference writes both json files with COCO image ids
+    r = subprocess.run(base + ["--mode", "inference", "--sample_gen", "greedy", "--gen_name", "c1"], cwd=tmp_path, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Loading prepared feature vector" in r.stdout and "Extracting features" not in r.stdout
+    val = json.load(open(tmp_path / "val_c1.json"))
+    test = json.load(open(tmp_path / "test_c1.json"))
+    assert len(val) == 4 and len(test) == 2 and all(isinstance(c["image_id"], int) and isinstance(c["caption"], str) for c in val + test)
+    # fine-tuning reads the images themselves (no preprocessed array here: files are decoded per batch) and starts
+    # from the ImageNet weight file
+    r = subprocess.run(base + ["--epochs", "1", "--max_steps", "2", "--fine_tune", "--checkpoint", "cocoft"], cwd=tmp_path, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Loading imagenet weights" in r.stdout and "decoding the image files per batch" in r.stdout
+    from vae_captioning_amd import tf_bundle
+    z = tf_bundle.read_bundle(str(tmp_path / "checkpoints" / "cocoft.ckpt"), names=["cnn/conv1_1/weights", "cnn/fc2/biases"])
+    assert z["cnn/conv1_1/weights"].shape == (3, 3, 3, 64) and not np.array_equal(z["cnn/conv1_1/weights"], PV["cnn/conv1_1/weights"])

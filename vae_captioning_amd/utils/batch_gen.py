@@ -2,9 +2,13 @@
 (utils/batch_gen.py:164-205, 296-345) followed by preprocess_captions
 (utils/caption_utils.py:4-25): what main.py:226-238 finally feeds.
 
-Only the caption / feature / cluster-vector side is here; JPEG / HDF5 image loading needs h5py and
-cv2, which this environment lacks (images can be supplied as an in-memory array instead).
+`BatchGenerator` is the compact in-memory form (captions + feature dict); `Batch_Generator` further down
+keeps the reference class's constructor and its train / val / test generators over image directories.
 """
+import glob as _glob
+import json as _json
+import pickle as _pickle
+
 import numpy as np
 
 
@@ -62,3 +66,186 @@ class BatchGenerator(object):
             b["features"] = np.stack([np.asarray(self.feats[n], np.float32).reshape(-1) for n in names])
             b["names"] = names
             yield b
+
+
+# ------------------------------------------------------------------------------------------------
+# The reference's generator class, file-system facing (utils/batch_gen.py:16-369): image names come
+# from a directory listing, images from precomputed feature dicts, from a preprocessed image array
+# (the HDF5 file's role) or from the image files themselves.
+# ------------------------------------------------------------------------------------------------
+def open_image_array(path):
+    """The `images (N, 224, 224, 3) uint8` array preprocess.py writes.  The reference keeps it in HDF5
+    (needs h5py, absent here); this build's preprocess.py writes the same array as .npy and memory-maps it."""
+    if path.endswith(".npy"):
+        return np.load(path, mmap_mode="r")
+    try:
+        import h5py  # noqa: F401
+    except ImportError:
+        raise ImportError("%s: reading HDF5 needs h5py, which is not installed; run this build's preprocess.py "
+                          "(writes the same array as .npy) and pass that file as hdf5_file" % path)
+    import h5py
+    return h5py.File(path, "r")["images"]
+
+
+class Batch_Generator(object):
+    """Constructor arguments, attributes and generator methods of utils/batch_gen.py:16-369.
+    next_batch      -> images, (inputs, labels), lengths, c_v           (training, shuffled, ragged last batch)
+    next_val_batch  -> images, (inputs, labels), lengths[, image_ids], c_v
+    next_test_batch -> images, image_ids, c_v
+    `images` is [B, 4096] when a feature dict is given, else [B, 224, 224, 3] uint8."""
+
+    def __init__(self, train_dir, train_cap_json=None, captions=None, batch_size=None, use_hdf5=False, hdf5_file=None,
+                 feature_dict=None, get_image_ids=False, get_test_ids=False, val_tr_unused=None,
+                 cluster_vectors=None, seed=42):
+        self.use_hdf5 = bool(use_hdf5) and feature_dict is None
+        if self.use_hdf5:
+            if not hdf5_file:
+                raise ValueError("Specify hdf5 file path")
+            import os
+            npy = os.path.splitext(hdf5_file)[0] + ".npy"
+            if not os.path.exists(hdf5_file) and os.path.exists(npy):
+                hdf5_file = npy  # what this build's preprocess.py writes
+            if not os.path.exists(hdf5_file):
+                print("No preprocessed image array at %s: decoding the image files per batch" % hdf5_file)
+                self.use_hdf5 = False
+        if self.use_hdf5:
+            with open("./pickles/itoi.pickle", "rb") as rf:
+                self.imtoi = _pickle.load(rf)
+            self.images = open_image_array(hdf5_file)
+        self._iterable = sorted(_glob.glob(train_dir + "*.jpg")) if val_tr_unused is None else list(val_tr_unused)
+        self._train_dir = train_dir
+        self._batch_size = batch_size or len(self._iterable)
+        if len(self._iterable) == 0:
+            raise FileNotFoundError("no *.jpg under %s" % train_dir)
+        self._train_cap_json = train_cap_json
+        if get_test_ids:  # the test set has no captions: ids come from image_info_test2014.json
+            with open(train_cap_json) as rf:
+                self._fn_to_id = {img["file_name"]: img["id"] for img in _json.load(rf)["images"]}
+        self.cap_instance = captions
+        self.captions = captions.captions_indexed if captions is not None else None
+        self.val_cap_instance, self.val_captions, self.val_feature_dict = None, None, None
+        self.rng = np.random.RandomState(seed)  # the reference seeds numpy globally with 42 here (:65-66)
+        self.feature_dict = feature_dict
+        self.get_image_ids = get_image_ids
+        self.unused_cap_in = None
+        self._cluster_vectors = cluster_vectors  # {file_name: 91-vector}; default: ./obj_vectors/c_v*.pickle
+
+    # -- training on train + part of val (utils/batch_gen.py:71-96)
+    def repartiton(self, val_cap_instance, val_feature_dict, gen_val_cap):
+        if not val_cap_instance:
+            raise ValueError("If use validation set images for training need to specify val_cap instance")
+        if not val_feature_dict:
+            raise ValueError("If use validation set images for training need to specify val_feature_dict")
+        self.val_cap_instance, self.val_captions = val_cap_instance, val_cap_instance.captions_indexed
+        val_dir = "/".join(self._train_dir.split("/")[:-2] + ["val2014/"])
+        val_list = sorted(_glob.glob(val_dir + "*.jpg"))
+        self.rng.shuffle(val_list)
+        if gen_val_cap is not None and gen_val_cap > 0:
+            self._iterable.extend(val_list[:-gen_val_cap])
+            self.unused_cap_in = val_list[-gen_val_cap:]
+        else:
+            self._iterable.extend(val_list)
+        self.val_feature_dict = val_feature_dict
+
+    # -- pieces
+    def _cv_dict(self, load_test=False):
+        if self._cluster_vectors is not None:
+            return self._cluster_vectors
+        with open("./obj_vectors/c_v_test.pickle" if load_test else "./obj_vectors/c_v.pickle", "rb") as rf:
+            c_v = _pickle.load(rf)
+        assert isinstance(c_v, dict), "cluster vector pickle must contain dict"
+        return c_v
+
+    def _lookup(self, d, alt, key):
+        if key in d:
+            return d[key]
+        if alt is not None and key in alt:
+            return alt[key]
+        raise KeyError(key)
+
+    def _images_c_v(self, names, c_v):
+        base = [n.split("/")[-1] for n in names]
+        cl_v = np.array([np.asarray(c_v.get(b, np.zeros(91)), np.float64) for b in base]) if c_v else np.array([])
+        if self.feature_dict:
+            images = np.stack([np.asarray(self._lookup(self.feature_dict, self.val_feature_dict, b)).reshape(-1) for b in base])
+        elif self.use_hdf5:
+            images = np.asarray(self.images[[self.imtoi[b] for b in base]])
+        else:
+            from .image_utils import load_image
+            images = np.stack([load_image(n) for n in names])
+        return images, cl_v
+
+    def _sorted_for_array(self, names):
+        """HDF5 fancy indexing wants increasing indices: reorder the batch by (index, name) (:152-162)."""
+        if not self.use_hdf5:
+            return list(names)
+        return [n for _, n in sorted((self.imtoi[n.split("/")[-1]], n) for n in names)]
+
+    def _captions_for(self, names, random_select=True, num_captions=1):
+        indexed = {}
+        for n in names:
+            b = n.split("/")[-1]
+            caps = self.captions.get(b) or (self.val_captions or {}).get(b) or []
+            indexed[b] = caps
+        nc = 1 if random_select else num_captions
+        ins, lab, lens = form_captions_batch(indexed, names, nc, self.rng)
+        if nc == 1:  # "if using random_select, temporary" squeeze (:341-344)
+            return ins[:, 0], lab[:, 0], lens[:, 0]
+        return ins, lab, lens
+
+    def _chunks(self, names):
+        for s in range(0, len(names), self._batch_size):
+            yield self._sorted_for_array(names[s:s + self._batch_size])
+
+    def _imid(self, names, test=False):
+        if test:
+            return [self._fn_to_id[n.split("/")[-1]] for n in names]
+        alt = self.val_cap_instance.filename_to_imid if self.val_cap_instance is not None else None
+        return [self._lookup(self.cap_instance.filename_to_imid, alt, n.split("/")[-1]) for n in names]
+
+    # -- generators
+    def next_batch(self, use_obj_vectors=False, num_captions=1):
+        c_v = self._cv_dict() if use_obj_vectors else None
+        self.rng.shuffle(self._iterable)
+        for names in self._chunks(self._iterable):
+            images, cl_v = self._images_c_v(names, c_v)
+            ins, lab, lens = self._captions_for(names, num_captions == 1, num_captions)
+            yield images, (ins, lab), lens, cl_v
+
+    def next_val_batch(self, get_image_ids=False, use_obj_vectors=False):
+        self.get_image_ids = get_image_ids
+        c_v = self._cv_dict() if use_obj_vectors else None
+        for names in self._chunks(self._iterable):
+            images, cl_v = self._images_c_v(names, c_v)
+            ins, lab, lens = self._captions_for(names)
+            if get_image_ids:
+                yield images, (ins, lab), lens, self._imid(names), cl_v
+            else:
+                yield images, (ins, lab), lens, cl_v
+
+    def next_test_batch(self, use_obj_vectors=False):
+        c_v = self._cv_dict(True) if use_obj_vectors else None
+        for names in self._chunks(self._iterable):
+            images, cl_v = self._images_c_v(names, c_v)
+            yield images, self._imid(names, True), cl_v
+
+    @property
+    def cap_dict(self):
+        return self.captions
+
+    def set_bs(self, batch_size):
+        self._batch_size = batch_size
+
+
+def feed_dict(images, captions, lengths, c_v, num_captions, fine_tune):
+    """One generator item -> the dict Trainer.set_batch takes (main.py:226-238: preprocess_captions when
+    num_captions > 1, cluster-vector column 0 dropped)."""
+    ins, lab = captions
+    if ins.ndim == 2:
+        ins, lab, lengths = ins[:, None, :], lab[:, None, :], np.asarray(lengths).reshape(-1, 1)
+    cv = np.asarray(c_v, np.float32)[:, 1:] if c_v is not None and len(c_v) else None
+    b = preprocess_captions(ins.astype(np.int32), lab.astype(np.int32), np.asarray(lengths, np.int32), cv)
+    b["images" if fine_tune else "features"] = np.asarray(images, np.float32)
+    if fine_tune:
+        b["features"] = np.zeros((len(images), 0), np.float32)
+    return b
