@@ -219,6 +219,23 @@ int vc_vgg_preprocess_f32(void* stream, const float* images, int B, int H, int W
 int vc_pad_dim_f32(void* stream, const float* src, long outer, int c_src, int c_dst, int inner, float* dst);
 
 /* ------------------------------------------------------------------------------------
+ * Beam-search bookkeeping after one decoder step, on device, one thread per image: the loop body of
+ * vae_model/decoder.py:254-293 with utils/top_n.py's TopN (heapq min-heap keyed by score; ties resolved by
+ * heapq's sift order, reproduced exactly).  Rows are [B, beam]: row b*beam + i is the i-th live beam of
+ * image b in heap-array order.
+ *   in : top_p / top_i [B*beam, beam]  the beam_size most probable words of every row, descending, stable
+ *        pcount [B] live beams; p_score / p_logprob (double) / p_len [B, beam]; sent_cur [B, beam, Lmax]
+ *   out: the same for the new live beams (sent_next), the complete-caption heap c_* (captions in the pool
+ *        c_sent [B, beam+1, Lmax], c_slot -> pool row, c_free = free-row bit mask, initially 2^(beam+1)-1),
+ *        and for the next step parent [B*beam] (row whose LSTM state each new beam continues) and tok [B*beam].
+ *   score of a completed caption = logprob / len^len_norm_f (len_norm_f <= 0: logprob); words with p < 1e-12 skipped.
+ * ---------------------------------------------------------------------------------- */
+int vc_beam_update(void* stream, int B, int beam, int Lmax, int eos, double len_norm_f, const float* top_p,
+                   const int32_t* top_i, int32_t* pcount, int32_t* ccount, double* p_score, double* p_logprob,
+                   int32_t* p_len, const int32_t* sent_cur, int32_t* sent_next, double* c_score, double* c_logprob,
+                   int32_t* c_len, int32_t* c_slot, int32_t* c_free, int32_t* c_sent, int32_t* parent, int32_t* tok);
+
+/* ------------------------------------------------------------------------------------
  * Host-side helper (the only entry point that takes HOST pointers): CRC-32C (Castagnoli) of a byte
  * range, continuing from *crc_inout (start with 0).  Used by the TensorFlow V2 checkpoint
  * ("tensor bundle") reader / writer for the per-tensor and per-block checksums

@@ -119,3 +119,64 @@ def test_sample_mode_generates_valid_tokens(lib):
     a = gen.sample(feats, None, eps, BOS, EOS, max_len=6, uniforms=u)
     b = gen.sample(feats, None, eps, BOS, EOS, max_len=6, uniforms=u)
     assert a == b and all(0 <= t < 40 for s in a for t in s) and all(1 <= len(s) <= 6 for s in a)
+
+
+@pytest.mark.parametrize("n", [1, 3, 5])
+def test_beam_update_replays_heapq_including_ties(lib, n):
+    """vc_beam_update vs the Python TopN / heapq bookkeeping of decoder.py:254-293 on synthetic top-k tables whose
+    probabilities are quantised to a few values (many exact score ties, many <EOS> hits): heap ARRAY order, scores,
+    captions and the parent / token rows for the next step must be identical after every round."""
+    import torch
+    from vae_captioning_amd.utils.top_n import Beam, TopN
+    from .gpu_util import P, dev, host, stream
+    rng = np.random.default_rng(n)
+    B, rounds, L, eos, bos, lnf = 7, 6, 12, 2, 1, 0.7
+    M = B * n
+    i32 = dict(dtype=torch.int32, device="cuda")
+    f64 = dict(dtype=torch.float64, device="cuda")
+    pcount, ccount = torch.ones(B, **i32), torch.zeros(B, **i32)
+    p_score, p_logprob, p_len = torch.zeros(M, **f64), torch.zeros(M, **f64), torch.ones(M, **i32)
+    sent = [torch.full((M, L), bos, **i32), torch.zeros((M, L), **i32)]
+    c_score, c_logprob, c_len, c_slot = torch.zeros(M, **f64), torch.zeros(M, **f64), torch.zeros(M, **i32), torch.zeros(M, **i32)
+    c_free = torch.full((B,), (1 << (n + 1)) - 1, **i32)
+    c_sent = torch.zeros((B * (n + 1), L), **i32)
+    parent, tok = torch.zeros(M, **i32), torch.zeros(M, **i32)
+    partial = [TopN(n) for _ in range(B)]
+    complete = [TopN(n) for _ in range(B)]
+    for b in range(B):
+        partial[b].push(Beam([bos], 0, 0.0, 0.0))
+    levels = np.array([0.5, 0.25, 0.25, 0.125, 1e-13], np.float32)
+    for it in range(rounds):
+        tv = np.sort(rng.choice(levels, size=(M, n)).astype(np.float32), axis=1)[:, ::-1].copy()
+        ti = rng.integers(2, 6, size=(M, n)).astype(np.int32)  # small vocabulary: <EOS> (= 2) comes up often
+        lib.vc_beam_update(stream(), B, n, L, eos, lnf, P(dev(tv)), P(dev(ti)), P(pcount), P(ccount), P(p_score), P(p_logprob), P(p_len),
+                           P(sent[it & 1]), P(sent[1 - (it & 1)]), P(c_score), P(c_logprob), P(c_len), P(c_slot), P(c_free), P(c_sent),
+                           P(parent), P(tok))
+        for b in range(B):  # the reference loop
+            lst = partial[b].extract()
+            partial[b].reset()
+            for i, bm in enumerate(lst):
+                for w, pw in zip(ti[b * n + i], tv[b * n + i]):
+                    if pw < 1e-12:
+                        continue
+                    s = bm.sentence + [int(w)]
+                    lp = bm.logprob + float(np.log(np.float64(pw)))
+                    if w == eos:
+                        complete[b].push(Beam(s, i, lp, lp / len(s) ** lnf))
+                    else:
+                        partial[b].push(Beam(s, i, lp, lp))
+        pc, cc = host(pcount), host(ccount)
+        ps, pl, sn = host(p_score).reshape(B, n), host(p_len).reshape(B, n), host(sent[1 - (it & 1)]).reshape(B, n, L)
+        cs, cl, csl, cst = host(c_score).reshape(B, n), host(c_len).reshape(B, n), host(c_slot).reshape(B, n), host(c_sent).reshape(B, n + 1, L)
+        par, tk = host(parent).reshape(B, n), host(tok).reshape(B, n)
+        for b in range(B):
+            heap = partial[b]._heap
+            assert pc[b] == len(heap)
+            for j, bm in enumerate(heap):  # heap ARRAY order, not sorted order
+                assert sn[b, j, :pl[b, j]].tolist() == bm.sentence and ps[b, j] == bm.score
+                assert par[b, j] == b * n + bm.state and tk[b, j] == bm.sentence[-1]
+            cheap = complete[b]._heap
+            assert cc[b] == len(cheap)
+            for j, bm in enumerate(cheap):
+                assert cst[b, csl[b, j], :cl[b, j]].tolist() == bm.sentence and cs[b, j] == bm.score
+    assert sum(len(c._heap) for c in complete) > 0

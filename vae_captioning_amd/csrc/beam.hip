@@ -1,0 +1,177 @@
+// Beam-search bookkeeping on device (vae_model/decoder.py:238-300 + utils/top_n.py:4-43).
+//
+// One thread per image replays, for its image, exactly what the reference's Python does after every
+// decoder step: walk the image's live beams in the order TopN.extract() returned them (the heap ARRAY order),
+// walk each beam's top-`beam_size` words in descending probability, skip p < 1e-12, and push the extended
+// caption into the image's `complete` (word == <EOS>, score = logprob / len**len_norm_f) or `partial`
+// (score = logprob) TopN.  TopN is a min-heap keyed by score only, driven with heapq's heappush /
+// heappushpop; ties are therefore resolved by heapq's sift order, which this file reproduces move for move
+// (CPython Lib/heapq.py: _siftdown, _siftup).  log-probabilities accumulate in double like the Python floats.
+//
+// Nothing here needs the host between decoder steps: the kernel also emits, for the next step, each new
+// beam's parent row (whose LSTM state it continues) and its last token.
+#include "common.h"
+#include "vaecap.h"
+
+namespace vc {
+
+constexpr int BEAM_MAX = 16;
+
+struct BeamItem {
+    double score, logprob;
+    int parent, tok, len, slot;
+};
+
+__device__ __forceinline__ bool item_lt(const BeamItem& a, const BeamItem& b) { return a.score < b.score; }
+
+__device__ void sift_down(BeamItem* heap, int startpos, int pos) {
+    const BeamItem newitem = heap[pos];
+    while (pos > startpos) {
+        const int parentpos = (pos - 1) >> 1;
+        if (item_lt(newitem, heap[parentpos])) {
+            heap[pos] = heap[parentpos];
+            pos = parentpos;
+            continue;
+        }
+        break;
+    }
+    heap[pos] = newitem;
+}
+
+__device__ void sift_up(BeamItem* heap, int n, int pos) {
+    const int startpos = pos;
+    const BeamItem newitem = heap[pos];
+    int childpos = 2 * pos + 1;
+    while (childpos < n) {
+        const int rightpos = childpos + 1;
+        if (rightpos < n && !item_lt(heap[childpos], heap[rightpos])) childpos = rightpos;
+        heap[pos] = heap[childpos];
+        pos = childpos;
+        childpos = 2 * pos + 1;
+    }
+    heap[pos] = newitem;
+    sift_down(heap, startpos, pos);
+}
+
+// TopN.push: returns the slot field of the item that left the heap (the popped root, or the rejected newcomer), -1 if none
+__device__ int topn_push(BeamItem* heap, int& count, int cap, const BeamItem& item) {
+    if (count < cap) {
+        heap[count] = item;
+        ++count;
+        sift_down(heap, 0, count - 1);
+        return -1;
+    }
+    if (count > 0 && item_lt(heap[0], item)) {
+        const int freed = heap[0].slot;
+        heap[0] = item;
+        sift_up(heap, count, 0);
+        return freed;
+    }
+    return item.slot;
+}
+
+struct BeamArgs {
+    int B, n, k, Lmax, eos;
+    double len_norm_f;
+    const float* tv;
+    const int32_t* ti;
+    int32_t *pcount, *ccount, *p_len, *c_len, *c_slot, *c_free;
+    double *p_score, *p_logprob, *c_score, *c_logprob;
+    const int32_t* sent_cur;
+    int32_t *sent_next, *c_sent, *parent, *tok;
+};
+
+__global__ __launch_bounds__(64) void beam_update_kernel(BeamArgs a) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= a.B) return;
+    const int n = a.n, L = a.Lmax;
+    const int np = a.pcount[b];
+    for (int j = 0; j < n; ++j) {  // defaults for slots that stay empty: continue row b*n with token 0 (ignored)
+        a.parent[b * n + j] = b * n;
+        a.tok[b * n + j] = 0;
+    }
+    if (np == 0) return;  // every beam of this image has ended
+    BeamItem part[BEAM_MAX], comp[BEAM_MAX];
+    int hn = 0, cn = a.ccount[b];
+    for (int j = 0; j < cn; ++j) {
+        comp[j].score = a.c_score[b * n + j];
+        comp[j].logprob = a.c_logprob[b * n + j];
+        comp[j].len = a.c_len[b * n + j];
+        comp[j].slot = a.c_slot[b * n + j];
+        comp[j].parent = comp[j].tok = 0;
+    }
+    int freemask = a.c_free[b];
+    const int32_t* cur = a.sent_cur + (long)b * n * L;
+    for (int i = 0; i < np; ++i) {
+        const long row = (long)b * n + i;
+        const double lp0 = a.p_logprob[row];
+        const int len0 = a.p_len[row];
+        for (int j = 0; j < a.k; ++j) {
+            const float pw = a.tv[row * a.k + j];
+            if (pw < 1e-12f) continue;
+            BeamItem it;
+            it.tok = a.ti[row * a.k + j];
+            it.parent = i;
+            it.len = len0 + 1;
+            it.logprob = lp0 + log((double)pw);
+            it.score = it.logprob;
+            it.slot = -1;
+            if (it.tok == a.eos) {
+                if (a.len_norm_f > 0) it.score = it.logprob / pow((double)it.len, a.len_norm_f);
+                // take a free pool slot, write the caption there, give it back if the heap does not keep it
+                int s = 0;
+                while (!((freemask >> s) & 1)) ++s;
+                freemask &= ~(1 << s);
+                it.slot = s;
+                int32_t* dst = a.c_sent + ((long)b * (n + 1) + s) * L;
+                for (int t = 0; t < len0; ++t) dst[t] = cur[i * L + t];
+                dst[len0] = it.tok;
+                const int freed = topn_push(comp, cn, n, it);
+                if (freed >= 0) freemask |= 1 << freed;
+            } else {
+                topn_push(part, hn, n, it);
+            }
+        }
+    }
+    int32_t* nxt = a.sent_next + (long)b * n * L;
+    for (int j = 0; j < hn; ++j) {
+        const long o = (long)b * n + j;
+        a.p_score[o] = part[j].score;
+        a.p_logprob[o] = part[j].logprob;
+        a.p_len[o] = part[j].len;
+        for (int t = 0; t < part[j].len - 1; ++t) nxt[j * L + t] = cur[part[j].parent * L + t];
+        nxt[j * L + part[j].len - 1] = part[j].tok;
+        a.parent[o] = b * n + part[j].parent;
+        a.tok[o] = part[j].tok;
+    }
+    a.pcount[b] = hn;
+    for (int j = 0; j < cn; ++j) {
+        const long o = (long)b * n + j;
+        a.c_score[o] = comp[j].score;
+        a.c_logprob[o] = comp[j].logprob;
+        a.c_len[o] = comp[j].len;
+        a.c_slot[o] = comp[j].slot;
+    }
+    a.ccount[b] = cn;
+    a.c_free[b] = freemask;
+}
+
+}  // namespace vc
+
+extern "C" int vc_beam_update(void* stream, int B, int beam, int Lmax, int eos, double len_norm_f, const float* top_p,
+                              const int32_t* top_i, int32_t* pcount, int32_t* ccount, double* p_score, double* p_logprob,
+                              int32_t* p_len, const int32_t* sent_cur, int32_t* sent_next, double* c_score, double* c_logprob,
+                              int32_t* c_len, int32_t* c_slot, int32_t* c_free, int32_t* c_sent, int32_t* parent, int32_t* tok) {
+    using namespace vc;
+    VC_CHECK_ARG(B > 0 && beam > 0 && beam <= BEAM_MAX && Lmax > 1, "beam size must be 1..16");
+    VC_CHECK_ARG(top_p && top_i && pcount && ccount && p_score && p_logprob && p_len && sent_cur && sent_next && c_score &&
+                 c_logprob && c_len && c_slot && c_free && c_sent && parent && tok, "null pointer");
+    BeamArgs a;
+    a.B = B; a.n = beam; a.k = beam; a.Lmax = Lmax; a.eos = eos; a.len_norm_f = len_norm_f;
+    a.tv = top_p; a.ti = top_i; a.pcount = pcount; a.ccount = ccount; a.p_len = p_len; a.c_len = c_len; a.c_slot = c_slot;
+    a.c_free = c_free; a.p_score = p_score; a.p_logprob = p_logprob; a.c_score = c_score; a.c_logprob = c_logprob;
+    a.sent_cur = sent_cur; a.sent_next = sent_next; a.c_sent = c_sent; a.parent = parent; a.tok = tok;
+    hipLaunchKernelGGL(beam_update_kernel, dim3(cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, a);
+    VC_LAUNCH_CHECK();
+    return 0;
+}

@@ -3,10 +3,11 @@
 
 The reference decodes ONE image and ONE beam per `sess.run` (batch 1, one Python<->runtime
 crossing per token per beam).  Here every round advances all images x all live beams in one
-batched LSTM step + logits GEMM + softmax + top-k on the GPU; only the O(beam) bookkeeping
-(TopN heaps, sentence lists, length-normalised scores) stays on the host, with the reference's
-exact semantics: stable top-`beam_size` expansion, p < 1e-12 skipped, score =
-logprob / len**0.7 for completed captions, `<BOS>` consumed twice (decoder.py:230-262).
+batched LSTM step + logits GEMM + softmax + top-k on the GPU, and the O(beam) bookkeeping (TopN
+heaps, sentence lists, length-normalised scores) runs in `vc_beam_update`, one thread per image,
+with the reference's exact semantics: stable top-`beam_size` expansion, p < 1e-12 skipped, heapq
+tie order, score = logprob / len**0.7 for completed captions, `<BOS>` consumed twice
+(decoder.py:230-262).  The host is not involved between decoder steps.
 Per-image semantics of the z input are those of batch 1: row b of the z_rnn input is the S
 samples of image b (the Q1 reshape is the identity at N = 1).
 """
@@ -122,117 +123,109 @@ class CaptionGenerator(object):
         return probs, c2, h2
 
     # ------------------------------------------------------------------ greedy (online_inference)
-    def greedy(self, features, c_v=None, eps=None, bos=1, eos=2, max_len=None):
+    def _trim(self, ids, eos):
+        """[steps, B] token ids -> per image the tokens up to and including its first <EOS>."""
+        ids = ids.cpu().numpy()
+        out = []
+        for b in range(ids.shape[1]):
+            col = ids[:, b].tolist()
+            out.append(col[:col.index(eos) + 1] if eos in col else col)
+        return out
+
+    def greedy(self, features, c_v=None, eps=None, bos=1, eos=2, max_len=None, check_every=4):
         """decoder.py:145-201 with sample_gen='greedy' for a batch of images: returns the list
-        of generated token-id lists (each ends with <EOS> unless max_len was hit)."""
+        of generated token-id lists (each ends with <EOS> unless max_len was hit).  Tokens stay on the
+        device; the host only asks "has every image emitted <EOS>?" every `check_every` steps."""
         max_len = max_len or self.p.gen_max_len
         c, h = self.init_state(features, c_v, eps)
         B = c.shape[0]
         tok = torch.full((B,), bos, dtype=torch.int32, device=self.e.dev)
-        out = [[] for _ in range(B)]
-        done = np.zeros(B, bool)
-        nxt = torch.empty((B,), dtype=torch.int32, device=self.e.dev)
-        for _ in range(max_len):
+        ids = torch.zeros((max_len, B), dtype=torch.int32, device=self.e.dev)
+        steps = 0
+        for it in range(max_len):
             logits, c, h = self.step(tok, c, h, want="logits")  # argmax(softmax**(1/t)/sum) == argmax(logits)
-            self.lib.vc_argmax_rows_f32(_stream(), P(logits), B, self.e.V, self.e.V, P(nxt))
-            ids = nxt.cpu().numpy()
-            for b in range(B):
-                if not done[b]:
-                    out[b].append(int(ids[b]))
-                    if ids[b] == eos:
-                        done[b] = True
-            if done.all():
+            tok = ids[it]
+            self.lib.vc_argmax_rows_f32(_stream(), P(logits), B, self.e.V, self.e.V, P(tok))
+            steps = it + 1
+            if check_every and steps % check_every == 0 and bool((ids[:steps] == eos).any(0).all().item()):
                 break
-            tok = nxt.clone()
-        return out
+        return self._trim(ids[:steps], eos)
 
-    def sample(self, features, c_v=None, eps=None, bos=1, eos=2, max_len=None, uniforms=None):
+    def sample(self, features, c_v=None, eps=None, bos=1, eos=2, max_len=None, uniforms=None, check_every=4):
         """decoder.py:145-201 with sample_gen='sample': tokens drawn from softmax(logits / temperature)
         (tf.multinomial).  uniforms [max_len, B] in [0,1) may be injected; otherwise Philox."""
         max_len = max_len or self.p.gen_max_len
         c, h = self.init_state(features, c_v, eps)
         B = c.shape[0]
         tok = torch.full((B,), bos, dtype=torch.int32, device=self.e.dev)
-        out = [[] for _ in range(B)]
-        done = np.zeros(B, bool)
-        nxt = torch.empty((B,), dtype=torch.int32, device=self.e.dev)
+        ids = torch.zeros((max_len, B), dtype=torch.int32, device=self.e.dev)
         u = torch.empty((B,), dtype=torch.float32, device=self.e.dev)
+        ud = self._dev(uniforms, np.float32) if uniforms is not None else None
+        steps = 0
         for it in range(max_len):
             logits, c, h = self.step(tok, c, h, want="logits")
-            if uniforms is not None:
-                u.copy_(torch.from_numpy(np.ascontiguousarray(uniforms[it], dtype=np.float32)))
+            if ud is not None:
+                u = ud[it]
             else:
                 self.lib.vc_philox_uniform_f32(_stream(), P(u), B, self.e.seed * 1000003 + 29, (16 + it) << 32, P(self.e.step))
-            self.lib.vc_multinomial_rows_f32(_stream(), P(logits), B, self.e.V, self.e.V, float(self.p.temperature), P(u), P(nxt))
-            ids = nxt.cpu().numpy()
-            for b in range(B):
-                if not done[b]:
-                    out[b].append(int(ids[b]))
-                    done[b] = ids[b] == eos
-            if done.all():
+            tok = ids[it]
+            self.lib.vc_multinomial_rows_f32(_stream(), P(logits), B, self.e.V, self.e.V, float(self.p.temperature), P(u), P(tok))
+            steps = it + 1
+            if check_every and steps % check_every == 0 and bool((ids[:steps] == eos).any(0).all().item()):
                 break
-            tok = nxt.clone()
-        return out
+        return self._trim(ids[:steps], eos)
 
     # ------------------------------------------------------------------ beam search
-    def beam_search(self, features, c_v=None, eps=None, bos=1, eos=2, beam_size=2, max_len=None, len_norm_f=0.7):
+    def beam_search(self, features, c_v=None, eps=None, bos=1, eos=2, beam_size=2, max_len=None, len_norm_f=0.7, check_every=4):
         """decoder.py:203-320 for a batch of images.  Returns per image the list of
-        (sentence, score) of the kept beams in descending score order."""
-        lib, e = self.lib, self.e
+        (sentence, score) of the kept beams in descending score order.
+
+        Rows are [B, beam_size] throughout; every round is gather-state -> LSTM step -> logits -> softmax ->
+        top-k -> vc_beam_update (the TopN bookkeeping, on device), with no host synchronisation except a
+        4-byte "is any beam alive" read every `check_every` rounds."""
+        lib, e, st = self.lib, self.e, _stream()
         max_len = max_len or self.p.gen_max_len
         c, h = self.init_state(features, c_v, eps)
-        B, Hd, V = c.shape[0], self.p.decoder_hidden, e.V
-        tok = torch.full((B,), bos, dtype=torch.int32, device=e.dev)
+        B, Hd, V, n = c.shape[0], self.p.decoder_hidden, e.V, int(beam_size)
+        dev = e.dev
+        tok = torch.full((B,), bos, dtype=torch.int32, device=dev)
         _, c, h = self.step(tok, c, h, want="logits")  # :230-236 -- probabilities discarded, state kept
-        partial = [TopN(beam_size) for _ in range(B)]
-        complete = [TopN(beam_size) for _ in range(B)]
-        for b in range(B):
-            partial[b].push(Beam([bos], b, 0.0, 0.0))  # state = row index into the current (c, h)
-        alive = [True] * B
-        for _ in range(max_len - 1):
-            rows, owner, plist = [], [], []
-            for b in range(B):
-                if not alive[b]:
-                    continue
-                lst = partial[b].extract()
-                partial[b].reset()
-                for bm in lst:
-                    rows.append(bm.state)
-                    owner.append(b)
-                    plist.append(bm)
-            if not rows:
-                break
-            M = len(rows)
-            idx = torch.tensor(rows, dtype=torch.int32, device=e.dev)
-            cg, hg = torch.empty((M, Hd), device=e.dev), torch.empty((M, Hd), device=e.dev)
-            lib.vc_embedding_gather_f32(_stream(), P(c), P(idx), M, Hd, c.shape[0], P(cg))
-            lib.vc_embedding_gather_f32(_stream(), P(h), P(idx), M, Hd, h.shape[0], P(hg))
-            tok = torch.tensor([bm.sentence[-1] for bm in plist], dtype=torch.int32, device=e.dev)
+        M, L = B * n, max_len + 2
+        i32 = dict(dtype=torch.int32, device=dev)
+        f64 = dict(dtype=torch.float64, device=dev)
+        pcount, ccount = torch.ones(B, **i32), torch.zeros(B, **i32)      # partial = [Beam([bos], state b, 0.0, 0.0)]
+        p_score, p_logprob, p_len = torch.zeros(M, **f64), torch.zeros(M, **f64), torch.ones(M, **i32)
+        sent = [torch.full((M, L), bos, **i32), torch.zeros((M, L), **i32)]
+        c_score, c_logprob, c_len, c_slot = torch.zeros(M, **f64), torch.zeros(M, **f64), torch.zeros(M, **i32), torch.zeros(M, **i32)
+        c_free = torch.full((B,), (1 << (n + 1)) - 1, **i32)
+        c_sent = torch.zeros((B * (n + 1), L), **i32)
+        parent = torch.arange(B, **i32).repeat_interleave(n).contiguous()  # every row starts from its image's state
+        tok = torch.full((M,), bos, **i32)
+        tv, ti = torch.empty((M, n), dtype=torch.float32, device=dev), torch.empty((M, n), **i32)
+        cg, hg = torch.empty((M, Hd), device=dev), torch.empty((M, Hd), device=dev)
+        last = 0
+        for it in range(max_len - 1):
+            lib.vc_embedding_gather_f32(st, P(c), P(parent), M, Hd, c.shape[0], P(cg))
+            lib.vc_embedding_gather_f32(st, P(h), P(parent), M, Hd, h.shape[0], P(hg))
             probs, c, h = self.step(tok, cg, hg)
-            tv = torch.empty((M, beam_size), dtype=torch.float32, device=e.dev)
-            ti = torch.empty((M, beam_size), dtype=torch.int32, device=e.dev)
-            lib.vc_topk_rows_f32(_stream(), P(probs), M, V, V, beam_size, P(tv), P(ti))
-            tvh, tih = tv.cpu().numpy(), ti.cpu().numpy()
-            for i, bm in enumerate(plist):
-                b = owner[i]
-                for w, pw in zip(tih[i], tvh[i]):
-                    if pw < 1e-12:
-                        continue
-                    sentence = bm.sentence + [int(w)]
-                    logprob = bm.logprob + np.log(pw)
-                    score = logprob
-                    if w == eos:
-                        if len_norm_f > 0:
-                            score /= len(sentence) ** len_norm_f
-                        complete[b].push(Beam(sentence, i, logprob, score))
-                    else:
-                        partial[b].push(Beam(sentence, i, logprob, score))
-            for b in range(B):
-                if alive[b] and partial[b].size() == 0:
-                    alive[b] = False
+            lib.vc_topk_rows_f32(st, P(probs), M, V, V, n, P(tv), P(ti))
+            lib.vc_beam_update(st, B, n, L, int(eos), float(len_norm_f), P(tv), P(ti), P(pcount), P(ccount), P(p_score), P(p_logprob),
+                               P(p_len), P(sent[it & 1]), P(sent[1 - (it & 1)]), P(c_score), P(c_logprob), P(c_len), P(c_slot),
+                               P(c_free), P(c_sent), P(parent), P(tok))
+            last = 1 - (it & 1)
+            if check_every and (it + 1) % check_every == 0 and int(pcount.sum().item()) == 0:
+                break
+        pc, cc = pcount.cpu().numpy(), ccount.cpu().numpy()
+        ps, pl = p_score.cpu().numpy().reshape(B, n), p_len.cpu().numpy().reshape(B, n)
+        cs, cl, csl = c_score.cpu().numpy().reshape(B, n), c_len.cpu().numpy().reshape(B, n), c_slot.cpu().numpy().reshape(B, n)
+        psent = sent[last].cpu().numpy().reshape(B, n, L)
+        csent = c_sent.cpu().numpy().reshape(B, n + 1, L)
         res = []
         for b in range(B):
-            top = complete[b] if complete[b].size() else partial[b]  # never mix complete and partial (:295-299)
-            beams = top.extract(sort=True)
+            if cc[b]:  # never mix complete and partial (:295-299)
+                beams = [Beam(csent[b, csl[b, j], :cl[b, j]].tolist(), None, None, float(cs[b, j])) for j in range(cc[b])]
+            else:
+                beams = [Beam(psent[b, j, :pl[b, j]].tolist(), None, None, float(ps[b, j])) for j in range(pc[b])]
+            beams.sort(reverse=True)  # TopN.extract(sort=True) on the heap array
             res.append([(bm.sentence, float(bm.score)) for bm in beams])
         return res
