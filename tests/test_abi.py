@@ -1,6 +1,7 @@
 """CPU: the C-ABI library builds, loads, and exports every symbol include/vaecap.h declares
 (no compute calls without a GPU)."""
 import ctypes
+import os
 
 import pytest
 
@@ -54,3 +55,34 @@ def test_no_device_is_an_error_not_a_fallback(built):
         pytest.skip("GPU present")
     with pytest.raises(abi.VaecapError):
         built.vc_device_check(0)
+
+
+def test_product_code_never_touches_the_oracle_or_the_reference():
+    """oracle/ is test infrastructure: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it,
+    and nothing that runs on the GPU box may read /root/reference."""
+    import ast
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    product = glob.glob(os.path.join(root, "vae_captioning_amd", "**", "*.py"), recursive=True) + \
+        [os.path.join(root, f) for f in ("main.py", "gen_caption.py", "preprocess.py")]
+    assert len(product) > 20
+    for path in product:
+        src = open(path).read()
+        assert "/root/reference" not in src, path
+        for node in ast.walk(ast.parse(src)):
+            names = []
+            if isinstance(node, ast.Import):
+                names = [a.name for a in node.names]
+            elif isinstance(node, ast.ImportFrom):
+                names = [node.module or ""]
+            assert not any(n == "oracle" or n.startswith("oracle.") for n in names), path
+    for path in (os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")):
+        src = open(path).read()
+        assert "/root/reference" not in src.replace('os.path.isdir("/root/reference")', ""), path
+    bench = open(os.path.join(root, "bench.py")).read()
+    # bench.py: the oracle appears only inside cpu_baseline()
+    tree = ast.parse(bench)
+    for node in tree.body:
+        uses = any(isinstance(n, (ast.Import, ast.ImportFrom)) and "oracle" in ast.dump(n) for n in ast.walk(node))
+        if uses:
+            assert isinstance(node, ast.FunctionDef) and "cpu_baseline" in node.name, getattr(node, "name", node)
