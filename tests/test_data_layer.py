@@ -194,3 +194,17 @@ def test_data_class_builds_vocabulary_and_generators(coco):
     assert len(list(vg.next_val_batch(get_image_ids=True))) == 2
     tg = data.get_test_data(2, pretrained=False)
     assert len(next(iter(tg.next_test_batch()))[1]) == 2
+
+
+def test_cluster_vectors_from_annotations_and_detections():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import prepare_cluster_vectors as pcv
+    j = dict(images=[dict(id=1, file_name="a.jpg"), dict(id=2, file_name="b.jpg"), dict(id=3, file_name="c.jpg")],
+             annotations=[dict(image_id=1, category_id=18), dict(image_id=1, category_id=18), dict(image_id=1, category_id=1),
+                          dict(image_id=2, category_id=90)])
+    cv = pcv.cluster_vectors_from_instances(j)
+    assert set(cv) == {"a.jpg", "b.jpg"} and cv["a.jpg"].shape == (91,)
+    assert cv["a.jpg"][18] == 0.5 and cv["a.jpg"][1] == 0.5 and cv["a.jpg"].sum() == 1.0 and cv["b.jpg"][90] == 1.0
+    ts = {"t.jpg": dict(classes=[[3.0, 7.0, 9.0]], scores=[[0.9, 0.4, 0.6]]), "u.jpg": dict(classes=[[5.0]], scores=[[0.1]])}
+    tv = pcv.cluster_vectors_from_scores(ts)
+    assert tv["t.jpg"][3] == 0.5 and tv["t.jpg"][9] == 0.5 and tv["t.jpg"][7] == 0 and tv["u.jpg"].sum() == 0
