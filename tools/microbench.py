@@ -74,7 +74,7 @@ def ablate(shapes=((4096, 4096, 4096), (8192, 8192, 8192), (25600, 10000, 512), 
 
 def conv():
     B = 64
-    for (name, H, ci, co) in [("1_1", 224, 4, 64), ("1_2", 224, 64, 64), ("2_1", 112, 64, 128), ("2_2", 112, 128, 128), ("3_2", 56, 256, 256), ("4_2", 28, 512, 512), ("5_2", 14, 512, 512)]:
+    for (name, H, ci, co) in [("1_1", 224, 4, 64), ("1_2", 224, 64, 64), ("2_1", 112, 64, 128), ("2_2", 112, 128, 128), ("3_1", 56, 128, 256), ("3_2", 56, 256, 256), ("4_1", 28, 256, 512), ("4_2", 28, 512, 512), ("5_2", 14, 512, 512)]:
         x, w, bias = rnd(B, H, H, ci), rnd(3, 3, ci, co), rnd(co)
         y, dx, dw = torch.empty(B, H, H, co, device="cuda"), torch.empty(B, H, H, ci, device="cuda"), torch.empty(3, 3, ci, co, device="cuda")
         dy = rnd(B, H, H, co)

@@ -259,10 +259,11 @@ static int wgrad_bn(int Cin, int Cout) { return Cout <= 64 ? 64 : 128; }
 
 static WgradPlan plan_wgrad(const ConvGeom& g) {
     const long tiles = (long)cdiv(9 * g.Cin, wgrad_bm(g.Cin, g.Cout)) * cdiv(g.Cout, wgrad_bn(g.Cin, g.Cout));
-    // Cin == 64 (192-row tiles): exactly one round of resident workgroups -- the 192 x 64 kernel (152 VGPRs) runs
-    // 3 per CU = 768, the 192 x 128 kernel (212 VGPRs) 2 per CU = 512; measured 94 / 103 TFLOP/s on conv1_2 /
-    // conv2_1 (256- / 128-row tiles: 79 / 84)
-    long splits = g.Cin == 64 ? (g.Cout <= 64 ? 768 : 512) / tiles : (1024 + tiles - 1) / tiles;
+    // Workgroups per launch = a whole number of rounds of resident workgroups, never a round and a bit (the ragged
+    // second round ran at a third of the occupancy: 1024-ish workgroups on 768 slots cost conv2_2 / conv3_x 10-17 %).
+    // 128 x 128 tiles run 3 per CU (768 slots): two rounds; Cin == 64 (192-row tiles): one round - the 192 x 64 kernel
+    // (152 VGPRs) runs 3 per CU = 768, the 192 x 128 kernel (212 VGPRs) 2 per CU = 512.
+    long splits = (g.Cin == 64 ? (g.Cout <= 64 ? 768 : 512) : 1536) / tiles;
     const long maxs = g.P / 512 > 0 ? g.P / 512 : 1;  // >= 16 K-tiles per split
     if (splits > maxs) splits = maxs;
     if (splits > 256) splits = 256;
