@@ -116,6 +116,7 @@ def main():
                          "dominant kernels can be bracketed by HIP events inside the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--images-per-gpu", type=int, default=0, help="override the workload's images per GPU (sweeps; the default is BASELINE's)")
     args = ap.parse_args()
 
     import torch
@@ -141,7 +142,9 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    w = WORKLOADS[args.workload]
+    w = dict(WORKLOADS[args.workload])
+    if args.images_per_gpu:
+        w["B"] = args.images_per_gpu
     p = make_params(w)
     if w.get("generate"):
         return bench_generation(args, torch, dist, lib, w, p, world, rank)
