@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define VC_ABI_VERSION 1
+#define VC_ABI_VERSION 2
 int vc_abi_version(void);
 const char* vc_last_error(void);
 /* 0 if a gfx950 device is usable from this process, else an error code. */
@@ -206,10 +206,14 @@ int vc_philox_bernoulli_f32(void* stream, float* out, long n, float keep, uint64
  *   vgg_preprocess images [B,H,W,3] (0..255 RGB) - mean -> NHWC4            (:31-34)
  *   pad_dim        dst[o][c][i] = c < c_src ? src[o][c][i] : 0  (pad / strip a middle dim)
  * ---------------------------------------------------------------------------------- */
+/* fwd / dgrad workspace (optional; NULL or too small -> single launch): lets the library run the last partial round of
+ * tiles as a K-split second launch instead of a ragged round (csrc/conv.hip, launch_rounds); 0 when not needed. */
+size_t vc_conv3x3_fwd_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+size_t vc_conv3x3_dgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
 int vc_conv3x3_fwd_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const float* w,
-                       const float* bias, float* y, int relu);
+                       const float* bias, float* y, int relu, float* ws, size_t ws_bytes);
 int vc_conv3x3_dgrad_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* dy, const float* w,
-                         const float* relu_src, float* dx);
+                         const float* relu_src, float* dx, float* ws, size_t ws_bytes);
 size_t vc_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
 int vc_conv3x3_wgrad_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const float* dy, float* dw,
                          float* db, int accumulate, float* ws, size_t ws_bytes);

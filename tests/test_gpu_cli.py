@@ -224,7 +224,9 @@ def test_coco_directory_training_and_inference(tmp_path, lib):
     name = sorted(feats)[3]
     img = load_image(coco + "images/train2014/" + name).astype(np.float32)[None]
     one = vgg.forward(torch.from_numpy(img).cuda()).cpu().numpy()
-    np.testing.assert_allclose(feats[name], one, rtol=1e-4, atol=1e-4)
+    # (a batch of 6 and a batch of 1 cut their convolutions into different main / K-split tail launches: same values up to
+    # fp32 summation order)
+    assert np.linalg.norm(feats[name] - one) <= 1e-5 * np.linalg.norm(one)
     # second run loads the cached pickles; inference writes both json files with COCO image ids
     r = subprocess.run(base + ["--mode", "inference", "--sample_gen", "greedy", "--gen_name", "c1"], cwd=tmp_path, env=env,
                        capture_output=True, text=True, timeout=900)

@@ -421,12 +421,12 @@ def test_conv3x3_fwd_dgrad_wgrad(lib, case):
     dxref, dwref, dbref = OV.conv3x3_bwd(x64, w64, dy.astype(np.float64))
     tx, tw, tdy = dev(x), dev(w), dev(dy)
     y = zeros(B, H, W, Co)
-    lib.vc_conv3x3_fwd_f32(stream(), B, H, W, Ci, Co, P(tx), P(tw), P(dev(b)), P(y), 1)
+    lib.vc_conv3x3_fwd_f32(stream(), B, H, W, Ci, Co, P(tx), P(tw), P(dev(b)), P(y), 1, None, 0)
     assert_close(host(y), yref, 2e-6 * np.sqrt(9 * Ci) + 1e-6, msg="conv fwd")
     dx = zeros(B, H, W, Ci)
-    lib.vc_conv3x3_dgrad_f32(stream(), B, H, W, Ci, Co, P(tdy), P(tw), P(tx), P(dx))
+    lib.vc_conv3x3_dgrad_f32(stream(), B, H, W, Ci, Co, P(tdy), P(tw), P(tx), P(dx), None, 0)
     assert_close(host(dx), dxref * (x > 0), 2e-6 * np.sqrt(9 * Co) + 1e-6, msg="conv dgrad (+relu mask)")
-    lib.vc_conv3x3_dgrad_f32(stream(), B, H, W, Ci, Co, P(tdy), P(tw), None, P(dx))
+    lib.vc_conv3x3_dgrad_f32(stream(), B, H, W, Ci, Co, P(tdy), P(tw), None, P(dx), None, 0)
     assert_close(host(dx), dxref, 2e-6 * np.sqrt(9 * Co) + 1e-6, msg="conv dgrad")
     dw = zeros(3, 3, Ci, Co)
     ws = empty_bytes(lib.vc_conv3x3_wgrad_workspace_bytes(B, H, W, Ci, Co))
@@ -440,6 +440,41 @@ def test_conv3x3_fwd_dgrad_wgrad(lib, case):
     ws2 = empty_bytes(lib.vc_colsum_workspace_bytes(B * H * W, Co))
     lib.vc_colsum_f32(stream(), P(tdy), B * H * W, Co, Co, P(db2), 0, P(ws2), ws2.numel() * 4)
     assert_close(host(db2), dbref, 1e-5, msg="colsum")
+
+
+@pytest.mark.parametrize("case", [(2, 224, 224, 64, 128, "fwd"), (2, 224, 224, 128, 64, "dgrad"), (9, 224, 224, 64, 64, "fwd"),
+                                  (1, 224, 320, 128, 256, "fwd"), (3, 14, 14, 512, 512, "both")], ids=lambda c: "x".join(map(str, c)))
+def test_conv_whole_rounds_tail_split(lib, case):
+    """Forward / data-gradient launches whose tile count is a whole number of rounds plus a few tiles run the
+    remainder as a K-split second launch (csrc/conv.hip launch_rounds): same values as the single launch up to the
+    summation order of the split rows, and the forward still matches the fp64 oracle on a sample of rows."""
+    B, H, W, Ci, Co, which = case
+    rng = np.random.default_rng(B + Ci)
+    x = torch.from_numpy(np.maximum(rng.standard_normal((B, H, W, Ci), dtype=np.float32), 0)).cuda()
+    w = torch.from_numpy(rng.standard_normal((3, 3, Ci, Co), dtype=np.float32) * np.float32(1 / np.sqrt(9 * Ci))).cuda()
+    b = torch.from_numpy(rng.standard_normal(Co, dtype=np.float32)).cuda()
+    dy = torch.from_numpy(rng.standard_normal((B, H, W, Co), dtype=np.float32)).cuda()
+    if which in ("fwd", "both"):
+        nb = lib.vc_conv3x3_fwd_workspace_bytes(B, H, W, Ci, Co)
+        assert nb > 0, "this shape must trigger the tail split"
+        ws = empty_bytes(nb)
+        y0, y1 = zeros(B, H, W, Co), zeros(B, H, W, Co)
+        lib.vc_conv3x3_fwd_f32(stream(), B, H, W, Ci, Co, P(x), P(w), P(b), P(y0), 1, None, 0)
+        lib.vc_conv3x3_fwd_f32(stream(), B, H, W, Ci, Co, P(x), P(w), P(b), P(y1), 1, P(ws), ws.numel() * 4)
+        assert_close(host(y1), host(y0), 4e-6 * np.sqrt(9 * Ci) + 1e-6, msg="fwd tail split vs single launch")
+        assert not torch.equal(y0, y1) or Ci * 9 <= 128      # the tail rows really took the split path
+        x64 = x[-1:, -6:].cpu().numpy().astype(np.float64)    # last rows of the last image: inside the tail
+        yref = np.maximum(OV.conv3x3_fwd(x64, w.cpu().numpy().astype(np.float64), b.cpu().numpy().astype(np.float64)), 0)
+        assert_close(host(y1)[-1, -5:], yref[0, 1:], 2e-6 * np.sqrt(9 * Ci) + 1e-6, msg="fwd tail rows vs oracle")
+    if which in ("dgrad", "both"):
+        nb = lib.vc_conv3x3_dgrad_workspace_bytes(B, H, W, Ci, Co)
+        assert nb > 0, "this shape must trigger the tail split"
+        ws = empty_bytes(nb)
+        d0, d1 = zeros(B, H, W, Ci), zeros(B, H, W, Ci)
+        for mask in (P(x), None):
+            lib.vc_conv3x3_dgrad_f32(stream(), B, H, W, Ci, Co, P(dy), P(w), mask, P(d0), None, 0)
+            lib.vc_conv3x3_dgrad_f32(stream(), B, H, W, Ci, Co, P(dy), P(w), mask, P(d1), P(ws), ws.numel() * 4)
+            assert_close(host(d1), host(d0), 4e-6 * np.sqrt(9 * Co) + 1e-6, msg="dgrad tail split vs single launch")
 
 
 def test_maxpool_and_preprocess(lib):

@@ -131,7 +131,8 @@ def test_fine_tune_step_matches_oracle(lib):
 def test_half_batch_chains_on_three_streams(lib, monkeypatch):
     """B = 2: the default three-stream schedule (two half-batch conv/pool chains + weight gradients on a
     third stream, trainer.VggEngine) vs the fp64 oracle forward, vs the oracle backward on the device's
-    forward decisions, and BIT-identical to the serial one-stream schedule (two steps: the first allocates)."""
+    forward decisions, and equal to the serial one-stream schedule up to fp32 summation order (full- and half-batch
+    launches cut their convolutions into different main / K-split tail launches); two steps: the first allocates."""
     p = Parameters()
     p.fine_tune = True
     rng = np.random.default_rng(12)
@@ -163,5 +164,7 @@ def test_half_batch_chains_on_three_streams(lib, monkeypatch):
             Gdev = ov.backward(P64, device_cache(eng, P64, 0.5), dfc2.astype(np.float64))
             for n, ref in Gdev.items():
                 assert rel_l2(G[n], ref) < 1e-4, (n, rel_l2(G[n], ref))
-    assert torch.equal(res["3"][0], res["1"][0])
-    assert torch.equal(res["3"][1], res["1"][1])
+    # (not bit-identical: the rows that fall into a K-split tail launch differ between full- and half-batch launches)
+    assert (res["3"][0] - res["1"][0]).norm() <= 1e-5 * res["1"][0].norm()
+    # gradients: a ReLU / arg-max decision that flips on a last-bit difference re-routes a whole window (module docstring)
+    assert (res["3"][1] - res["1"][1]).norm() <= 2e-3 * res["1"][1].norm()

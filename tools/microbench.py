@@ -79,10 +79,12 @@ def conv():
         y, dx, dw = torch.empty(B, H, H, co, device="cuda"), torch.empty(B, H, H, ci, device="cuda"), torch.empty(3, 3, ci, co, device="cuda")
         dy = rnd(B, H, H, co)
         ws = torch.empty(lib.vc_conv3x3_wgrad_workspace_bytes(B, H, H, ci, co) // 4 + 4, device="cuda")
+        tw = torch.empty(max(lib.vc_conv3x3_fwd_workspace_bytes(B, H, H, ci, co), lib.vc_conv3x3_dgrad_workspace_bytes(B, H, H, ci, co), 16) // 4 + 4, device="cuda")
+        tb = tw.numel() * 4 if os.environ.get("VC_NO_TAIL") != "1" else 0
         fl = 2e-9 * B * H * H * 9 * ci * co
-        for nm, fn in (("fwd", lambda: lib.vc_conv3x3_fwd_f32(st(), B, H, H, ci, co, P(x), P(w), P(bias), P(y), 1)),
-                       ("dgrad", lambda: lib.vc_conv3x3_dgrad_f32(st(), B, H, H, ci, co, P(dy), P(w), P(x), P(dx))),
-                       ("dgr-nomask", lambda: lib.vc_conv3x3_dgrad_f32(st(), B, H, H, ci, co, P(dy), P(w), None, P(dx))),
+        for nm, fn in (("fwd", lambda: lib.vc_conv3x3_fwd_f32(st(), B, H, H, ci, co, P(x), P(w), P(bias), P(y), 1, P(tw), tb)),
+                       ("dgrad", lambda: lib.vc_conv3x3_dgrad_f32(st(), B, H, H, ci, co, P(dy), P(w), P(x), P(dx), P(tw), tb)),
+                       ("dgr-nomask", lambda: lib.vc_conv3x3_dgrad_f32(st(), B, H, H, ci, co, P(dy), P(w), None, P(dx), P(tw), tb)),
                        ("wgrad", lambda: lib.vc_conv3x3_wgrad_f32(st(), B, H, H, ci, co, P(x), P(dy), P(dw), P(bias), 0, P(ws), ws.numel() * 4))):
             med, mn = timeit(fn, reps=5)
             print("conv%s %-10s B=%d H=%3d %3d->%3d: %8.3f ms  %6.1f TFLOP/s" % (name, nm, B, H, ci, co, med, fl / med))

@@ -13,6 +13,6 @@ A = torch.rand(8192, 8192, device="cuda") * 2 - 1
 Bm = torch.rand(8192, 8192, device="cuda") * 2 - 1
 C = torch.empty(8192, 8192, device="cuda")
 for _ in range(3):
-    lib.vc_conv3x3_fwd_f32(st(), B, H, H, ci, co, P(x), P(w), P(bias), P(y), 1)
+    lib.vc_conv3x3_fwd_f32(st(), B, H, H, ci, co, P(x), P(w), P(bias), P(y), 1, None, 0)
     lib.vc_gemm_f32(st(), 0, 0, 8192, 8192, 8192, P(A), 8192, P(Bm), 8192, P(C), 8192, None, 0, None, 0)
 torch.cuda.synchronize()

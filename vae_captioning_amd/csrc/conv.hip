@@ -119,6 +119,11 @@ struct ConvArgs {
     int relu;
     int tiles_n, ntiles, kchunk;
     float* bias_ws;      // wgrad: [splits, Cout] partial column sums of dy (bias gradient), or null
+    // fwd / dgrad "tail" launch (the last partial round of tiles, K split so that it fills the chip once):
+    int tile0;           // first tile of this launch (tiles before it belong to the main launch)
+    float* tail_ws;      // null: normal epilogue; else raw partial sums [split][tail_rows][N]
+    long tail_row0;      // first output row of the tail
+    long tail_rows;
 };
 
 // Column sums of the dy tile staged in LDS (KM image Bs[k][BN+4]); thread t owns column t % BN and the
@@ -141,11 +146,59 @@ struct ColsumHook {
     }
 };
 
+static inline int grid_for(long work_items, int per_block = 256, int cap = 4096) {
+    long b = (work_items + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (int)b;
+}
+
+// Tail launch: the split's raw partial sums of this tile -> tail_ws[split][row - tail_row0][col]
+template <class CFG>
+__device__ __forceinline__ void tail_store(f32x16 (&acc)[CFG::TM][CFG::TN], float* smem, const ConvArgs& c, int m0, int n0, int ncols) {
+    float* out = c.tail_ws + (long)blockIdx.y * c.tail_rows * ncols;
+    epilogue_rows<CFG>(acc, smem, [&](int r, int cc, float4 v) {
+        const long row = m0 + r;
+        const int col = n0 + cc;
+        if (row >= c.g.P || col >= ncols) return;
+        *reinterpret_cast<float4*>(out + (row - c.tail_row0) * ncols + col) = v;
+    });
+}
+
+// Sum of the tail's K splits (fixed order) + the epilogue the main launch applies in registers.
+template <int KIND>
+__global__ __launch_bounds__(256) void conv_tail_reduce_kernel(const float4* __restrict__ ws, int splits, long rows, int nc4, long row0,
+                                                               const float* __restrict__ aux, int relu, float4* __restrict__ out) {
+    const long total = rows * nc4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        float4 v = ws[i];
+        for (int z = 1; z < splits; ++z) {
+            const float4 t = ws[(long)z * total + i];
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        const long o = row0 * nc4 + i;
+        if (KIND == CONV_FWD) {
+            if (aux) {
+                const float4 bv = reinterpret_cast<const float4*>(aux)[i % nc4];
+                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+            }
+            if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        } else if (aux) {
+            const float4 m = reinterpret_cast<const float4*>(aux)[o];
+            if (!(m.x > 0.f)) v.x = 0.f;
+            if (!(m.y > 0.f)) v.y = 0.f;
+            if (!(m.z > 0.f)) v.z = 0.f;
+            if (!(m.w > 0.f)) v.w = 0.f;
+        }
+        out[o] = v;
+    }
+}
+
 template <class CFG, int KIND>
 __global__ __launch_bounds__(CFG::NT) void conv_kernel(ConvArgs c) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const ConvGeom& g = c.g;
-    const int id = xcd_remap(blockIdx.x, c.ntiles);
+    const int id = c.tile0 + xcd_remap(blockIdx.x, c.ntiles);
     const int m0 = (id / c.tiles_n) * CFG::BM;
     const int n0 = (id % c.tiles_n) * CFG::BN;
     f32x16 acc[CFG::TM][CFG::TN];
@@ -155,7 +208,14 @@ __global__ __launch_bounds__(CFG::NT) void conv_kernel(ConvArgs c) {
         la.x = c.a; la.g = g; la.lc = g.lc_in; la.sign = 1;
         LoadKM<true> lb;
         lb.p = c.b; lb.ld = g.Cout; lb.R = g.Cout; lb.K = 9 * g.Cin;
-        mfma_mainloop<CFG, MODE_MK, MODE_KM>(acc, la, lb, m0, n0, 0, 9 * g.Cin, smem);
+        const int Kf = 9 * g.Cin;
+        const int kb = c.tail_ws ? blockIdx.y * c.kchunk : 0;
+        const int ke = c.tail_ws ? (kb + c.kchunk < Kf ? kb + c.kchunk : Kf) : Kf;
+        mfma_mainloop<CFG, MODE_MK, MODE_KM>(acc, la, lb, m0, n0, kb, ke, smem);
+        if (c.tail_ws) {
+            tail_store<CFG>(acc, smem, c, m0, n0, g.Cout);
+            return;
+        }
         epilogue_rows<CFG>(acc, smem, [&](int r, int cc, float4 v) {
             const long row = m0 + r;
             const int col = n0 + cc;
@@ -172,7 +232,14 @@ __global__ __launch_bounds__(CFG::NT) void conv_kernel(ConvArgs c) {
         la.x = c.a; la.g = g; la.lc = g.lc_out; la.sign = -1;
         LoadWeightsT lb;
         lb.w = c.b; lb.g = g;
-        mfma_mainloop<CFG, MODE_MK, MODE_MK>(acc, la, lb, m0, n0, 0, 9 * g.Cout, smem);
+        const int Kf = 9 * g.Cout;
+        const int kb = c.tail_ws ? blockIdx.y * c.kchunk : 0;
+        const int ke = c.tail_ws ? (kb + c.kchunk < Kf ? kb + c.kchunk : Kf) : Kf;
+        mfma_mainloop<CFG, MODE_MK, MODE_MK>(acc, la, lb, m0, n0, kb, ke, smem);
+        if (c.tail_ws) {
+            tail_store<CFG>(acc, smem, c, m0, n0, g.Cin);
+            return;
+        }
         epilogue_rows<CFG>(acc, smem, [&](int r, int cc, float4 v) {
             const long row = m0 + r;
             const int col = n0 + cc;
@@ -282,14 +349,91 @@ template <class C, int KIND>
 static void launch_cfg(hipStream_t st, ConvArgs& c, int Mrows, int Ncols, int splits) {
     c.tiles_n = cdiv(Ncols, C::BN);
     c.ntiles = cdiv(Mrows, C::BM) * c.tiles_n;
+    c.tile0 = 0; c.tail_ws = nullptr; c.tail_row0 = 0; c.tail_rows = 0;
     hipLaunchKernelGGL((conv_kernel<C, KIND>), dim3(c.ntiles, splits), dim3(C::NT), C::SMEM_BYTES, st, c);
 }
 
+// Forward / data-gradient launches are cut into whole rounds of resident workgroups: a launch of 2.04 rounds costs 2.33
+// (measured on conv4_2 at 64 images: 1520 tiles 1.83 ms, 1544 tiles 2.13 ms -- the ragged last round runs one
+// workgroup per CU at a third of the chip's rate).  The main launch takes floor(rounds) x slots tiles (whole tile rows);
+// the remaining tile rows run as a second launch with K split so that it is again one full round of (short)
+// workgroups, and conv_tail_reduce_kernel sums the splits in fixed order and applies the epilogue.
+struct TailPlan {
+    int main_tiles, tail_tiles, splits, kchunk;
+    long row0, rows;
+};
+
+template <class C>
+static TailPlan plan_tail(long P, int Ncols, int K, int slots) {
+    TailPlan t;
+    const int tiles_n = cdiv(Ncols, C::BN);
+    const int tiles_m = (int)cdiv(P, (long)C::BM);
+    const int T = tiles_m * tiles_n;
+    t.main_tiles = T; t.tail_tiles = 0; t.splits = 1; t.kchunk = 0; t.row0 = P; t.rows = 0;
+    const int full = (T / slots) * slots;
+    if (full == T) return t;
+    const int main_m = full / tiles_n;  // whole tile rows (0: less than one round of tiles -> all of them are split)
+    const int tail = T - main_m * tiles_n;
+    int S = slots / tail;  // (rounding up to 784 workgroups for 392 tiles was measured slower than leaving them unsplit)
+    const int ktiles = cdiv(K, 32);
+    if (S > ktiles / 4) S = ktiles / 4;  // >= 4 K-tiles per split
+    if (S > 32) S = 32;
+    if (S < 2) return t;
+    t.kchunk = cdiv(ktiles, S) * 32;
+    t.splits = cdiv(K, t.kchunk);
+    t.main_tiles = main_m * tiles_n;
+    t.tail_tiles = tail;
+    t.row0 = (long)main_m * C::BM;
+    t.rows = P - t.row0;
+    return t;
+}
+
+template <class C, int KIND>
+static int launch_rounds(hipStream_t st, ConvArgs& c, long P, int Ncols, int K, int slots, float* ws, size_t ws_bytes) {
+    const TailPlan t = plan_tail<C>(P, Ncols, K, slots);
+    c.tiles_n = cdiv(Ncols, C::BN);
+    c.tile0 = 0; c.tail_ws = nullptr; c.tail_row0 = 0; c.tail_rows = 0; c.kchunk = 0;
+    const size_t need = (size_t)t.splits * t.rows * Ncols * sizeof(float);
+    if (t.tail_tiles == 0 || !ws || ws_bytes < need) {  // no ragged round, or no workspace given: one launch
+        c.ntiles = (int)cdiv(P, (long)C::BM) * c.tiles_n;
+        hipLaunchKernelGGL((conv_kernel<C, KIND>), dim3(c.ntiles, 1), dim3(C::NT), C::SMEM_BYTES, st, c);
+        return launch_status("conv");
+    }
+    if (t.main_tiles > 0) {
+        c.ntiles = t.main_tiles;
+        hipLaunchKernelGGL((conv_kernel<C, KIND>), dim3(c.ntiles, 1), dim3(C::NT), C::SMEM_BYTES, st, c);
+        if (int e = launch_status("conv")) return e;
+    }
+    ConvArgs d = c;
+    d.tile0 = t.main_tiles; d.ntiles = t.tail_tiles; d.kchunk = t.kchunk; d.tail_ws = ws; d.tail_row0 = t.row0; d.tail_rows = t.rows;
+    hipLaunchKernelGGL((conv_kernel<C, KIND>), dim3(d.ntiles, t.splits), dim3(C::NT), C::SMEM_BYTES, st, d);
+    if (int e = launch_status("conv tail")) return e;
+    const int nc4 = Ncols / 4;
+    hipLaunchKernelGGL((conv_tail_reduce_kernel<KIND>), dim3(grid_for(t.rows * nc4)), dim3(256), 0, st, (const float4*)ws, t.splits, t.rows,
+                       nc4, t.row0, c.aux, c.relu, (float4*)c.out);
+    return launch_status("conv tail reduce");
+}
+
+// resident workgroups per chip: the 128 x 128 kernels run 3 per CU (164-168 VGPRs), the 256 x 64 ones 2 (184-196)
+constexpr int SLOTS_WIDE = 768, SLOTS_NARROW = 512;
+
 template <int KIND>
-static void launch_conv(hipStream_t st, ConvArgs& c, int Mrows, int Ncols, int splits) {
-    if (KIND == CONV_WGRAD && Mrows <= 64) {
+static size_t rounds_workspace(long P, int Ncols, int K) {
+    const TailPlan t = Ncols <= 64 ? plan_tail<ConvCfgNarrow>(P, Ncols, K, SLOTS_NARROW) : plan_tail<ConvCfgWide>(P, Ncols, K, SLOTS_WIDE);
+    return t.tail_tiles ? (size_t)t.splits * t.rows * Ncols * sizeof(float) : 0;
+}
+
+template <int KIND>
+static int launch_fwd_dgrad(hipStream_t st, ConvArgs& c, long P, int Ncols, int K, float* ws, size_t ws_bytes) {
+    if (Ncols <= 64) return launch_rounds<ConvCfgNarrow, KIND>(st, c, P, Ncols, K, SLOTS_NARROW, ws, ws_bytes);
+    return launch_rounds<ConvCfgWide, KIND>(st, c, P, Ncols, K, SLOTS_WIDE, ws, ws_bytes);
+}
+
+static void launch_wgrad(hipStream_t st, ConvArgs& c, int Mrows, int Ncols, int splits) {
+    constexpr int KIND = CONV_WGRAD;
+    if (Mrows <= 64) {
         launch_cfg<ConvCfgSmall, KIND>(st, c, Mrows, Ncols, splits);
-    } else if (KIND == CONV_WGRAD && Mrows == 576) {
+    } else if (Mrows == 576) {
         if (Ncols <= 64) launch_cfg<ConvCfgW192n, KIND>(st, c, Mrows, Ncols, splits);
         else launch_cfg<ConvCfgW192w, KIND>(st, c, Mrows, Ncols, splits);
     } else if (Ncols <= 64) {
@@ -373,37 +517,38 @@ __global__ __launch_bounds__(256) void pad_dim_kernel(const float* __restrict__ 
     }
 }
 
-static inline int grid_for(long work_items, int per_block = 256, int cap = 4096) {
-    long b = (work_items + per_block - 1) / per_block;
-    if (b < 1) b = 1;
-    if (b > cap) b = cap;
-    return (int)b;
-}
-
 }  // namespace vc
 
 using namespace vc;
 
+extern "C" size_t vc_conv3x3_fwd_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
+    ConvGeom g;
+    if (make_geom(g, B, H, W, Cin, Cout)) return 0;
+    return rounds_workspace<CONV_FWD>(g.P, Cout, 9 * Cin);
+}
+
+extern "C" size_t vc_conv3x3_dgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
+    ConvGeom g;
+    if (make_geom(g, B, H, W, Cin, Cout)) return 0;
+    return rounds_workspace<CONV_DGRAD>(g.P, Cin, 9 * Cout);
+}
+
 extern "C" int vc_conv3x3_fwd_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const float* w,
-                                  const float* bias, float* y, int relu) {
+                                  const float* bias, float* y, int relu, float* ws, size_t ws_bytes) {
     ConvArgs c;
     VC_CHECK_ARG(x && w && y && B > 0 && H > 0 && W > 0, "bad argument");
     if (make_geom(c.g, B, H, W, Cin, Cout)) return fail(VC_EINVAL, "%s: Cin/Cout must be powers of two >= 4", __func__);
     c.a = x; c.b = w; c.out = y; c.aux = bias; c.relu = relu; c.kchunk = 0; c.bias_ws = nullptr;
-    launch_conv<CONV_FWD>((hipStream_t)stream, c, (int)c.g.P, Cout, 1);
-    VC_LAUNCH_CHECK();
-    return 0;
+    return launch_fwd_dgrad<CONV_FWD>((hipStream_t)stream, c, c.g.P, Cout, 9 * Cin, ws, ws_bytes);
 }
 
 extern "C" int vc_conv3x3_dgrad_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* dy, const float* w,
-                                    const float* relu_src, float* dx) {
+                                    const float* relu_src, float* dx, float* ws, size_t ws_bytes) {
     ConvArgs c;
     VC_CHECK_ARG(dy && w && dx && B > 0 && H > 0 && W > 0, "bad argument");
     if (make_geom(c.g, B, H, W, Cin, Cout)) return fail(VC_EINVAL, "%s: Cin/Cout must be powers of two >= 4", __func__);
     c.a = dy; c.b = w; c.out = dx; c.aux = relu_src; c.relu = 0; c.kchunk = 0; c.bias_ws = nullptr;
-    launch_conv<CONV_DGRAD>((hipStream_t)stream, c, (int)c.g.P, Cin, 1);
-    VC_LAUNCH_CHECK();
-    return 0;
+    return launch_fwd_dgrad<CONV_DGRAD>((hipStream_t)stream, c, c.g.P, Cin, 9 * Cout, ws, ws_bytes);
 }
 
 extern "C" size_t vc_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
@@ -424,7 +569,7 @@ extern "C" int vc_conv3x3_wgrad_f32(void* stream, int B, int H, int W, int Cin, 
         return fail(VC_EWORKSPACE, "%s: workspace too small (need vc_conv3x3_wgrad_workspace_bytes)", __func__);
     c.a = x; c.b = dy; c.out = ws; c.aux = nullptr; c.relu = 0; c.kchunk = p.kchunk;
     c.bias_ws = db ? ws + (size_t)p.splits * MN : nullptr;
-    launch_conv<CONV_WGRAD>((hipStream_t)stream, c, 9 * Cin, Cout, p.splits);
+    launch_wgrad((hipStream_t)stream, c, 9 * Cin, Cout, p.splits);
     VC_LAUNCH_CHECK();
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(MN)), dim3(256), 0, (hipStream_t)stream, ws, p.splits, MN, dw, accumulate);
     VC_LAUNCH_CHECK();

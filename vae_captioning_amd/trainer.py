@@ -26,6 +26,7 @@ class VggEngine(object):
         self.buf = {}
         self.ws = None
         self.ws_bytes = 0
+        self.tail_ws = {}
         self.train = bool(p.fine_tune) and p.mode == "training"
         self.keep = float(p.cnn_dropout) if self.train else 1.0  # main.py:67-73
         self.wd = float(p.weight_decay) if self.train else 0.0
@@ -59,6 +60,21 @@ class VggEngine(object):
         if nbytes > self.ws_bytes:
             self.ws = torch.empty(max(int(nbytes), 1 << 20) // 4 + 16, dtype=torch.float32, device=self.dev)
             self.ws_bytes = self.ws.numel() * 4
+
+    def _chain_ws(self, i, nb):
+        """Workspace of conv chain i (one per stream: chains run concurrently) for the K-split tail launches of the
+        forward / data-gradient convolutions at nb images."""
+        key = (i, nb)
+        t = self.tail_ws.get(key)
+        if t is None:
+            lib, need, H, W = self.lib, 0, 224, 224
+            for name, ci, co in spec.VGG_CONV:
+                cie = 4 if ci == 3 else ci
+                need = max(need, lib.vc_conv3x3_fwd_workspace_bytes(nb, H, W, cie, co), lib.vc_conv3x3_dgrad_workspace_bytes(nb, H, W, cie, co))
+                if name in spec.VGG_POOL_AFTER:
+                    H, W = H // 2, W // 2
+            t = self.tail_ws[key] = torch.empty(max(need, 16) // 4 + 16, dtype=torch.float32, device=self.dev)
+        return t
 
     def gemm(self, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias=None, flags=0):
         self._need_ws(self.lib.vc_gemm_workspace_bytes(M, N, K))
@@ -130,11 +146,13 @@ class VggEngine(object):
             y = self._b("y_" + name, (B, H, W, co))
             pooled = name in spec.VGG_POOL_AFTER
             yp = self._b("p_" + name, (B, H // 2, W // 2, co)) if pooled else None
-            for b0, nb, strm in halves:
+            for ch, (b0, nb, strm) in enumerate(halves):
+                tws = self._chain_ws(ch, nb)
                 with torch.cuda.stream(strm):
                     sh = _stream()
                     self._timed("conv_fwd", 2.0 * nb * H * W * 9 * ci * co,
-                                lambda: lib.vc_conv3x3_fwd_f32(sh, nb, H, W, cie, co, P(x[b0:]), P(w), P(S.param(bn)), P(y[b0:]), 1))
+                                lambda: lib.vc_conv3x3_fwd_f32(sh, nb, H, W, cie, co, P(x[b0:]), P(w), P(S.param(bn)), P(y[b0:]), 1,
+                                                               P(tws), tws.numel() * 4))
                     if pooled:
                         lib.vc_maxpool2x2_fwd_f32(sh, nb, H, W, co, P(y[b0:]), P(yp[b0:]))
             self.acts.append((name, x, H, W, cie, co, w))
@@ -246,11 +264,12 @@ class VggEngine(object):
             if li > 0:
                 prev_is_pool = self.acts[li - 1][0] == "P"
                 dx = self._b("dx_%d" % li, (B, H, W, ci))
-                for b0, nb, strm in halves:
+                for ch, (b0, nb, strm) in enumerate(halves):
+                    tws = self._chain_ws(ch, nb)
                     with torch.cuda.stream(strm):
                         sh = _stream()
                         self._timed("conv_dgrad", fl * nb / B, lambda: lib.vc_conv3x3_dgrad_f32(
-                            sh, nb, H, W, ci, co, P(d[b0:]), P(w), None if prev_is_pool else P(x[b0:]), P(dx[b0:])))
+                            sh, nb, H, W, ci, co, P(d[b0:]), P(w), None if prev_is_pool else P(x[b0:]), P(dx[b0:]), P(tws), tws.numel() * 4))
                 d = dx
         if split:
             main.wait_stream(side)
