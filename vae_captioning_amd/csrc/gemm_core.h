@@ -183,43 +183,54 @@ __device__ __forceinline__ void mfma_mainloop(f32x16 (&acc)[CFG::TM][CFG::TN], A
         }
         if (!(ABL & 1) && k0 + 32 < k_end) gload(k0 + 32);
         hook(As, Bs);
+        if (ABL & 4) {
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {  // two chunks of 8 MFMA k-steps
-            if (!(ABL & 4))
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm) {
-                const int r = (wm * TM + tm) * 32 + li;
-                if (AMODE == MODE_MK) {
-                    const float4 v0 = *reinterpret_cast<const float4*>(&As[r * 36 + lh * 16 + c * 8]);
-                    const float4 v1 = *reinterpret_cast<const float4*>(&As[r * 36 + lh * 16 + c * 8 + 4]);
-                    a[tm][0] = v0.x; a[tm][1] = v0.y; a[tm][2] = v0.z; a[tm][3] = v0.w;
-                    a[tm][4] = v1.x; a[tm][5] = v1.y; a[tm][6] = v1.z; a[tm][7] = v1.w;
-                } else {
-#pragma unroll
-                    for (int s = 0; s < 8; ++s) a[tm][s] = As[(lh * 16 + c * 8 + s) * (BM + 4) + r];
-                }
-            }
-            if (!(ABL & 4))
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn) {
-                const int r = (wn * TN + tn) * 32 + li;
-                if (BMODE == MODE_MK) {
-                    const float4 v0 = *reinterpret_cast<const float4*>(&Bs[r * 36 + lh * 16 + c * 8]);
-                    const float4 v1 = *reinterpret_cast<const float4*>(&Bs[r * 36 + lh * 16 + c * 8 + 4]);
-                    b[tn][0] = v0.x; b[tn][1] = v0.y; b[tn][2] = v0.z; b[tn][3] = v0.w;
-                    b[tn][4] = v1.x; b[tn][5] = v1.y; b[tn][6] = v1.z; b[tn][7] = v1.w;
-                } else {
-#pragma unroll
-                    for (int s = 0; s < 8; ++s) b[tn][s] = Bs[(lh * 16 + c * 8 + s) * (BN + 4) + r];
-                }
-            }
-#pragma unroll
-            for (int s = 0; s < 8; ++s)
+            for (int s = 0; s < 16; ++s)
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn)
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][s], b[tn][s], acc[tm][tn], 0, 0, 0);
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][s & 7], b[tn][s & 7], acc[tm][tn], 0, 0, 0);
+        } else {
+            // Four chunks of 4 MFMA k-steps; the fragments of chunk c+1 are read from LDS while the 16 MFMAs of chunk c
+            // run (two fragment sets, 32 VGPRs in all: the same as one 8-step set).
+            float fa[2][TM][4], fb[2][TN][4];
+            auto frag = [&](int c, int buf) {
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) {
+                    const int r = (wm * TM + tm) * 32 + li;
+                    if (AMODE == MODE_MK) {
+                        const float4 v = *reinterpret_cast<const float4*>(&As[r * 36 + lh * 16 + c * 4]);
+                        fa[buf][tm][0] = v.x; fa[buf][tm][1] = v.y; fa[buf][tm][2] = v.z; fa[buf][tm][3] = v.w;
+                    } else {
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) fa[buf][tm][s] = As[(lh * 16 + c * 4 + s) * (BM + 4) + r];
+                    }
+                }
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    const int r = (wn * TN + tn) * 32 + li;
+                    if (BMODE == MODE_MK) {
+                        const float4 v = *reinterpret_cast<const float4*>(&Bs[r * 36 + lh * 16 + c * 4]);
+                        fb[buf][tn][0] = v.x; fb[buf][tn][1] = v.y; fb[buf][tn][2] = v.z; fb[buf][tn][3] = v.w;
+                    } else {
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) fb[buf][tn][s] = Bs[(lh * 16 + c * 4 + s) * (BN + 4) + r];
+                    }
+                }
+            };
+            frag(0, 0);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (c + 1 < 4) frag(c + 1, (c + 1) & 1);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                        for (int tn = 0; tn < TN; ++tn)
+                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c & 1][tm][s], fb[c & 1][tn][s], acc[tm][tn], 0, 0, 0);
+            }
         }
     }
 }
