@@ -152,7 +152,7 @@ def main(params):
             else:
                 it = SyntheticBatches(params, steps_per_epoch, params.seed + 17 * e + rank).next_batch()
             for batch in it:
-                if batch["features"].shape[0] != params.batch_size:
+                if batch["cap_dec"].shape[0] != params.batch_size * params.num_captions:
                     continue  # ragged last batch: shapes are static on device
                 tr.set_batch(batch)
                 # ---- one sess.run([kld, rec_loss, lower_bound, optimize, optimize_cnn, annealing]) ----

@@ -110,6 +110,12 @@ def test_main_cli_training_then_inference(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     caps = json.load(open(tmp_path / "val_t1.json"))
     assert len(caps) == 8 and set(caps[0]) == {"image_id", "caption"}
+    # --fine_tune on synthetic images (VGG16 on device, CNN optimiser, npz checkpoint format)
+    r = subprocess.run(base + ["--epochs", "1", "--max_steps", "2", "--fine_tune", "--bs", "2", "--ckpt_format", "npz", "--checkpoint", "ft"],
+                       cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    z = np.load(tmp_path / "checkpoints" / "ft.ckpt.npz")
+    assert z["cnn/fc1/weights"].shape == (25088, 4096) and "decoder/rnn_logits/kernel" in z.files
 
 
 def test_bench_two_ranks_through_torchrun_on_one_gpu(tmp_path):
