@@ -210,6 +210,11 @@ class CaptionEngine(object):
     def load_params(self, named):
         """named: {reference variable name -> numpy array} (spec.caption_variables names)."""
         p = self.p
+        need = [n for n, _ in spec.caption_variables(p, self.V)]
+        missing = [n for n in need if n not in named]
+        if missing:  # tf.train.Saver.restore raises NotFoundError for the same situation
+            raise KeyError("checkpoint lacks %d variable(s) of this model (prior=%s, no_encoder=%s, c_v=%s), e.g. %s -- was it saved "
+                           "with different options?" % (len(missing), p.prior, p.no_encoder, p.use_c_v, missing[0]))
         for name in self.store.names():
             if name == "encoder/heads/kernel":
                 ks = [named[spec.head_scope(p.prior, k) + "dense/kernel"] for k in range(K_CL)]
