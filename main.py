@@ -77,9 +77,12 @@ def main(params):
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    backend = os.environ.get("VC_DIST_BACKEND", "nccl")  # gloo: several ranks on ONE GPU (tests only)
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local if backend == "nccl" else local % torch.cuda.device_count())
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend, rank=rank, world_size=world)
     real = coco_train = coco_val = coco_test = None
     if params.captions_json and params.features_pickle:
         # precomputed-feature path of the reference's data layer (utils/data.py + utils/batch_gen.py)

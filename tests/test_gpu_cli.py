@@ -144,6 +144,12 @@ def test_bench_two_ranks_through_torchrun_on_one_gpu(tmp_path):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert d["n_gpus"] == 2 and np.isfinite(d["final_losses"]["rec_loss"]) and np.isfinite(d["final_losses"]["kld"])
+    # the headline workload (VGG16 fine-tuning): four asynchronous gradient buckets under the three-stream backward
+    cmd[cmd.index("cfg2")] = "cfg4"
+    r = subprocess.run(cmd + ["--images-per-gpu", "2"], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["config"]["global_caption_rows"] == 20 and np.isfinite(d["final_losses"]["rec_loss"])
 
 
 def test_gen_caption_cli_single_image(tmp_path, lib):
