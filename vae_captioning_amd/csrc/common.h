@@ -82,4 +82,9 @@ __device__ __forceinline__ float block_max(float v, float* sh) {
     return t;
 }
 
+// gemm.hip: split-K partial products for consumers that reduce them in their own kernel (lstm.hip)
+int gemm_partials_f32(hipStream_t st, int ta, int tb, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
+                      float* ws, size_t ws_bytes, int max_splits, int* splits_out);
+size_t gemm_partials_bytes(int M, int N, int K, int max_splits);
+
 }  // namespace vc

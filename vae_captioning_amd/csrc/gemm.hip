@@ -155,6 +155,41 @@ static void dispatch_modes(hipStream_t st, const GemmArgs& g, int ta, int tb) {
 using Cfg128 = TileCfg<2, 2, 2, 2>;
 using Cfg64 = TileCfg<2, 2, 1, 1>;
 
+// Split-K partial products only (no reduce, no bias): ws[s][M][N] = op(A) op(B) over the s-th K range, 64 x 64 tiles.
+// For consumers that sum the partials themselves (the LSTM gate kernels).  Returns the number of splits written
+// (chosen so that tiles x splits is about one round of resident workgroups, each split >= 2 K-tiles, <= max_splits).
+int gemm_partials_f32(hipStream_t st, int ta, int tb, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
+                      float* ws, size_t ws_bytes, int max_splits, int* splits_out) {
+    const int tiles_m = cdiv(M, 64), tiles_n = cdiv(N, 64);
+    const long tiles = (long)tiles_m * tiles_n;
+    long S = 768 / tiles;
+    if (S > K / 64) S = K / 64;
+    if (S > max_splits) S = max_splits;
+    if (S < 1) S = 1;
+    int kchunk = cdiv(cdiv(K, (int)S), 32) * 32;
+    const int splits = cdiv(K, kchunk);
+    if (!ws || ws_bytes < (size_t)splits * M * N * sizeof(float)) return fail(VC_EWORKSPACE, "%s: workspace too small", __func__);
+    GemmArgs g;
+    g.A = A; g.B = B; g.C = ws; g.bias = nullptr; g.ws = ws;
+    g.lda = lda; g.ldb = ldb; g.ldc = N; g.M = M; g.N = N; g.K = K;
+    g.tiles_n = tiles_n; g.ntiles = tiles_m * tiles_n; g.kchunk = kchunk; g.splits = splits; g.flags = 0;
+    auto al = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+    const bool vec = al(A) && al(B) && (lda % 4 == 0) && (ldb % 4 == 0) && ((ta ? M : K) % 4 == 0) && ((tb ? K : N) % 4 == 0);
+    if (vec) dispatch_modes<Cfg64, true>(st, g, ta, tb); else dispatch_modes<Cfg64, false>(st, g, ta, tb);
+    *splits_out = splits;
+    return launch_status(__func__);
+}
+
+size_t gemm_partials_bytes(int M, int N, int K, int max_splits) {
+    const long tiles = (long)cdiv(M, 64) * cdiv(N, 64);
+    long S = 768 / tiles;
+    if (S > K / 64) S = K / 64;
+    if (S > max_splits) S = max_splits;
+    if (S < 1) S = 1;
+    const int kchunk = cdiv(cdiv(K, (int)S), 32) * 32;
+    return (size_t)cdiv(K, kchunk) * M * N * sizeof(float);
+}
+
 }  // namespace vc
 
 extern "C" size_t vc_gemm_workspace_bytes(int M, int N, int K) {

@@ -148,14 +148,25 @@ __global__ __launch_bounds__(CFG::NT) void lstm_step_bwd_kernel(LstmBwdArgs a) {
 // ---- split form: the recurrent GEMM through vc_gemm_f32 (64x64 tiles + split-K fill the chip even
 // at N = 320 rows, where the fused kernel above has only 50 workgroups) followed by these
 // element-wise gate kernels.  Same arithmetic, same buffers; chosen by the sequence drivers.
+// part: `nsplit` split-K partial products h_{t-1}.Wh [N, 4H] each (fixed summation order), or null when the recurrent
+// product has already been accumulated into gact.
 __global__ __launch_bounds__(256) void lstm_gates_fwd_kernel(float* __restrict__ gact, const float* __restrict__ c_prev,
                                                              const float* __restrict__ h_prev, const int32_t* __restrict__ lens,
-                                                             float* __restrict__ c_out, float* __restrict__ h_out, int N, int H, int t) {
+                                                             float* __restrict__ c_out, float* __restrict__ h_out, int N, int H, int t,
+                                                             const float* __restrict__ part, int nsplit) {
     const long total = (long)N * H;
+    const long pstride = (long)N * 4 * H;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int row = (int)(i / H), u = (int)(i % H);
         float* g = gact + (long)row * 4 * H + u;
-        const float ig = sigmoidf_(g[0]), jg = tanhf(g[H]), fg = sigmoidf_(g[2 * H] + 1.0f), og = sigmoidf_(g[3 * H]);
+        float p0 = g[0], p1 = g[H], p2 = g[2 * H], p3 = g[3 * H];
+        if (part) {
+            const float* q = part + (long)row * 4 * H + u;
+            float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f;
+            for (int z = 0; z < nsplit; ++z, q += pstride) { r0 += q[0]; r1 += q[H]; r2 += q[2 * H]; r3 += q[3 * H]; }
+            p0 += r0; p1 += r1; p2 += r2; p3 += r3;
+        }
+        const float ig = sigmoidf_(p0), jg = tanhf(p1), fg = sigmoidf_(p2 + 1.0f), og = sigmoidf_(p3);
         const float cp = c_prev[i];
         const float c = fg * cp + ig * jg;
         const float h = og * tanhf(c);
@@ -170,13 +181,16 @@ __global__ __launch_bounds__(256) void lstm_gates_bwd_kernel(const float* __rest
                                                              const float* __restrict__ dh_ext, float* __restrict__ dH_run,
                                                              float* __restrict__ dC_run, const float* __restrict__ act,
                                                              const float* __restrict__ c_prev, const float* __restrict__ c_cur,
-                                                             float* __restrict__ dG, int N, int H, int t, int first) {
+                                                             float* __restrict__ dG, int N, int H, int t, int first, int nsplit) {
     const long total = (long)N * H;
     for (long si = (long)blockIdx.x * 256 + threadIdx.x; si < total; si += (long)gridDim.x * 256) {
         const int row = (int)(si / H), u = (int)(si % H);
         const int len = lens[row];
         float dh = dH_run[si];
-        if (!first && (t + 1 < len)) dh = rec[si];
+        if (!first && (t + 1 < len)) {  // rec: nsplit split-K partials of dG[t+1].Wh^T, summed in fixed order
+            dh = rec[si];
+            for (int z = 1; z < nsplit; ++z) dh += rec[(long)z * total + si];
+        }
         if (dh_ext) dh += dh_ext[si];
         dH_run[si] = dh;
         const float* ac = act + (long)row * 4 * H + u;
@@ -252,8 +266,8 @@ extern "C" int vc_lstm_set_mode(int split) {
 
 extern "C" size_t vc_lstm_seq_workspace_bytes(int T, int N, int E, int H) {
     size_t w = vc_gemm_workspace_bytes(E, 4 * H, T * N);
-    size_t w6 = vc_gemm_workspace_bytes(N, 4 * H, H);
-    size_t w7 = vc_gemm_workspace_bytes(N, H, 4 * H);
+    size_t w6 = vc::gemm_partials_bytes(N, 4 * H, H, 8);
+    size_t w7 = vc::gemm_partials_bytes(N, H, 4 * H, 16);
     if (w6 > w) w = w6;
     if (w7 > w) w = w7;
     size_t w2 = vc_gemm_workspace_bytes(H, 4 * H, T * N);
@@ -285,10 +299,11 @@ extern "C" int vc_lstm_seq_fwd_f32(void* stream, int T, int N, int E, int H, con
     for (int t = 0; t < T; ++t) {
         float* g = act + (long)t * N * 4 * H;
         if (g_lstm_split) {
-            rc = vc_gemm_f32(stream, 0, 0, N, 4 * H, H, hs + t * NH, H, Wh, 4 * H, g, 4 * H, nullptr, VC_GEMM_ACCUMULATE, ws, ws_bytes);
+            int ns = 1;  // recurrent product as split-K partials in ws; the gate kernel sums them (no separate reduce launch)
+            rc = gemm_partials_f32((hipStream_t)stream, 0, 0, N, 4 * H, H, hs + t * NH, H, Wh, 4 * H, ws, ws_bytes, 8, &ns);
             if (rc) return rc;
             hipLaunchKernelGGL(lstm_gates_fwd_kernel, dim3(eg), dim3(256), 0, (hipStream_t)stream, g, cs + t * NH, hs + t * NH, lens_eff,
-                               cs + (t + 1) * NH, hs + (t + 1) * NH, N, H, t);
+                               cs + (t + 1) * NH, hs + (t + 1) * NH, N, H, t, ws, ns);
             rc = launch_status(__func__);
         } else {
             rc = vc_lstm_step_fwd_f32(stream, N, H, t, hs + t * NH, cs + t * NH, Wh, g, lens_eff, cs + (t + 1) * NH, hs + (t + 1) * NH);
@@ -314,18 +329,19 @@ extern "C" int vc_lstm_seq_bwd_f32(void* stream, int T, int N, int E, int H, con
     const long NH = (long)N * H, NG = (long)N * 4 * H;
     int rc;
     const int eg = (int)((NH + 255) / 256) < 2048 ? (int)((NH + 255) / 256) : 2048;
-    // split form scratch: the recurrent product dG[t+1].Wh^T lives in dX (free until the final GEMM)
-    float* rec = dX;
+    // split form: the recurrent product dG[t+1].Wh^T as split-K partials in ws, summed by the gate kernel
+    const float* rec = ws;
     for (int t = T - 1; t >= 0; --t) {
         const int first = (t == T - 1);
         const float* ext = dhs_ext ? dhs_ext + (t + 1) * NH : nullptr;
-        if (g_lstm_split && (long)T * N * E >= NH) {
+        if (g_lstm_split) {
+            int ns = 1;
             if (!first) {
-                rc = vc_gemm_f32(stream, 0, 1, N, H, 4 * H, dG + (t + 1) * NG, 4 * H, Wh, 4 * H, rec, H, nullptr, 0, ws, ws_bytes);
+                rc = gemm_partials_f32((hipStream_t)stream, 0, 1, N, H, 4 * H, dG + (t + 1) * NG, 4 * H, Wh, 4 * H, ws, ws_bytes, 16, &ns);
                 if (rc) return rc;
             }
             hipLaunchKernelGGL(lstm_gates_bwd_kernel, dim3(eg), dim3(256), 0, (hipStream_t)stream, rec, lens_eff, ext, dH_run, dC_run,
-                               act + t * NG, cs + t * NH, cs + (t + 1) * NH, dG + t * NG, N, H, t, first);
+                               act + t * NG, cs + t * NH, cs + (t + 1) * NH, dG + t * NG, N, H, t, first, ns);
             rc = launch_status(__func__);
         } else {
             rc = vc_lstm_step_bwd_f32(stream, N, H, t, first, first ? nullptr : dG + (t + 1) * NG, Wh, lens_eff, ext, dH_run, dC_run,
