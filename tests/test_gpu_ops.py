@@ -61,6 +61,32 @@ def test_gemm_flags_and_ldc(lib):
     assert_close(host(C), ref, 2e-5, msg="gemm relu+accumulate, ldc > N (padding untouched)")
 
 
+@pytest.mark.parametrize("ta,tb,flags", [(0, 0, 0), (0, 1, 1), (1, 0, 2), (1, 1, 3)])
+def test_gemm_whole_rounds_tail(lib, ta, tb, flags):
+    """776 tiles of 128 x 128 = one round of 768 resident workgroups + one tile row: that row runs as a K-split second
+    launch (csrc/gemm.hip plan_gemm, tail_splits) whose reduce applies bias / ReLU / accumulate like the main launch."""
+    M, N, K = 12400, 1024, 512
+    assert lib.vc_gemm_workspace_bytes(M, N, K) == 4 * (M - 96 * 128) * N * 4
+    rng = np.random.default_rng(9 + flags)
+    A = rng.standard_normal((M, K), dtype=np.float32)
+    B = rng.standard_normal((K, N), dtype=np.float32)
+    bias = rng.standard_normal(N, dtype=np.float32)
+    C0 = rng.standard_normal((M, N), dtype=np.float32)
+    ref = A.astype(np.float64) @ B.astype(np.float64) + bias
+    if flags & 2:
+        ref = ref + C0
+    if flags & 1:
+        ref = np.maximum(ref, 0)
+    dA, dB, C = dev(A.T if ta else A), dev(B.T if tb else B), dev(C0)
+    ws = empty_bytes(lib.vc_gemm_workspace_bytes(M, N, K))
+    lib.vc_gemm_f32(stream(), ta, tb, M, N, K, P(dA), M if ta else K, P(dB), K if tb else N, P(C), N, P(dev(bias)), flags, P(ws), ws.numel() * 4)
+    assert_close(host(C), ref, 2e-6 * np.sqrt(K) + 2e-6, msg="gemm tail ta=%d tb=%d flags=%d" % (ta, tb, flags))
+    C2 = dev(C0)   # no workspace: single launch, same values up to summation order of the tail rows
+    lib.vc_gemm_f32(stream(), ta, tb, M, N, K, P(dA), M if ta else K, P(dB), K if tb else N, P(C2), N, P(dev(bias)), flags, None, 0)
+    assert_close(host(C2), ref, 2e-6 * np.sqrt(K) + 2e-6, msg="gemm single launch")
+    assert torch.equal(C[:96 * 128], C2[:96 * 128]) and not torch.equal(C[96 * 128:], C2[96 * 128:])
+
+
 def test_gemm_rejects_bad_arguments(lib):
     from vae_captioning_amd.abi import VaecapError
     with pytest.raises(VaecapError):

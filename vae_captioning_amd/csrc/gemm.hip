@@ -20,12 +20,15 @@ struct GemmArgs {
     int kchunk;  // K range per split (multiple of 32)
     int splits;
     int flags;
+    int tile0;       // first tile of this launch (tail launches start after the main launch's tiles)
+    long ws_row0;    // split partials are stored as ws[split][row - ws_row0][N] with ws_rows rows per split
+    long ws_rows;
 };
 
 template <class CFG, int AM, int BMD, bool VEC, int ABL = 0>
 __global__ __launch_bounds__(CFG::NT) void gemm_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int id = xcd_remap(blockIdx.x, g.ntiles);
+    const int id = g.tile0 + xcd_remap(blockIdx.x, g.ntiles);
     const int m0 = (id / g.tiles_n) * CFG::BM;
     const int n0 = (id % g.tiles_n) * CFG::BN;
     const int kb = blockIdx.y * g.kchunk;
@@ -39,7 +42,7 @@ __global__ __launch_bounds__(CFG::NT) void gemm_kernel(GemmArgs g) {
     if (ABL == 8) mfma_mainloop_db<CFG, AM, BMD>(acc, la, lb, m0, n0, kb, ke, smem);
     else mfma_mainloop<CFG, AM, BMD, decltype(la), decltype(lb), ABL>(acc, la, lb, m0, n0, kb, ke, smem);
     const bool split = g.splits > 1;
-    float* out = split ? g.ws + (long)blockIdx.y * g.M * g.N : g.C;
+    float* out = split ? g.ws + ((long)blockIdx.y * g.ws_rows - g.ws_row0) * g.N : g.C;
     const long ldo = split ? g.N : g.ldc;
     const bool vec_out = ((ldo & 3) == 0) && ((((uintptr_t)out) & 15) == 0);
     epilogue_rows<CFG>(acc, smem, [&](int r, int c, float4 v) {
@@ -97,6 +100,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 struct GemmPlan {
     bool big;  // 128x128 tile, else 64x64
     int splits, kchunk, tiles_m, tiles_n;
+    // whole rounds (128x128 tiles, no global split-K): the tile rows beyond the last full round of 768 resident workgroups
+    // run as a second launch with K split `tail_splits` ways (see conv.hip launch_rounds for the measurement behind it)
+    int main_m, tail_splits, tail_kchunk;
 };
 
 static GemmPlan plan_gemm(int M, int N, int K) {
@@ -134,6 +140,24 @@ static GemmPlan plan_gemm(int M, int N, int K) {
     if (kchunk < 32) kchunk = 32;
     p.splits = cdiv(K, kchunk);
     p.kchunk = kchunk;
+    p.main_m = p.tiles_m; p.tail_splits = 1; p.tail_kchunk = 0;
+    if (p.big && p.splits == 1) {
+        const int slots = 768, T = p.tiles_m * p.tiles_n;
+        const int full = (T / slots) * slots;
+        if (full > 0 && full < T) {
+            const int main_m = full / p.tiles_n;
+            const int tail = T - main_m * p.tiles_n;
+            const int ktiles = cdiv(K, 32);
+            int S = slots / tail;
+            if (S > ktiles / 4) S = ktiles / 4;
+            if (S > 32) S = 32;
+            if (S >= 2) {
+                p.tail_kchunk = cdiv(ktiles, S) * 32;
+                p.tail_splits = cdiv(K, p.tail_kchunk);
+                p.main_m = main_m;
+            }
+        }
+    }
     return p;
 }
 
@@ -173,6 +197,7 @@ int gemm_partials_f32(hipStream_t st, int ta, int tb, int M, int N, int K, const
     g.A = A; g.B = B; g.C = ws; g.bias = nullptr; g.ws = ws;
     g.lda = lda; g.ldb = ldb; g.ldc = N; g.M = M; g.N = N; g.K = K;
     g.tiles_n = tiles_n; g.ntiles = tiles_m * tiles_n; g.kchunk = kchunk; g.splits = splits; g.flags = 0;
+    g.tile0 = 0; g.ws_row0 = 0; g.ws_rows = M;
     auto al = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
     const bool vec = al(A) && al(B) && (lda % 4 == 0) && (ldb % 4 == 0) && ((ta ? M : K) % 4 == 0) && ((tb ? K : N) % 4 == 0);
     if (vec) dispatch_modes<Cfg64, true>(st, g, ta, tb); else dispatch_modes<Cfg64, false>(st, g, ta, tb);
@@ -194,7 +219,9 @@ size_t gemm_partials_bytes(int M, int N, int K, int max_splits) {
 
 extern "C" size_t vc_gemm_workspace_bytes(int M, int N, int K) {
     vc::GemmPlan p = vc::plan_gemm(M, N, K);
-    return p.splits > 1 ? (size_t)p.splits * M * N * sizeof(float) : 0;
+    if (p.splits > 1) return (size_t)p.splits * M * N * sizeof(float);
+    if (p.tail_splits > 1) return (size_t)p.tail_splits * (M - (long)p.main_m * 128) * N * sizeof(float);
+    return 0;
 }
 
 extern "C" int vc_gemm_f32(void* stream, int ta, int tb, int M, int N, int K, const float* A, long lda, const float* B,
@@ -214,9 +241,13 @@ extern "C" int vc_gemm_f32(void* stream, int ta, int tb, int M, int N, int K, co
     g.M = M; g.N = N; g.K = K;
     g.tiles_n = p.tiles_n; g.ntiles = p.tiles_m * p.tiles_n;
     g.kchunk = p.kchunk; g.splits = p.splits; g.flags = flags;
+    g.tile0 = 0; g.ws_row0 = 0; g.ws_rows = M;
     auto al = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
     const bool vec = al(A) && al(B) && (lda % 4 == 0) && (ldb % 4 == 0) && ((ta ? M : K) % 4 == 0) &&
                      ((tb ? K : N) % 4 == 0);
+    const long tail_row0 = (long)p.main_m * 128;
+    const bool tail = p.tail_splits > 1 && ws && ws_bytes >= (size_t)p.tail_splits * (M - tail_row0) * N * sizeof(float);
+    if (tail) g.ntiles = p.main_m * p.tiles_n;  // whole rounds; the remaining tile rows follow as a K-split launch
     if (p.big) {
         if (vec) dispatch_modes<Cfg128, true>(st, g, ta, tb); else dispatch_modes<Cfg128, false>(st, g, ta, tb);
     } else {
@@ -228,6 +259,20 @@ extern "C" int vc_gemm_f32(void* stream, int ta, int tb, int M, int N, int K, co
         int blocks = cdiv(MN, 256);
         if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws, p.splits, MN, N, C, ldc, bias, flags);
+        VC_LAUNCH_CHECK();
+    }
+    if (tail) {
+        GemmArgs t = g;
+        t.tile0 = p.main_m * p.tiles_n;
+        t.ntiles = (p.tiles_m - p.main_m) * p.tiles_n;
+        t.kchunk = p.tail_kchunk; t.splits = p.tail_splits;
+        t.ws_row0 = tail_row0; t.ws_rows = M - tail_row0;
+        if (vec) dispatch_modes<Cfg128, true>(st, t, ta, tb); else dispatch_modes<Cfg128, false>(st, t, ta, tb);
+        VC_LAUNCH_CHECK();
+        const long MN = t.ws_rows * N;
+        int blocks = cdiv(MN, 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws, t.splits, MN, N, C + tail_row0 * ldc, ldc, bias, flags);
         VC_LAUNCH_CHECK();
     }
     return 0;
@@ -242,6 +287,7 @@ extern "C" int vc_debug_gemm_ablate_f32(void* stream, int variant, int M, int N,
     g.A = A; g.B = B; g.C = C; g.bias = nullptr; g.ws = nullptr;
     g.lda = K; g.ldb = N; g.ldc = N; g.M = M; g.N = N; g.K = K;
     g.tiles_n = N / 128; g.ntiles = (M / 128) * (N / 128); g.kchunk = K; g.splits = 1; g.flags = 0;
+    g.tile0 = 0; g.ws_row0 = 0; g.ws_rows = M;
     dim3 grid(g.ntiles, 1);
     hipStream_t st = (hipStream_t)stream;
 #define VC_ABL(V) case V: hipLaunchKernelGGL((gemm_kernel<Cfg128, MODE_MK, MODE_KM, true, V>), grid, dim3(Cfg128::NT), Cfg128::SMEM_BYTES, st, g); break;
