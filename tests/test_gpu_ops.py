@@ -65,8 +65,9 @@ def test_gemm_flags_and_ldc(lib):
 def test_gemm_whole_rounds_tail(lib, ta, tb, flags):
     """776 tiles of 128 x 128 = one round of 768 resident workgroups + one tile row: that row runs as a K-split second
     launch (csrc/gemm.hip plan_gemm, tail_splits) whose reduce applies bias / ReLU / accumulate like the main launch."""
-    M, N, K = 12400, 1024, 512
-    assert lib.vc_gemm_workspace_bytes(M, N, K) == 4 * (M - 96 * 128) * N * 4
+    M, N, K = 12400, 1024, 1024
+    assert lib.vc_gemm_workspace_bytes(M, N, K) == 2 * (M - 96 * 128) * N * 4   # 2 splits of 16 K-tiles
+    assert lib.vc_gemm_workspace_bytes(M, N, 512) == 0                          # K too short to split: single launch
     rng = np.random.default_rng(9 + flags)
     A = rng.standard_normal((M, K), dtype=np.float32)
     B = rng.standard_normal((K, N), dtype=np.float32)

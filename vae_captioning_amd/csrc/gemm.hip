@@ -149,7 +149,7 @@ static GemmPlan plan_gemm(int M, int N, int K) {
             const int tail = T - main_m * p.tiles_n;
             const int ktiles = cdiv(K, 32);
             int S = slots / tail;
-            if (S > ktiles / 4) S = ktiles / 4;
+            if (S > ktiles / 16) S = ktiles / 16;  // >= 16 K-tiles per split (K = 512: any split of the tail measured slower than none)
             if (S > 32) S = 32;
             if (S >= 2) {
                 p.tail_kchunk = cdiv(ktiles, S) * 32;
