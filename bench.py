@@ -198,6 +198,7 @@ def main():
             tr._step()
     roof = roofline_from_timer(timer, tr.vgg is not None)
     roof["instrumented_pass"] = instrumented_pass
+    roof["hbm_kernels"] = hbm_from_timer(timer)
     # HBM-side bytes per launch of the same kernels, from the rocprofv3 --pmc passes of this command
     # (profiles/, FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); cannot be collected from inside the process.
     tj = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
@@ -275,6 +276,19 @@ def bench_generation(args, torch, dist, lib, w, p, world, rank):
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def hbm_from_timer(timer):
+    """The HBM-bound kernels of the path (embedding gather, softmax cross-entropy, optimiser update): algorithmic bytes
+     / HIP-event duration, against the 8 TB/s HBM3E peak of MI355X_MICROARCH.md."""
+    sm = timer.summary()
+    out = {}
+    for tag in ("hbm_embedding_gather", "hbm_softmax_xent", "hbm_adam"):
+        if tag in sm and sm[tag]["seconds"] > 0:
+            gbs = sm[tag]["flops"] / sm[tag]["seconds"] / 1e9
+            out[tag[4:]] = {"launches": sm[tag]["launches"], "avg_us": round(1e6 * sm[tag]["seconds"] / sm[tag]["launches"], 2),
+                            "achieved_GBps": round(gbs, 1), "frac_of_8TBps": round(gbs / 8000.0, 3)}
+    return out
 
 
 def roofline_from_timer(timer, fine_tune):

@@ -405,7 +405,9 @@ class CaptionEngine(object):
         cv = self.buf.get("c_v")
         Xe = self._b("Xe", (Te, N, E))
         Xe[:self.n_init_e].copy_(Xd[:self.n_init_e])
-        lib.vc_embedding_gather_f32(st, P(S.param("encoder/enc_embeddings")), P(self.buf["cap_enc_t"]), T * N, E, V, P(Xe[self.n_init_e]))
+        # (KernelTimer "work" of the HBM-bound kernels = algorithmic BYTES, SURVEY.md section 8d: ids + gathered rows + written rows)
+        self._timed("hbm_embedding_gather", T * N * (4.0 + 8.0 * E),
+                    lambda: lib.vc_embedding_gather_f32(st, P(S.param("encoder/enc_embeddings")), P(self.buf["cap_enc_t"]), T * N, E, V, P(Xe[self.n_init_e])))
         act_e, cs_e, hs_e = self._b("act_e", (Te, N, 4 * He)), self._b("cs_e", (Te + 1, N, He)), self._b("hs_e", (Te + 1, N, He))
         self._need_ws(lib.vc_lstm_seq_workspace_bytes(Te, N, E, He))
         cs_e[0].zero_(); hs_e[0].zero_()
@@ -467,7 +469,8 @@ class CaptionEngine(object):
             zi = self.n_init_d - 1
             self.gemm(0, 0, N, E, Sm * L, z, Sm * L, S.param("decoder/net/z_rnn/kernel"), E, Xd[zi], E, S.param("decoder/net/z_rnn/bias"))
         xw = Xd[self.n_init_d]
-        lib.vc_embedding_gather_f32(st, P(S.param("decoder/net/dec_embeddings")), P(self.buf["cap_dec_t"]), T * N, E, V, P(xw))
+        self._timed("hbm_embedding_gather", T * N * (4.0 + 8.0 * E),
+                    lambda: lib.vc_embedding_gather_f32(st, P(S.param("decoder/net/dec_embeddings")), P(self.buf["cap_dec_t"]), T * N, E, V, P(xw)))
         if p.dec_keep_rate < 1:  # no train/eval switch in the reference (Q21)
             lib.vc_dropout_f32(st, P(xw), P(self.buf["drop_in"]), p.dec_keep_rate, T * N * E, P(xw))
         act_d, cs_d, hs_d = self._b("act_d", (Td, N, 4 * Hd)), self._b("cs_d", (Td + 1, N, Hd)), self._b("hs_d", (Td + 1, N, Hd))
@@ -504,7 +507,8 @@ class CaptionEngine(object):
         Ng = N * self.world
         gscale = dp.scales(N, self.world, vector_loss)[0]
         row_loss = self._b("row_loss", (T * N,))
-        lib.vc_softmax_xent_f32(st, P(logits), P(labels), T * N, V, V, P(den), gscale, P(row_loss), 1 if train else 0)
+        self._timed("hbm_softmax_xent", 8.0 * T * N * V,  # logits read once, d(logits) written in place
+                    lambda: lib.vc_softmax_xent_f32(st, P(logits), P(labels), T * N, V, V, P(den), gscale, P(row_loss), 1 if train else 0))
         lib.vc_reduce_sum_f32(st, P(row_loss), T * N, 1.0, P(self.red), 0)
         self._finalize_losses(kl_sum, Ng, ann)
         return self.out
@@ -647,7 +651,8 @@ class CaptionEngine(object):
         lib.vc_clip_finalize_f32(st, P(self.part), nb + 1, float(p.lstm_clip_by_norm), P(self.ns))
         scale = self.ns.data_ptr() + 4
         if p.optimizer == "Adam":
-            lib.vc_adam_f32(st, P(S.p), P(S.g), P(S.slot("m")), P(S.slot("v")), S.n, P(self.scal), scale, 0.8, 0.999, 1e-8, 0.0)
+            self._timed("hbm_adam", 28.0 * S.n,  # p, g, m, v read; p, m, v written
+                        lambda: lib.vc_adam_f32(st, P(S.p), P(S.g), P(S.slot("m")), P(S.slot("v")), S.n, P(self.scal), scale, 0.8, 0.999, 1e-8, 0.0))
         elif p.optimizer == "SGD":
             lib.vc_sgd_f32(st, P(S.p), P(S.g), S.n, self.scal.data_ptr() + 8, scale, 0.0)
         else:

@@ -281,7 +281,8 @@ class VggEngine(object):
         gradient wd*w is folded into the update."""
         p, lib, st, S = self.p, self.lib, _stream(), self.store
         if p.cnn_optimizer == "Adam":
-            lib.vc_adam_f32(st, P(S.p), P(S.g), P(S.slot("m")), P(S.slot("v")), S.n, scal.data_ptr() + 12, None, 0.8, 0.999, 1e-8, self.wd)
+            self._timed("hbm_adam", 28.0 * S.n, lambda: lib.vc_adam_f32(
+                st, P(S.p), P(S.g), P(S.slot("m")), P(S.slot("v")), S.n, scal.data_ptr() + 12, None, 0.8, 0.999, 1e-8, self.wd))
         elif p.cnn_optimizer == "SGD":
             lib.vc_sgd_f32(st, P(S.p), P(S.g), S.n, scal.data_ptr() + 16, None, self.wd)
         else:
