@@ -182,16 +182,33 @@ using Cfg64 = TileCfg<2, 2, 1, 1>;
 // Split-K partial products only (no reduce, no bias): ws[s][M][N] = op(A) op(B) over the s-th K range, 64 x 64 tiles.
 // For consumers that sum the partials themselves (the LSTM gate kernels).  Returns the number of splits written
 // (chosen so that tiles x splits is about one round of resident workgroups, each split >= 2 K-tiles, <= max_splits).
-int gemm_partials_f32(hipStream_t st, int ta, int tb, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
-                      float* ws, size_t ws_bytes, int max_splits, int* splits_out) {
-    const int tiles_m = cdiv(M, 64), tiles_n = cdiv(N, 64);
-    const long tiles = (long)tiles_m * tiles_n;
+struct PartialPlan {
+    bool big;
+    int splits, kchunk;
+};
+
+static PartialPlan plan_partials(int M, int N, int K, int max_splits) {
+    PartialPlan p;
+    const long t128 = (long)cdiv(M, 128) * cdiv(N, 128);
+    p.big = false;  // 128 x 128 tiles measured slower for the LSTM step products at N = 320 and N = 1280 (+10-20 % per step)
+    (void)t128;
+    const long tiles = p.big ? t128 : (long)cdiv(M, 64) * cdiv(N, 64);
     long S = 768 / tiles;
-    if (S > K / 64) S = K / 64;
+    const int min_k = p.big ? 128 : 64;
+    if (S > K / min_k) S = K / min_k;
     if (S > max_splits) S = max_splits;
     if (S < 1) S = 1;
-    int kchunk = cdiv(cdiv(K, (int)S), 32) * 32;
-    const int splits = cdiv(K, kchunk);
+    p.kchunk = cdiv(cdiv(K, (int)S), 32) * 32;
+    p.splits = cdiv(K, p.kchunk);
+    return p;
+}
+
+int gemm_partials_f32(hipStream_t st, int ta, int tb, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
+                      float* ws, size_t ws_bytes, int max_splits, int* splits_out) {
+    const PartialPlan pp = plan_partials(M, N, K, max_splits);
+    const int b = pp.big ? 128 : 64;
+    const int tiles_m = cdiv(M, b), tiles_n = cdiv(N, b);
+    const int splits = pp.splits, kchunk = pp.kchunk;
     if (!ws || ws_bytes < (size_t)splits * M * N * sizeof(float)) return fail(VC_EWORKSPACE, "%s: workspace too small", __func__);
     GemmArgs g;
     g.A = A; g.B = B; g.C = ws; g.bias = nullptr; g.ws = ws;
@@ -200,19 +217,17 @@ int gemm_partials_f32(hipStream_t st, int ta, int tb, int M, int N, int K, const
     g.tile0 = 0; g.ws_row0 = 0; g.ws_rows = M;
     auto al = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
     const bool vec = al(A) && al(B) && (lda % 4 == 0) && (ldb % 4 == 0) && ((ta ? M : K) % 4 == 0) && ((tb ? K : N) % 4 == 0);
-    if (vec) dispatch_modes<Cfg64, true>(st, g, ta, tb); else dispatch_modes<Cfg64, false>(st, g, ta, tb);
+    if (pp.big) {
+        if (vec) dispatch_modes<Cfg128, true>(st, g, ta, tb); else dispatch_modes<Cfg128, false>(st, g, ta, tb);
+    } else {
+        if (vec) dispatch_modes<Cfg64, true>(st, g, ta, tb); else dispatch_modes<Cfg64, false>(st, g, ta, tb);
+    }
     *splits_out = splits;
     return launch_status(__func__);
 }
 
 size_t gemm_partials_bytes(int M, int N, int K, int max_splits) {
-    const long tiles = (long)cdiv(M, 64) * cdiv(N, 64);
-    long S = 768 / tiles;
-    if (S > K / 64) S = K / 64;
-    if (S > max_splits) S = max_splits;
-    if (S < 1) S = 1;
-    const int kchunk = cdiv(cdiv(K, (int)S), 32) * 32;
-    return (size_t)cdiv(K, kchunk) * M * N * sizeof(float);
+    return (size_t)plan_partials(M, N, K, max_splits).splits * M * N * sizeof(float);
 }
 
 }  // namespace vc
