@@ -114,13 +114,23 @@ static GemmPlan plan_gemm(int M, int N, int K) {
     const long t128 = (long)cdiv(M, 128) * cdiv(N, 128);
     long sa = 1;
     if (t128 <= 128) {
-        sa = (640 + t128 - 1) / t128;
+        sa = 768 / t128;  // one whole round of the 768 resident 128 x 128 workgroups (a ragged 640 cost ~15 %)
         const long maxs = K / 512;
         if (sa > maxs) sa = maxs;
         if (sa > 64) sa = 64;
         if (sa < 1) sa = 1;
+    } else if (t128 < 384) {
+        // 129..383 tiles: pick the split count whose workgroup total is closest below a whole number of rounds, charging
+        // the partial-sum traffic (S x 8 B per output element vs 2 K flop): worth it only for deep K (512 x 10000 x 25600:
+        // 316 tiles x 7 splits = 2.88 rounds).  Otherwise 64 x 64 tiles as before.
+        double best = 0.88;  // what the 64 x 64 path reaches on these shapes, relative to a full round of 128 x 128 tiles
+        for (long S = 2; S <= 16 && K / S >= 1024; ++S) {
+            const double r = (double)(t128 * S) / 768.0;
+            const double eff = r / (double)(long)(r + 0.999999) * (1.0 - 100.0 * (double)S / (double)K);
+            if (eff > best) { best = eff; sa = S; }
+        }
     }
-    p.big = t128 >= 384 || (t128 <= 128 && t128 * sa >= 256);
+    p.big = t128 >= 384 || (t128 <= 128 && t128 * sa >= 256) || (t128 > 128 && sa > 1);
     const int b = p.big ? 128 : 64;
     p.tiles_m = cdiv(M, b);
     p.tiles_n = cdiv(N, b);
