@@ -110,6 +110,17 @@ def lstm():
         print("lstm bwd seq N=%4d T=%d: %8.3f ms (%.1f us/step) %6.1f TFLOP/s" % (N, T, med, 1e3 * med / T, 2 * fl / med))
 
 
+def mid():
+    """129..383-tile shapes (VC_GEMM_FORCE_S sweeps the split count of the 128 x 128 path)"""
+    for (ta, tb, M, N, K) in [(0, 1, 6400, 512, 10000), (1, 0, 512, 10000, 6400), (0, 1, 12800, 512, 10000), (0, 0, 12800, 512, 2048), (0, 0, 6400, 1024, 2048), (0, 0, 5120, 2048, 512), (1, 0, 2048, 2048, 28160)]:
+        A = rnd(K, M) if ta else rnd(M, K)
+        B = rnd(N, K) if tb else rnd(K, N)
+        C = torch.empty(M, N, device="cuda")
+        ws = torch.empty(max(lib.vc_gemm_workspace_bytes(M, N, K), 16) // 4 + 4, device="cuda")
+        med, mn = timeit(lambda: lib.vc_gemm_f32(st(), ta, tb, M, N, K, P(A), M if ta else K, P(B), K if tb else N, P(C), N, None, 0, P(ws), ws.numel() * 4), reps=5)
+        print("gemm ta=%d tb=%d %6d x %6d x %6d: %8.3f ms  %6.1f TFLOP/s  ws %.0f MB" % (ta, tb, M, N, K, med, 2e-9 * M * N * K / med, ws.numel() * 4 / 1e6))
+
+
 def fc():
     """the six VGG fc GEMMs of a 64-image step (weight-bandwidth bound: fc1 = 411 MB, fc2 = 67 MB) + caption-side skinny shapes"""
     Bn = 64

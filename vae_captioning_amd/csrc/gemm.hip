@@ -119,16 +119,15 @@ static GemmPlan plan_gemm(int M, int N, int K) {
         if (sa > maxs) sa = maxs;
         if (sa > 64) sa = 64;
         if (sa < 1) sa = 1;
-    } else if (t128 < 384) {
-        // 129..383 tiles: pick the split count whose workgroup total is closest below a whole number of rounds, charging
-        // the partial-sum traffic (S x 8 B per output element vs 2 K flop): worth it only for deep K (512 x 10000 x 25600:
-        // 316 tiles x 7 splits = 2.88 rounds).  Otherwise 64 x 64 tiles as before.
-        double best = 0.88;  // what the 64 x 64 path reaches on these shapes, relative to a full round of 128 x 128 tiles
-        for (long S = 2; S <= 16 && K / S >= 1024; ++S) {
-            const double r = (double)(t128 * S) / 768.0;
-            const double eff = r / (double)(long)(r + 0.999999) * (1.0 - 100.0 * (double)S / (double)K);
-            if (eff > best) { best = eff; sa = S; }
-        }
+    } else if (t128 < 768) {
+        // Less than one round of 128 x 128 tiles: K is split so that ~1200 shorter workgroups share the chip (finer
+        // granularity evens out the 1-vs-2 workgroups per CU of an unsplit launch), as long as a split keeps >= 20
+        // K-tiles.  Measured (tools/microbench.py mid): 6400 x 512 x 10000  83 -> 100 TFLOP/s (S = 5..6),
+        // 512 x 10000 x 6400  91 -> 102 (S = 4), 12800 x 512 x 10000  104 -> 116 (S = 3), 512 x 10000 x 25600  106 -> 121.
+        sa = (1200 + t128 / 2) / t128;
+        const long maxs = K / 640;
+        if (sa > maxs) sa = maxs;
+        if (sa < 1) sa = 1;
     }
     p.big = t128 >= 384 || (t128 <= 128 && t128 * sa >= 256) || (t128 > 128 && sa > 1);
     const int b = p.big ? 128 : 64;
