@@ -374,9 +374,11 @@ static TailPlan plan_tail(long P, int Ncols, int K, int slots) {
     if (full == T) return t;
     const int main_m = full / tiles_n;  // whole tile rows (0: less than one round of tiles -> all of them are split)
     const int tail = T - main_m * tiles_n;
-    int S = slots / tail;  // (rounding up to 784 workgroups for 392 tiles was measured slower than leaving them unsplit)
+    // whole launch below one round (conv5): ~1200 short workgroups balance the CUs better than 392 long ones (gemm.hip
+    // plan_gemm has the measurements); a tail after full rounds fills exactly one more round
+    int S = main_m == 0 ? (1200 + tail / 2) / tail : slots / tail;
     const int ktiles = cdiv(K, 32);
-    if (S > ktiles / 4) S = ktiles / 4;  // >= 4 K-tiles per split
+    if (S > ktiles / (main_m == 0 ? 16 : 4)) S = ktiles / (main_m == 0 ? 16 : 4);  // >= 4 K-tiles per split of a tail, >= 16 when everything is split
     if (S > 32) S = 32;
     if (S < 2) return t;
     t.kchunk = cdiv(ktiles, S) * 32;
