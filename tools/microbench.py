@@ -85,7 +85,8 @@ def conv():
         for nm, fn in (("fwd", lambda: lib.vc_conv3x3_fwd_f32(st(), B, H, H, ci, co, P(x), P(w), P(bias), P(y), 1, P(tw), tb)),
                        ("dgrad", lambda: lib.vc_conv3x3_dgrad_f32(st(), B, H, H, ci, co, P(dy), P(w), P(x), P(dx), P(tw), tb)),
                        ("dgr-nomask", lambda: lib.vc_conv3x3_dgrad_f32(st(), B, H, H, ci, co, P(dy), P(w), None, P(dx), P(tw), tb)),
-                       ("wgrad", lambda: lib.vc_conv3x3_wgrad_f32(st(), B, H, H, ci, co, P(x), P(dy), P(dw), P(bias), 0, P(ws), ws.numel() * 4))):
+                       ("wgrad", lambda: lib.vc_conv3x3_wgrad_f32(st(), B, H, H, ci, co, P(x), P(dy), P(dw), P(bias), 0, P(ws), ws.numel() * 4)),
+                       ("wgrad-nobias", lambda: lib.vc_conv3x3_wgrad_f32(st(), B, H, H, ci, co, P(x), P(dy), P(dw), None, 0, P(ws), ws.numel() * 4))):
             med, mn = timeit(fn, reps=5)
             print("conv%s %-10s B=%d H=%3d %3d->%3d: %8.3f ms  %6.1f TFLOP/s" % (name, nm, B, H, ci, co, med, fl / med))
 
