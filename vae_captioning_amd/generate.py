@@ -17,7 +17,7 @@ import torch
 from . import spec
 from .abi import ptr as P
 from .engine import K_CL, _stream
-from .utils.top_n import Beam, TopN
+from .utils.top_n import Beam
 
 # vae_model/decoder.py:56 -- category ids absent from MSCOCO (obj_vectors/category_index.pickle)
 UN_CLUSTERS = {0, 66, 68, 69, 71, 12, 45, 83, 26, 29, 30}
