@@ -1,7 +1,14 @@
-import sys, os, torch
+"""Workload for SQ-counter probes (rocprofv3 --pmc ...): conv3_2-shaped forward / data gradient / weight gradient at
+64 images and the 8192^3 GEMM, three launches each.  Summarise with tools/pmc_probe_summary.py."""
+import os
+import sys
+
+import torch
+
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
-from vae_captioning_amd import abi
-from vae_captioning_amd.abi import ptr as P
+from vae_captioning_amd import abi  # noqa: E402
+from vae_captioning_amd.abi import ptr as P  # noqa: E402
+
 lib = abi.load()
 st = lambda: torch.cuda.current_stream().cuda_stream
 B, H, ci, co = 64, 56, 256, 256
@@ -9,10 +16,16 @@ x = torch.rand(B, H, H, ci, device="cuda") * 2 - 1
 w = torch.rand(3, 3, ci, co, device="cuda") * 2 - 1
 bias = torch.rand(co, device="cuda")
 y = torch.empty(B, H, H, co, device="cuda")
+dy = torch.rand(B, H, H, co, device="cuda") * 2 - 1
+dx = torch.empty(B, H, H, ci, device="cuda")
+dw = torch.empty(3, 3, ci, co, device="cuda")
+ws = torch.empty(lib.vc_conv3x3_wgrad_workspace_bytes(B, H, H, ci, co) // 4 + 4, device="cuda")
 A = torch.rand(8192, 8192, device="cuda") * 2 - 1
 Bm = torch.rand(8192, 8192, device="cuda") * 2 - 1
 C = torch.empty(8192, 8192, device="cuda")
 for _ in range(3):
     lib.vc_conv3x3_fwd_f32(st(), B, H, H, ci, co, P(x), P(w), P(bias), P(y), 1, None, 0)
+    lib.vc_conv3x3_dgrad_f32(st(), B, H, H, ci, co, P(dy), P(w), P(x), P(dx), None, 0)
+    lib.vc_conv3x3_wgrad_f32(st(), B, H, H, ci, co, P(x), P(dy), P(dw), None, 0, P(ws), ws.numel() * 4)
     lib.vc_gemm_f32(st(), 0, 0, 8192, 8192, 8192, P(A), 8192, P(Bm), 8192, P(C), 8192, None, 0, None, 0)
 torch.cuda.synchronize()

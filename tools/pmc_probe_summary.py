@@ -1,12 +1,21 @@
+"""python tools/pmc_probe_summary.py <dir>: per-kernel-kind averages of every counter collected over tools/pmc_probe.py."""
 import collections
 import csv
 import glob
+import re
 import sys
-for f in sorted(glob.glob(sys.argv[1] + "/*/*counter_collection.csv")):
+
+for f in sorted(glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)):
     d = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
-        k = "conv" if "conv_kernel" in r["Kernel_Name"] else ("gemm" if "gemm_kernel" in r["Kernel_Name"] else None)
+        n = r["Kernel_Name"]
+        k = None
+        m = re.search(r"conv_kernel<.*>,\s*(\d)\s*>\(", n)
+        if m:
+            k = "conv_" + {"0": "fwd", "1": "dgrad", "2": "wgrad"}[m.group(1)]
+        elif "gemm_kernel" in n:
+            k = "gemm"
         if k:
             d[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    for k in d:
+    for k in sorted(d):
         print(k, {c: "%.4g" % (sum(v) / len(v)) for c, v in d[k].items()})
