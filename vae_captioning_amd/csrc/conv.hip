@@ -296,7 +296,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 using ConvCfgWide = TileCfg<2, 2, 2, 2>;    // 128 x 128
-using ConvCfgNarrow = TileCfg<4, 1, 2, 2>;  // 256 x 64 (64-channel layers), 256 threads
+using ConvCfgNarrow = TileCfg<4, 1, 2, 2>;  // 256 x 64, 256 threads (weight gradients with <= 64 output channels)
+using ConvCfgN2 = TileCfg<2, 2, 2, 1>;      // 128 x 64, waves 64 x 32: forward / data gradient of the 64-channel layers (116-120 VGPRs,
+                                            // 4 workgroups per CU; the 256 x 64 tile needed 184-196 VGPRs = 2 per CU: conv1_2 108 -> 115 TFLOP/s)
 
 static int ilog2_exact(int v) {
     int l = 0;
@@ -416,18 +418,18 @@ static int launch_rounds(hipStream_t st, ConvArgs& c, long P, int Ncols, int K, 
     return launch_status("conv tail reduce");
 }
 
-// resident workgroups per chip: the 128 x 128 kernels run 3 per CU (164-168 VGPRs), the 256 x 64 ones 2 (184-196)
-constexpr int SLOTS_WIDE = 768, SLOTS_NARROW = 512;
+// workgroups per round: the 128 x 128 kernels run 3 per CU (164-168 VGPRs)
+constexpr int SLOTS_WIDE = 768, SLOTS_N2 = 768;  // (N2: 768 measured best of 768 / 1024 / 1280)
 
 template <int KIND>
 static size_t rounds_workspace(long P, int Ncols, int K) {
-    const TailPlan t = Ncols <= 64 ? plan_tail<ConvCfgNarrow>(P, Ncols, K, SLOTS_NARROW) : plan_tail<ConvCfgWide>(P, Ncols, K, SLOTS_WIDE);
+    const TailPlan t = Ncols <= 64 ? plan_tail<ConvCfgN2>(P, Ncols, K, SLOTS_N2) : plan_tail<ConvCfgWide>(P, Ncols, K, SLOTS_WIDE);
     return t.tail_tiles ? (size_t)t.splits * t.rows * Ncols * sizeof(float) : 0;
 }
 
 template <int KIND>
 static int launch_fwd_dgrad(hipStream_t st, ConvArgs& c, long P, int Ncols, int K, float* ws, size_t ws_bytes) {
-    if (Ncols <= 64) return launch_rounds<ConvCfgNarrow, KIND>(st, c, P, Ncols, K, SLOTS_NARROW, ws, ws_bytes);
+    if (Ncols <= 64) return launch_rounds<ConvCfgN2, KIND>(st, c, P, Ncols, K, SLOTS_N2, ws, ws_bytes);
     return launch_rounds<ConvCfgWide, KIND>(st, c, P, Ncols, K, SLOTS_WIDE, ws, ws_bytes);
 }
 
