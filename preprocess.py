@@ -1,54 +1,59 @@
 #!/usr/bin/env python
-"""Resize every train2014 + val2014 image to 224x224 RGB once and store them in one array, with the
-file-name -> row index map in ./pickles/itoi.pickle: the reference's preprocess.py:10-45.
+"""One-off image preprocessing for `--fine_tune` training (role of the reference's preprocess.py:10-45).
 
-    python preprocess.py --coco_dir /data/coco --output_h5 train_val.npy
+Every train2014 and val2014 JPEG is decoded, resized to 224 x 224 RGB (utils/image_utils.load_image) and stored as one
+row of a single uint8 array; `./pickles/itoi.pickle` maps a file name to its row.  The reference keeps that array in an
+HDF5 data set called "images"; h5py is not part of this image, so the identical `(N, 224, 224, 3) uint8` array is written as
+a memory-mappable `.npy` instead and `Batch_Generator` opens it wherever the reference opens the HDF5 file
+(`Parameters.hdf5_file`; a `.hdf5` name resolves to the `.npy` next to it).
 
-The reference writes the array into an HDF5 dataset "images" (N, 224, 224, 3) uint8; h5py is not available
-here, so the SAME array is written as a memory-mappable .npy (numpy's open_memmap).  `--fine_tune` training
-reads it through `Parameters.hdf5_file` exactly where the reference reads the HDF5 file
-(vae_captioning_amd/utils/batch_gen.py, open_image_array)."""
+    python preprocess.py --coco_dir /data/coco --output_h5 /data/coco/train_val.npy
+"""
 import argparse
-import glob
 import os
 import pickle
 import sys
+from glob import glob
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, ROOT)
-
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from vae_captioning_amd.utils.image_utils import load_image  # noqa: E402
 
+SIDE = 224
 
-def main(params):
-    coco_dir, out = params["coco_dir"], params["output_h5"]
-    if not out.endswith(".npy"):
-        out = os.path.splitext(out)[0] + ".npy"
-    tr_files = sorted(glob.glob(coco_dir + "/images/train2014/*.jpg"))
-    val_files = sorted(glob.glob(coco_dir + "/images/val2014/*jpg"))
-    imgs = tr_files + val_files
-    if len(imgs) == 0:
-        raise ValueError("no images under %s/images/{train2014,val2014}" % coco_dir)
-    N = len(imgs)
-    dset = np.lib.format.open_memmap(out, mode="w+", dtype=np.uint8, shape=(N, 224, 224, 3))
-    imtoi = {}
-    for i, image_path in enumerate(imgs):
-        dset[i] = load_image(image_path, shape=(224, 224))
-        imtoi[image_path.split("/")[-1]] = i
-        if i % 1000 == 0:
-            print("processing %d/%d (%.2f%% done)" % (i, N, i * 100.0 / N))
-    dset.flush()
-    os.makedirs("./pickles", exist_ok=True)
-    with open("./pickles/itoi.pickle", "wb") as wf:
-        pickle.dump(obj=imtoi, file=wf)
-        print("Saved image name to indices pickle")
-    print("wrote ", out)
+
+def image_files(coco_dir):
+    """train2014 first, then val2014 -- the row order the index pickle records."""
+    found = []
+    for split in ("train2014", "val2014"):
+        found += sorted(glob(os.path.join(coco_dir, "images", split, "*.jpg")))
+    return found
+
+
+def build(coco_dir, array_path, index_path="./pickles/itoi.pickle", report_every=1000):
+    files = image_files(coco_dir)
+    if not files:
+        raise ValueError("no *.jpg under %s/images/train2014 or val2014" % coco_dir)
+    rows = np.lib.format.open_memmap(array_path, mode="w+", dtype=np.uint8, shape=(len(files), SIDE, SIDE, 3))
+    index = {}
+    for row, path in enumerate(files):
+        rows[row] = load_image(path, shape=(SIDE, SIDE))
+        index[os.path.basename(path)] = row
+        if row % report_every == 0:
+            print("image %d of %d (%.1f %%)" % (row, len(files), 100.0 * row / len(files)))
+    rows.flush()
+    os.makedirs(os.path.dirname(index_path) or ".", exist_ok=True)
+    with open(index_path, "wb") as fh:
+        pickle.dump(index, fh)
+    print("wrote %s (%d images) and %s" % (array_path, len(files), index_path))
+    return len(files)
 
 
 if __name__ == "__main__":
-    parser = argparse.ArgumentParser()
-    parser.add_argument("--output_h5", default="train_val.npy", help="output image array (.npy; the reference's h5 file)")
-    parser.add_argument("--coco_dir", help="MSCOCO directory")
-    main(vars(parser.parse_args()))
+    ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    ap.add_argument("--output_h5", default="train_val.npy", help="output image array (.npy; plays the reference's h5 file)")
+    ap.add_argument("--coco_dir", required=True, help="MSCOCO directory (contains images/train2014, images/val2014)")
+    a = ap.parse_args()
+    target = a.output_h5 if a.output_h5.endswith(".npy") else os.path.splitext(a.output_h5)[0] + ".npy"
+    build(a.coco_dir, target)
