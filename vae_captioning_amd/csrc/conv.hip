@@ -332,7 +332,10 @@ static WgradPlan plan_wgrad(const ConvGeom& g) {
     // second round ran at a third of the occupancy: 1024-ish workgroups on 768 slots cost conv2_2 / conv3_x 10-17 %).
     // 128 x 128 tiles run 3 per CU (768 slots): two rounds; Cin == 64 (192-row tiles): one round - the 192 x 64 kernel
     // (152 VGPRs) runs 3 per CU = 768, the 192 x 128 kernel (212 VGPRs) 2 per CU = 512.
-    long splits = (g.Cin == 64 ? (g.Cout <= 64 ? 768 : 512) : 1536) / tiles;
+    // (two rounds for the small outputs; one for the 512-channel layers, whose 9.4 MB partial sums make the reduce
+    // launch cost as much as the second round gains)
+    const long big_out = 9L * g.Cin * g.Cout >= (1L << 21);
+    long splits = (g.Cin == 64 ? (g.Cout <= 64 ? 768 : 512) : (big_out ? 768 : 1536)) / tiles;
     const long maxs = g.P / 512 > 0 ? g.P / 512 : 1;  // >= 16 K-tiles per split
     if (splits > maxs) splits = maxs;
     if (splits > 256) splits = 256;
