@@ -25,6 +25,8 @@ GEMM_SHAPES = [
     (64, 64, 32), (33, 47, 19), (100, 70, 50), (256, 384, 128), (1280, 2048, 256),
     (300, 256, 4096), (20, 10000, 512), (1280, 256, 15000), (768, 2048, 2560), (1, 4, 4),
     (129, 131, 37),
+    (3200, 512, 5000),    # 100 tiles of 128 x 128: one whole round through split-K (768 / tiles)
+    (5000, 640, 2600),    # 200 tiles: below one round, K split into ~1200 workgroups
 ]
 
 
