@@ -506,6 +506,27 @@ def test_conv_whole_rounds_tail_split(lib, case):
             assert_close(host(d1), host(d0), 4e-6 * np.sqrt(9 * Co) + 1e-6, msg="dgrad tail split vs single launch")
 
 
+def test_conv_workspace_too_small_means_single_launch_and_beam_argument_checks(lib):
+    from vae_captioning_amd.abi import VaecapError
+    B, H, W, Ci, Co = 2, 224, 224, 64, 128
+    need = lib.vc_conv3x3_fwd_workspace_bytes(B, H, W, Ci, Co)
+    assert need > 0
+    x, w, b = zeros(B, H, W, Ci) + 1.0, zeros(3, 3, Ci, Co) + 0.01, zeros(Co)
+    y0, y1 = zeros(B, H, W, Co), zeros(B, H, W, Co)
+    ws = empty_bytes(need)
+    lib.vc_conv3x3_fwd_f32(stream(), B, H, W, Ci, Co, P(x), P(w), P(b), P(y0), 1, None, 0)
+    lib.vc_conv3x3_fwd_f32(stream(), B, H, W, Ci, Co, P(x), P(w), P(b), P(y1), 1, P(ws), need - 4)   # one float short: not used
+    assert torch.equal(y0, y1)
+    i32 = dict(dtype=torch.int32, device="cuda")
+    d = torch.zeros(64, dtype=torch.float64, device="cuda")
+    z = torch.zeros(4096, **i32)
+    f = zeros(64)
+    with pytest.raises(VaecapError):   # beam sizes above 16 are rejected, not truncated
+        lib.vc_beam_update(stream(), 1, 17, 8, 2, 0.7, P(f), P(z), P(z), P(z), P(d), P(d), P(z), P(z), P(z), P(d), P(d), P(z), P(z), P(z), P(z), P(z), P(z))
+    with pytest.raises(VaecapError):
+        lib.vc_beam_update(stream(), 1, 2, 8, 2, 0.7, None, P(z), P(z), P(z), P(d), P(d), P(z), P(z), P(z), P(d), P(d), P(z), P(z), P(z), P(z), P(z), P(z))
+
+
 def test_maxpool_and_preprocess(lib):
     rng = np.random.default_rng(51)
     B, H, W, C = 2, 8, 12, 64
