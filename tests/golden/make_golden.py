@@ -90,3 +90,14 @@ if __name__ == "__main__":
         run_case(name, kw)
     cmn = decode.init_clusters(90, 150)
     np.savez_compressed(os.path.join(HERE, "cluster_means_seed42.npz"), c_means=cmn)
+    # The reference ships one data file on this path: obj_vectors/category_index.pickle, the MSCOCO category table
+    # ({id: {'id', 'name'}}, 80 entries) whose id gaps are decoder.py:56's `un_clusters`.  Stored as data (json), only
+    # when the reference tree is mounted (it is not on the GPU box).
+    ref = "/root/reference/obj_vectors/category_index.pickle"
+    if os.path.exists(ref):
+        import json
+        import pickle
+        with open(ref, "rb") as fh:
+            cat = pickle.load(fh)
+        with open(os.path.join(HERE, "category_index.json"), "w") as fh:
+            json.dump({str(k): cat[k]["name"] for k in sorted(cat)}, fh, indent=0)

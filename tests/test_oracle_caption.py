@@ -109,6 +109,16 @@ def test_cluster_means_known_answer():
 
 def test_un_clusters_are_the_category_gaps():
     assert decode.UN_CLUSTERS == {0, 12, 26, 29, 30, 45, 66, 68, 69, 71, 83}
+    # ... and they are exactly the ids 0..90 missing from the reference's own category table
+    # (tests/golden/category_index.json, extracted from obj_vectors/category_index.pickle by make_golden.py)
+    import json
+    import os
+    from vae_captioning_amd import generate
+    with open(os.path.join(os.path.dirname(__file__), "golden", "category_index.json")) as fh:
+        cat = json.load(fh)
+    assert len(cat) == 80 and cat["1"] == "person" and cat["90"] == "toothbrush"
+    gaps = set(range(91)) - {int(k) for k in cat}
+    assert gaps == decode.UN_CLUSTERS == generate.UN_CLUSTERS
 
 
 def test_q5_global_norm_uses_undeduplicated_slices():
