@@ -188,8 +188,9 @@ int vc_momentum_f32(void* stream, float* p, const float* g, float* accum, long n
 /* ------------------------------------------------------------------------------------
  * Philox4x32-10 counter-based RNG (replaces TF's random_normal / dropout streams; the
  * streams cannot match TF's, parity tests inject noise instead).  Element i comes from
- * counter (i/4, offset) word i%4; `step` (device int, may be NULL) is added to the high
- * offset word so graph replays draw fresh numbers.
+ * counter (i/4, offset) word i%4 under key (seed lo, seed hi + step); `step` (device int, may be
+ * NULL) lives in the KEY so that graph replays draw fresh numbers and stream ids kept in
+ * offset >> 32 never alias across steps.
  * ---------------------------------------------------------------------------------- */
 int vc_philox_u32(void* stream, uint32_t* out, long n, uint64_t seed, uint64_t offset, const int32_t* step);
 int vc_philox_normal_f32(void* stream, float* out, long n, uint64_t seed, uint64_t offset, const int32_t* step);
@@ -221,6 +222,19 @@ int vc_maxpool2x2_fwd_f32(void* stream, int B, int H, int W, int C, const float*
 int vc_maxpool2x2_bwd_f32(void* stream, int B, int H, int W, int C, const float* x, const float* dy, float* dx, int relu_grad);
 int vc_vgg_preprocess_f32(void* stream, const float* images, int B, int H, int W, float* out_nhwc4);
 int vc_pad_dim_f32(void* stream, const float* src, long outer, int c_src, int c_dst, int inner, float* dst);
+
+/* Patch-staged forward / data gradient (csrc/conv_patch.hip): the workgroup stages the halo patch of its 128 output
+ * pixels in LDS once per 32-channel chunk and walks the nine taps as constant LDS offsets; the weights come pre-packed
+ * [tap][C/4][N][4] (pack once per optimiser step: transpose 0 for forward, 1 = flipped + transposed for the data
+ * gradient).  Same results as conv3x3_fwd / conv3x3_dgrad up to fp32 summation order.  Shapes: gathered channels % 32 == 0,
+ * output channels % 64 == 0, (W % 8 == 0 and H % 4 == 0) or (H*W >= 128 and W <= ~30); ask vc_conv3x3_patch_supported. */
+int vc_conv3x3_patch_supported(int B, int H, int W, int Cin, int Cout, int dgrad);
+size_t vc_conv3x3_packed_workspace_bytes(int B, int H, int W, int Cin, int Cout, int dgrad);
+int vc_conv3x3_pack_f32(void* stream, int Cin, int Cout, const float* w, int transpose, float* wp);
+int vc_conv3x3_fwd_packed_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const float* wp,
+                              const float* bias, float* y, int relu, float* ws, size_t ws_bytes);
+int vc_conv3x3_dgrad_packed_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* dy, const float* wpt,
+                                const float* relu_src, float* dx, float* ws, size_t ws_bytes);
 
 /* ------------------------------------------------------------------------------------
  * Beam-search bookkeeping after one decoder step, on device, one thread per image: the loop body of

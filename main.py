@@ -56,17 +56,17 @@ class SyntheticBatches(object):
             yield b
 
 
-def coco_batches(gen, params, epoch_rule=False):
+def coco_batches(gen, params, epoch_rule=False, world=1):
     """Batch_Generator.next_batch items -> Trainer.set_batch dicts (main.py:222-238).  epoch_rule: keep
     re-shuffling and passing over the data until steps * batch_size > num_ex_per_epoch (main.py:217-221,256-259;
-    --max_steps overrides)."""
+    --max_steps overrides); batch_size is the GLOBAL batch (world * per-rank batch) in data-parallel runs."""
     from vae_captioning_amd.utils.batch_gen import feed_dict
     steps = 0
     while True:
         for images, captions, lengths, c_v in gen.next_batch(use_obj_vectors=params.use_c_v, num_captions=params.num_captions):
             yield feed_dict(images, captions, lengths, c_v, params.num_captions, params.fine_tune)
             steps += 1
-            if epoch_rule and (steps >= params.max_steps if params.max_steps else steps * params.batch_size > params.num_ex_per_epoch):
+            if epoch_rule and (steps >= params.max_steps if params.max_steps else steps * params.batch_size * world > params.num_ex_per_epoch):
                 return
         if not epoch_rule:
             return
@@ -99,7 +99,8 @@ def main(params):
         if params.cluster_pickle:
             with open(params.cluster_pickle, "rb") as rf:
                 cvs = pickle.load(rf)
-        real = BatchGenerator(caps.index_captions(cap_dict.word2idx), feats, params.batch_size, cvs, seed=params.seed + rank)
+        real = BatchGenerator(caps.index_captions(cap_dict.word2idx), feats, params.batch_size, cvs, seed=params.seed,
+                              shard=(rank, world) if world > 1 else None)
     elif params.synthetic:
         cap_dict = SyntheticDictionary(params.vocab_size)
     else:
@@ -111,7 +112,7 @@ def main(params):
         coco = Data(params, extract_features=not params.fine_tune, weights_path=params.image_net_weights_path,
                     repartiton=repartiton and not params.fine_tune, gen_val_cap=params.gen_val_captions)
         cap_dict = coco.dictionary
-        coco_train = coco.load_train_data_generator(params.batch_size, params.fine_tune)
+        coco_train = coco.load_train_data_generator(params.batch_size, params.fine_tune, shard=(rank, world) if world > 1 else None)
         coco_val = coco.get_valid_data(params.batch_size, val_tr_unused=coco_train.unused_cap_in, pretrained=not params.fine_tune)
         coco_test = coco.get_test_data(params.batch_size, pretrained=not params.fine_tune) if os.path.exists(coco.test_cap_json) else None
         os.makedirs("./pickles", exist_ok=True)
@@ -123,20 +124,30 @@ def main(params):
     params._vc_trainer = tr  # the facades below share it (session.get)
     tr.load_state_dict({**spec.init_caption_params(params, params.vocab_size, seed=params.seed),
                         **(spec.init_vgg_params(seed=params.seed) if params.fine_tune else {})})
-    if params.fine_tune and params.mode == "training" and not params.restore:
+    if params.mode == "training" and not params.restore:
+        # main.py:205-208: the ImageNet weights are loaded whether or not the CNN is fine-tuned (the VGG16 variables always
+        # exist in the reference graph and are saved with every checkpoint, quirk Q22)
         if os.path.exists(params.image_net_weights_path):
-            print("Loading imagenet weights for futher usage")  # main.py:205-208
-            tr.vgg.load_weights(params.image_net_weights_path)
-        else:
+            print("Loading imagenet weights for futher usage")
+            if params.fine_tune:
+                tr.vgg.load_weights(params.image_net_weights_path)
+            else:
+                from vae_captioning_amd.trainer import imagenet_weights
+                tr.cnn_host = imagenet_weights(params.image_net_weights_path)
+        elif params.fine_tune:
             print("No %s: VGG16 starts from random weights" % params.image_net_weights_path)
+        else:
+            print("No %s: checkpoints of this run will not contain the cnn/* variables" % params.image_net_weights_path)
     # saver.save(sess, "./checkpoints/{}.ckpt") (main.py:286-288): TF V2 checkpoint files by default,
     # --ckpt_format npz for a name-keyed numpy archive
     ckpt = "./checkpoints/%s.ckpt" % params.checkpoint + (".npz" if params.ckpt_format == "npz" else "")
     if params.restore or params.mode == "inference":
-        if os.path.exists(ckpt if params.ckpt_format == "npz" else ckpt + ".index"):
-            print("Restoring from checkpoint")
-            tr.restore(ckpt)
-    steps_per_epoch = params.max_steps or (params.num_ex_per_epoch // params.batch_size + 1)  # main.py:217-221
+        have = ckpt if params.ckpt_format == "npz" else ckpt + ".index"
+        if not os.path.exists(have):  # saver.restore raises NotFoundError (main.py:209-212, ops/inference.py:6-7)
+            raise FileNotFoundError("checkpoint %s not found (--restore / --mode inference need ./checkpoints/%s.ckpt*)" % (have, params.checkpoint))
+        print("Restoring from checkpoint")
+        tr.restore(ckpt)
+    steps_per_epoch = params.max_steps or (params.num_ex_per_epoch // (params.batch_size * world) + 1)  # main.py:217-221, global batch
     say = print if rank == 0 else (lambda *a, **k: None)
 
     if params.mode == "training":
@@ -147,11 +158,12 @@ def main(params):
         optimize_cnn = (lambda: 0.0)
         if params.fine_tune:
             optimize_cnn, _ = optimizers.cnn_optimizer(None, params)
+        gs = 0  # host mirror of global_step (it restarts at 0 on --restore, Q11): no device sync on non-print steps
         for e in range(params.num_epochs):
             if real is not None:
                 it = real.next_batch(use_obj_vectors=spec.uses_ci(params), num_captions=params.num_captions)
             elif coco_train is not None:
-                it = coco_batches(coco_train, params, epoch_rule=True)
+                it = coco_batches(coco_train, params, epoch_rule=True, world=world)
             else:
                 it = SyntheticBatches(params, steps_per_epoch, params.seed + 17 * e + rank).next_batch()
             for batch in it:
@@ -172,10 +184,10 @@ def main(params):
                 cap.fw_loss(train=True)                                 # main.py:152-177
                 optimize()                                              # main.py:179
                 optimize_cnn()                                          # main.py:183
-                gs = int(global_step.item()) - 1
-                if gs % 500 == 0:
+                gs += 1
+                if (gs - 1) % 500 == 0:
                     kl, rl, lb, ann = tr.losses()
-                    say("Epoch: {} Iteration: {} VLB: {} Rec Loss: {}".format(e, gs, lb, rl))
+                    say("Epoch: {} Iteration: {} VLB: {} Rec Loss: {}".format(e, gs - 1, lb, rl))
                     if not params.no_encoder:
                         say("Annealing coefficient:{} KLD: {}".format(ann, kl))
             kl, rl, lb, ann = tr.losses()

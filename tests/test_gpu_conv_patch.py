@@ -1,0 +1,122 @@
+"""Patch-staged 3x3 convolution (csrc/conv_patch.hip: forward and data gradient with LDS-staged halo patches and
+pre-packed weights; utils/image_embeddings.py:36-212) against the fp64 numpy oracle, through the C ABI.
+Tolerance: 2e-6 * sqrt(K) of the tensor max (fp32 MFMA accumulation over K = 9*C terms vs fp64)."""
+import numpy as np
+import pytest
+import torch
+
+from .gpu_util import P, assert_close, dev, empty_bytes, host, stream, zeros
+
+pytestmark = pytest.mark.gpu
+
+from oracle import vgg as OV  # noqa: E402  (checker only)
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from vae_captioning_amd import abi
+    return abi.load()
+
+
+def _pack(lib, w, transpose):
+    wp = torch.empty(w.numel(), dtype=torch.float32, device="cuda")
+    Ci, Co = int(w.shape[2]), int(w.shape[3])
+    lib.vc_conv3x3_pack_f32(stream(), Ci, Co, P(w), transpose, P(wp))
+    return wp
+
+
+def test_pack_layout(lib):
+    """packed[tap][c/4][n][c%4]: forward = w[tap][c][n]; data gradient = w[8 - tap][n][c] (flipped taps, transposed)."""
+    rng = np.random.default_rng(0)
+    w = rng.standard_normal((3, 3, 8, 12), dtype=np.float32)
+    tw = dev(w)
+    f = host(_pack(lib, tw, 0)).reshape(9, 2, 12, 4)
+    assert np.array_equal(f, w.reshape(9, 2, 4, 12).transpose(0, 1, 3, 2))
+    t = host(_pack(lib, tw, 1)).reshape(9, 3, 8, 4)
+    wt = w.reshape(9, 8, 12)[::-1]                       # tap' = 8 - tap
+    assert np.array_equal(t, wt.reshape(9, 8, 3, 4).transpose(0, 2, 1, 3))
+
+
+# (B, H, W, Cin, Cout): SUB tiling (W % 8 == 0, H % 4 == 0) incl. partial last tile, 64- and 128-wide column tiles;
+# FLAT tiling (everything else with H*W >= 128): tiles that straddle two images, ragged last tile, W != H
+CASES = [(2, 8, 8, 32, 64), (3, 4, 8, 32, 128), (3, 12, 16, 64, 128), (1, 56, 56, 64, 64), (2, 28, 40, 128, 256),
+         (3, 14, 14, 32, 64), (2, 28, 28, 64, 128), (5, 14, 14, 96, 128), (2, 12, 20, 32, 64), (1, 20, 12, 64, 192)]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "x".join(map(str, c)))
+def test_patch_fwd_dgrad_match_oracle(lib, case):
+    B, H, W, Ci, Co = case
+    assert lib.vc_conv3x3_patch_supported(B, H, W, Ci, Co, 0) == 1
+    rng = np.random.default_rng(sum(case))
+    x = np.maximum(rng.standard_normal((B, H, W, Ci), dtype=np.float32), 0)
+    w = rng.standard_normal((3, 3, Ci, Co), dtype=np.float32) * np.float32(1 / np.sqrt(9 * Ci))
+    b = rng.standard_normal(Co, dtype=np.float32)
+    dy = rng.standard_normal((B, H, W, Co), dtype=np.float32)
+    x64, w64 = x.astype(np.float64), w.astype(np.float64)
+    pre = OV.conv3x3_fwd(x64, w64, b.astype(np.float64))
+    tx, tw, tdy = dev(x), dev(w), dev(dy)
+    wp = _pack(lib, tw, 0)
+    y = zeros(B, H, W, Co)
+    lib.vc_conv3x3_fwd_packed_f32(stream(), B, H, W, Ci, Co, P(tx), P(wp), P(dev(b)), P(y), 1, None, 0)
+    assert_close(host(y), np.maximum(pre, 0), 2e-6 * np.sqrt(9 * Ci) + 1e-6, msg="patch fwd (+bias, relu)")
+    lib.vc_conv3x3_fwd_packed_f32(stream(), B, H, W, Ci, Co, P(tx), P(wp), None, P(y), 0, None, 0)
+    assert_close(host(y), pre - b, 2e-6 * np.sqrt(9 * Ci) + 1e-6, msg="patch fwd (no bias, no relu)")
+    if lib.vc_conv3x3_patch_supported(B, H, W, Ci, Co, 1):
+        dxref, _, _ = OV.conv3x3_bwd(x64, w64, dy.astype(np.float64))
+        wpt = _pack(lib, tw, 1)
+        dx = zeros(B, H, W, Ci)
+        lib.vc_conv3x3_dgrad_packed_f32(stream(), B, H, W, Ci, Co, P(tdy), P(wpt), P(tx), P(dx), None, 0)
+        assert_close(host(dx), dxref * (x > 0), 2e-6 * np.sqrt(9 * Co) + 1e-6, msg="patch dgrad (+relu mask)")
+        lib.vc_conv3x3_dgrad_packed_f32(stream(), B, H, W, Ci, Co, P(tdy), P(wpt), None, P(dx), None, 0)
+        assert_close(host(dx), dxref, 2e-6 * np.sqrt(9 * Co) + 1e-6, msg="patch dgrad")
+    else:
+        assert Ci % 64 != 0  # the data gradient's output columns are the input channels
+
+
+def test_patch_unsupported_shapes_are_refused(lib):
+    from vae_captioning_amd.abi import VaecapError
+    assert lib.vc_conv3x3_patch_supported(2, 224, 224, 4, 64, 0) == 0     # conv1_1: 4 gathered channels
+    assert lib.vc_conv3x3_patch_supported(2, 6, 6, 32, 64, 0) == 0         # FLAT needs H*W >= 128
+    assert lib.vc_conv3x3_patch_supported(2, 30, 60, 32, 64, 0) == 0       # FLAT patch would not fit the LDS budget
+    x, wp, y = zeros(2, 6, 6, 32), zeros(9 * 32 * 64), zeros(2, 6, 6, 64)
+    with pytest.raises(VaecapError):
+        lib.vc_conv3x3_fwd_packed_f32(stream(), 2, 6, 6, 32, 64, P(x), P(wp), None, P(y), 0, None, 0)
+
+
+@pytest.mark.parametrize("case", [(4, 224, 224, 64, 64, "fwd"), (4, 224, 224, 64, 128, "fwd"), (3, 112, 112, 128, 128, "both"), (6, 28, 28, 512, 512, "both"),
+                                  (44, 14, 14, 512, 512, "dgrad")], ids=lambda c: "x".join(map(str, c)))
+def test_patch_whole_rounds_tail_split_and_old_kernel(lib, case):
+    """With a workspace the tiles beyond the last whole round of resident workgroups run as a K-split launch; results
+    agree with the single launch and with the implicit-GEMM kernel of conv.hip up to fp32 summation order, and are
+    bit-reproducible."""
+    B, H, W, Ci, Co, which = case
+    rng = np.random.default_rng(B + Ci)
+    x = torch.from_numpy(np.maximum(rng.standard_normal((B, H, W, Ci), dtype=np.float32), 0)).cuda()
+    w = torch.from_numpy(rng.standard_normal((3, 3, Ci, Co), dtype=np.float32) * np.float32(1 / np.sqrt(9 * Ci))).cuda()
+    b = torch.from_numpy(rng.standard_normal(Co, dtype=np.float32)).cuda()
+    dy = torch.from_numpy(rng.standard_normal((B, H, W, Co), dtype=np.float32)).cuda()
+    if which in ("fwd", "both"):
+        wp = _pack(lib, w, 0)
+        nb = lib.vc_conv3x3_packed_workspace_bytes(B, H, W, Ci, Co, 0)
+        assert nb > 0, "this shape must trigger the tail split"
+        ws = empty_bytes(nb)
+        y0, y1, y2, y3 = (zeros(B, H, W, Co) for _ in range(4))
+        lib.vc_conv3x3_fwd_packed_f32(stream(), B, H, W, Ci, Co, P(x), P(wp), P(b), P(y0), 1, None, 0)
+        lib.vc_conv3x3_fwd_packed_f32(stream(), B, H, W, Ci, Co, P(x), P(wp), P(b), P(y1), 1, P(ws), ws.numel() * 4)
+        lib.vc_conv3x3_fwd_packed_f32(stream(), B, H, W, Ci, Co, P(x), P(wp), P(b), P(y2), 1, P(ws), ws.numel() * 4)
+        lib.vc_conv3x3_fwd_f32(stream(), B, H, W, Ci, Co, P(x), P(w), P(b), P(y3), 1, None, 0)
+        assert torch.equal(y1, y2), "not bit-reproducible"
+        assert_close(host(y1), host(y0), 4e-6 * np.sqrt(9 * Ci) + 1e-6, msg="fwd tail split vs single launch")
+        assert_close(host(y0), host(y3), 4e-6 * np.sqrt(9 * Ci) + 1e-6, msg="patch fwd vs implicit-GEMM fwd")
+    if which in ("dgrad", "both"):
+        wpt = _pack(lib, w, 1)
+        nb = lib.vc_conv3x3_packed_workspace_bytes(B, H, W, Ci, Co, 1)
+        assert nb > 0, "this shape must trigger the tail split"
+        ws = empty_bytes(nb)
+        d0, d1, d3 = (zeros(B, H, W, Ci) for _ in range(3))
+        for mask in (P(x), None):
+            lib.vc_conv3x3_dgrad_packed_f32(stream(), B, H, W, Ci, Co, P(dy), P(wpt), mask, P(d0), None, 0)
+            lib.vc_conv3x3_dgrad_packed_f32(stream(), B, H, W, Ci, Co, P(dy), P(wpt), mask, P(d1), P(ws), ws.numel() * 4)
+            lib.vc_conv3x3_dgrad_f32(stream(), B, H, W, Ci, Co, P(dy), P(w), mask, P(d3), None, 0)
+            assert_close(host(d1), host(d0), 4e-6 * np.sqrt(9 * Co) + 1e-6, msg="dgrad tail split vs single launch")
+            assert_close(host(d0), host(d3), 4e-6 * np.sqrt(9 * Co) + 1e-6, msg="patch dgrad vs implicit-GEMM dgrad")

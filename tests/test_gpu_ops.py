@@ -432,6 +432,26 @@ def test_philox_bit_exact_and_moments(lib):
     assert abs(host(y).mean() - 0.7) < 2e-3 and set(np.unique(host(y))) == {0.0, 1.0}
 
 
+def test_philox_streams_do_not_alias_across_steps(lib):
+    """The engine keeps a stream id in offset >> 32 (eps 1, drop_in 2, drop_out 3, fc masks 8 / 9) and advances a device
+    step counter.  step is part of the KEY: stream k at step s+1 must not repeat stream k+1 at step s (it did while
+    step shared the high counter word with the stream id)."""
+    n, seed = 4096, 1234 * 1000003
+    draws = {}
+    for sid in (1, 2, 3, 8, 9):
+        for s in (0, 1, 2):
+            out = torch.zeros(n, dtype=torch.int32, device="cuda")
+            st = torch.tensor([s], dtype=torch.int32, device="cuda")
+            lib.vc_philox_u32(stream(), P(out), n, seed, sid << 32, P(st))
+            draws[(sid, s)] = host(out).view(np.uint32).copy()
+    keys = sorted(draws)
+    for i, a in enumerate(keys):
+        for b in keys[i + 1:]:
+            assert (draws[a] == draws[b]).mean() < 0.01, (a, b)
+    # bit-exact definition: key = (seed lo, seed hi + step), counter = (quad, offset)
+    np.testing.assert_array_equal(draws[(2, 1)][:64], _philox_ref(64, seed + (1 << 32), 2 << 32))
+
+
 # ----------------------------------------------------------------------------- VGG kernels
 CONV_CASES = [(2, 8, 6, 4, 8), (1, 14, 14, 64, 128), (2, 12, 10, 64, 64), (1, 7, 7, 512, 512), (3, 16, 16, 4, 64),
               (1, 28, 28, 128, 256), (1, 10, 10, 64, 256)]

@@ -140,16 +140,17 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 }
 
 // mode 0: raw uint32; 1: N(0,1) via Box-Muller; 2: Bernoulli(keep) as 0/1 floats; 3: uniform [0,1)
-// `step` (nullable, device): added to the high counter word so that a captured graph draws a
-// fresh stream every replay without any host-side argument change.
+// `step` (nullable, device): added to the high KEY word so that a captured graph draws a fresh
+// stream every replay without any host-side argument change.  (Counter words stay (element quad,
+// offset): callers put a stream id into offset >> 32, so step must not share a word with it --
+// stream k at step s+1 would repeat stream k+1 at step s.)
 __global__ __launch_bounds__(256) void philox_kernel(void* __restrict__ out, long n, uint64_t seed, uint64_t offset, int mode,
                                                      float keep, const int32_t* __restrict__ step) {
     const long nq = (n + 3) >> 2;
-    const uint32_t hi = (uint32_t)(offset >> 32) + (step ? (uint32_t)step[0] : 0u);
+    const uint32_t k1 = (uint32_t)(seed >> 32) + (step ? (uint32_t)step[0] : 0u);
     for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < nq; q += (long)gridDim.x * 256) {
         uint32_t r[4];
-        philox4x32_10((uint32_t)q, (uint32_t)((uint64_t)q >> 32), (uint32_t)offset, hi, (uint32_t)seed,
-                      (uint32_t)(seed >> 32), r);
+        philox4x32_10((uint32_t)q, (uint32_t)((uint64_t)q >> 32), (uint32_t)offset, (uint32_t)(offset >> 32), (uint32_t)seed, k1, r);
         float f[4];
         if (mode == 1) {
             const float u1 = ((float)r[0] + 1.0f) * 2.3283064365386963e-10f;  // (0,1]

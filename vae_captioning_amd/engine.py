@@ -194,7 +194,7 @@ class CaptionEngine(object):
         if self.enc and p.prior == "AG":
             self.c_means = torch.from_numpy(init_clusters(K_CL, p.latent_size)).to(device)
         self.ann_on = int((not p.fine_tune) and (not p.restore) and p.ann_param > 1)  # main.py:163-170
-        self.decay_steps = int(p.num_ex_per_epoch / (p.batch_size + 0.001) * p.num_epochs_per_decay)
+        self.decay_steps = int(p.num_ex_per_epoch / (p.batch_size * world + 0.001) * p.num_epochs_per_decay)  # ops/optimizers.py:24-25, global batch
 
     def _reduce_scatter(self, out, inp):
         """sum-reduce-scatter of inp [world*n, L] into out [n, L] (RCCL; backends without the primitive,

@@ -6,12 +6,28 @@ the single flat gradient buffer (caption-side grads | reduction scalars | VGG gr
 plus a 4-byte all-reduce of the non-PAD token count that the CE gradient scale needs
 before backward (main.py:156-157 divides by the GLOBAL count).
 """
+import os
+
 import numpy as np
 import torch
 
 from . import abi, spec
 from .abi import ptr as P
 from .engine import TAIL, CaptionEngine, FlatStore, _stream, internal_caption_variables, _round
+
+
+def imagenet_weights(weight_file):
+    """{cnn/* variable name: float32 array} from a vgg16_weights.npz, by the reference's rule
+    (utils/image_embeddings.py:240-246, quirk Q18): the first 30 ALPHABETICALLY SORTED arrays (conv1_1_W, conv1_1_b ...
+    conv5_3_b, fc6_W, fc6_b, fc7_W, fc7_b) are assigned to `parameters` in creation order; fc8_* are skipped."""
+    names = [n for n, _ in spec.vgg_variables()]
+    out = {}
+    with np.load(weight_file) as w:
+        for i, k in enumerate(sorted(w.keys())):
+            if i == 30:
+                break
+            out[names[i]] = np.ascontiguousarray(w[k], dtype=np.float32)
+    return out
 
 
 class VggEngine(object):
@@ -37,6 +53,9 @@ class VggEngine(object):
         # wgrads run on a side stream so that the tail of one kernel (the last partial round of workgroups)
         # is filled by the other instead of idling the chip
         import os
+        # patch-staged forward / data-gradient kernels (csrc/conv_patch.hip) wherever the layer shape allows; VC_CONV_PATCH=0
+        # keeps every layer on the implicit-GEMM kernels of csrc/conv.hip (A/B runs)
+        self.use_patch = os.environ.get("VC_CONV_PATCH", "1") != "0"
         nstreams = int(os.environ.get("VC_VGG_STREAMS", "3"))
         self.side = torch.cuda.Stream() if nstreams >= 2 else None
         self.side2 = torch.cuda.Stream() if nstreams >= 3 else None
@@ -70,7 +89,8 @@ class VggEngine(object):
             lib, need, H, W = self.lib, 0, 224, 224
             for name, ci, co in spec.VGG_CONV:
                 cie = 4 if ci == 3 else ci
-                need = max(need, lib.vc_conv3x3_fwd_workspace_bytes(nb, H, W, cie, co), lib.vc_conv3x3_dgrad_workspace_bytes(nb, H, W, cie, co))
+                need = max(need, lib.vc_conv3x3_fwd_workspace_bytes(nb, H, W, cie, co), lib.vc_conv3x3_dgrad_workspace_bytes(nb, H, W, cie, co),
+                           lib.vc_conv3x3_packed_workspace_bytes(nb, H, W, cie, co, 0), lib.vc_conv3x3_packed_workspace_bytes(nb, H, W, cie, co, 1))
                 if name in spec.VGG_POOL_AFTER:
                     H, W = H // 2, W // 2
             t = self.tail_ws[key] = torch.empty(max(need, 16) // 4 + 16, dtype=torch.float32, device=self.dev)
@@ -86,11 +106,41 @@ class VggEngine(object):
         else:
             fn()
 
+    def _pack_weights(self, backward):
+        """[tap][C/4][N][4] copies of the 3x3 kernels for the patch-staged convolutions (forward layout, and the flipped
+        + transposed one of the data gradient when a backward pass follows).  Runs on the weight-gradient stream, which is
+        idle during the forward pass; returns the event the convolution chains wait for (conv1_1 does not need it)."""
+        if not self.use_patch:
+            return None
+        lib, S = self.lib, self.store
+        main = torch.cuda.current_stream()
+        st = self.side2 if self.side2 is not None else (self.side if self.side is not None else main)
+        if st != main:
+            st.wait_stream(main)
+        with torch.cuda.stream(st):
+            sh = _stream()
+            for name, ci, co in spec.VGG_CONV:
+                if ci % 32:
+                    continue
+                w = S.param(spec.vgg_var_names(name)[0])
+                lib.vc_conv3x3_pack_f32(sh, ci, co, P(w), 0, P(self._b("wp_" + name, (9 * ci * co,))))
+                if backward:
+                    lib.vc_conv3x3_pack_f32(sh, ci, co, P(w), 1, P(self._b("wpt_" + name, (9 * ci * co,))))
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+        return ev
+
+    def _patch_ok(self, nb, H, W, ci, co, dgrad):
+        return self.use_patch and ci % 32 == 0 and bool(self.lib.vc_conv3x3_patch_supported(nb, H, W, ci, co, dgrad))
+
     def colsum(self, x, rows, cols, out):
         self._need_ws(self.lib.vc_colsum_workspace_bytes(rows, cols))
         self.lib.vc_colsum_f32(_stream(), P(x), rows, cols, cols, P(out), 0, P(self.ws), self.ws_bytes)
 
     def load_params(self, named):
+        missing = [n for n in self.store.names() if n not in named]
+        if missing:  # tf.train.Saver.restore raises NotFoundError for the same situation
+            raise KeyError("checkpoint lacks %d cnn/* variable(s), e.g. %s -- it was written without the VGG16 variables" % (len(missing), missing[0]))
         for name in self.store.names():
             dst = self.store.param(name)
             if tuple(np.shape(named[name])) != tuple(dst.shape):
@@ -99,13 +149,8 @@ class VggEngine(object):
 
     def load_weights(self, weight_file):
         """utils/image_embeddings.py:240-246: first 30 alphabetically sorted npz arrays."""
-        w = np.load(weight_file)
-        keys = sorted(w.keys())
-        names = self.store.names()
-        for i, k in enumerate(keys):
-            if i == 30:
-                break
-            self.store.param(names[i]).copy_(torch.from_numpy(np.ascontiguousarray(w[k], dtype=np.float32)))
+        for name, arr in imagenet_weights(weight_file).items():
+            self.store.param(name).copy_(torch.from_numpy(arr))
 
     def state_dict(self):
         torch.cuda.synchronize()
@@ -130,6 +175,7 @@ class VggEngine(object):
         lib.vc_vgg_preprocess_f32(st, P(images), B, H, W, P(x))
         w4 = self._b("w1_4", (3, 3, 4, 64))
         lib.vc_pad_dim_f32(st, P(S.param("cnn/conv1_1/weights")), 9, 3, 4, 64, P(w4))
+        packed, waited = self._pack_weights(self.train), set()
         self.acts = []  # (layer name, input tensor, H, W, Cin_eff, Cout, weights used)
         # The conv / pool chain of one image is independent of every other image: with two streams the
         # batch is pushed through as two half-batch chains so that the tail of each kernel (its last partial
@@ -150,9 +196,18 @@ class VggEngine(object):
                 tws = self._chain_ws(ch, nb)
                 with torch.cuda.stream(strm):
                     sh = _stream()
-                    self._timed("conv_fwd", 2.0 * nb * H * W * 9 * ci * co,
-                                lambda: lib.vc_conv3x3_fwd_f32(sh, nb, H, W, cie, co, P(x[b0:]), P(w), P(S.param(bn)), P(y[b0:]), 1,
-                                                               P(tws), tws.numel() * 4))
+                    if self._patch_ok(nb, H, W, cie, co, 0):
+                        if packed is not None and ch not in waited:
+                            torch.cuda.current_stream().wait_event(packed)
+                            waited.add(ch)
+                        wp = self.buf["wp_" + name]
+                        self._timed("conv_fwd", 2.0 * nb * H * W * 9 * ci * co,
+                                    lambda: lib.vc_conv3x3_fwd_packed_f32(sh, nb, H, W, cie, co, P(x[b0:]), P(wp), P(S.param(bn)), P(y[b0:]), 1,
+                                                                          P(tws), tws.numel() * 4))
+                    else:
+                        self._timed("conv_fwd", 2.0 * nb * H * W * 9 * ci * co,
+                                    lambda: lib.vc_conv3x3_fwd_f32(sh, nb, H, W, cie, co, P(x[b0:]), P(w), P(S.param(bn)), P(y[b0:]), 1,
+                                                                   P(tws), tws.numel() * 4))
                     if pooled:
                         lib.vc_maxpool2x2_fwd_f32(sh, nb, H, W, co, P(y[b0:]), P(yp[b0:]))
             self.acts.append((name, x, H, W, cie, co, w))
@@ -268,8 +323,13 @@ class VggEngine(object):
                     tws = self._chain_ws(ch, nb)
                     with torch.cuda.stream(strm):
                         sh = _stream()
-                        self._timed("conv_dgrad", fl * nb / B, lambda: lib.vc_conv3x3_dgrad_f32(
-                            sh, nb, H, W, ci, co, P(d[b0:]), P(w), None if prev_is_pool else P(x[b0:]), P(dx[b0:]), P(tws), tws.numel() * 4))
+                        if self._patch_ok(nb, H, W, ci, co, 1) and ("wpt_" + name) in self.buf:
+                            wpt = self.buf["wpt_" + name]
+                            self._timed("conv_dgrad", fl * nb / B, lambda: lib.vc_conv3x3_dgrad_packed_f32(
+                                sh, nb, H, W, ci, co, P(d[b0:]), P(wpt), None if prev_is_pool else P(x[b0:]), P(dx[b0:]), P(tws), tws.numel() * 4))
+                        else:
+                            self._timed("conv_dgrad", fl * nb / B, lambda: lib.vc_conv3x3_dgrad_f32(
+                                sh, nb, H, W, ci, co, P(d[b0:]), P(w), None if prev_is_pool else P(x[b0:]), P(dx[b0:]), P(tws), tws.numel() * 4))
                 d = dx
         if split:
             main.wait_stream(side)
@@ -311,6 +371,7 @@ class Trainer(object):
                 self.cap.reg_scale = self.vgg.wd / 2.0  # l2_regularizer(wd)(w) = wd * sum(w^2)/2
         self.images = None
         self.graph = None
+        self.cnn_host = None  # {cnn/* name: array} written into checkpoints when VGG16 is not on device (state_dict)
         self.n_cap = n_cap
         # Data-parallel gradient exchange.  Logically ONE sum-all-reduce of `gall` per step; with VGG
         # fine-tuning it is issued as four asynchronous pieces in the order the gradients become final
@@ -401,15 +462,29 @@ class Trainer(object):
 
     # ------------------------------------------------------------------ checkpoints
     def state_dict(self):
+        """Every trainable variable of the reference graph (main.py:186-191).  The reference builds the VGG16 variables
+        even when it trains on precomputed features (on a dummy input, with the ImageNet weights loaded "for further
+        usage", main.py:63-66,205-208, quirk Q22), so its checkpoints always carry cnn/*: without --fine_tune they come
+        from `cnn_host` (set by main.py from the ImageNet npz, or kept from the checkpoint that was restored)."""
         d = self.cap.state_dict()
         if self.vgg is not None:
             d.update(self.vgg.state_dict())
+        elif self.cnn_host is not None:
+            d.update(self.cnn_host)
         return d
 
-    def load_state_dict(self, d):
+    def load_state_dict(self, d, imagenet_path=None):
         self.cap.load_params(d)
+        cnn = {k: v for k, v in d.items() if k.startswith("cnn/")}
         if self.vgg is not None:
-            self.vgg.load_params(d)
+            if not cnn and imagenet_path and os.path.exists(imagenet_path):
+                # a checkpoint written without cnn/* (older runs of this build with precomputed features)
+                print("checkpoint has no cnn/* variables: loading VGG16 from %s" % imagenet_path)
+                self.vgg.load_weights(imagenet_path)
+            else:
+                self.vgg.load_params(d)
+        elif cnn:
+            self.cnn_host = cnn  # carried along so that the next save writes them again
 
     def save(self, path):
         """saver.save (main.py:286-288): the trainable variables under the reference's names
@@ -424,9 +499,10 @@ class Trainer(object):
 
     def restore(self, path):
         """saver.restore (main.py:201-204, gen_caption.py:113-115): every variable of this model must be present."""
+        inet = getattr(self.p, "image_net_weights_path", None)
         if path.endswith(".npz"):
             with np.load(path) as z:
-                self.load_state_dict({k: z[k] for k in z.files})
+                self.load_state_dict({k: z[k] for k in z.files}, imagenet_path=inet)
         else:
             from . import tf_bundle
-            self.load_state_dict(tf_bundle.read_bundle(path))
+            self.load_state_dict(tf_bundle.read_bundle(path), imagenet_path=inet)

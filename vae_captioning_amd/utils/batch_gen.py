@@ -42,20 +42,34 @@ def preprocess_captions(inputs, labels, lengths, c_v=None):
     return out
 
 
+def shard_ranges(n, batch_size, shard=None):
+    """[lo, hi) index ranges of the successive batches one rank reads from a list of n shuffled examples.
+    shard None: the reference's chunks of batch_size with a ragged last one (utils/batch_gen.py:180-183).
+    shard (rank, world): data-parallel training -- the list is cut into GLOBAL batches of world*batch_size examples and
+    rank r reads rows [r*batch_size, (r+1)*batch_size) of each (dp.shard_batch's rule); a ragged last global batch is
+    dropped on every rank alike (shapes are static on device and the ranks must step together)."""
+    if shard is None:
+        return [(s, min(s + batch_size, n)) for s in range(0, n, batch_size)]
+    rank, world = shard
+    g = batch_size * world
+    return [(s + rank * batch_size, s + (rank + 1) * batch_size) for s in range(0, n - g + 1, g)]
+
+
 class BatchGenerator(object):
     """next_batch(): dicts in the layout Trainer.set_batch takes.  features: {file_name: [1, F] or [F]}
     (the reference's feature pickles); cluster vectors: {file_name: 91-vector}, column 0 dropped
     (main.py:236)."""
 
-    def __init__(self, indexed_captions, features, batch_size, cluster_vectors=None, seed=42):
+    def __init__(self, indexed_captions, features, batch_size, cluster_vectors=None, seed=42, shard=None):
         self.caps, self.feats, self.bs, self.cv = indexed_captions, features, batch_size, cluster_vectors
         self.names = [n for n in indexed_captions if n in features]
         self.rng = np.random.default_rng(seed)
+        self.shard = shard  # (rank, world): every rank shuffles identically and takes its slice of each GLOBAL batch
 
     def next_batch(self, use_obj_vectors=False, num_captions=1, shuffle=True):
         order = self.rng.permutation(len(self.names)) if shuffle else np.arange(len(self.names))
-        for s in range(0, len(order), self.bs):
-            names = [self.names[i] for i in order[s:s + self.bs]]
+        for lo, hi in shard_ranges(len(order), self.bs, self.shard):
+            names = [self.names[i] for i in order[lo:hi]]
             ins, lab, lens = form_captions_batch(self.caps, names, num_captions, self.rng)
             if ins.ndim == 2:
                 ins, lab, lens = ins[:, None, :], lab[:, None, :], lens.reshape(-1, 1)
@@ -96,7 +110,8 @@ class Batch_Generator(object):
 
     def __init__(self, train_dir, train_cap_json=None, captions=None, batch_size=None, use_hdf5=False, hdf5_file=None,
                  feature_dict=None, get_image_ids=False, get_test_ids=False, val_tr_unused=None,
-                 cluster_vectors=None, seed=42):
+                 cluster_vectors=None, seed=42, shard=None):
+        self.shard = shard  # (rank, world) for data-parallel training (see shard_ranges); None = the reference's behaviour
         self.use_hdf5 = bool(use_hdf5) and feature_dict is None
         if self.use_hdf5:
             if not hdf5_file:
@@ -193,9 +208,9 @@ class Batch_Generator(object):
             return ins[:, 0], lab[:, 0], lens[:, 0]
         return ins, lab, lens
 
-    def _chunks(self, names):
-        for s in range(0, len(names), self._batch_size):
-            yield self._sorted_for_array(names[s:s + self._batch_size])
+    def _chunks(self, names, shard=None):
+        for lo, hi in shard_ranges(len(names), self._batch_size, shard):
+            yield self._sorted_for_array(names[lo:hi])
 
     def _imid(self, names, test=False):
         if test:
@@ -206,8 +221,8 @@ class Batch_Generator(object):
     # -- generators
     def next_batch(self, use_obj_vectors=False, num_captions=1):
         c_v = self._cv_dict() if use_obj_vectors else None
-        self.rng.shuffle(self._iterable)
-        for names in self._chunks(self._iterable):
+        self.rng.shuffle(self._iterable)  # same seed on every rank: identical order, disjoint slices
+        for names in self._chunks(self._iterable, self.shard):
             images, cl_v = self._images_c_v(names, c_v)
             ins, lab, lens = self._captions_for(names, num_captions == 1, num_captions)
             yield images, (ins, lab), lens, cl_v

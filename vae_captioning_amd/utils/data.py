@@ -84,9 +84,11 @@ class Data(object):
     def _image_source(self):
         return dict(use_hdf5=self.params.use_hdf5, hdf5_file=self.params.hdf5_file)
 
-    def load_train_data_generator(self, batch_size, fine_tune=False, usehdf5=True):
+    def load_train_data_generator(self, batch_size, fine_tune=False, usehdf5=True, shard=None):
+        """shard = (rank, world) (additive, data-parallel training): see batch_gen.shard_ranges."""
         from_images = fine_tune or not self.train_feature_dict
         kw = self._image_source() if from_images else {}
+        kw["shard"] = shard
         self.train_batch_gen = Batch_Generator(self.train_dir, self.train_cap_json, self.captions_tr, batch_size,
                                                feature_dict=None if from_images else self.train_feature_dict, **kw)
         if self.repartiton:  # train on train2014 + val2014 minus the last gen_val_cap images (utils/batch_gen.py:71-96)
