@@ -235,6 +235,14 @@ int vc_conv3x3_fwd_packed_f32(void* stream, int B, int H, int W, int Cin, int Co
                               const float* bias, float* y, int relu, float* ws, size_t ws_bytes);
 int vc_conv3x3_dgrad_packed_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* dy, const float* wpt,
                                 const float* relu_src, float* dx, float* ws, size_t ws_bytes);
+/* Patch-staged weight gradient: a workgroup owns 64 input channels x all nine taps x 64 output channels and stages the
+ * halo patch of every 4 x 8 pixel sub-tile once (the nine taps share it).  Same contract as conv3x3_wgrad (split-K into the
+ * workspace, deterministic reduce, db != NULL also returns the bias gradient).  Shapes: Cin % 64 == 0, Cout % 64 == 0,
+ * W % 8 == 0, H % 4 == 0; ask vc_conv3x3_wgrad_patch_supported. */
+int vc_conv3x3_wgrad_patch_supported(int B, int H, int W, int Cin, int Cout);
+size_t vc_conv3x3_wgrad_patch_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+int vc_conv3x3_wgrad_patch_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const float* dy, float* dw,
+                               float* db, int accumulate, float* ws, size_t ws_bytes);
 
 /* ------------------------------------------------------------------------------------
  * Beam-search bookkeeping after one decoder step, on device, one thread per image: the loop body of

@@ -120,3 +120,52 @@ def test_patch_whole_rounds_tail_split_and_old_kernel(lib, case):
             lib.vc_conv3x3_dgrad_f32(stream(), B, H, W, Ci, Co, P(dy), P(w), mask, P(d3), None, 0)
             assert_close(host(d1), host(d0), 4e-6 * np.sqrt(9 * Co) + 1e-6, msg="dgrad tail split vs single launch")
             assert_close(host(d0), host(d3), 4e-6 * np.sqrt(9 * Co) + 1e-6, msg="patch dgrad vs implicit-GEMM dgrad")
+
+
+# ---- weight gradient ------------------------------------------------------------------------------------------------
+# 4 x 8 sub-tile kernel (W % 8 == 0, H % 4 == 0), then the FLAT kernels of the 28- and 14-wide layers (K-tiles that straddle image
+# rows and images, a ragged last K-tile when B*H*W % 32 != 0)
+WG_CASES = [(2, 8, 8, 64, 64), (3, 4, 8, 64, 128), (2, 12, 16, 128, 64), (1, 56, 56, 64, 64), (2, 28, 40, 128, 192), (5, 8, 16, 64, 64),
+            (2, 28, 28, 64, 128), (1, 28, 28, 128, 256), (3, 14, 14, 128, 128), (5, 14, 14, 64, 256), (3, 20, 14, 64, 128), (2, 9, 28, 64, 128)]
+
+
+@pytest.mark.parametrize("case", WG_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_patch_wgrad_matches_oracle(lib, case):
+    B, H, W, Ci, Co = case
+    assert lib.vc_conv3x3_wgrad_patch_supported(B, H, W, Ci, Co) == 1
+    rng = np.random.default_rng(sum(case))
+    x = np.maximum(rng.standard_normal((B, H, W, Ci), dtype=np.float32), 0)
+    w = rng.standard_normal((3, 3, Ci, Co), dtype=np.float32)
+    dy = rng.standard_normal((B, H, W, Co), dtype=np.float32)
+    _, dwref, dbref = OV.conv3x3_bwd(x.astype(np.float64), w.astype(np.float64), dy.astype(np.float64))
+    tx, tdy = dev(x), dev(dy)
+    ws = empty_bytes(lib.vc_conv3x3_wgrad_patch_workspace_bytes(B, H, W, Ci, Co))
+    dw, db = zeros(3, 3, Ci, Co), zeros(Co)
+    lib.vc_conv3x3_wgrad_patch_f32(stream(), B, H, W, Ci, Co, P(tx), P(tdy), P(dw), P(db), 0, P(ws), ws.numel() * 4)
+    assert_close(host(dw), dwref, 2e-6 * np.sqrt(B * H * W) + 1e-6, msg="patch wgrad")
+    assert_close(host(db), dbref, 1e-5, msg="patch wgrad bias gradient")
+    lib.vc_conv3x3_wgrad_patch_f32(stream(), B, H, W, Ci, Co, P(tx), P(tdy), P(dw), None, 1, P(ws), ws.numel() * 4)
+    assert_close(host(dw), 2 * dwref, 2e-6 * np.sqrt(B * H * W) + 1e-6, msg="patch wgrad accumulate, no bias")
+
+
+def test_patch_wgrad_large_matches_implicit_gemm_and_is_reproducible(lib):
+    B, H, W, Ci, Co = 8, 112, 112, 64, 128
+    rng = np.random.default_rng(5)
+    x = torch.from_numpy(np.maximum(rng.standard_normal((B, H, W, Ci), dtype=np.float32), 0)).cuda()
+    dy = torch.from_numpy(rng.standard_normal((B, H, W, Co), dtype=np.float32)).cuda()
+    ws = empty_bytes(max(lib.vc_conv3x3_wgrad_patch_workspace_bytes(B, H, W, Ci, Co), lib.vc_conv3x3_wgrad_workspace_bytes(B, H, W, Ci, Co)))
+    d0, d1, d2 = zeros(3, 3, Ci, Co), zeros(3, 3, Ci, Co), zeros(3, 3, Ci, Co)
+    b0, b2 = zeros(Co), zeros(Co)
+    lib.vc_conv3x3_wgrad_patch_f32(stream(), B, H, W, Ci, Co, P(x), P(dy), P(d0), P(b0), 0, P(ws), ws.numel() * 4)
+    lib.vc_conv3x3_wgrad_patch_f32(stream(), B, H, W, Ci, Co, P(x), P(dy), P(d1), None, 0, P(ws), ws.numel() * 4)
+    lib.vc_conv3x3_wgrad_f32(stream(), B, H, W, Ci, Co, P(x), P(dy), P(d2), P(b2), 0, P(ws), ws.numel() * 4)
+    assert torch.equal(d0, d1), "not bit-reproducible"
+    assert_close(host(d0), host(d2), 4e-6 * np.sqrt(B * H * W) + 1e-6, msg="patch wgrad vs implicit-GEMM wgrad")
+    assert_close(host(b0), host(b2), 1e-5, msg="bias gradient")
+
+
+def test_patch_wgrad_unsupported_shapes(lib):
+    assert lib.vc_conv3x3_wgrad_patch_supported(2, 28, 20, 256, 512) == 0   # neither W % 8 == 0 nor one of the FLAT widths
+    assert lib.vc_conv3x3_wgrad_patch_supported(2, 28, 28, 256, 64) == 0    # FLAT kernels: 128 output channels per workgroup
+    assert lib.vc_conv3x3_wgrad_patch_supported(2, 224, 224, 4, 64) == 0    # conv1_1
+    assert lib.vc_conv3x3_wgrad_patch_supported(2, 56, 56, 96, 64) == 0     # Cin % 64

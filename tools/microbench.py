@@ -137,6 +137,25 @@ def convsweep():
                 H, ci, co, B, tiles, tiles / 512.0, t1, fl / t1, t2, fl / t2, t3, fl / t3), flush=True)
 
 
+def convw():
+    """patch-staged weight gradient against the implicit-GEMM one, VGG16 layer shapes"""
+    for B in (64, 32):
+        for (name, H, ci, co) in [("1_2", 224, 64, 64), ("2_1", 112, 64, 128), ("2_2", 112, 128, 128), ("3_1", 56, 128, 256), ("3_2", 56, 256, 256),
+                                  ("4_1", 28, 256, 512), ("4_2", 28, 512, 512), ("5_2", 14, 512, 512)]:
+            x, dy, bias = rnd(B, H, H, ci), rnd(B, H, H, co), rnd(co)
+            dw = torch.empty(3, 3, ci, co, device="cuda")
+            ws = torch.empty(max(lib.vc_conv3x3_wgrad_workspace_bytes(B, H, H, ci, co), lib.vc_conv3x3_wgrad_patch_workspace_bytes(B, H, H, ci, co)) // 4 + 4, device="cuda")
+            fl = 2e-9 * B * H * H * 9 * ci * co
+            res = {}
+            for nm, fn in (("wgrad", lambda: lib.vc_conv3x3_wgrad_f32(st(), B, H, H, ci, co, P(x), P(dy), P(dw), P(bias), 0, P(ws), ws.numel() * 4)),
+                           ("wgrad-patch", lambda: lib.vc_conv3x3_wgrad_patch_f32(st(), B, H, H, ci, co, P(x), P(dy), P(dw), P(bias), 0, P(ws), ws.numel() * 4)),
+                           ("wgrad-patch-nb", lambda: lib.vc_conv3x3_wgrad_patch_f32(st(), B, H, H, ci, co, P(x), P(dy), P(dw), None, 0, P(ws), ws.numel() * 4))):
+                med, mn = timeit(fn, reps=5)
+                res[nm] = med
+                print("conv%s %-14s B=%d H=%3d %3d->%3d: %8.3f ms  %6.1f TFLOP/s" % (name, nm, B, H, ci, co, med, fl / med), flush=True)
+            print("conv%s B=%d speed-up wgrad %.3f" % (name, B, res["wgrad"] / res["wgrad-patch"]), flush=True)
+
+
 def lstm():
   for mode in (0, 1):
     lib.vc_lstm_set_mode(mode)

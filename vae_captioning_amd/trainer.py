@@ -274,7 +274,8 @@ class VggEngine(object):
         if after_fc is not None:
             after_fc()
         dw4 = self._b("dw1_4", (3, 3, 4, 64))
-        self._need_ws(max(lib.vc_conv3x3_wgrad_workspace_bytes(B, a[2], a[3], a[4], a[5]) for a in self.acts if a[0] != "P"))
+        self._need_ws(max(max(lib.vc_conv3x3_wgrad_workspace_bytes(B, a[2], a[3], a[4], a[5]), lib.vc_conv3x3_wgrad_patch_workspace_bytes(B, a[2], a[3], a[4], a[5]))
+                          for a in self.acts if a[0] != "P"))
         main = torch.cuda.current_stream()
         side, side2 = self.side, self.side2
         # streams: with 3, the data-gradient chain runs as two half-batch chains (main, side) and every
@@ -302,6 +303,8 @@ class VggEngine(object):
                 if ci == 4:
                     self._timed("conv_wgrad", fl, lambda: lib.vc_conv3x3_wgrad_f32(sw, B, H, W, ci, co, P(x), P(d), P(dw4), P(S.grad(bn)), 0, P(self.ws), self.ws_bytes))
                     lib.vc_pad_dim_f32(sw, P(dw4), 9, 4, 3, 64, P(S.grad(wn)))
+                elif self.use_patch and lib.vc_conv3x3_wgrad_patch_supported(B, H, W, ci, co):
+                    self._timed("conv_wgrad", fl, lambda: lib.vc_conv3x3_wgrad_patch_f32(sw, B, H, W, ci, co, P(x), P(d), P(S.grad(wn)), P(S.grad(bn)), 0, P(self.ws), self.ws_bytes))
                 else:
                     self._timed("conv_wgrad", fl, lambda: lib.vc_conv3x3_wgrad_f32(sw, B, H, W, ci, co, P(x), P(d), P(S.grad(wn)), P(S.grad(bn)), 0, P(self.ws), self.ws_bytes))
             if wst is not None:
