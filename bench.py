@@ -117,6 +117,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--images-per-gpu", type=int, default=0, help="override the workload's images per GPU (sweeps; the default is BASELINE's)")
+    ap.add_argument("--fresh-batch", type=int, default=0, metavar="K",
+                    help="rotate K distinct host batches through Trainer.set_batch INSIDE the timed region (token upload, device index "
+                         "build for the embedding gradient, image upload from pinned memory), i.e. the step main.py runs; 0 = one "
+                         "HBM-resident batch (the headline figure: inputs resident when the timed region starts)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: the workload's images per GPU on every rank (global batch grows with N); strong: the GLOBAL batch is "
+                         "fixed at 8 x the per-GPU figure (cfg4: 512 images) and divided over the ranks")
+    ap.add_argument("--vocab", type=int, default=VOCAB, help="vocabulary size (secondary lines: 11313 = the reference's observed size)")
+    ap.add_argument("--variable-len", action="store_true", help="caption lengths ~ clip(N(11,3), 6, 20) instead of all 20 (secondary line)")
+    ap.add_argument("--num-captions", type=int, default=0, help="captions per image (secondary line nc = 1; default: the reference's 5)")
     args = ap.parse_args()
 
     import torch
@@ -145,20 +155,31 @@ def main():
     w = dict(WORKLOADS[args.workload])
     if args.images_per_gpu:
         w["B"] = args.images_per_gpu
+    if args.scaling == "strong":  # "1/2/4-GPU points ... at B=512 total (strong)"
+        assert (8 * w["B"]) % world == 0
+        w["B"] = 8 * w["B"] // world
     p = make_params(w)
+    if args.num_captions:
+        p.num_captions = args.num_captions
+    vocab = args.vocab
+    p.vocab_size = vocab
     if w.get("generate"):
         return bench_generation(args, torch, dist, lib, w, p, world, rank)
     rng = np.random.default_rng(args.seed + rank)
     B = w["B"]
     N = B * p.num_captions
-    tr = Trainer(p, VOCAB, device="cuda", lib=lib, world=world, rank=rank, seed=args.seed)
-    tr.load_state_dict({**spec.init_caption_params(p, VOCAB, seed=1), **(spec.init_vgg_params(seed=2) if p.fine_tune else {})})
-    batch = synth.make_batch(rng, B, p.num_captions, T_LEN, VOCAB, use_ci=spec.uses_ci(p), images=p.fine_tune)
+    tr = Trainer(p, vocab, device="cuda", lib=lib, world=world, rank=rank, seed=args.seed)
+    tr.load_state_dict({**spec.init_caption_params(p, vocab, seed=1), **(spec.init_vgg_params(seed=2) if p.fine_tune else {})})
+    mk = lambda: synth.make_batch(rng, B, p.num_captions, T_LEN, vocab, use_ci=spec.uses_ci(p), images=p.fine_tune, variable_len=args.variable_len)
+    batch = mk()
+    fresh = [batch] + [mk() for _ in range(max(0, args.fresh_batch - 1))] if args.fresh_batch else None
     tr.set_batch(batch)  # inputs resident in HBM before the timed region; noise is generated on device
 
     from vae_captioning_amd.engine import KernelTimer
     use_graph = bool(args.graph) and world == 1
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
+        if fresh:
+            tr.set_batch(fresh[i % len(fresh)])
         tr._step()
     timer = KernelTimer()
     if use_graph:
@@ -167,12 +188,16 @@ def main():
         tr.cap.timer = timer
         if tr.vgg is not None:
             tr.vgg.timer = timer
+    if world > 1:
+        tr.dp_stats = []
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        if fresh:
+            tr.set_batch(fresh[i % len(fresh)])
         tr.train_step()
     torch.cuda.synchronize()
     if world > 1:
@@ -185,6 +210,18 @@ def main():
         dt = float(t.item())
     kld, rec, lb, ann = tr.losses()
     assert np.isfinite(rec) and np.isfinite(lb), "non-finite loss"
+    dp_info = None
+    if world > 1:  # per-bucket stall of the compute stream on the gradient all-reduce (ms per step, mean over the timed steps)
+        from vae_captioning_amd import dp as dpm
+        bk = dpm.gradient_buckets(tr.n_cap, tr.gall.numel(), tr.off_fc, tr.off_c3)
+        dp_info = {"backend": backend, "rccl_world_size": dist.get_world_size(), "all_reduce_bytes_per_step": int(tr.gall.numel() * 4),
+                   "buckets_bytes": [int((b - a) * 4) for a, b in bk] if (tr.buckets and tr.vgg is not None) else [int(tr.gall.numel() * 4)]}
+        if tr.dp_stats:
+            torch.cuda.synchronize()
+            w = {}
+            for i, nbytes, e0, e1 in tr.dp_stats:
+                w.setdefault(i, []).append(e0.elapsed_time(e1))
+            dp_info["bucket_wait_ms"] = [round(float(np.mean(w[i])), 4) for i in sorted(w)]
 
     # ---- roofline of the dominant kernel family from the HIP events of the timed region
     instrumented_pass = False
@@ -213,15 +250,19 @@ def main():
         "unit": "captions/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1000 * dt / args.steps, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s: %s" % (args.workload, json.dumps(w, sort_keys=True)), "images_per_gpu": B,
                    "captions_per_image": p.num_captions, "caption_rows_per_gpu": N, "global_caption_rows": N * world,
-                   "seq_len": T_LEN, "vocab": VOCAB, "gen_z_samples": p.gen_z_samples, "hipgraph": use_graph,
-                   "parallelism": "dp%d" % world},
+                   "seq_len": T_LEN, "vocab": vocab, "variable_len": bool(args.variable_len), "gen_z_samples": p.gen_z_samples,
+                   "hipgraph": use_graph, "parallelism": "dp%d" % world, "rccl_world_size": dist.get_world_size() if world > 1 else 1,
+                   "inputs": ("%d host batches rotated through set_batch inside the timed region" % len(fresh)) if fresh
+                             else "one batch resident in HBM"},
         "final_losses": {"rec_loss": round(rec, 5), "kld": round(kld, 5)},
         "roofline": roof,
     }
+    if dp_info:
+        out["data_parallel"] = dp_info
     if rank == 0:
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, w, args.seed)
@@ -266,7 +307,7 @@ def bench_generation(args, torch, dist, lib, w, p, world, rank):
     roof["instrumented_pass"] = False
     out = {"metric": "captions/sec generated (beam search)", "value": round(B * world * args.steps / dt, 2), "unit": "captions/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * dt / args.steps, 3),
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": "cfg5: %s" % json.dumps(w, sort_keys=True), "images_per_gpu": B, "beam_size": w["beam"],
                       "gen_z_samples": w["z"], "gen_max_len": p.gen_max_len, "vocab": VOCAB, "parallelism": "replicas%d" % world,
                       "mean_caption_len": round(float(np.mean([len(r[0][0]) for r in res])), 2)},
@@ -292,24 +333,32 @@ def hbm_from_timer(timer):
 
 
 def roofline_from_timer(timer, fine_tune):
-    """achieved = algorithmic FLOPs of the dominant kernel family's launches / the union of their
-    HIP-event intervals (plain sum when nothing overlaps).  cfg4: the implicit-GEMM convolution kernels (forward, dgrad, wgrad; wgrad includes its
-    split-K reduce).  Caption-only workloads: the [T*N, H] x [H, V] logits GEMM."""
+    """Dominant kernel family: cfg4 = the 3x3 convolution calls (forward, data gradient, weight gradient; a call = its main
+    launch + K-split tail launch + split reduce); caption-only workloads = the [T*N, H] x [H, V] logits GEMM.
+      achieved / frac        = algorithmic FLOPs / UNION of the calls' HIP-event intervals (= frac_union)
+      frac_serial            = algorithmic FLOPs / SUM of the calls' durations
+    With the default single VGG stream nothing overlaps and the two coincide; both are recomputable from the tracked rocprofv3
+    summary of the same command (profiles/*_kernel_stats.md ends with the family's summed and union dispatch time,
+    tools/rocpd_stats.py)."""
     tags = ["conv_fwd", "conv_dgrad", "conv_wgrad"] if fine_tune else ["logits_gemm"]
     sm = timer.summary(family=tags)
     fl = sum(sm[t]["flops"] for t in tags)
-    sec = sm["__union__"]  # union of the launch intervals: dgrad / wgrad of a layer overlap on two streams
+    sec = sm["__union__"]
+    ser = sum(sm[t]["seconds"] for t in tags)
     n = sum(sm[t]["launches"] for t in tags)
     ach = fl / sec / 1e12
     per = {t: dict(launches=sm[t]["launches"], avg_us=round(1e6 * sm[t]["seconds"] / sm[t]["launches"], 2),
                    tflops=round(sm[t]["flops"] / sm[t]["seconds"] / 1e12, 2)) for t in tags}
-    return {"bound": "mfma", "kernel": "vc::conv_kernel<TileCfg,{fwd,dgrad,wgrad}>" if fine_tune else "vc::gemm_kernel<128x128,MK,KM> (logits)",
+    return {"bound": "mfma",
+            "kernel": "vc::conv_patch_kernel / vc::wgrad_patch_kernel / vc::wgrad_flat_kernel (+ vc::conv_kernel for conv1_1)" if fine_tune
+                      else "vc::gemm_kernel<128x128,MK,KM> (logits)",
             "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+            "frac_union": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "frac_serial": round(fl / ser / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+            "family_flops": fl, "family_seconds_union": round(sec, 6), "family_seconds_serial": round(ser, 6),
             "traffic": None, "launches": n, "avg_launch_us": round(1e6 * sec / n, 2), "per_kernel": per,
-            "streams": int(os.environ.get("VC_VGG_STREAMS", "3")) if fine_tune else 1,
-            "note": "achieved = algorithmic FLOPs of the family / UNION of its launch intervals (HIP events on each launch's own stream); "
-                    "per_kernel.avg_us are per-launch durations and agree with rocprofv3's averages -- with >1 stream the launches share "
-                    "the chip, so per-launch TFLOP/s is not the family rate (VC_VGG_STREAMS=1 gives the serial figures, profiles/README.md)"}
+            "streams": int(os.environ.get("VC_VGG_STREAMS", "1")) if fine_tune else 1,
+            "note": "achieved = algorithmic FLOPs of the family's calls in the timed region / union of their HIP-event intervals "
+                    "(events recorded on the stream each call is launched on)"}
 
 
 if __name__ == "__main__":

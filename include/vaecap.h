@@ -63,6 +63,15 @@ int vc_embedding_scatter_add_f32(void* stream, float* dtable, const int32_t* ids
  * bit-identical.  Hot tokens are handled by calling it twice (sub-segments, then partial rows). */
 int vc_embedding_grad_sorted_f32(void* stream, float* dtable, const int32_t* order, const int32_t* seg_start, int E,
                                  int nrows, const float* dX);
+/* Inverted index of the token ids for the call pair above, built on device (stable counting sort, integer work, no
+ * atomics): order [R] = stable argsort of clip(ids, 0, vocab-1); seg1 [max_subsegments + 1] = boundaries into `order` of
+ * sub-segments of <= chunk positions that never cross an id boundary (entries past the real count are R: empty
+ * sub-segments, so the first-level call may always run over max_subsegments rows -- no host read-back); seg2 [vocab + 1] =
+ * for every id the range of its sub-segments.  ws: int32 scratch of vc_embedding_index_workspace_bytes. */
+size_t vc_embedding_index_workspace_bytes(long R, int vocab);
+size_t vc_embedding_index_max_subsegments(long R, int vocab, int chunk);
+int vc_embedding_grad_index(void* stream, const int32_t* ids, long R, int vocab, int chunk, int32_t* order, int32_t* seg1,
+                            int32_t* seg2, int32_t* ws, size_t ws_bytes);
 int vc_mark_rows_f32(void* stream, float* touched, const int32_t* ids, long n, int vocab);
 
 /* ------------------------------------------------------------------------------------

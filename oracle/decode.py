@@ -143,7 +143,7 @@ def beam_search(P, cfg, feature, c_v_row, eps, bos, eos, c_means=None, beam_size
                 if p < 1e-12:
                     continue
                 sentence = pc.sentence + [w]
-                logprob = pc.logprob + np.log(p)
+                logprob = pc.logprob + float(np.log(np.float32(p)))  # decoder.py:282: float32 log (p is a float32 softmax output), float64 sum
                 score = logprob
                 if w == eos:
                     if len_norm_f > 0:

@@ -208,3 +208,54 @@ def test_cluster_vectors_from_annotations_and_detections():
     ts = {"t.jpg": dict(classes=[[3.0, 7.0, 9.0]], scores=[[0.9, 0.4, 0.6]]), "u.jpg": dict(classes=[[5.0]], scores=[[0.1]])}
     tv = pcv.cluster_vectors_from_scores(ts)
     assert tv["t.jpg"][3] == 0.5 and tv["t.jpg"][9] == 0.5 and tv["t.jpg"][7] == 0 and tv["u.jpg"].sum() == 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# data-parallel sharding of the training generators (main.py --coco_dir / --captions_json under torchrun)
+def test_shard_ranges_partition_every_global_batch():
+    from vae_captioning_amd.utils.batch_gen import shard_ranges
+    n, bs = 103, 8
+    assert shard_ranges(n, bs) == [(s, min(s + bs, n)) for s in range(0, n, bs)]          # the reference's chunks, ragged last one
+    for world in (2, 4):
+        per_rank = [shard_ranges(n, bs, (r, world)) for r in range(world)]
+        steps = n // (bs * world)
+        assert all(len(p) == steps for p in per_rank)                                      # every rank steps the same number of times
+        for k in range(steps):
+            rows = sorted(i for p in per_rank for i in range(*p[k]))
+            assert rows == list(range(k * bs * world, (k + 1) * bs * world))               # disjoint, cover the global batch exactly
+            assert all(hi - lo == bs for p in per_rank for lo, hi in [p[k]])
+
+
+def test_two_ranks_see_disjoint_examples_of_one_shuffle():
+    caps = {"im%03d" % i: [[1, 3 + i % 5, 2]] for i in range(40)}
+    feats = {k: np.full((1, 8), i, np.float32) for i, k in enumerate(caps)}
+    gens = [BatchGenerator(caps, feats, 4, seed=7, shard=(r, 2)) for r in range(2)]
+    a, b = (list(g.next_batch(num_captions=1)) for g in gens)
+    assert len(a) == len(b) == 5
+    seen = []
+    for x, y in zip(a, b):
+        assert not set(x["names"]) & set(y["names"])
+        seen += x["names"] + y["names"]
+    assert sorted(seen) == sorted(caps)                 # one epoch = every example exactly once over the two ranks
+    one = [n for bt in BatchGenerator(caps, feats, 8, seed=7).next_batch(num_captions=1) for n in bt["names"]]
+    assert seen == one                                  # and in the order a single rank with the global batch size would read them
+
+
+def test_imagenet_npz_is_assigned_in_sorted_key_order(tmp_path):
+    """utils/image_embeddings.py:240-246 (quirk Q18): the first 30 ALPHABETICALLY sorted arrays go to `parameters` in creation
+    order, whatever order the archive stores them in; fc8_* (sorted last) are skipped."""
+    from vae_captioning_amd import spec
+    from vae_captioning_amd.trainer import imagenet_weights
+    keys = ["conv%d_%d_%s" % (b, i, s) for b, reps in ((1, 2), (2, 2), (3, 3), (4, 3), (5, 3)) for i in range(1, reps + 1) for s in ("W", "b")]
+    keys += ["fc6_W", "fc6_b", "fc7_W", "fc7_b", "fc8_W", "fc8_b"]
+    rng = np.random.default_rng(3)
+    stored = list(keys)
+    rng.shuffle(stored)
+    path = str(tmp_path / "vgg16_weights.npz")
+    np.savez(path, **{k: np.full((2,), float(keys.index(k)), np.float64) for k in stored})
+    got = imagenet_weights(path)
+    names = [n for n, _ in spec.vgg_variables()]
+    assert list(got) == names and len(got) == 30
+    for i, n in enumerate(names):   # sorted(keys) == keys here: conv1_1_W, conv1_1_b, ... fc7_b, fc8_W, fc8_b
+        assert got[n].dtype == np.float32 and got[n][0] == float(i), n
+    assert sorted(keys) == keys

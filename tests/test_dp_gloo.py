@@ -147,3 +147,29 @@ def test_global_q1_noise_slices_tile_the_global_sample_tensor():
         np.testing.assert_array_equal(e.reshape(nl, S * L), zin[r * nl:(r + 1) * nl])
         t = dp.shard_noise({"eps": eps}, r, world, Ng, "tower")["eps"]
         np.testing.assert_array_equal(t, eps[:, r * nl:(r + 1) * nl])
+
+
+def test_gradient_buckets_are_disjoint_and_cover_the_flat_buffer():
+    """The ONE logical all-reduce of `gall` is issued as four pieces with VGG fine-tuning (trainer.Trainer._step): the slices
+    must be disjoint, cover [0, len(gall)) exactly, and each VGG piece must hold exactly the layers whose gradients are final
+    when it is issued (fc1/fc2 first, then conv3_1..conv5_3, then conv1_1..conv2_2)."""
+    from vae_captioning_amd import dp, spec
+    from vae_captioning_amd.engine import TAIL, flat_offsets, internal_caption_variables
+    from vae_captioning_amd.utils.parameters import Parameters
+    p = Parameters()
+    p.fine_tune = True
+    _, n_cap = flat_offsets(internal_caption_variables(p, 10000))
+    n_cap += TAIL
+    voff, n_vgg = flat_offsets(spec.vgg_variables())
+    off_fc, off_c3 = n_cap + voff["cnn/fc1/weights"][0], n_cap + voff["cnn/conv3_1/weights"][0]
+    bk = dp.gradient_buckets(n_cap, n_cap + n_vgg, off_fc, off_c3)
+    assert len(bk) == 4 and all(lo < hi for lo, hi in bk)
+    srt = sorted(bk)
+    assert srt[0][0] == 0 and srt[-1][1] == n_cap + n_vgg
+    assert all(a[1] == b[0] for a, b in zip(srt, srt[1:]))          # no gap, no overlap
+    inside = lambda name, b: b[0] <= n_cap + voff[name][0] and n_cap + voff[name][0] + int(np.prod(voff[name][1])) <= b[1]
+    assert bk[0] == (0, n_cap)
+    assert inside("cnn/fc1/weights", bk[1]) and inside("cnn/fc2/biases", bk[1])
+    assert inside("cnn/conv3_1/weights", bk[2]) and inside("cnn/conv5_3/biases_conv", bk[2]) and not inside("cnn/conv2_2/weights", bk[2])
+    assert inside("cnn/conv1_1/weights", bk[3]) and inside("cnn/conv2_2/biases", bk[3])
+    assert dp.gradient_buckets(n_cap, n_cap) == [(0, n_cap)]        # caption-only runs: the single all-reduce

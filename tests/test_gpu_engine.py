@@ -217,3 +217,33 @@ def test_collective_code_path_on_a_one_rank_rccl_group(lib):
             np.testing.assert_array_equal(res[0][1][k], res[1][1][k])
     finally:
         dist.destroy_process_group()
+
+
+def test_gmm_component_is_drawn_on_device_from_softmax_of_the_cluster_vector(lib):
+    """encoder.py:72-75 (quirk Q15): tf.multinomial(c_i_ph, 1) uses the cluster vector as LOGITS.  Without injected noise the
+    engine draws the component on the device (Philox uniform + inverse CDF): in range, reproducible for a given step, fresh on
+    the next step, and distributed as softmax(c_v)."""
+    p = small_params(prior="GMM")
+    p.num_captions, p.batch_size = 1, 4000
+    V, B, T = 60, 4000, 4
+    rng = np.random.default_rng(0)
+    batch = synth.make_batch(rng, B, 1, T, V, use_ci=True, feature_size=p.cnn_feature_size)
+    cv = np.zeros((B, 90), np.float32)
+    cv[:, 3], cv[:, 17] = 2.0, 1.0                       # every row the same logits: frequencies estimate softmax(c_v)
+    batch["c_v"] = cv
+    e = CaptionEngine(p, V, lib=lib, seed=5)
+    e.load_params(spec.init_caption_params(p, V, seed=1))
+    e.set_batch(batch)                                   # no noise injected
+    draws = []
+    for s in (0, 0, 1):
+        e.step.fill_(s)
+        e.fw_prepare(train=False)
+        draws.append(e.buf["gmm_idx"].cpu().numpy().copy())
+    assert draws[0].min() >= 0 and draws[0].max() < 90
+    np.testing.assert_array_equal(draws[0], draws[1])
+    assert (draws[0] != draws[2]).mean() > 0.5
+    pr = np.exp(cv[0].astype(np.float64)); pr /= pr.sum()
+    freq = np.bincount(draws[0], minlength=90) / B
+    assert np.abs(freq - pr).max() < 0.03, (freq[[3, 17]], pr[[3, 17]])
+    e.forward(train=True)                                # and the step runs end to end with the drawn components
+    assert np.isfinite(e.out.cpu().numpy()).all()

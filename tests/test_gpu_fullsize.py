@@ -6,6 +6,10 @@ size-independent properties, and the data-parallel scaling rules on the device.
   * cfg2 at full size (256 images, 1280 rows, T=20, V=10000, S=100): repeated runs are bit-identical,
     the directional derivative of the loss along the computed gradient matches a finite difference,
     and the loss is invariant to permuting caption rows of the --no_encoder baseline (cfg1 graph);
+  * cfg3 at full size (AG prior + cluster vectors, 256 images): bit-reproducible, and the gradient is the derivative of the
+    SUM of the per-row lower bound (quirk Q3) by a finite difference;
+  * cfg5 at full size (GMM prior, beam 5, 10 z samples, 128 images, V=10000, 30 steps): token ids of the first images equal
+    the oracle's per-image beam search at the same dimensions;
   * cfg4 at 8 images: VGG16 + caption step is bit-reproducible and finite."""
 import numpy as np
 import pytest
@@ -116,7 +120,7 @@ def _cfg2_engine(lib, seed=0, **kw):
         setattr(p, k, v)
     V, T = 10000, 20
     rng = np.random.default_rng(seed)
-    batch = synth.make_batch(rng, 256, 5, T, V, variable_len=True)
+    batch = synth.make_batch(rng, 256, 5, T, V, variable_len=True, use_ci=spec.uses_ci(p))
     e = CaptionEngine(p, V, lib=lib, seed=7)
     e.load_params(spec.init_caption_params(p, V, seed=1))
     return p, e, batch
@@ -179,3 +183,60 @@ def test_cfg4_small_batch_fine_tune_step_reproducible(lib):
         res.append((tr.losses(), tr.gall.clone()))
     assert res[0][0] == res[1][0] and all(np.isfinite(res[0][0]))
     assert torch.equal(res[0][1], res[1][1])
+
+
+def test_cfg3_full_size_ag_cv_is_reproducible_and_differentiates_the_summed_vector_loss(lib):
+    """BASELINE config 3 (--c_v --prior AG, 256 images = 1280 rows, V = 10000, S = 100).  Quirk Q3: the AG lower bound is a
+    VECTOR over rows and tf.gradients differentiates its sum = N * (rec_loss + ann * mean(kld) / 10)."""
+    p, e, batch = _cfg2_engine(lib, prior="AG", use_c_v=True)
+    e.set_batch(batch)
+    outs = []
+    for _ in range(2):
+        e.step.zero_()
+        e.forward(); e.backward(); e.pack_tail()
+        outs.append((e.out.clone(), e.store.g.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert np.isfinite(outs[0][0].cpu().numpy()).all()
+    N = 256 * 5
+    g = outs[0][1][:e.store.n]
+    gn2 = float((g.double() ** 2).sum().item())
+    p0 = e.store.p.clone()
+    eps = 1e-2 / np.sqrt(gn2)
+    vals = []
+    for sgn in (+1, -1):
+        e.store.p.copy_(p0 + sgn * eps * g)
+        e.step.zero_()
+        e.forward(train=False)
+        vals.append(N * float(e.out[2].item()))
+    e.store.p.copy_(p0)
+    fd = (vals[0] - vals[1]) / (2 * eps)
+    assert abs(fd - gn2) <= 0.05 * gn2, (fd, gn2, vals)
+
+
+def test_cfg5_full_size_beam_search_token_ids_match_oracle(lib):
+    """BASELINE config 5: GMM prior, beam width 5, 10 z samples, 128 images per batch, V = 10000, gen_max_len 30.  The whole
+    batch is decoded on the device; the first images are re-decoded by the oracle (per image, fp64) at the same dimensions
+    with the same injected eps: identical token ids for every returned beam."""
+    from oracle import decode as od
+    from vae_captioning_amd.generate import CaptionGenerator
+    BOS, EOS = 1, 2
+    p = Parameters()
+    p.prior, p.mode, p.num_captions, p.gen_z_samples, p.beam_size, p.batch_size = "GMM", "inference", 1, 10, 5, 128
+    V, B = 10000, 128
+    rng = np.random.default_rng(9)
+    P0 = spec.init_caption_params(p, V, seed=3)
+    for k in P0:  # larger weights -> peaked distributions (random init is near-uniform over 10000 words: top-k order would be fp noise)
+        P0[k] = (P0[k] * 3).astype(np.float32) if not k.endswith("bias") else rng.normal(0, 0.5, P0[k].shape).astype(np.float32)
+    feats = np.maximum(rng.standard_normal((B, p.cnn_feature_size)), 0).astype(np.float32)
+    cv = np.zeros((B, 90), np.float32)
+    eps = rng.standard_normal((p.gen_z_samples, B, p.latent_size)).astype(np.float32)
+    eng = CaptionEngine(p, V, lib=lib)
+    eng.load_params(P0)
+    got = CaptionGenerator(eng).beam_search(feats, cv, eps, BOS, EOS, beam_size=5, max_len=p.gen_max_len)
+    assert len(got) == B and all(1 <= len(beams) <= 5 for beams in got)
+    P64 = {k: v.astype(np.float64) for k, v in P0.items()}
+    for b in range(3):
+        sents, scores = od.beam_search(P64, p, feats[b].astype(np.float64), cv[b].astype(np.float64), eps[:, b:b + 1].astype(np.float64),
+                                       BOS, EOS, beam_size=5, max_len=p.gen_max_len)
+        assert [s for s, _ in got[b]] == sents, (b, got[b], sents, scores)
+        np.testing.assert_allclose([sc for _, sc in got[b]], scores, rtol=1e-4, atol=1e-5)

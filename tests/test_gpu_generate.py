@@ -160,7 +160,7 @@ def test_beam_update_replays_heapq_including_ties(lib, n):
                     if pw < 1e-12:
                         continue
                     s = bm.sentence + [int(w)]
-                    lp = bm.logprob + float(np.log(np.float64(pw)))
+                    lp = bm.logprob + float(np.log(np.float32(pw)))  # decoder.py:282: float32 log, float64 sum
                     if w == eos:
                         complete[b].push(Beam(s, i, lp, lp / len(s) ** lnf))
                     else:
@@ -180,3 +180,48 @@ def test_beam_update_replays_heapq_including_ties(lib, n):
             for j, bm in enumerate(cheap):
                 assert cst[b, csl[b, j], :cl[b, j]].tolist() == bm.sentence and cs[b, j] == bm.score
     assert sum(len(c._heap) for c in complete) > 0
+
+
+def test_beam_update_matches_reference_topn_fixture(lib):
+    """vc_beam_update against heap states recorded from THE REFERENCE's TopN / Beam classes (tests/golden/ref_beam_rounds.json,
+    written by tests/golden/make_ref_fixtures.py from /root/reference/utils/top_n.py): same top-k tables in, and after every
+    round the live / complete heaps must hold the same captions in the same heap-array slots with the same scores
+    (score ties included), the same parent rows and next tokens.  Bit-exact: scores are float64 sums of float32 logs."""
+    import json
+    import os
+    import torch
+    from .gpu_util import P, dev, host, stream
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_beam_rounds.json")))
+    for rec in fx:
+        n, B, eos, bos, lnf, L = rec["n"], rec["B"], rec["eos"], rec["bos"], rec["len_norm_f"], 12
+        M = B * n
+        i32 = dict(dtype=torch.int32, device="cuda")
+        f64 = dict(dtype=torch.float64, device="cuda")
+        pcount, ccount = torch.ones(B, **i32), torch.zeros(B, **i32)
+        p_score, p_logprob, p_len = torch.zeros(M, **f64), torch.zeros(M, **f64), torch.ones(M, **i32)
+        sent = [torch.full((M, L), bos, **i32), torch.zeros((M, L), **i32)]
+        c_score, c_logprob, c_len, c_slot = torch.zeros(M, **f64), torch.zeros(M, **f64), torch.zeros(M, **i32), torch.zeros(M, **i32)
+        c_free = torch.full((B,), (1 << (n + 1)) - 1, **i32)
+        c_sent = torch.zeros((B * (n + 1), L), **i32)
+        parent, tok = torch.zeros(M, **i32), torch.zeros(M, **i32)
+        for it, rnd in enumerate(rec["rounds"]):
+            tv, ti = np.array(rnd["top_p"], np.float32), np.array(rnd["top_i"], np.int32)
+            lib.vc_beam_update(stream(), B, n, L, eos, lnf, P(dev(tv)), P(dev(ti)), P(pcount), P(ccount), P(p_score), P(p_logprob), P(p_len),
+                               P(sent[it & 1]), P(sent[1 - (it & 1)]), P(c_score), P(c_logprob), P(c_len), P(c_slot), P(c_free), P(c_sent),
+                               P(parent), P(tok))
+            pc, cc = host(pcount), host(ccount)
+            ps, plp, pl = host(p_score).reshape(B, n), host(p_logprob).reshape(B, n), host(p_len).reshape(B, n)
+            sn = host(sent[1 - (it & 1)]).reshape(B, n, L)
+            cs, clp, cl = host(c_score).reshape(B, n), host(c_logprob).reshape(B, n), host(c_len).reshape(B, n)
+            csl, cst = host(c_slot).reshape(B, n), host(c_sent).reshape(B, n + 1, L)
+            par, tk = host(parent).reshape(B, n), host(tok).reshape(B, n)
+            for b in range(B):
+                heap = rnd["partial"][b]
+                assert pc[b] == len(heap), (n, it, b)
+                for j, bm in enumerate(heap):
+                    assert sn[b, j, :pl[b, j]].tolist() == bm["sentence"] and ps[b, j] == bm["score"] and plp[b, j] == bm["logprob"], (n, it, b, j)
+                    assert par[b, j] == b * n + bm["parent"] and tk[b, j] == bm["sentence"][-1]
+                cheap = rnd["complete"][b]
+                assert cc[b] == len(cheap), (n, it, b)
+                for j, bm in enumerate(cheap):
+                    assert cst[b, csl[b, j], :cl[b, j]].tolist() == bm["sentence"] and cs[b, j] == bm["score"] and clp[b, j] == bm["logprob"]

@@ -577,3 +577,61 @@ def test_maxpool_and_preprocess(lib):
     back = zeros(3, 3, 3, 64)
     lib.vc_pad_dim_f32(stream(), P(w4), 9, 4, 3, 64, P(back))
     np.testing.assert_array_equal(host(back), w3)
+
+
+@pytest.mark.parametrize("V", [11313, 1003, 6])
+def test_softmax_xent_padded_pitch_keeps_the_register_kernel(lib, V):
+    """V % 4 != 0 (the reference's observed vocabulary is 11313) with the row pitch padded to a multiple of 4: same values as the
+    oracle, the padding columns must not influence max / sum and end up as zeros (exp(-inf)) in the in-place gradient."""
+    rng = np.random.default_rng(V + 1)
+    R, ld = 200, (V + 3) // 4 * 4
+    logits = (rng.standard_normal((R, V), dtype=np.float32) * 3).astype(np.float32)
+    padded = np.full((R, ld), 1e30, np.float32)  # poison: would dominate the max if it were read as data
+    padded[:, :V] = logits
+    labels = rng.integers(1, V, size=R).astype(np.int32)
+    labels[::5] = 0
+    loss, cache = O.xent_masked_fwd(logits.astype(np.float64), labels)
+    dref = O.xent_masked_bwd(cache, 2.0)
+    tl, den, rl = dev(padded), zeros(1), zeros(R)
+    lib.vc_count_nonzero_i32(stream(), P(dev(labels)), R, P(den))
+    lib.vc_softmax_xent_f32(stream(), P(tl), P(dev(labels)), R, V, ld, P(den), 2.0, P(rl), 1)
+    got = host(tl)
+    assert_close(got[:, :V], dref, 1e-5, msg="dlogits V=%d ld=%d" % (V, ld))
+    assert np.all(got[:, V:] == 0)
+    np.testing.assert_allclose(host(rl).sum() / host(den)[0], loss, rtol=1e-5)
+
+
+@pytest.mark.parametrize("case", [(6400, 10000), (25600, 10000), (25600, 11313), (333, 50), (40, 7)], ids=lambda c: "%dx%d" % c)
+def test_embedding_index_on_device_equals_the_host_index(lib, case):
+    """vc_embedding_grad_index (stable counting sort on device) vs engine.embedding_grad_index (numpy argsort + bincount): same
+    order, same sub-segment boundaries, same per-id ranges; unused sub-segments are empty.  Integer work: bit-exact.  Ids include
+    hot tokens (<PAD> / <BOS> / <EOS> thousands of times) and out-of-range values (clipped like the gather does)."""
+    from vae_captioning_amd.engine import embedding_grad_index
+    R, V = case
+    rng = np.random.default_rng(R + V)
+    ids = rng.integers(3, V, size=R).astype(np.int32)
+    ids[rng.random(R) < 0.3] = 0
+    ids[rng.random(R) < 0.05] = 1
+    ids[rng.random(R) < 0.05] = 2
+    ids[:2] = [-5, V + 9]
+    order, seg1, seg2 = embedding_grad_index(ids, V)
+    nmax = int(lib.vc_embedding_index_max_subsegments(R, V, 32))
+    assert nmax >= seg1.size - 1
+    i32 = dict(dtype=torch.int32, device="cuda")
+    d_order, d_seg1, d_seg2 = torch.full((R,), -1, **i32), torch.full((nmax + 1,), -1, **i32), torch.full((V + 1,), -1, **i32)
+    ws = empty_bytes(lib.vc_embedding_index_workspace_bytes(R, V))
+    for _ in range(2):  # twice: the scratch counters are rebuilt every call
+        lib.vc_embedding_grad_index(stream(), P(dev(ids)), R, V, 32, P(d_order), P(d_seg1), P(d_seg2), P(ws), ws.numel() * 4)
+    np.testing.assert_array_equal(host(d_order), order)
+    np.testing.assert_array_equal(host(d_seg2), seg2)
+    np.testing.assert_array_equal(host(d_seg1)[:seg1.size], seg1)
+    assert np.all(host(d_seg1)[seg1.size:] == R)
+    # and the two-level sum over the device index reproduces the dense scatter-add
+    E = 8
+    dX = rng.standard_normal((R, E), dtype=np.float32)
+    part, table = zeros(nmax, E), zeros(V, E)
+    lib.vc_embedding_grad_sorted_f32(stream(), P(part), P(d_order), P(d_seg1), E, nmax, P(dev(dX)))
+    lib.vc_embedding_grad_sorted_f32(stream(), P(table), None, P(d_seg2), E, V, P(part))
+    ref = np.zeros((V, E), np.float64)
+    np.add.at(ref, np.clip(ids, 0, V - 1), dX.astype(np.float64))
+    assert_close(host(table), ref, 1e-5, msg="embedding gradient through the device index")

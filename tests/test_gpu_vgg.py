@@ -168,3 +168,70 @@ def test_half_batch_chains_on_three_streams(lib, monkeypatch):
     assert (res["3"][0] - res["1"][0]).norm() <= 1e-5 * res["1"][0].norm()
     # gradients: a ReLU / arg-max decision that flips on a last-bit difference re-routes a whole window (module docstring)
     assert (res["3"][1] - res["1"][1]).norm() <= 2e-3 * res["1"][1].norm()
+
+
+def test_load_weights_assigns_a_shuffled_npz_in_sorted_key_order(lib, tmp_path):
+    """VggEngine.load_weights (utils/image_embeddings.py:240-246, quirk Q18) at the real VGG16 shapes: the archive stores its
+    arrays in shuffled order and carries fc8_*; every cnn/* variable must receive the array of the same rank in SORTED key
+    order (conv1_1_W, conv1_1_b, ... fc6_W, fc6_b, fc7_W, fc7_b) and fc8 must be ignored."""
+    keys = ["conv%d_%d_%s" % (b, i, sfx) for b, reps in ((1, 2), (2, 2), (3, 3), (4, 3), (5, 3)) for i in range(1, reps + 1) for sfx in ("W", "b")]
+    keys += ["fc6_W", "fc6_b", "fc7_W", "fc7_b"]
+    shapes = [s for _, s in spec.vgg_variables()]
+    arrays = {k: np.full(shp, 0.001 * (i + 1), np.float32) for i, (k, shp) in enumerate(zip(keys, shapes))}
+    arrays["fc8_W"], arrays["fc8_b"] = np.full((4096, 1000), 7.0, np.float32), np.full((1000,), 7.0, np.float32)
+    order = list(arrays)
+    np.random.default_rng(1).shuffle(order)
+    path = str(tmp_path / "vgg16_weights.npz")
+    np.savez(path, **{k: arrays[k] for k in order})
+    p = Parameters()
+    p.fine_tune = True
+    vgg = VggEngine(p, lib=lib)
+    vgg.load_weights(path)
+    sd = vgg.state_dict()
+    for i, (name, shp) in enumerate(spec.vgg_variables()):
+        assert sd[name].shape == tuple(shp) and np.all(sd[name] == np.float32(0.001 * (i + 1))), name
+
+
+def test_checkpoints_carry_cnn_variables_without_fine_tune_and_restore_into_fine_tune(lib, tmp_path):
+    """main.py:186-191 + quirk Q22: the reference's checkpoints always hold cnn/* (ImageNet weights are loaded "for further
+    usage" even when training on precomputed features).  A checkpoint written WITHOUT --fine_tune must therefore restore
+    into a --fine_tune model; one that lacks cnn/* falls back to the ImageNet npz or fails with a clear message."""
+    from vae_captioning_amd.trainer import imagenet_weights
+    p = Parameters()
+    p.embed_size, p.encoder_hidden, p.decoder_hidden, p.latent_size, p.gen_z_samples = 16, 32, 32, 6, 3
+    V = 50
+    P0 = spec.init_caption_params(p, V, seed=1)
+    PV = spec.init_vgg_params(seed=2)
+    tr = Trainer(p, V, lib=lib)
+    tr.load_state_dict(P0)
+    assert not any(k.startswith("cnn/") for k in tr.state_dict())
+    tr.cnn_host = PV                                    # what main.py sets from the ImageNet npz
+    ck = str(tmp_path / "plain.ckpt.npz")
+    tr.save(ck)
+    p2 = Parameters()
+    for k in ("embed_size", "encoder_hidden", "decoder_hidden", "latent_size", "gen_z_samples"):
+        setattr(p2, k, getattr(p, k))
+    p2.fine_tune = True
+    tr2 = Trainer(p2, V, lib=lib)
+    tr2.restore(ck)
+    got = tr2.state_dict()
+    for k in list(PV)[:4] + list(PV)[-2:]:
+        np.testing.assert_array_equal(got[k], PV[k])
+    # restoring a checkpoint that has cnn/* into a model without VGG16 keeps them for the next save
+    tr3 = Trainer(p, V, lib=lib)
+    tr3.restore(ck)
+    assert set(k for k in tr3.state_dict() if k.startswith("cnn/")) == set(PV)
+    # a checkpoint without cnn/*: clear error, or the ImageNet file when it exists
+    ck2 = str(tmp_path / "nocnn.ckpt.npz")
+    np.savez(ck2, **P0)
+    p2.image_net_weights_path = str(tmp_path / "missing.npz")
+    with pytest.raises(KeyError, match="cnn/"):
+        Trainer(p2, V, lib=lib).restore(ck2)
+    inet = str(tmp_path / "vgg16_weights.npz")
+    keys = ["conv%d_%d_%s" % (b, i, sfx) for b, reps in ((1, 2), (2, 2), (3, 3), (4, 3), (5, 3)) for i in range(1, reps + 1) for sfx in ("W", "b")]
+    keys += ["fc6_W", "fc6_b", "fc7_W", "fc7_b"]
+    np.savez(inet, **{k: PV[n] for k, (n, _) in zip(keys, spec.vgg_variables())})
+    p2.image_net_weights_path = inet
+    tr4 = Trainer(p2, V, lib=lib)
+    tr4.restore(ck2)
+    np.testing.assert_array_equal(tr4.state_dict()["cnn/fc2/biases"], imagenet_weights(inet)["cnn/fc2/biases"])

@@ -24,6 +24,42 @@ def main(path, top=40):
         print("| `%s` | %d | %.3f | %.2f | %.2f | %.2f | %.2f | %d | %d | %d | %d | %d | %d..%d |" % (
             name, r[1], r[2] / 1e6, r[2] / r[1] / 1e3, r[3] / 1e3, r[4] / 1e3, 100.0 * r[2] / total, r[5], r[6], r[7], r[8], r[9], r[10], r[11]))
     print("\ntotal kernel time %.3f ms over %d dispatches" % (total / 1e6, sum(r[1] for r in rows)))
+    families(db)
+
+
+# kernel families of the roofline report (substring match on the mangled kernel name)
+FAMILIES = [
+    ("3x3 convolution (fwd + dgrad + wgrad, incl. K-split tails and split reduces)",
+     ["conv_kernel", "conv_patch_kernel", "wgrad_patch_kernel", "wgrad_flat_kernel", "conv_tail_reduce", "patch_tail_reduce",
+      "wgrad_reduce_kernel", "wgrad_patch_reduce"]),
+    ("GEMM (vc::gemm_kernel + split-K reduce)", ["gemm_kernel", "splitk_reduce"]),
+    ("LSTM recurrence (step / gate kernels)", ["lstm_"]),
+    ("softmax cross-entropy", ["xent_"]),
+    ("optimiser (Adam / SGD / Momentum)", ["adam_kernel", "sgd_kernel", "momentum_kernel"]),
+]
+
+
+def families(db):
+    """Per kernel family: dispatches, SUM of dispatch durations (the serial time) and UNION of the dispatch intervals (the time
+    at least one kernel of the family was running; smaller than the sum when launches overlap on several streams).
+    bench.py's roofline.frac = family FLOPs / union; frac_serial = family FLOPs / sum -- steps traced = dispatches of
+    preprocess_kernel (one per fine-tune step) or of xent kernels (one per caption step)."""
+    rows = db.execute("select s.kernel_name, d.start, d.end from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s "
+                      "on d.kernel_id = s.id order by d.start").fetchall()
+    steps = sum(1 for r in rows if "preprocess_kernel" in r[0]) or sum(1 for r in rows if "xent_" in r[0])
+    print("\n| kernel family | dispatches | sum of durations ms | union of intervals ms | per step (of %d traced) sum / union ms |" % steps)
+    print("|---|---|---|---|---|")
+    for title, pats in FAMILIES:
+        iv = [(a, b) for n, a, b in rows if any(p in n for p in pats)]
+        if not iv:
+            continue
+        tot, uni, end = sum(b - a for a, b in iv), 0, -1
+        for a, b in iv:  # already sorted by start
+            if b <= end:
+                continue
+            uni += b - max(a, end)
+            end = b
+        print("| %s | %d | %.3f | %.3f | %.3f / %.3f |" % (title, len(iv), tot / 1e6, uni / 1e6, tot / 1e6 / max(steps, 1), uni / 1e6 / max(steps, 1)))
 
 
 if __name__ == "__main__":

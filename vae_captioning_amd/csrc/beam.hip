@@ -6,7 +6,8 @@
 // caption into the image's `complete` (word == <EOS>, score = logprob / len**len_norm_f) or `partial`
 // (score = logprob) TopN.  TopN is a min-heap keyed by score only, driven with heapq's heappush /
 // heappushpop; ties are therefore resolved by heapq's sift order, which this file reproduces move for move
-// (CPython Lib/heapq.py: _siftdown, _siftup).  log-probabilities accumulate in double like the Python floats.
+// (CPython Lib/heapq.py: _siftdown, _siftup).  Each word's log-probability is a float32 log (np.log of a float32
+// probability), accumulated in double like the reference's Python / numpy float64 sums.
 //
 // Nothing here needs the host between decoder steps: the kernel also emits, for the next step, each new
 // beam's parent row (whose LSTM state it continues) and its last token.
@@ -108,12 +109,12 @@ __global__ __launch_bounds__(64) void beam_update_kernel(BeamArgs a) {
         const int len0 = a.p_len[row];
         for (int j = 0; j < a.k; ++j) {
             const float pw = a.tv[row * a.k + j];
-            if (pw < 1e-12f) continue;
+            if ((double)pw < 1e-12) continue;  // decoder.py:279: float32 p against the Python float 1e-12
             BeamItem it;
             it.tok = a.ti[row * a.k + j];
             it.parent = i;
             it.len = len0 + 1;
-            it.logprob = lp0 + log((double)pw);
+            it.logprob = lp0 + (double)logf(pw);  // decoder.py:282: np.log of a float32 is a float32; the SUM is a float64
             it.score = it.logprob;
             it.slot = -1;
             if (it.tok == a.eos) {

@@ -87,6 +87,98 @@ __global__ __launch_bounds__(256) void segment_grad_kernel(float* __restrict__ d
     }
 }
 
+// ---- inverted index for the deterministic embedding gradient, built ON DEVICE (was numpy argsort + bincount on the
+// host inside every set_batch).  A stable counting sort of the R token ids in three launches:
+//   count : block (vocabulary block, segment s of the positions): thread v counts its id in segment s   -> cnt[s][v]
+//   scan  : one workgroup: per-id totals, exclusive scans -> first slot of every (segment, id), the sub-segment table
+//           seg1 (chunks of <= `chunk` positions, never crossing an id boundary) and seg2 (sub-segment range of each id)
+//   place : same grid as count: thread v walks segment s again and writes the positions of its id in order
+// Every thread compares its id against the segment's ids streamed through LDS (broadcast reads): R/segments x V
+// comparisons per launch, a few microseconds at R = 25600, V = 10000.  Integer work, no atomics: bit-identical to
+// engine.embedding_grad_index (numpy) by construction.
+constexpr int IDX_TILE = 1024;
+
+template <bool PLACE>
+__global__ __launch_bounds__(256) void embidx_scan_ids_kernel(const int32_t* __restrict__ ids, long R, int vocab, long seg_len,
+                                                              int32_t* __restrict__ cnt /* [segs][vocab]: counts, or first slots */,
+                                                              int32_t* __restrict__ order) {
+    __shared__ __attribute__((aligned(16))) int32_t tile[IDX_TILE];
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    const long p0 = (long)blockIdx.y * seg_len;
+    const long p1 = p0 + seg_len < R ? p0 + seg_len : R;
+    int32_t cur = 0;
+    if (PLACE && v < vocab) cur = cnt[(long)blockIdx.y * vocab + v];
+    for (long base = p0; base < p1; base += IDX_TILE) {
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < IDX_TILE / 256; ++u) {
+            const long p = base + threadIdx.x + 256 * u;
+            int32_t id = -1;
+            if (p < p1) {
+                id = ids[p];
+                id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+            }
+            tile[threadIdx.x + 256 * u] = id;
+        }
+        __syncthreads();
+        const int n = (int)(p1 - base < IDX_TILE ? p1 - base : IDX_TILE);
+        for (int j = 0; j < n; j += 4) {
+            const int4 q = *reinterpret_cast<const int4*>(&tile[j]);  // same address in every lane: LDS broadcast
+            if (PLACE) {
+                if (q.x == v) order[cur++] = (int32_t)(base + j);
+                if (q.y == v) order[cur++] = (int32_t)(base + j + 1);
+                if (q.z == v) order[cur++] = (int32_t)(base + j + 2);
+                if (q.w == v) order[cur++] = (int32_t)(base + j + 3);
+            } else {
+                cur += (q.x == v) + (q.y == v) + (q.z == v) + (q.w == v);
+            }
+        }
+    }
+    if (!PLACE && v < vocab) cnt[(long)blockIdx.y * vocab + v] = cur;
+}
+
+__global__ __launch_bounds__(1024) void embidx_scan_kernel(int32_t* __restrict__ cnt, int segs, int vocab, long R, int chunk, int nsub_max,
+                                                           int32_t* __restrict__ seg1, int32_t* __restrict__ seg2) {
+    __shared__ int32_t sh_a[1024], sh_b[1024];
+    const int t = threadIdx.x;
+    const int per = (vocab + 1023) / 1024;
+    const int v0 = t * per, v1 = v0 + per < vocab ? v0 + per : vocab;
+    // pass 1: per-thread sums of the id totals and of the sub-segment counts
+    int32_t a = 0, b = 0;
+    for (int v = v0; v < v1; ++v) {
+        int32_t tot = 0;
+        for (int s = 0; s < segs; ++s) tot += cnt[(long)s * vocab + v];
+        a += tot;
+        b += (tot + chunk - 1) / chunk;
+    }
+    sh_a[t] = a; sh_b[t] = b;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {  // inclusive Hillis-Steele scans of both
+        const int32_t xa = t >= o ? sh_a[t - o] : 0, xb = t >= o ? sh_b[t - o] : 0;
+        __syncthreads();
+        sh_a[t] += xa; sh_b[t] += xb;
+        __syncthreads();
+    }
+    int32_t start = sh_a[t] - a, sub = sh_b[t] - b;  // exclusive prefixes of this thread's first id
+    const int32_t nsub = sh_b[1023];
+    // pass 2: first slot of every (segment, id); seg2; seg1 of the id's sub-segments
+    for (int v = v0; v < v1; ++v) {
+        int32_t tot = 0;
+        for (int s = 0; s < segs; ++s) {
+            const int32_t c = cnt[(long)s * vocab + v];
+            cnt[(long)s * vocab + v] = start + tot;
+            tot += c;
+        }
+        seg2[v] = sub;
+        const int32_t ns = (tot + chunk - 1) / chunk;
+        for (int w = 0; w < ns; ++w) seg1[sub + w] = start + w * chunk;
+        start += tot;
+        sub += ns;
+    }
+    if (t == 0) seg2[vocab] = nsub;
+    for (int k = nsub + t; k <= nsub_max; k += 1024) seg1[k] = (int32_t)R;  // closes the last sub-segment; the unused ones are empty
+}
+
 __global__ __launch_bounds__(256) void mark_rows_kernel(float* __restrict__ touched, const int32_t* __restrict__ ids,
                                                         long n, int vocab) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
@@ -340,6 +432,37 @@ extern "C" int vc_embedding_grad_sorted_f32(void* stream, float* dtable, const i
         hipLaunchKernelGGL(segment_grad_kernel<true>, dim3(grid_for((long)nrows * 64, 256, 8192)), dim3(256), 0, (hipStream_t)stream, dtable, order, seg_start, E, nrows, dX);
     else
         hipLaunchKernelGGL(segment_grad_kernel<false>, dim3(grid_for((long)nrows * 64, 256, 8192)), dim3(256), 0, (hipStream_t)stream, dtable, order, seg_start, E, nrows, dX);
+    VC_LAUNCH_CHECK();
+    return 0;
+}
+
+static int embidx_segs(long R) {
+    long s = (R + 511) / 512;
+    return (int)(s < 1 ? 1 : (s > 32 ? 32 : s));
+}
+
+extern "C" size_t vc_embedding_index_workspace_bytes(long R, int vocab) {
+    return (size_t)embidx_segs(R) * (size_t)vocab * sizeof(int32_t);
+}
+
+extern "C" size_t vc_embedding_index_max_subsegments(long R, int vocab, int chunk) {
+    return chunk > 0 ? (size_t)(R / chunk + vocab) : 0;
+}
+
+extern "C" int vc_embedding_grad_index(void* stream, const int32_t* ids, long R, int vocab, int chunk, int32_t* order,
+                                       int32_t* seg1, int32_t* seg2, int32_t* ws, size_t ws_bytes) {
+    VC_CHECK_ARG(ids && order && seg1 && seg2 && R > 0 && vocab > 0 && chunk > 0 && R < (1L << 31), "bad argument");
+    const int segs = embidx_segs(R);
+    if (!ws || ws_bytes < (size_t)segs * vocab * sizeof(int32_t))
+        return fail(VC_EWORKSPACE, "%s: workspace too small (need vc_embedding_index_workspace_bytes)", __func__);
+    const long seg_len = ((R + segs - 1) / segs + 3) / 4 * 4;
+    const int nsub_max = (int)(R / chunk + vocab);
+    const dim3 grid(cdiv(vocab, 256), segs);
+    hipLaunchKernelGGL(embidx_scan_ids_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, ids, R, vocab, seg_len, ws, order);
+    VC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(embidx_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, ws, segs, vocab, R, chunk, nsub_max, seg1, seg2);
+    VC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(embidx_scan_ids_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, ids, R, vocab, seg_len, ws, order);
     VC_LAUNCH_CHECK();
     return 0;
 }

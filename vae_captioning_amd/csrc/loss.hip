@@ -19,7 +19,7 @@ static inline int grid_for(long work_items, int per_block = 256, int cap = 2048)
 
 // ---------------------------------------------------------------------------------------
 // tf.nn.sparse_softmax_cross_entropy_with_logits + mask + div (main.py:152-158, Q8).
-// One workgroup per row; the row (V <= 12288, V % 4 == 0) lives in registers, so the
+// One workgroup per row; the row (V <= 12288, row pitch % 4 == 0) lives in registers, so the
 // logits are read ONCE from HBM and overwritten in place by d(loss)/d(logits):
 //   ce = logsumexp(x) - x[label]; mask = (label != 0); row_loss = ce * mask
 //   dlogits = (softmax(x) - onehot(label)) * mask * gscale / den[0]
@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void xent_reg_kernel(float* __restrict__ logit
     __shared__ float sh[4];
     const long row = blockIdx.x;
     float4* p = reinterpret_cast<float4*>(logits + row * ld);
-    const int V4 = V >> 2;
+    const int V4 = (V + 3) >> 2;  // V % 4 != 0 (the reference's observed 11313): the row's last quad reaches into the ld padding
     const int label = labels[row];
     float4 x[XENT_MAXQ];
     float mx = -INFINITY;
@@ -44,6 +44,11 @@ __global__ __launch_bounds__(256) void xent_reg_kernel(float* __restrict__ logit
         const int i = threadIdx.x + q * 256;
         if (i < V4) {
             x[q] = p[i];
+            if (i * 4 + 3 >= V) {  // columns >= V do not exist: -inf drops them from the max and the sum (exp -> 0, gradient 0)
+                if (i * 4 + 1 >= V) x[q].y = -INFINITY;
+                if (i * 4 + 2 >= V) x[q].z = -INFINITY;
+                x[q].w = -INFINITY;
+            }
             mx = fmaxf(mx, fmaxf(fmaxf(x[q].x, x[q].y), fmaxf(x[q].z, x[q].w)));
         }
     }
@@ -368,7 +373,8 @@ extern "C" int vc_softmax_xent_f32(void* stream, float* logits, const int32_t* l
     VC_CHECK_ARG(!write_grad || den, "den required for the gradient");
     if (rows == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    const bool reg = (V % 4 == 0) && (ld % 4 == 0) && (V <= XENT_MAXQ * 256 * 4) && (((uintptr_t)logits & 15) == 0);
+    // register kernel: rows of whole float4 quads -- V % 4 == 0, or a row pitch padded to a multiple of 4 (ld >= roundup(V, 4))
+    const bool reg = (ld % 4 == 0) && (ld >= (long)((V + 3) / 4) * 4) && (V <= XENT_MAXQ * 256 * 4) && (((uintptr_t)logits & 15) == 0);
     dim3 g((unsigned)rows), b(256);
     if (reg) {
         if (write_grad) hipLaunchKernelGGL(xent_reg_kernel<true>, g, b, 0, st, logits, labels, V, ld, den, gscale, row_loss);

@@ -67,3 +67,14 @@ def scales(n_local_rows, world, vector_loss):
     kl_scale_*: multiplies ann * dKL in vc_latent_bwd_f32;  inv_n: 1 / global row count."""
     n_global = n_local_rows * world
     return (float(n_global) if vector_loss else 1.0, 0.1 / n_global, 0.1, 1.0 / n_global)
+
+
+def gradient_buckets(n_cap, n_total, off_fc=None, off_c3=None):
+    """[lo, hi) slices of the flat gradient buffer `gall` = [caption grads + tail scalars | VGG grads] in the order their
+    all-reduces are issued.  Caption-only: the one buffer.  With VGG fine-tuning the ONE logical all-reduce is issued as four
+    pieces in the order the gradients become final during the backward pass (so that RCCL runs under the convolution
+    backward): caption side | fc1 + fc2 (89 % of the VGG bytes, final first) | conv3_1 .. conv5_3 | conv1_1 .. conv2_2.
+    The slices are disjoint and cover [0, n_total) exactly (tests/test_dp_gloo.py)."""
+    if off_fc is None or n_total == n_cap:
+        return [(0, n_total)]
+    return [(0, n_cap), (off_fc, n_total), (off_c3, off_fc), (n_cap, off_c3)]

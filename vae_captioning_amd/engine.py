@@ -81,16 +81,21 @@ class KernelTimer(object):
         return out
 
 
+def flat_offsets(entries):
+    """{name: (offset, shape)} and the total length of a flat buffer holding `entries` back to back, each padded to 64 floats."""
+    offsets, off = {}, 0
+    for name, shape in entries:
+        offsets[name] = (off, tuple(shape))
+        off += _round(int(np.prod(shape)))
+    return offsets, off
+
+
 class FlatStore(object):
     """Named views over flat parameter / gradient / optimiser-slot buffers."""
 
     def __init__(self, entries, device, tail=0, grad_backing=None):
         self.entries = list(entries)
-        self.offsets = {}
-        off = 0
-        for name, shape in self.entries:
-            self.offsets[name] = (off, tuple(shape))
-            off += _round(int(np.prod(shape)))
+        self.offsets, off = flat_offsets(self.entries)
         self.n = off
         self.tail = tail
         self.device = device
@@ -174,6 +179,8 @@ class CaptionEngine(object):
         emb = [n for n in names if n.endswith("embeddings")]
         self.n_dense = self.store.offset(emb[0]) if emb else self.store.n
         self.buf = {}
+        self.pinned, self.pin_ev = {}, {}
+        self.gmm_draw = False
         self.ws = None
         self.ws_bytes = 0
         i32 = dict(dtype=torch.int32, device=device)
@@ -284,55 +291,76 @@ class CaptionEngine(object):
         else:
             fn()
 
-    def colsum(self, x, rows, cols, out, accumulate=0):
+    def colsum(self, x, rows, cols, out, accumulate=0, ld=None):
         self._need_ws(self.lib.vc_colsum_workspace_bytes(rows, cols))
-        self.lib.vc_colsum_f32(_stream(), P(x), rows, cols, cols, P(out), accumulate, P(self.ws), self.ws_bytes)
+        self.lib.vc_colsum_f32(_stream(), P(x), rows, cols, ld or cols, P(out), accumulate, P(self.ws), self.ws_bytes)
 
-    def dense_bwd_w(self, x, rows, fin, fout, dy, wname, bname):
-        """dW = x^T.dy, db = colsum(dy) written straight into the flat gradient buffer."""
-        self.gemm(1, 0, fin, fout, rows, x, fin, dy, fout, self.store.grad(wname), fout)
-        self.colsum(dy, rows, fout, self.store.grad(bname))
+    def dense_bwd_w(self, x, rows, fin, fout, dy, wname, bname, ld_dy=None):
+        """dW = x^T.dy, db = colsum(dy) written straight into the flat gradient buffer (ld_dy: row pitch of dy, default fout)."""
+        self.gemm(1, 0, fin, fout, rows, x, fin, dy, ld_dy or fout, self.store.grad(wname), fout)
+        self.colsum(dy, rows, fout, self.store.grad(bname), ld=ld_dy)
 
     # ---------------------------------------------------------------- inputs
     def set_batch(self, batch, noise=None):
         """Upload one batch (numpy, reference layout: cap_* are [N, T])."""
         p = self.p
         nc = p.num_captions if p.mode == "training" else 1
-        up = lambda name, a, dt: self._b(name, a.shape, dt).copy_(torch.from_numpy(np.ascontiguousarray(a)))
+        up = self._upload
         if "features" in batch:
-            up("features", batch["features"].astype(np.float32), torch.float32)
+            up("features", np.asarray(batch["features"], np.float32), torch.float32)
         cap_dec = np.asarray(batch["cap_dec"], np.int32)
         cap_enc = np.asarray(batch["cap_enc"], np.int32)
         self.N, self.T = cap_dec.shape
         self.B = self.N // nc
         self.nc = nc
-        up("cap_dec_t", cap_dec.T, torch.int32)
-        up("cap_enc_t", cap_enc.T, torch.int32)
-        for key, ids in (("dec", cap_dec.T.reshape(-1)), ("enc", cap_enc.T.reshape(-1))):
-            order, seg1, seg2 = embedding_grad_index(ids, self.V)
-            up("order_" + key, order, torch.int32)
-            up("seg1_" + key, seg1, torch.int32)
-            up("seg2_" + key, seg2, torch.int32)
+        R = self.N * self.T
+        lib, st = self.lib, _stream()
+        self._need_ws(lib.vc_embedding_index_workspace_bytes(R, self.V))
+        nsub = int(lib.vc_embedding_index_max_subsegments(R, self.V, 32))
+        for key, ids in (("dec", cap_dec), ("enc", cap_enc)):
+            t = up("cap_%s_t" % key, ids.T, torch.int32)
+            # inverted index of the token ids for the deterministic embedding gradient: stable counting sort ON DEVICE
+            # (it was a numpy argsort + bincount on the host in every set_batch; embedding_grad_index below is that host form,
+            # kept as the test reference)
+            lib.vc_embedding_grad_index(st, P(t), R, self.V, 32, P(self._b("order_" + key, (R,), torch.int32)),
+                                        P(self._b("seg1_" + key, (nsub + 1,), torch.int32)), P(self._b("seg2_" + key, (self.V + 1,), torch.int32)),
+                                        P(self.ws), self.ws_bytes)
         lens = np.asarray(batch["lengths"], np.int32)
         up("lens_e", lens + self.n_init_e, torch.int32)
         up("lens_d", lens + self.n_init_d, torch.int32)
         if self.use_ci:
-            up("c_v", batch["c_v"].astype(np.float32), torch.float32)
+            up("c_v", np.asarray(batch["c_v"], np.float32), torch.float32)
         self.inject = noise is not None
+        self.gmm_draw = False
         if noise is not None:
             for k in ("eps", "drop_in", "drop_out"):
                 if k in noise:
-                    up(k, noise[k].astype(np.float32), torch.float32)
+                    up(k, np.asarray(noise[k], np.float32), torch.float32)
             if "gmm_idx" in noise:
                 up("gmm_idx", np.asarray(noise["gmm_idx"], np.int32), torch.int32)
         elif self.enc and p.prior == "GMM":
-            # encoder.py:72: tf.multinomial(c_i_ph, 1) -- the cluster vector used as LOGITS (Q15)
-            cv = batch["c_v"].astype(np.float64)
-            pr = np.exp(cv - cv.max(1, keepdims=True))
-            pr /= pr.sum(1, keepdims=True)
-            rs = np.random.default_rng(self.seed + int(self.step.item()))
-            idx = np.array([rs.choice(K_CL, p=pr[n]) for n in range(self.N)], np.int32)
-            up("gmm_idx", idx, torch.int32)
+            # encoder.py:72: tf.multinomial(c_i_ph, 1) -- the cluster vector used as LOGITS (Q15): drawn on device in _noise()
+            # (Philox uniforms + inverse CDF of softmax(c_v); no host loop, no read-back of the step counter)
+            self.gmm_draw = True
+
+    def _upload(self, name, a, dt):
+        """Host array -> persistent device buffer through a persistent PINNED staging buffer, asynchronously on the current
+        stream (pageable memory would make every copy a synchronous staged transfer)."""
+        a = np.ascontiguousarray(a)
+        dst = self._b(name, a.shape, dt)
+        pin = self.pinned.get(name)
+        if pin is None or tuple(pin.shape) != tuple(a.shape) or pin.dtype != dt:
+            pin = self.pinned[name] = torch.empty(a.shape, dtype=dt, pin_memory=True)
+            self.pin_ev[name] = None
+        ev = self.pin_ev.get(name)
+        if ev is not None:
+            ev.synchronize()  # the previous copy out of this staging buffer has finished (it normally has, a step ago)
+        pin.numpy()[...] = a
+        dst.copy_(pin, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self.pin_ev[name] = ev
+        return dst
 
     def _noise(self):
         """Device-generated noise when none was injected (Philox, advanced by the step counter)."""
@@ -347,6 +375,10 @@ class CaptionEngine(object):
         if p.dec_lstm_drop < 1:
             m = self._b("drop_out", (T, N, p.decoder_hidden))
             lib.vc_philox_bernoulli_f32(st, P(m), m.numel(), p.dec_lstm_drop, self.seed * 1000003 + self.rank, 3 << 32, P(self.step))
+        if self.gmm_draw:  # encoder.py:72-75: component index ~ Categorical(softmax(c_v)) per row
+            u = self._b("gmm_u", (N,))
+            lib.vc_philox_uniform_f32(st, P(u), N, self.seed * 1000003 + self.rank, 4 << 32, P(self.step))
+            lib.vc_multinomial_rows_f32(st, P(self.buf["c_v"]), N, K_CL, K_CL, 1.0, P(u), P(self._b("gmm_idx", (N,), torch.int32)))
 
     # ---------------------------------------------------------------- forward
     def forward(self, features=None, train=True):
@@ -486,10 +518,11 @@ class CaptionEngine(object):
             lib.vc_dropout_f32(st, P(outs), P(self.buf["drop_out"]), p.dec_lstm_drop, T * N * Hd, P(od))
             outs = od
         self.outs = outs
-        logits = self._b("logits", (T * N, V))
+        Vp = _round(V, 4)  # row pitch of the logits: a multiple of 4 keeps the register cross-entropy kernel for V = 11313
+        logits = self._b("logits", (T * N, Vp))
         self._timed("logits_gemm", 2.0 * T * N * V * Hd,
-                    lambda: self.gemm(0, 0, T * N, V, Hd, outs, Hd, S.param("decoder/rnn_logits/kernel"), V, logits, V, S.param("decoder/rnn_logits/bias")))
-        return logits
+                    lambda: self.gemm(0, 0, T * N, V, Hd, outs, Hd, S.param("decoder/rnn_logits/kernel"), V, logits, Vp, S.param("decoder/rnn_logits/bias")))
+        return logits[:, :V]  # (a view: the padding columns are not part of x_logits)
 
     def fw_loss(self, train=True):
         """main.py:152-177: masked CE (+ in-place gradient when train), loss scalars."""
@@ -508,7 +541,7 @@ class CaptionEngine(object):
         gscale = dp.scales(N, self.world, vector_loss)[0]
         row_loss = self._b("row_loss", (T * N,))
         self._timed("hbm_softmax_xent", 8.0 * T * N * V,  # logits read once, d(logits) written in place
-                    lambda: lib.vc_softmax_xent_f32(st, P(logits), P(labels), T * N, V, V, P(den), gscale, P(row_loss), 1 if train else 0))
+                    lambda: lib.vc_softmax_xent_f32(st, P(logits), P(labels), T * N, V, _round(V, 4), P(den), gscale, P(row_loss), 1 if train else 0))
         lib.vc_reduce_sum_f32(st, P(row_loss), T * N, 1.0, P(self.red), 0)
         self._finalize_losses(kl_sum, Ng, ann)
         return self.out
@@ -538,10 +571,11 @@ class CaptionEngine(object):
         ann = self.scal[1:2]
         dlogits = self.buf["logits"]
         outs = self.outs
-        self.dense_bwd_w(outs, T * N, Hd, V, dlogits, "decoder/rnn_logits/kernel", "decoder/rnn_logits/bias")
+        Vp = _round(V, 4)
+        self.dense_bwd_w(outs, T * N, Hd, V, dlogits, "decoder/rnn_logits/kernel", "decoder/rnn_logits/bias", ld_dy=Vp)
         dhs = self._b("dhs_d", (Td + 1, N, Hd))  # external gradient w.r.t. every decoder state; init steps stay 0
         douts = dhs[nid + 1:]
-        self.gemm(0, 1, T * N, Hd, V, dlogits, V, S.param("decoder/rnn_logits/kernel"), V, douts, Hd)
+        self.gemm(0, 1, T * N, Hd, V, dlogits, Vp, S.param("decoder/rnn_logits/kernel"), V, douts, Hd)
         if p.dec_lstm_drop < 1:
             lib.vc_dropout_f32(st, P(douts), P(self.buf["drop_out"]), p.dec_lstm_drop, T * N * Hd, P(douts))
         dH, dC = self._b("dH_d", (N, Hd), zero=True), self._b("dC_d", (N, Hd), zero=True)
@@ -631,7 +665,7 @@ class CaptionEngine(object):
         two levels: sub-segments of <= 32 positions -> partial rows -> table rows."""
         lib, st, E = self.lib, _stream(), self.p.embed_size
         seg1, seg2 = self.buf["seg1_" + key], self.buf["seg2_" + key]
-        nsub = seg1.numel() - 1
+        nsub = seg1.numel() - 1  # the upper bound R/32 + V: sub-segments past the batch's real count are empty (seg1 == R)
         part = self._b("embpart_" + key, (max(nsub, 1), E))
         lib.vc_embedding_grad_sorted_f32(st, P(part), P(self.buf["order_" + key]), P(seg1), E, nsub, P(dX))
         lib.vc_embedding_grad_sorted_f32(st, P(self.store.grad(name)), None, P(seg2), E, self.V, P(part))

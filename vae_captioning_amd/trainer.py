@@ -56,7 +56,7 @@ class VggEngine(object):
         # patch-staged forward / data-gradient kernels (csrc/conv_patch.hip) wherever the layer shape allows; VC_CONV_PATCH=0
         # keeps every layer on the implicit-GEMM kernels of csrc/conv.hip (A/B runs)
         self.use_patch = os.environ.get("VC_CONV_PATCH", "1") != "0"
-        nstreams = int(os.environ.get("VC_VGG_STREAMS", "3"))
+        nstreams = int(os.environ.get("VC_VGG_STREAMS", "1"))
         self.side = torch.cuda.Stream() if nstreams >= 2 else None
         self.side2 = torch.cuda.Stream() if nstreams >= 3 else None
         self.part = torch.zeros(self.lib.vc_sumsq_blocks(), dtype=torch.float32, device=device)
@@ -374,6 +374,7 @@ class Trainer(object):
                 self.cap.reg_scale = self.vgg.wd / 2.0  # l2_regularizer(wd)(w) = wd * sum(w^2)/2
         self.images = None
         self.graph = None
+        self.dp_stats = None  # list: per-bucket (index, bytes, event before wait, event after wait) when bench.py asks for it
         self.cnn_host = None  # {cnn/* name: array} written into checkpoints when VGG16 is not on device (state_dict)
         self.n_cap = n_cap
         # Data-parallel gradient exchange.  Logically ONE sum-all-reduce of `gall` per step; with VGG
@@ -389,10 +390,7 @@ class Trainer(object):
     def set_batch(self, batch, noise=None):
         self.cap.set_batch(batch, noise)
         if self.fine:
-            img = np.ascontiguousarray(batch["images"], dtype=np.float32)
-            if self.images is None or tuple(self.images.shape) != img.shape:
-                self.images = torch.zeros(img.shape, dtype=torch.float32, device=self.dev)
-            self.images.copy_(torch.from_numpy(img))
+            self.images = self.cap._upload("images", np.asarray(batch["images"], np.float32), torch.float32)  # pinned staging, async
             if noise is not None and "cnn_drop1" in noise:
                 self.vgg.set_masks(noise["cnn_drop1"], noise["cnn_drop2"])
 
@@ -407,12 +405,21 @@ class Trainer(object):
         dfe = cap.backward(want_dfeatures=vgg is not None)
         cap.pack_tail()
         if self.collectives and self.buckets and vgg is not None and vgg.train and self.reduce_async_fn is not None:
-            pending = [self.reduce_async_fn(self.gall[:self.n_cap])]
-            vgg.backward(dfe, after_fc=lambda: pending.append(self.reduce_async_fn(self.gall[self.off_fc:])),
-                         after_layer=("conv3_1", lambda: pending.append(self.reduce_async_fn(self.gall[self.off_c3:self.off_fc]))))
-            pending.append(self.reduce_async_fn(self.gall[self.n_cap:self.off_c3]))
-            for h in pending:
-                h.wait()
+            from . import dp
+            bk = dp.gradient_buckets(self.n_cap, self.gall.numel(), self.off_fc, self.off_c3)
+            issue = lambda i: self.reduce_async_fn(self.gall[bk[i][0]:bk[i][1]])
+            pending = [issue(0)]
+            vgg.backward(dfe, after_fc=lambda: pending.append(issue(1)), after_layer=("conv3_1", lambda: pending.append(issue(2))))
+            pending.append(issue(3))
+            for i, h in enumerate(pending):
+                if self.dp_stats is not None:  # how long the compute stream stalls on each bucket (bench.py reports it)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    h.wait()
+                    e1.record()
+                    self.dp_stats.append((i, (bk[i][1] - bk[i][0]) * 4, e0, e1))
+                else:
+                    h.wait()
         else:
             if vgg is not None and vgg.train:
                 vgg.backward(dfe)
