@@ -114,10 +114,29 @@ def _lstm_case(T, N, E, H, seed, full_len=False):
     return X, W, b, lens
 
 
-@pytest.mark.parametrize("dims", [(6, 70, 32, 64, False), (4, 700, 48, 96, False), (3, 1280, 256, 512, True)],
-                         ids=["small", "mid-128rows", "cfg2-shape"])
+@pytest.mark.parametrize("dims", [(6, 70, 32, 64, False), (4, 700, 48, 96, False), (3, 1280, 256, 512, True), (5, 330, 64, 512, True),
+                                  (4, 650, 32, 1024, True)],
+                         ids=["small", "mid-128rows", "cfg2-shape", "cfg4-rows-ragged-wide-kernels", "H1024-wide-kernels"])
 def test_lstm_seq_fwd_bwd(lib, dims):
     T, N, E, H, full = dims
+    lib.vc_lstm_set_mode(3 if H % 512 == 0 else 2)  # 3: the wide fused kernels for forward AND backward (auto uses only the forward one)
+    try:
+        _lstm_seq_check(lib, T, N, E, H)
+    finally:
+        lib.vc_lstm_set_mode(2)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_lstm_sequence_modes_agree_with_oracle(lib, mode):
+    """every driver mode (round-1 fused kernels, GEMM + gate kernels, auto) on the cfg4 row count at H = 512"""
+    lib.vc_lstm_set_mode(mode)
+    try:
+        _lstm_seq_check(lib, 3, 320, 64, 512)
+    finally:
+        lib.vc_lstm_set_mode(2)
+
+
+def _lstm_seq_check(lib, T, N, E, H):
     X, W, b, lens = _lstm_case(T, N, E, H, seed=T * N)
     rng = np.random.default_rng(1)
     dhs = rng.standard_normal((T + 1, N, H), dtype=np.float32) * np.float32(0.1)

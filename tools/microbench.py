@@ -157,10 +157,10 @@ def convw():
 
 
 def lstm():
-  for mode in (0, 1):
+  for mode in (2, 1):
     lib.vc_lstm_set_mode(mode)
-    print("lstm mode", mode, "(1 = gemm + gate kernels, 0 = fused step kernels)")
-    for N in (320, 1280):
+    print("lstm mode", mode, "(2 = wide fused step kernels, 1 = gemm + gate kernels, 0 = round-1 fused step kernels)")
+    for N in (160, 320, 1280):
         H, E, T = 512, 256, 22
         X, W, b = rnd(T, N, E), rnd(E + H, 4 * H) * 0.05, rnd(4 * H) * 0.1
         lens = torch.full((N,), T, dtype=torch.int32, device="cuda")
@@ -174,6 +174,7 @@ def lstm():
         dX, dW, db = torch.empty(T, N, E, device="cuda"), torch.empty(E + H, 4 * H, device="cuda"), torch.empty(4 * H, device="cuda")
         med, _ = timeit(lambda: lib.vc_lstm_seq_bwd_f32(st(), T, N, E, H, P(X), P(W), P(lens), P(act), P(cs), P(hs), P(dhs), P(dH), P(dC), P(dG), P(dX), P(dW), P(db), P(ws), ws.numel() * 4), reps=5)
         print("lstm bwd seq N=%4d T=%d: %8.3f ms (%.1f us/step) %6.1f TFLOP/s" % (N, T, med, 1e3 * med / T, 2 * fl / med))
+  lib.vc_lstm_set_mode(2)
 
 
 def mid():

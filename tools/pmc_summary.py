@@ -20,7 +20,15 @@ def family(name):
         k = re.search(r">,\s*(\d)\s*>\(", name)
         kinds = {"0": "fwd", "1": "dgrad", "2": "wgrad"}
         return "conv_kernel<%s>" % kinds.get(k.group(1) if k else "?", "?")
+    if "conv_patch_kernel" in name:  # conv_patch_kernel<TN, SCHEME, KIND>
+        k = re.search(r"conv_patch_kernel<\s*\d+,\s*\d+,\s*(\d)\s*>", name)
+        return "conv_patch_kernel<%s>" % {"0": "fwd", "1": "dgrad"}.get(k.group(1) if k else "?", "?")
+    if "wgrad_flat_kernel" in name or "wgrad_patch_kernel" in name:
+        return "wgrad_patch/flat_kernel"
     return base
+
+
+CONV_FAMILY = ("conv_kernel", "conv_patch_kernel", "wgrad_patch", "conv_tail_reduce", "patch_tail_reduce", "wgrad_reduce", "wgrad_patch_reduce")
 
 
 def main(root):
@@ -56,6 +64,20 @@ def main(root):
             # SQ_VALU_MFMA_BUSY_CYCLES is summed over SEs/SIMDs; normalise by active cycles x 1024 SIMDs
             mfma = "%.1f" % (100.0 * c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (c["GRBM_GUI_ACTIVE"] * 1024 / 8))
         print("| `%s` | %d | %.2f | %.2f | %.2f | %.3f | %s | %s |" % (fam, n, fetch, 2 * fetch, write, (2 * fetch + write) / n, mfma, clk))
+    # the convolution family as a whole, per traced step (one preprocess_kernel launch per fine-tune step)
+    steps = max(calls.get("preprocess_kernel", 0), 1)
+    conv = [(fam, c) for fam, c in data.items() if any(k in fam for k in CONV_FAMILY)]
+    rd = sum(2 * c.get("FETCH_SIZE", 0) * 1024 for _, c in conv)
+    wr = sum(c.get("WRITE_SIZE", 0) * 1024 for _, c in conv)
+    print("\nconvolution family (all 3x3 convolution kernels incl. tails and split reduces): %.2f GB read (2 x FETCH_SIZE) + %.2f GB written "
+          "= %.2f GB per step over %d traced steps" % (rd / 1e9 / steps, wr / 1e9 / steps, (rd + wr) / 1e9 / steps, steps))
+    if len(sys.argv) > 2:
+        import json
+        json.dump({"bytes_per_step": (rd + wr) / steps, "read_bytes_per_step": rd / steps, "write_bytes_per_step": wr / steps, "steps_traced": steps,
+                   "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python bench.py --steps 4 --warmup 1 --no-cpu-baseline`; "
+                             "(2 x FETCH_SIZE [gfx950 16-B/lane stream correction, MI355X_MICROARCH.md] + WRITE_SIZE) KiB summed over every 3x3 "
+                             "convolution kernel (main, K-split tail, split reduce) / traced steps; L2-miss-side traffic (Infinity-Cache hits are "
+                             "counted); tools/pmc_summary.py"}, open(sys.argv[2], "w"), indent=1)
 
 
 if __name__ == "__main__":

@@ -90,8 +90,9 @@ __global__ __launch_bounds__(256) void segment_grad_kernel(float* __restrict__ d
 // ---- inverted index for the deterministic embedding gradient, built ON DEVICE (was numpy argsort + bincount on the
 // host inside every set_batch).  A stable counting sort of the R token ids in three launches:
 //   count : block (vocabulary block, segment s of the positions): thread v counts its id in segment s   -> cnt[s][v]
-//   scan  : one workgroup: per-id totals, exclusive scans -> first slot of every (segment, id), the sub-segment table
-//           seg1 (chunks of <= `chunk` positions, never crossing an id boundary) and seg2 (sub-segment range of each id)
+//   scan  : three small launches (per-id totals; one-workgroup exclusive scans through LDS; per-id finish) -> first slot of
+//           every (segment, id), the sub-segment table seg1 (chunks of <= `chunk` positions, never crossing an id boundary)
+//           and seg2 (sub-segment range of each id)
 //   place : same grid as count: thread v walks segment s again and writes the positions of its id in order
 // Every thread compares its id against the segment's ids streamed through LDS (broadcast reads): R/segments x V
 // comparisons per launch, a few microseconds at R = 25600, V = 10000.  Integer work, no atomics: bit-identical to
@@ -137,46 +138,68 @@ __global__ __launch_bounds__(256) void embidx_scan_ids_kernel(const int32_t* __r
     if (!PLACE && v < vocab) cnt[(long)blockIdx.y * vocab + v] = cur;
 }
 
-__global__ __launch_bounds__(1024) void embidx_scan_kernel(int32_t* __restrict__ cnt, int segs, int vocab, long R, int chunk, int nsub_max,
-                                                           int32_t* __restrict__ seg1, int32_t* __restrict__ seg2) {
-    __shared__ int32_t sh_a[1024], sh_b[1024];
+// scan, stage 1 (thread = id, coalesced): per-id totals and sub-segment counts; cnt[s][v] becomes the id-local prefix over segments
+__global__ __launch_bounds__(256) void embidx_totals_kernel(int32_t* __restrict__ cnt, int segs, int vocab, int chunk,
+                                                            int32_t* __restrict__ tot, int32_t* __restrict__ nsub) {
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= vocab) return;
+    int32_t t = 0;
+    for (int s = 0; s < segs; ++s) {
+        const int32_t c = cnt[(long)s * vocab + v];
+        cnt[(long)s * vocab + v] = t;
+        t += c;
+    }
+    tot[v] = t;
+    nsub[v] = (t + chunk - 1) / chunk;
+}
+
+// scan, stage 2 (one workgroup): exclusive scans over the ids of the totals (-> first slot of each id) and of the sub-segment
+// counts (-> seg2), through LDS so that global accesses stay coalesced
+__global__ __launch_bounds__(1024) void embidx_scan_kernel(const int32_t* __restrict__ tot, const int32_t* __restrict__ nsub, int vocab,
+                                                           int32_t* __restrict__ starts, int32_t* __restrict__ seg2) {
+    extern __shared__ int32_t sh[];  // [2][vocab] + [2][1024]
+    int32_t* a = sh;
+    int32_t* b = sh + vocab;
+    int32_t* pa = sh + 2 * vocab;
+    int32_t* pb = pa + 1024;
     const int t = threadIdx.x;
+    for (int v = t; v < vocab; v += 1024) { a[v] = tot[v]; b[v] = nsub[v]; }
+    __syncthreads();
     const int per = (vocab + 1023) / 1024;
     const int v0 = t * per, v1 = v0 + per < vocab ? v0 + per : vocab;
-    // pass 1: per-thread sums of the id totals and of the sub-segment counts
-    int32_t a = 0, b = 0;
-    for (int v = v0; v < v1; ++v) {
-        int32_t tot = 0;
-        for (int s = 0; s < segs; ++s) tot += cnt[(long)s * vocab + v];
-        a += tot;
-        b += (tot + chunk - 1) / chunk;
-    }
-    sh_a[t] = a; sh_b[t] = b;
+    int32_t sa = 0, sb = 0;
+    for (int v = v0; v < v1; ++v) { sa += a[v]; sb += b[v]; }
+    pa[t] = sa; pb[t] = sb;
     __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {  // inclusive Hillis-Steele scans of both
-        const int32_t xa = t >= o ? sh_a[t - o] : 0, xb = t >= o ? sh_b[t - o] : 0;
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int32_t xa = t >= o ? pa[t - o] : 0, xb = t >= o ? pb[t - o] : 0;
         __syncthreads();
-        sh_a[t] += xa; sh_b[t] += xb;
+        pa[t] += xa; pb[t] += xb;
         __syncthreads();
     }
-    int32_t start = sh_a[t] - a, sub = sh_b[t] - b;  // exclusive prefixes of this thread's first id
-    const int32_t nsub = sh_b[1023];
-    // pass 2: first slot of every (segment, id); seg2; seg1 of the id's sub-segments
+    int32_t ea = pa[t] - sa, eb = pb[t] - sb;
     for (int v = v0; v < v1; ++v) {
-        int32_t tot = 0;
-        for (int s = 0; s < segs; ++s) {
-            const int32_t c = cnt[(long)s * vocab + v];
-            cnt[(long)s * vocab + v] = start + tot;
-            tot += c;
-        }
-        seg2[v] = sub;
-        const int32_t ns = (tot + chunk - 1) / chunk;
-        for (int w = 0; w < ns; ++w) seg1[sub + w] = start + w * chunk;
-        start += tot;
-        sub += ns;
+        const int32_t ca = a[v], cb = b[v];
+        a[v] = ea; b[v] = eb;
+        ea += ca; eb += cb;
     }
-    if (t == 0) seg2[vocab] = nsub;
-    for (int k = nsub + t; k <= nsub_max; k += 1024) seg1[k] = (int32_t)R;  // closes the last sub-segment; the unused ones are empty
+    __syncthreads();
+    for (int v = t; v < vocab; v += 1024) { starts[v] = a[v]; seg2[v] = b[v]; }
+    if (t == 0) seg2[vocab] = pb[1023];
+}
+
+// scan, stage 3 (thread = id): first slot of every (segment, id); the id's sub-segment boundaries; unused sub-segments -> empty
+__global__ __launch_bounds__(256) void embidx_finish_kernel(int32_t* __restrict__ cnt, int segs, int vocab, long R, int chunk, int nsub_max,
+                                                            const int32_t* __restrict__ tot, const int32_t* __restrict__ starts,
+                                                            int32_t* __restrict__ seg1, const int32_t* __restrict__ seg2) {
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    const int32_t nsub = seg2[vocab];
+    for (int k = nsub + v; k <= nsub_max; k += gridDim.x * 256) seg1[k] = (int32_t)R;  // closes the last sub-segment; the rest are empty
+    if (v >= vocab) return;
+    const int32_t st = starts[v];
+    for (int s = 0; s < segs; ++s) cnt[(long)s * vocab + v] += st;
+    const int32_t ns = (tot[v] + chunk - 1) / chunk, sb = seg2[v];
+    for (int w = 0; w < ns; ++w) seg1[sb + w] = st + w * chunk;
 }
 
 __global__ __launch_bounds__(256) void mark_rows_kernel(float* __restrict__ touched, const int32_t* __restrict__ ids,
@@ -442,7 +465,7 @@ static int embidx_segs(long R) {
 }
 
 extern "C" size_t vc_embedding_index_workspace_bytes(long R, int vocab) {
-    return (size_t)embidx_segs(R) * (size_t)vocab * sizeof(int32_t);
+    return ((size_t)embidx_segs(R) + 3) * (size_t)vocab * sizeof(int32_t);  // cnt[segs][vocab] + totals + sub-segment counts + first slots
 }
 
 extern "C" size_t vc_embedding_index_max_subsegments(long R, int vocab, int chunk) {
@@ -453,14 +476,24 @@ extern "C" int vc_embedding_grad_index(void* stream, const int32_t* ids, long R,
                                        int32_t* seg1, int32_t* seg2, int32_t* ws, size_t ws_bytes) {
     VC_CHECK_ARG(ids && order && seg1 && seg2 && R > 0 && vocab > 0 && chunk > 0 && R < (1L << 31), "bad argument");
     const int segs = embidx_segs(R);
-    if (!ws || ws_bytes < (size_t)segs * vocab * sizeof(int32_t))
+    if (!ws || ws_bytes < ((size_t)segs + 3) * vocab * sizeof(int32_t))
         return fail(VC_EWORKSPACE, "%s: workspace too small (need vc_embedding_index_workspace_bytes)", __func__);
+    VC_CHECK_ARG((size_t)vocab * 8 + 8192 <= 160 * 1024, "vocabulary too large for the single-workgroup scan (<= 19456 ids)");
+    int32_t* tot = ws + (size_t)segs * vocab;
+    int32_t* nsb = tot + vocab;
+    int32_t* starts = nsb + vocab;
     const long seg_len = ((R + segs - 1) / segs + 3) / 4 * 4;
     const int nsub_max = (int)(R / chunk + vocab);
     const dim3 grid(cdiv(vocab, 256), segs);
     hipLaunchKernelGGL(embidx_scan_ids_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, ids, R, vocab, seg_len, ws, order);
     VC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(embidx_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, ws, segs, vocab, R, chunk, nsub_max, seg1, seg2);
+    hipLaunchKernelGGL(embidx_totals_kernel, dim3(grid.x), dim3(256), 0, (hipStream_t)stream, ws, segs, vocab, chunk, tot, nsb);
+    VC_LAUNCH_CHECK();
+    if ((size_t)vocab * 8 + 8192 > 64 * 1024)  // more than the default 64 KB of dynamic LDS
+        (void)hipFuncSetAttribute((const void*)embidx_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)vocab * 8 + 8192));
+    hipLaunchKernelGGL(embidx_scan_kernel, dim3(1), dim3(1024), (size_t)vocab * 8 + 8192, (hipStream_t)stream, tot, nsb, vocab, starts, seg2);
+    VC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(embidx_finish_kernel, dim3(grid.x), dim3(256), 0, (hipStream_t)stream, ws, segs, vocab, R, chunk, nsub_max, tot, starts, seg1, seg2);
     VC_LAUNCH_CHECK();
     hipLaunchKernelGGL(embidx_scan_ids_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, ids, R, vocab, seg_len, ws, order);
     VC_LAUNCH_CHECK();

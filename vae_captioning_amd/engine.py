@@ -141,6 +141,10 @@ def internal_caption_variables(p, vocab):
                 heads_done = True
             continue
         fused.append((name, shape))
+    # the logits layer is stored with its vocabulary dimension padded to a multiple of 4 (zero columns): its three GEMMs keep
+    # 16-byte operand loads for vocabularies such as the reference's observed 11313 (checkpoints carry the unpadded arrays)
+    Vp = _round(int(vocab), 4)
+    fused = [(n, (sh[0], Vp)) if n == "decoder/rnn_logits/kernel" else ((n, (Vp,)) if n == "decoder/rnn_logits/bias" else (n, sh)) for n, sh in fused]
     emb = [e for e in fused if e[0].endswith("embeddings")]
     rest = [e for e in fused if not e[0].endswith("embeddings")]
     return rest + emb
@@ -164,6 +168,7 @@ class CaptionEngine(object):
         # "tower": every rank mixes inside its own shard (what N towers of the reference graph compute).
         self.q1_mode = q1_mode
         self.V = int(vocab)
+        self.Vp = _round(self.V, 4)
         self.lib = lib or abi.load()
         self.dev = device
         self.world, self.rank, self.group = world, rank, group
@@ -179,7 +184,7 @@ class CaptionEngine(object):
         emb = [n for n in names if n.endswith("embeddings")]
         self.n_dense = self.store.offset(emb[0]) if emb else self.store.n
         self.buf = {}
-        self.pinned, self.pin_ev = {}, {}
+        self.pinned, self.copy_stream = {}, None
         self.gmm_draw = False
         self.ws = None
         self.ws_bytes = 0
@@ -233,6 +238,8 @@ class CaptionEngine(object):
                 arr = np.concatenate(ks + ls, axis=0)
             else:
                 arr = named[name]
+            if name.startswith("decoder/rnn_logits/") and np.shape(arr)[-1] == self.V != self.Vp:  # zero-pad the vocabulary columns
+                arr = np.concatenate([arr, np.zeros(np.shape(arr)[:-1] + (self.Vp - self.V,), np.float32)], axis=-1)
             dst = self.store.param(name)
             if tuple(np.shape(arr)) != tuple(dst.shape):
                 raise ValueError("%s: checkpoint shape %s, model shape %s" % (name, tuple(np.shape(arr)), tuple(dst.shape)))
@@ -252,6 +259,8 @@ class CaptionEngine(object):
                 for k in range(K_CL):
                     out[spec.head_scope(p.prior, k) + "dense/bias"] = a[k * L:(k + 1) * L].copy()
                     out[spec.head_scope(p.prior, k) + "dense_1/bias"] = a[(K_CL + k) * L:(K_CL + k + 1) * L].copy()
+            elif name.startswith("decoder/rnn_logits/"):
+                out[name] = np.ascontiguousarray(a[..., :self.V])
             else:
                 out[name] = a
         return out
@@ -301,66 +310,105 @@ class CaptionEngine(object):
         self.colsum(dy, rows, fout, self.store.grad(bname), ld=ld_dy)
 
     # ---------------------------------------------------------------- inputs
-    def set_batch(self, batch, noise=None):
-        """Upload one batch (numpy, reference layout: cap_* are [N, T])."""
+    def set_batch(self, batch, noise=None, extra=()):
+        """Upload one batch (numpy, reference layout: cap_* are [N, T]).  Every host array of the batch (token ids, lengths,
+        cluster vectors, features or images, injected noise) travels in ONE pinned staging buffer and ONE asynchronous H2D copy
+        (ten separate copies cost a queue hand-off each: ~1 ms per step); the device buffers are typed views of the landing buffer.
+        extra: further (name, array, torch dtype) items for the same copy (the Trainer's images)."""
         p = self.p
         nc = p.num_captions if p.mode == "training" else 1
-        up = self._upload
+        items = list(extra)
         if "features" in batch:
-            up("features", np.asarray(batch["features"], np.float32), torch.float32)
+            items.append(("features", np.asarray(batch["features"], np.float32), torch.float32))
         cap_dec = np.asarray(batch["cap_dec"], np.int32)
         cap_enc = np.asarray(batch["cap_enc"], np.int32)
         self.N, self.T = cap_dec.shape
         self.B = self.N // nc
         self.nc = nc
         R = self.N * self.T
-        lib, st = self.lib, _stream()
-        self._need_ws(lib.vc_embedding_index_workspace_bytes(R, self.V))
-        nsub = int(lib.vc_embedding_index_max_subsegments(R, self.V, 32))
-        for key, ids in (("dec", cap_dec), ("enc", cap_enc)):
-            t = up("cap_%s_t" % key, ids.T, torch.int32)
-            # inverted index of the token ids for the deterministic embedding gradient: stable counting sort ON DEVICE
-            # (it was a numpy argsort + bincount on the host in every set_batch; embedding_grad_index below is that host form,
-            # kept as the test reference)
-            lib.vc_embedding_grad_index(st, P(t), R, self.V, 32, P(self._b("order_" + key, (R,), torch.int32)),
-                                        P(self._b("seg1_" + key, (nsub + 1,), torch.int32)), P(self._b("seg2_" + key, (self.V + 1,), torch.int32)),
-                                        P(self.ws), self.ws_bytes)
+        items += [("cap_dec_t", cap_dec.T, torch.int32), ("cap_enc_t", cap_enc.T, torch.int32)]
         lens = np.asarray(batch["lengths"], np.int32)
-        up("lens_e", lens + self.n_init_e, torch.int32)
-        up("lens_d", lens + self.n_init_d, torch.int32)
+        items += [("lens_e", lens + self.n_init_e, torch.int32), ("lens_d", lens + self.n_init_d, torch.int32)]
         if self.use_ci:
-            up("c_v", np.asarray(batch["c_v"], np.float32), torch.float32)
+            items.append(("c_v", np.asarray(batch["c_v"], np.float32), torch.float32))
         self.inject = noise is not None
         self.gmm_draw = False
         if noise is not None:
             for k in ("eps", "drop_in", "drop_out"):
                 if k in noise:
-                    up(k, np.asarray(noise[k], np.float32), torch.float32)
+                    items.append((k, np.asarray(noise[k], np.float32), torch.float32))
             if "gmm_idx" in noise:
-                up("gmm_idx", np.asarray(noise["gmm_idx"], np.int32), torch.int32)
-        elif self.enc and p.prior == "GMM":
+                items.append(("gmm_idx", np.asarray(noise["gmm_idx"], np.int32), torch.int32))
+        else:
+            for k in ("eps", "drop_in", "drop_out", "gmm_idx"):  # views of an earlier injected batch: device-generated noise gets its own buffers
+                self.buf.pop(k, None)
+        if noise is None and self.enc and p.prior == "GMM":
             # encoder.py:72: tf.multinomial(c_i_ph, 1) -- the cluster vector used as LOGITS (Q15): drawn on device in _noise()
             # (Philox uniforms + inverse CDF of softmax(c_v); no host loop, no read-back of the step counter)
             self.gmm_draw = True
+        slot = self._upload_pack(items)
+        # inverted index of the token ids for the deterministic embedding gradient: stable counting sort ON DEVICE (it was a numpy
+        # argsort + bincount on the host in every set_batch; embedding_grad_index below is that host form, kept as the test reference).
+        # It runs on the copy stream right behind the upload, i.e. under the previous step, into the buffers of batch slot `slot`.
+        lib = self.lib
+        nb = lib.vc_embedding_index_workspace_bytes(R, self.V)
+        nsub = int(lib.vc_embedding_index_max_subsegments(R, self.V, 32))
+        main = torch.cuda.current_stream()
+        with torch.cuda.stream(self.copy_stream):
+            st = _stream()
+            iws = self._b("idx_ws", (nb // 4 + 16,), torch.int32)
+            for key in ("dec", "enc"):
+                o, s1, s2 = (self._b("%s_%s_%d" % (n, key, slot), shp, torch.int32) for n, shp in (("order", (R,)), ("seg1", (nsub + 1,)), ("seg2", (self.V + 1,))))
+                lib.vc_embedding_grad_index(st, P(self.buf["cap_%s_t" % key]), R, self.V, 32, P(o), P(s1), P(s2), P(iws), iws.numel() * 4)
+                self.buf["order_" + key], self.buf["seg1_" + key], self.buf["seg2_" + key] = o, s1, s2
+            done = torch.cuda.Event()
+            done.record(self.copy_stream)
+        main.wait_event(done)
 
-    def _upload(self, name, a, dt):
-        """Host array -> persistent device buffer through a persistent PINNED staging buffer, asynchronously on the current
-        stream (pageable memory would make every copy a synchronous staged transfer)."""
-        a = np.ascontiguousarray(a)
-        dst = self._b(name, a.shape, dt)
-        pin = self.pinned.get(name)
-        if pin is None or tuple(pin.shape) != tuple(a.shape) or pin.dtype != dt:
-            pin = self.pinned[name] = torch.empty(a.shape, dtype=dt, pin_memory=True)
-            self.pin_ev[name] = None
-        ev = self.pin_ev.get(name)
+    def _upload_pack(self, items):
+        """[(name, host array, torch dtype)] -> self.buf[name] device tensors, through one pinned staging buffer (a ring of
+        three, so the host may run two steps ahead of the device) and one asynchronous copy on the current stream."""
+        arrs, offs, off = [], [], 0
+        for name, a, dt in items:
+            a = np.ascontiguousarray(a, dtype=np.float32 if dt == torch.float32 else np.int32)
+            arrs.append(a)
+            offs.append(off)
+            off += (a.nbytes + 255) // 256 * 256
+        total = max(off, 256)
+        st = self.pinned.get("__pack__")
+        if st is None or st["bytes"] != total:
+            st = self.pinned["__pack__"] = dict(bytes=total, k=0, j=0, e_prev=None,
+                                                devs=[torch.empty(total, dtype=torch.uint8, device=self.dev) for _ in range(2)],
+                                                ring=[[torch.empty(total, dtype=torch.uint8, pin_memory=True), None] for _ in range(3)])
+        if self.copy_stream is None:
+            self.copy_stream = torch.cuda.Stream()
+        k = st["k"]
+        st["k"] = (k + 1) % 3
+        pin, ev = st["ring"][k]
         if ev is not None:
-            ev.synchronize()  # the previous copy out of this staging buffer has finished (it normally has, a step ago)
-        pin.numpy()[...] = a
-        dst.copy_(pin, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream())
-        self.pin_ev[name] = ev
-        return dst
+            ev.synchronize()  # the copy that last read this staging buffer (three batches ago) has finished
+        host = pin.numpy()
+        for a, o in zip(arrs, offs):
+            host[o:o + a.nbytes] = a.reshape(-1).view(np.uint8)
+        # The copy runs on its own stream, UNDER the step that is still executing: it lands in the device buffer of the step before
+        # that one (two landing buffers alternate), so it only has to wait for the work that was enqueued before the PREVIOUS
+        # set_batch call; the compute stream then waits for the copy.
+        main = torch.cuda.current_stream()
+        e_now = torch.cuda.Event()
+        e_now.record(main)
+        dev = st["devs"][st["j"]]
+        st["j"] ^= 1
+        if st["e_prev"] is not None:
+            self.copy_stream.wait_event(st["e_prev"])
+        with torch.cuda.stream(self.copy_stream):
+            dev.copy_(pin, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.copy_stream)
+        st["e_prev"] = e_now
+        st["ring"][k][1] = ev
+        for (name, _, dt), a, o in zip(items, arrs, offs):
+            self.buf[name] = dev[o:o + a.nbytes].view(dt).view(a.shape)
+        return st["j"] ^ 1  # the landing slot of this batch; the caller makes the compute stream wait for the copy stream
 
     def _noise(self):
         """Device-generated noise when none was injected (Philox, advanced by the step counter)."""
@@ -521,7 +569,7 @@ class CaptionEngine(object):
         Vp = _round(V, 4)  # row pitch of the logits: a multiple of 4 keeps the register cross-entropy kernel for V = 11313
         logits = self._b("logits", (T * N, Vp))
         self._timed("logits_gemm", 2.0 * T * N * V * Hd,
-                    lambda: self.gemm(0, 0, T * N, V, Hd, outs, Hd, S.param("decoder/rnn_logits/kernel"), V, logits, Vp, S.param("decoder/rnn_logits/bias")))
+                    lambda: self.gemm(0, 0, T * N, Vp, Hd, outs, Hd, S.param("decoder/rnn_logits/kernel"), Vp, logits, Vp, S.param("decoder/rnn_logits/bias")))
         return logits[:, :V]  # (a view: the padding columns are not part of x_logits)
 
     def fw_loss(self, train=True):
@@ -572,10 +620,10 @@ class CaptionEngine(object):
         dlogits = self.buf["logits"]
         outs = self.outs
         Vp = _round(V, 4)
-        self.dense_bwd_w(outs, T * N, Hd, V, dlogits, "decoder/rnn_logits/kernel", "decoder/rnn_logits/bias", ld_dy=Vp)
+        self.dense_bwd_w(outs, T * N, Hd, Vp, dlogits, "decoder/rnn_logits/kernel", "decoder/rnn_logits/bias")  # padding columns of dlogits are 0
         dhs = self._b("dhs_d", (Td + 1, N, Hd))  # external gradient w.r.t. every decoder state; init steps stay 0
         douts = dhs[nid + 1:]
-        self.gemm(0, 1, T * N, Hd, V, dlogits, Vp, S.param("decoder/rnn_logits/kernel"), V, douts, Hd)
+        self.gemm(0, 1, T * N, Hd, Vp, dlogits, Vp, S.param("decoder/rnn_logits/kernel"), Vp, douts, Hd)
         if p.dec_lstm_drop < 1:
             lib.vc_dropout_f32(st, P(douts), P(self.buf["drop_out"]), p.dec_lstm_drop, T * N * Hd, P(douts))
         dH, dC = self._b("dH_d", (N, Hd), zero=True), self._b("dC_d", (N, Hd), zero=True)

@@ -115,7 +115,7 @@ class CaptionGenerator(object):
         lib.vc_lstm_step_fwd_f32(st, M, Hd, 0, P(h), P(c), W.data_ptr() + E * 4 * Hd * 4, P(gact), P(ones), P(c2), P(h2))
         logits = torch.empty((M, V), dtype=torch.float32, device=e.dev)
         e._timed("logits_gemm", 2.0 * M * V * Hd,
-                 lambda: e.gemm(0, 0, M, V, Hd, h2, Hd, S.param("decoder/rnn_logits/kernel"), V, logits, V, S.param("decoder/rnn_logits/bias")))
+                 lambda: e.gemm(0, 0, M, V, Hd, h2, Hd, S.param("decoder/rnn_logits/kernel"), e.Vp, logits, V, S.param("decoder/rnn_logits/bias")))
         if want == "logits":
             return logits, c2, h2
         probs = torch.empty_like(logits)

@@ -388,9 +388,10 @@ class Trainer(object):
         self.off_c3 = n_cap + self.vgg.store.offset("cnn/conv3_1/weights") if self.vgg is not None else None
 
     def set_batch(self, batch, noise=None):
-        self.cap.set_batch(batch, noise)
+        extra = [("images", np.asarray(batch["images"], np.float32), torch.float32)] if self.fine else []
+        self.cap.set_batch(batch, noise, extra=extra)  # one pinned staging buffer, one asynchronous copy
         if self.fine:
-            self.images = self.cap._upload("images", np.asarray(batch["images"], np.float32), torch.float32)  # pinned staging, async
+            self.images = self.cap.buf["images"]
             if noise is not None and "cnn_drop1" in noise:
                 self.vgg.set_masks(noise["cnn_drop1"], noise["cnn_drop2"])
 
