@@ -44,9 +44,6 @@ int vc_device_check(int device);
 size_t vc_gemm_workspace_bytes(int M, int N, int K);
 int vc_gemm_f32(void* stream, int ta, int tb, int M, int N, int K, const float* A, long lda, const float* B,
                 long ldb, float* C, long ldc, const float* bias, int flags, float* ws, size_t ws_bytes);
-/* Benchmark-only: the NN 128x128 kernel with main-loop stages ablated (bit 1: no global loads, 2: no
- * LDS stores/barriers, 4: no LDS reads); output is meaningless for variant != 0.  tools/microbench.py. */
-int vc_debug_gemm_ablate_f32(void* stream, int variant, int M, int N, int K, const float* A, const float* B, float* C);
 
 /* ------------------------------------------------------------------------------------
  * Embedding lookup and its gradient.   tf.nn.embedding_lookup, vae_model/encoder.py:31-36,

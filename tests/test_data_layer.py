@@ -259,3 +259,19 @@ def test_imagenet_npz_is_assigned_in_sorted_key_order(tmp_path):
     for i, n in enumerate(names):   # sorted(keys) == keys here: conv1_1_W, conv1_1_b, ... fc7_b, fc8_W, fc8_b
         assert got[n].dtype == np.float32 and got[n][0] == float(i), n
     assert sorted(keys) == keys
+
+
+def test_hdf5_image_container_when_h5py_is_available(coco, tmp_path, monkeypatch):
+    """The reference's image container (preprocess.py:25-45 writes data set "images" (N, 224, 224, 3) uint8; utils/batch_gen.py:152-162
+    reads it with increasing indices).  Runs wherever h5py is installed (not in the build image: there the same array is a .npy,
+    covered by test_image_paths_and_preprocessed_array)."""
+    h5py = pytest.importorskip("h5py")
+    import preprocess
+    monkeypatch.chdir(tmp_path)
+    n = preprocess.build(coco, str(tmp_path / "train_val.h5"), index_path=str(tmp_path / "pickles" / "itoi.pickle"))
+    with h5py.File(str(tmp_path / "train_val.h5"), "r") as f:
+        assert f["images"].shape == (n, 224, 224, 3) and f["images"].dtype == np.uint8
+    from vae_captioning_amd.utils.batch_gen import open_image_array
+    arr = open_image_array(str(tmp_path / "train_val.h5"))
+    idx = sorted({0, n - 1, n // 2})
+    assert np.asarray(arr[idx]).shape == (len(idx), 224, 224, 3)

@@ -103,3 +103,40 @@ def test_bundle_round_trip(tmp_path):
     with pytest.raises(ValueError):
         tb.read_bundle(prefix, names=["encoder/enc_embeddings"])
     assert np.array_equal(tb.read_bundle(prefix, names=["lengths"])["lengths"], tensors["lengths"])
+
+
+def test_index_file_equals_a_hand_assembled_table():
+    """A one-tensor bundle index assembled BYTE BY BYTE here from the published formats -- LevelDB table_format.md (block =
+    prefix-compressed entries + restart array; 5-byte block trailer = compression type 0 + masked CRC-32C of contents + type;
+    48-byte footer = metaindex handle, index handle, zero padding to 40, magic 0xdb4775248b80fb57 little-endian) and
+    tensorflow/core/protobuf/tensor_bundle.proto (BundleHeaderProto under key "", BundleEntryProto under the tensor name) --
+    must equal what tf_bundle.build_table emits, and must parse back.  The only shared code is crc32c, which
+    test_crc32c_known_answers_and_native_path pins with the RFC 3720 vectors."""
+    import struct
+    u32 = lambda v: struct.pack("<I", v)
+    header = bytes([0x08, 0x01, 0x1A, 0x02, 0x08, 0x01])                   # num_shards = 1, version { producer = 1 }
+    entry = bytes([0x08, 0x01,                                             # dtype = DT_FLOAT
+                   0x12, 0x08, 0x12, 0x02, 0x08, 0x02, 0x12, 0x02, 0x08, 0x03,   # shape { dim { size: 2 } dim { size: 3 } }
+                   0x28, 0x18,                                             # size = 24 bytes (shard_id = 0, offset = 0 omitted)
+                   0x35]) + u32(0xCAFEF00D)                                # crc32c (masked), fixed32
+    key = b"a/b"
+    data = (bytes([0, 0, len(header)]) + header +                          # entry 1: shared 0, non-shared 0 (key ""), value
+            bytes([0, len(key), len(entry)]) + key + entry +               # entry 2: shares nothing with ""
+            u32(0) + u32(1))                                               # restart array [0], one restart
+    trailer = lambda blk: b"\x00" + u32(tb.mask_crc(tb.crc32c(blk + b"\x00")))
+    out = data + trailer(data)
+    meta = u32(0) + u32(1)                                                 # empty metaindex block
+    meta_off = len(out)
+    out += meta + trailer(meta)
+    handle = bytes([0, len(data)])                                         # BlockHandle(offset 0, size) as varints (< 128 each)
+    index = bytes([0, 1, len(handle)]) + b"b" + handle + u32(0) + u32(1)   # separator after the last key "a/b": short successor "b"
+    index_off = len(out)
+    out += index + trailer(index)
+    footer = bytes([meta_off, len(meta)]) + bytes([index_off, len(index)])
+    out += footer + b"\x00" * (40 - len(footer)) + bytes.fromhex("57fb808b247547db")
+    assert len(out) - index_off - len(index) - 5 == 48
+    assert tb.encode_header(1) == header and tb.encode_entry(1, (2, 3), 0, 0, 24, 0xCAFEF00D) == entry
+    assert tb.build_table([(b"", header), (key, entry)]) == out
+    assert tb.parse_table(out) == [(b"", header), (key, entry)]
+    d = tb.decode_entry(tb.parse_table(out)[1][1])
+    assert (d["dtype"], d["shape"], d["size"], d["crc32c"]) == (1, [2, 3], 24, 0xCAFEF00D)

@@ -57,13 +57,17 @@ def gemmt():
 
 
 def ablate(shapes=((4096, 4096, 4096), (8192, 8192, 8192), (25600, 10000, 512), (200704, 256, 2304), (12544, 512, 4608))):
+    import ctypes
+    mb_path = os.path.join(os.path.dirname(abi.LIB_PATH), "libvaecap_microbench.so")  # make -C vae_captioning_amd/csrc microbench
+    mb = ctypes.CDLL(mb_path)
+    mb.vc_debug_gemm_ablate_f32.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     names = {0: "full", 8: "double-buffered", 2: "no lds-store/barrier", 7: "mfma only"}
     for (M, N, K) in shapes:
         M, N = M // 128 * 128, N // 128 * 128
         A, B, C = rnd(M, K), rnd(K, N), torch.empty(M, N, device="cuda")
         ref = None
         for v, nm in names.items():
-            med, mn = timeit(lambda: lib.vc_debug_gemm_ablate_f32(st(), v, M, N, K, P(A), P(B), P(C)))
+            med, mn = timeit(lambda: mb.vc_debug_gemm_ablate_f32(st(), v, M, N, K, P(A), P(B), P(C)))
             chk = ""
             if v == 0:
                 ref = C.clone()

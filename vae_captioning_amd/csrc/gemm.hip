@@ -5,6 +5,9 @@
 #include <type_traits>
 #include "gemm_core.h"
 #include "vaecap.h"
+#ifdef VC_MICROBENCH
+#include "vaecap_microbench.h"
+#endif
 
 namespace vc {
 
@@ -39,8 +42,11 @@ __global__ __launch_bounds__(CFG::NT) void gemm_kernel(GemmArgs g) {
     la.p = g.A; la.ld = g.lda; la.R = g.M; la.K = g.K;
     typename std::conditional<BMD == MODE_MK, LoadMK<VEC>, LoadKM<VEC>>::type lb;
     lb.p = g.B; lb.ld = g.ldb; lb.R = g.N; lb.K = g.K;
+#ifdef VC_MICROBENCH  // ablation variants exist only in the microbenchmark build (make microbench), never in libvaecap.so
     if (ABL == 8) mfma_mainloop_db<CFG, AM, BMD>(acc, la, lb, m0, n0, kb, ke, smem);
-    else mfma_mainloop<CFG, AM, BMD, decltype(la), decltype(lb), ABL>(acc, la, lb, m0, n0, kb, ke, smem);
+    else
+#endif
+    mfma_mainloop<CFG, AM, BMD, decltype(la), decltype(lb), ABL>(acc, la, lb, m0, n0, kb, ke, smem);
     const bool split = g.splits > 1;
     float* out = split ? g.ws + ((long)blockIdx.y * g.ws_rows - g.ws_row0) * g.N : g.C;
     const long ldo = split ? g.N : g.ldc;
@@ -302,8 +308,9 @@ extern "C" int vc_gemm_f32(void* stream, int ta, int tb, int M, int N, int K, co
     return 0;
 }
 
-// Benchmark-only entry (tools/microbench.py): the NN 128x128 kernel with parts of its main loop
-// ablated (results are then meaningless); variant 0 == vc_gemm_f32's kernel for aligned NN operands.
+#ifdef VC_MICROBENCH
+// Benchmark-only entry (tools/microbench.py ablate, built by `make microbench` into libvaecap_microbench.so): the NN 128x128
+// kernel with parts of its main loop ablated (results are then meaningless); variant 0 == vc_gemm_f32's kernel for aligned NN operands.
 extern "C" int vc_debug_gemm_ablate_f32(void* stream, int variant, int M, int N, int K, const float* A, const float* B, float* C) {
     using namespace vc;
     VC_CHECK_ARG(A && B && C && M % 128 == 0 && N % 128 == 0 && K % 32 == 0, "debug entry: multiples of 128/128/32 only");
@@ -325,3 +332,4 @@ extern "C" int vc_debug_gemm_ablate_f32(void* stream, int variant, int M, int N,
     VC_LAUNCH_CHECK();
     return 0;
 }
+#endif  // VC_MICROBENCH

@@ -235,6 +235,7 @@ __device__ __forceinline__ void mfma_mainloop(f32x16 (&acc)[CFG::TM][CFG::TN], A
     }
 }
 
+#ifdef VC_MICROBENCH  // measured and not adopted; kept for tools/microbench.py ablate only
 // Double-buffered variant: ONE barrier per K-tile.  Tile t is consumed from LDS buffer t&1 while the
 // global loads of tile t+1 are in flight; they are written to the other buffer after the MFMAs.
 // (A wave can only reach the store of iteration t after every wave passed the barrier of iteration
@@ -323,6 +324,8 @@ __device__ __forceinline__ void mfma_mainloop_db(f32x16 (&acc)[CFG::TM][CFG::TN]
         cur ^= 1;
     }
 }
+
+#endif  // VC_MICROBENCH
 
 template <class CFG>
 __device__ __forceinline__ void acc_zero(f32x16 (&acc)[CFG::TM][CFG::TN]) {
