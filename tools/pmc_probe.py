@@ -1,5 +1,6 @@
 """Workload for SQ-counter probes (rocprofv3 --pmc ...): conv3_2-shaped forward / data gradient / weight gradient at
-64 images and the 8192^3 GEMM, three launches each.  Summarise with tools/pmc_probe_summary.py."""
+64 images -- the implicit-GEMM kernels of conv.hip and the patch-staged kernels of conv_patch.hip -- the conv4_2-shaped FLAT weight
+gradient and the 8192^3 GEMM, three launches each.  Summarise with tools/pmc_probe_summary.py."""
 import os
 import sys
 
@@ -19,7 +20,16 @@ y = torch.empty(B, H, H, co, device="cuda")
 dy = torch.rand(B, H, H, co, device="cuda") * 2 - 1
 dx = torch.empty(B, H, H, ci, device="cuda")
 dw = torch.empty(3, 3, ci, co, device="cuda")
-ws = torch.empty(lib.vc_conv3x3_wgrad_workspace_bytes(B, H, H, ci, co) // 4 + 4, device="cuda")
+ws = torch.empty(max(lib.vc_conv3x3_wgrad_workspace_bytes(B, H, H, ci, co), lib.vc_conv3x3_wgrad_patch_workspace_bytes(B, H, H, ci, co),
+                     lib.vc_conv3x3_wgrad_patch_workspace_bytes(B, 28, 28, 512, 512)) // 4 + 4, device="cuda")
+wp, wpt = torch.empty(9 * ci * co, device="cuda"), torch.empty(9 * ci * co, device="cuda")
+lib.vc_conv3x3_pack_f32(st(), ci, co, P(w), 0, P(wp))
+lib.vc_conv3x3_pack_f32(st(), ci, co, P(w), 1, P(wpt))
+tw = torch.empty(max(lib.vc_conv3x3_packed_workspace_bytes(B, H, H, ci, co, 0), 16) // 4 + 4, device="cuda")
+# conv4_2 shape for the FLAT weight-gradient kernel
+x4 = torch.rand(B, 28, 28, 512, device="cuda") * 2 - 1
+dy4 = torch.rand(B, 28, 28, 512, device="cuda") * 2 - 1
+dw4 = torch.empty(3, 3, 512, 512, device="cuda")
 A = torch.rand(8192, 8192, device="cuda") * 2 - 1
 Bm = torch.rand(8192, 8192, device="cuda") * 2 - 1
 C = torch.empty(8192, 8192, device="cuda")
@@ -27,5 +37,9 @@ for _ in range(3):
     lib.vc_conv3x3_fwd_f32(st(), B, H, H, ci, co, P(x), P(w), P(bias), P(y), 1, None, 0)
     lib.vc_conv3x3_dgrad_f32(st(), B, H, H, ci, co, P(dy), P(w), P(x), P(dx), None, 0)
     lib.vc_conv3x3_wgrad_f32(st(), B, H, H, ci, co, P(x), P(dy), P(dw), None, 0, P(ws), ws.numel() * 4)
+    lib.vc_conv3x3_fwd_packed_f32(st(), B, H, H, ci, co, P(x), P(wp), P(bias), P(y), 1, P(tw), tw.numel() * 4)
+    lib.vc_conv3x3_dgrad_packed_f32(st(), B, H, H, ci, co, P(dy), P(wpt), P(x), P(dx), P(tw), tw.numel() * 4)
+    lib.vc_conv3x3_wgrad_patch_f32(st(), B, H, H, ci, co, P(x), P(dy), P(dw), None, 0, P(ws), ws.numel() * 4)
+    lib.vc_conv3x3_wgrad_patch_f32(st(), B, 28, 28, 512, 512, P(x4), P(dy4), P(dw4), None, 0, P(ws), ws.numel() * 4)
     lib.vc_gemm_f32(st(), 0, 0, 8192, 8192, 8192, P(A), 8192, P(Bm), 8192, P(C), 8192, None, 0, None, 0)
 torch.cuda.synchronize()
