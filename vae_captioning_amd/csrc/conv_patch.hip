@@ -18,6 +18,7 @@
 //          the 224 / 112 / 56 layers); sub-tiles are image-local, so pooling windows never straddle a tile;
 //   FLAT : 128 consecutive pixels of the flattened [B*H*W] order; the patch is every image row the range touches
 //          +-1, row pitch W + 2, with one zero row between two images (the 28 / 14 layers).
+#include <stdlib.h>
 #include "gemm_core.h"
 #include "vaecap.h"
 
@@ -358,6 +359,25 @@ struct PatchPlan {
     int tiles_m, tiles_n;
 };
 
+constexpr int PATCH_CUS = 256;
+
+// Estimated time of a launch of T tiles of nch 32-channel chunks, in units of one chunk of ONE tile (see the measurements at
+// plan_patch_tail): whole rounds of one tile per CU + the cheapest way to run the remaining tiles (unsplit, or their chunk range
+// split into `cps`-chunk pieces that cover all CUs again + partial-sum traffic + one more launch).
+static double patch_launch_cost(int T, int nch, int* cps_out) {
+    const int tail = T % PATCH_CUS;
+    double best = tail ? nch + 0.2 : 0.0;
+    int best_cps = nch;
+    if (tail && nch >= 2)
+        for (int cps = 1; cps < nch; ++cps) {
+            const int splits = cdiv(nch, cps);
+            const double cost = cdiv((long)tail * splits, PATCH_CUS) * (cps + 0.2) + 0.002 * splits * tail + 0.6;
+            if (cost < best - 1e-9) { best = cost; best_cps = cps; }
+        }
+    if (cps_out) *cps_out = best_cps;
+    return (T / PATCH_CUS) * (nch + 0.2) + best;
+}
+
 static PatchPlan plan_patch(int B, int H, int W, int C, int N) {
     PatchPlan p;
     p.scheme = -1;
@@ -382,7 +402,20 @@ static PatchPlan plan_patch(int B, int H, int W, int C, int N) {
         p.scheme = PATCH_FLAT;
         p.tiles_m = cdiv(g.P, 128);
     }
+    // 128 x 128 or 128 x 64 tiles: both run at the same steady-state rate once a tile has >= 4 chunks (measured: conv4_2 146.3 vs
+    // 146.8 TFLOP/s), so the narrower tile is taken whenever its finer launch quantum wastes less of the last round (conv5_x at 64
+    // images: 392 wide tiles = 1.53 per CU -> 126 TFLOP/s; 784 narrow tiles = 3 rounds + a 16-tile split tail -> 141).  A chunk of
+    // a wide tile costs two units.  With C = 64 (two chunks per tile) the wide tile's fewer prologues win.
     p.TN = N % 128 == 0 ? 2 : 1;
+    if (p.TN == 2 && C >= 128) {
+        const double wide = 2.0 * patch_launch_cost(p.tiles_m * (N / 128), C / 32, nullptr);
+        const double narrow = patch_launch_cost(p.tiles_m * (N / 64), C / 32, nullptr);
+        if (narrow < wide - 1e-9) p.TN = 1;
+    }
+    if (const char* e = getenv("VC_PATCH_TN")) {  // experiments only (tools/microbench.py)
+        if (atoi(e) == 1) p.TN = 1;
+        if (atoi(e) == 2 && N % 128 == 0) p.TN = 2;
+    }
     p.tiles_n = N / (p.TN * 64);
     return p;
 }
@@ -394,8 +427,6 @@ static PatchPlan plan_patch(int B, int H, int W, int C, int N) {
 // floor(T / 256) * 256 tiles; the remaining tiles run as a second launch whose K range (the 32-channel chunks) is split
 // so that the short workgroups again cover all 256 CUs evenly, and patch_tail_reduce_kernel sums the splits in fixed
 // order and applies the epilogue.  The split is chosen by the cost model below (unit: the time of one chunk).
-constexpr int PATCH_CUS = 256;
-
 struct PatchTail {
     int main_tiles, tail_tiles, splits, cps;
 };
@@ -406,18 +437,11 @@ static PatchTail plan_patch_tail(const PatchPlan& p) {
     const int nch = p.g.C / 32;
     const int tail = T % PATCH_CUS;
     t.main_tiles = T; t.tail_tiles = 0; t.splits = 1; t.cps = nch;
-    if (tail == 0 || nch < 2) return t;
-    // cost(cps) = rounds of short workgroups x (chunks each + prologue / epilogue) + partial-sum traffic + one more launch
-    double best = nch + 0.2;  // unsplit: one tile on `tail` CUs
-    int best_cps = nch;
-    for (int cps = 1; cps < nch; ++cps) {
-        const int splits = cdiv(nch, cps);
-        const double cost = cdiv((long)tail * splits, PATCH_CUS) * (cps + 0.2) + 0.002 * splits * tail + 0.6;
-        if (cost < best - 1e-9) { best = cost; best_cps = cps; }
-    }
-    if (best_cps == nch) return t;
-    t.cps = best_cps;
-    t.splits = cdiv(nch, best_cps);
+    int cps = nch;
+    patch_launch_cost(T, nch, &cps);
+    if (tail == 0 || cps == nch) return t;
+    t.cps = cps;
+    t.splits = cdiv(nch, cps);
     t.main_tiles = T - tail;
     t.tail_tiles = tail;
     return t;
