@@ -241,6 +241,10 @@ size_t vc_conv3x3_packed_workspace_bytes(int B, int H, int W, int Cin, int Cout,
 int vc_conv3x3_pack_f32(void* stream, int Cin, int Cout, const float* w, int transpose, float* wp);
 int vc_conv3x3_fwd_packed_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const float* wp,
                               const float* bias, float* y, int relu, float* ws, size_t ws_bytes);
+/* forward with the 2x2 / stride 2 max-pool fused into the epilogue: writes y AND ypool = max_pool2x2(y) [B, H/2, W/2, Cout] (the
+ * 4 x 8 sub-tile tiling only: W % 8 == 0, H % 4 == 0; a pooling window never straddles a tile) */
+int vc_conv3x3_fwd_pool_packed_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const float* wp,
+                                   const float* bias, float* y, float* ypool, int relu, float* ws, size_t ws_bytes);
 int vc_conv3x3_dgrad_packed_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* dy, const float* wpt,
                                 const float* relu_src, float* dx, float* ws, size_t ws_bytes);
 /* Patch-staged weight gradient: a workgroup owns 64 input channels x all nine taps x 64 output channels and stages the

@@ -169,3 +169,32 @@ def test_patch_wgrad_unsupported_shapes(lib):
     assert lib.vc_conv3x3_wgrad_patch_supported(2, 28, 28, 256, 64) == 0    # FLAT kernels: 128 output channels per workgroup
     assert lib.vc_conv3x3_wgrad_patch_supported(2, 224, 224, 4, 64) == 0    # conv1_1
     assert lib.vc_conv3x3_wgrad_patch_supported(2, 56, 56, 96, 64) == 0     # Cin % 64
+
+
+@pytest.mark.parametrize("case", [(2, 8, 16, 32, 64), (3, 12, 8, 64, 128), (4, 224, 224, 64, 64), (3, 112, 112, 128, 128), (5, 56, 56, 256, 256),
+                                  (7, 56, 56, 128, 256)], ids=lambda c: "x".join(map(str, c)))
+def test_fused_maxpool_epilogue_equals_separate_pool(lib, case):
+    """vc_conv3x3_fwd_pool_packed_f32 writes y and max_pool2x2(y): both bit-identical to the unfused pair (the max of the raw
+    sums + bias + ReLU equals the max of the finished activations: bias add and ReLU are monotone), with and without the
+    K-split tail launch (whose reduce kernel pools as well)."""
+    B, H, W, Ci, Co = case
+    rng = np.random.default_rng(B + H)
+    x = torch.from_numpy(np.maximum(rng.standard_normal((B, H, W, Ci), dtype=np.float32), 0)).cuda()
+    w = torch.from_numpy(rng.standard_normal((3, 3, Ci, Co), dtype=np.float32) * np.float32(1 / np.sqrt(9 * Ci))).cuda()
+    b = torch.from_numpy(rng.standard_normal(Co, dtype=np.float32)).cuda()
+    wp = _pack(lib, w, 0)
+    nb = lib.vc_conv3x3_packed_workspace_bytes(B, H, W, Ci, Co, 0)
+    ws = empty_bytes(nb)
+    for use_ws in ([False, True] if nb > 0 else [False]):
+        wsp, wsb = (P(ws), ws.numel() * 4) if use_ws else (None, 0)
+        y0, y1 = zeros(B, H, W, Co), zeros(B, H, W, Co)
+        p0, p1 = zeros(B, H // 2, W // 2, Co), torch.full((B, H // 2, W // 2, Co), -7.0, device="cuda")
+        lib.vc_conv3x3_fwd_packed_f32(stream(), B, H, W, Ci, Co, P(x), P(wp), P(b), P(y0), 1, wsp, wsb)
+        lib.vc_maxpool2x2_fwd_f32(stream(), B, H, W, Co, P(y0), P(p0))
+        lib.vc_conv3x3_fwd_pool_packed_f32(stream(), B, H, W, Ci, Co, P(x), P(wp), P(b), P(y1), P(p1), 1, wsp, wsb)
+        assert torch.equal(y0, y1)
+        assert torch.equal(p0, p1), (use_ws, float((p0 - p1).abs().max()))
+    from vae_captioning_amd.abi import VaecapError
+    with pytest.raises(VaecapError):  # FLAT tiling: no fused pool
+        lib.vc_conv3x3_fwd_pool_packed_f32(stream(), 2, 14, 14, 32, 64, P(zeros(2, 14, 14, 32)), P(zeros(9 * 32 * 64)), None, P(zeros(2, 14, 14, 64)),
+                                           P(zeros(2, 7, 7, 64)), 1, None, 0)

@@ -52,6 +52,7 @@ struct PatchArgs {
     // K-split tail launch (blockIdx.y = split): chunk range of a split and the raw partial sums [split][tail tile][128][BN]
     int chunks_per_split;
     float* tail_ws;
+    float* pool;       // forward, SUB tiling only: also write max_pool2x2(out) [B, H/2, W/2, N] (null: no pooling)
 };
 
 // ---- tile geometry ------------------------------------------------------------------------------
@@ -142,8 +143,8 @@ struct PatchLds {
     }
 };
 
-template <int TN, int SCHEME, int KIND>
-__global__ __launch_bounds__(256, 2) void conv_patch_kernel(PatchArgs a) {
+template <int TN, int SCHEME, int KIND, bool POOL = false>
+__global__ __launch_bounds__(256, (POOL && TN == 1) ? 3 : 2) void conv_patch_kernel(PatchArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using CFG = PatchCfg<TN>;
     constexpr int NVP = PatchLds<SCHEME>::NVP;
@@ -287,6 +288,31 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(PatchArgs a) {
             if (!(m.w > 0.f)) v.w = 0.f;
         }
         *reinterpret_cast<float4*>(a.out + p * N + col) = v;
+    }, [&](int tm, const float* T, int LD) {
+        // fused 2x2 / stride 2 max-pool (utils/image_embeddings.py:59-63 ...): the 32 rows of the strip are one 4 x 8 sub-tile, i.e.
+        // eight complete pooling windows per column; max commutes with the bias add and the ReLU (both monotone)
+        if (!POOL) return;
+        constexpr int QPR = TN * 8;
+        const int sub_row0 = (wm * 2 + tm) * 32;
+        for (int it = lane; it < 8 * QPR; it += 64) {
+            const int pq = it / QPR, cq = it - pq * QPR;
+            const int r0 = (pq >> 2) * 16 + (pq & 3) * 2;  // window rows r0, r0+1 (x+1), r0+8 (y+1), r0+9
+            const long p = map.out_pixel(sub_row0 + r0);
+            if (p < 0) continue;
+            const float4 q0 = *reinterpret_cast<const float4*>(&T[r0 * LD + cq * 4]), q1 = *reinterpret_cast<const float4*>(&T[(r0 + 1) * LD + cq * 4]);
+            const float4 q2 = *reinterpret_cast<const float4*>(&T[(r0 + 8) * LD + cq * 4]), q3 = *reinterpret_cast<const float4*>(&T[(r0 + 9) * LD + cq * 4]);
+            float4 v = make_float4(fmaxf(fmaxf(q0.x, q1.x), fmaxf(q2.x, q3.x)), fmaxf(fmaxf(q0.y, q1.y), fmaxf(q2.y, q3.y)),
+                                   fmaxf(fmaxf(q0.z, q1.z), fmaxf(q2.z, q3.z)), fmaxf(fmaxf(q0.w, q1.w), fmaxf(q2.w, q3.w)));
+            const int col = n0 + wn * TN * 32 + cq * 4;
+            if (a.aux) {
+                const float4 bv = *reinterpret_cast<const float4*>(a.aux + col);
+                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+            }
+            if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            const long prow = p / g.W;                       // b*H + y with y even (and H even): the pooled row is prow / 2
+            const int px = (int)(p - prow * g.W) >> 1;
+            *reinterpret_cast<float4*>(a.pool + ((prow >> 1) * (g.W >> 1) + px) * N + col) = v;
+        }
     });
 }
 
@@ -326,6 +352,25 @@ __global__ __launch_bounds__(256) void patch_tail_reduce_kernel(PatchArgs a, int
             if (!(m.w > 0.f)) v.w = 0.f;
         }
         *reinterpret_cast<float4*>(a.out + p * g.N + col) = v;
+        if (KIND == PK_FWD && SCHEME == PATCH_SUB && a.pool && !(r & 1) && !(r & 8)) {  // top-left pixel of a pooling window
+            // raw sums of the three other pixels of the window: rows r+1, r+8, r+9 of the same tile
+            float4 m = ws[i];
+            for (int z = 1; z < splits; ++z) { const float4 t = ws[(long)z * per_split + i]; m.x += t.x; m.y += t.y; m.z += t.z; m.w += t.w; }
+            const long offs[3] = {(long)qpr, 8L * qpr, 9L * qpr};
+            for (int k = 0; k < 3; ++k) {
+                float4 s = ws[i + offs[k]];
+                for (int z = 1; z < splits; ++z) { const float4 t = ws[(long)z * per_split + i + offs[k]]; s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w; }
+                m.x = fmaxf(m.x, s.x); m.y = fmaxf(m.y, s.y); m.z = fmaxf(m.z, s.z); m.w = fmaxf(m.w, s.w);
+            }
+            if (a.aux) {
+                const float4 bv = *reinterpret_cast<const float4*>(a.aux + col);
+                m.x += bv.x; m.y += bv.y; m.z += bv.z; m.w += bv.w;
+            }
+            if (a.relu) { m.x = fmaxf(m.x, 0.f); m.y = fmaxf(m.y, 0.f); m.z = fmaxf(m.z, 0.f); m.w = fmaxf(m.w, 0.f); }
+            const long prow = p / g.W;
+            const int px = (int)(p - prow * g.W) >> 1;
+            *reinterpret_cast<float4*>(a.pool + ((prow >> 1) * (g.W >> 1) + px) * g.N + col) = m;
+        }
     }
 }
 
@@ -453,7 +498,7 @@ static size_t patch_workspace(const PatchPlan& p) {
     return t.tail_tiles ? (size_t)t.splits * t.tail_tiles * 128 * (p.TN * 64) * sizeof(float) : 0;
 }
 
-template <int TN, int SCHEME, int KIND>
+template <int TN, int SCHEME, int KIND, bool POOL = false>
 static int launch_patch(hipStream_t st, const PatchPlan& p, PatchArgs& a, float* ws, size_t ws_bytes) {
     const PatchTail t = plan_patch_tail(p);
     constexpr int smem = PatchLds<SCHEME>::template bytes<TN>();
@@ -463,12 +508,12 @@ static int launch_patch(hipStream_t st, const PatchPlan& p, PatchArgs& a, float*
     const size_t need = (size_t)t.splits * t.tail_tiles * 128 * (TN * 64) * sizeof(float);
     if (t.tail_tiles == 0 || !ws || ws_bytes < need) {
         a.ntiles = p.tiles_m * p.tiles_n;
-        hipLaunchKernelGGL((conv_patch_kernel<TN, SCHEME, KIND>), dim3(a.ntiles, 1), dim3(256), smem, st, a);
+        hipLaunchKernelGGL((conv_patch_kernel<TN, SCHEME, KIND, POOL>), dim3(a.ntiles, 1), dim3(256), smem, st, a);
         return launch_status("conv patch");
     }
     if (t.main_tiles > 0) {
         a.ntiles = t.main_tiles;
-        hipLaunchKernelGGL((conv_patch_kernel<TN, SCHEME, KIND>), dim3(a.ntiles, 1), dim3(256), smem, st, a);
+        hipLaunchKernelGGL((conv_patch_kernel<TN, SCHEME, KIND, POOL>), dim3(a.ntiles, 1), dim3(256), smem, st, a);
         if (int e = launch_status("conv patch")) return e;
     }
     PatchArgs d = a;
@@ -484,6 +529,8 @@ static int launch_patch(hipStream_t st, const PatchPlan& p, PatchArgs& a, float*
 
 template <int KIND>
 static int dispatch_patch(hipStream_t st, const PatchPlan& p, PatchArgs& a, float* ws, size_t ws_bytes) {
+    if (KIND == PK_FWD && a.pool)  // fused 2x2 max-pool: 4 x 8 sub-tile tiling only (checked by the caller)
+        return p.TN == 2 ? launch_patch<2, PATCH_SUB, PK_FWD, true>(st, p, a, ws, ws_bytes) : launch_patch<1, PATCH_SUB, PK_FWD, true>(st, p, a, ws, ws_bytes);
     if (p.scheme == PATCH_SUB)
         return p.TN == 2 ? launch_patch<2, PATCH_SUB, KIND>(st, p, a, ws, ws_bytes) : launch_patch<1, PATCH_SUB, KIND>(st, p, a, ws, ws_bytes);
     return p.TN == 2 ? launch_patch<2, PATCH_FLAT, KIND>(st, p, a, ws, ws_bytes) : launch_patch<1, PATCH_FLAT, KIND>(st, p, a, ws, ws_bytes);
@@ -826,7 +873,9 @@ static WgradPatchPlan plan_wgrad_patch(int B, int H, int W, int Cin, int Cout) {
     } else {
         return p;
     }
-    long splits = 512 / p.tiles;             // two workgroups per CU
+    long slots = 512;                        // two workgroups per CU
+    if (const char* e = getenv("VC_WGRAD_SLOTS")) slots = atol(e) > 0 ? atol(e) : 512;  // experiments only
+    long splits = slots / p.tiles;
     if (splits > 256) splits = 256;          // (bounds the partial-sum traffic of the few-tile layers)
     if (splits > p.nsubs / 8) splits = p.nsubs / 8;  // >= 8 K-tiles per split
     if (splits < 1) splits = 1;
@@ -865,7 +914,17 @@ extern "C" int vc_conv3x3_fwd_packed_f32(void* stream, int B, int H, int W, int 
     const PatchPlan p = plan_patch(B, H, W, Cin, Cout);
     if (p.scheme < 0) return fail(VC_EINVAL, "%s: shape not supported by the patch kernel (vc_conv3x3_patch_supported)", __func__);
     PatchArgs a;
-    a.g = p.g; a.x = x; a.wp = wp; a.out = y; a.aux = bias; a.relu = relu;
+    a.g = p.g; a.x = x; a.wp = wp; a.out = y; a.aux = bias; a.relu = relu; a.pool = nullptr;
+    return dispatch_patch<PK_FWD>((hipStream_t)stream, p, a, ws, ws_bytes);
+}
+
+extern "C" int vc_conv3x3_fwd_pool_packed_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const float* wp,
+                                              const float* bias, float* y, float* ypool, int relu, float* ws, size_t ws_bytes) {
+    VC_CHECK_ARG(x && wp && y && ypool, "null pointer");
+    const PatchPlan p = plan_patch(B, H, W, Cin, Cout);
+    if (p.scheme != PATCH_SUB) return fail(VC_EINVAL, "%s: the fused max-pool needs the 4 x 8 sub-tile tiling (W %% 8 == 0, H %% 4 == 0, Cin %% 32 == 0, Cout %% 64 == 0)", __func__);
+    PatchArgs a;
+    a.g = p.g; a.x = x; a.wp = wp; a.out = y; a.aux = bias; a.relu = relu; a.pool = ypool;
     return dispatch_patch<PK_FWD>((hipStream_t)stream, p, a, ws, ws_bytes);
 }
 
@@ -875,7 +934,7 @@ extern "C" int vc_conv3x3_dgrad_packed_f32(void* stream, int B, int H, int W, in
     const PatchPlan p = plan_patch(B, H, W, Cout, Cin);
     if (p.scheme < 0) return fail(VC_EINVAL, "%s: shape not supported by the patch kernel (vc_conv3x3_patch_supported)", __func__);
     PatchArgs a;
-    a.g = p.g; a.x = dy; a.wp = wpt; a.out = dx; a.aux = relu_src; a.relu = 0;
+    a.g = p.g; a.x = dy; a.wp = wpt; a.out = dx; a.aux = relu_src; a.relu = 0; a.pool = nullptr;
     return dispatch_patch<PK_DGRAD>((hipStream_t)stream, p, a, ws, ws_bytes);
 }
 

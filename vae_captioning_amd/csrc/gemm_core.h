@@ -362,8 +362,14 @@ struct AccCoord {
 // f(row, col, v): row / col relative to the workgroup tile, col % 4 == 0, v = 4 consecutive columns.
 // Must be called by all threads (contains __syncthreads); smem is reused (>= WM*WN*32*(TN*32+4) floats).
 // ---------------------------------------------------------------------------
-template <class CFG, class F>
-__device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[CFG::TM][CFG::TN], float* smem, F f) {
+struct NoStripHook {
+    __device__ __forceinline__ void operator()(int, const float*, int) const {}
+};
+// g(tm, strip, LD): optional hook called by every lane after tile row-block tm of its wave has been written to the wave's LDS
+// strip (32 rows x TN*32 columns, row pitch LD floats) and streamed out through f -- lets a kernel derive a second output from
+// the whole 32-row block (conv_patch.hip: the fused 2x2 max-pool).
+template <class CFG, class F, class G = NoStripHook>
+__device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[CFG::TM][CFG::TN], float* smem, F f, G g = G()) {
     constexpr int TM = CFG::TM, TN = CFG::TN;
     constexpr int LD = TN * 32 + 4;        // floats per staged row (16-B aligned, rows 4 banks apart)
     constexpr int QPR = TN * 8;            // float4 per row
@@ -387,6 +393,7 @@ __device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[CFG::TM][CFG::TN], f
             const float4 v = *reinterpret_cast<const float4*>(&T[row * LD + cq * 4]);
             f((wm * TM + tm) * 32 + row, wn * TN * 32 + cq * 4, v);
         }
+        g(tm, T, LD);
         __syncthreads();
     }
 }

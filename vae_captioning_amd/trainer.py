@@ -201,6 +201,11 @@ class VggEngine(object):
                             torch.cuda.current_stream().wait_event(packed)
                             waited.add(ch)
                         wp = self.buf["wp_" + name]
+                        if pooled and W % 8 == 0 and H % 4 == 0:  # 2x2 max-pool fused into the epilogue (4 x 8 sub-tile tiling)
+                            self._timed("conv_fwd", 2.0 * nb * H * W * 9 * ci * co,
+                                        lambda: lib.vc_conv3x3_fwd_pool_packed_f32(sh, nb, H, W, cie, co, P(x[b0:]), P(wp), P(S.param(bn)), P(y[b0:]),
+                                                                                   P(yp[b0:]), 1, P(tws), tws.numel() * 4))
+                            continue
                         self._timed("conv_fwd", 2.0 * nb * H * W * 9 * ci * co,
                                     lambda: lib.vc_conv3x3_fwd_packed_f32(sh, nb, H, W, cie, co, P(x[b0:]), P(wp), P(S.param(bn)), P(y[b0:]), 1,
                                                                           P(tws), tws.numel() * 4))
