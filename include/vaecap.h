@@ -87,10 +87,12 @@ int vc_lstm_step_fwd_f32(void* stream, int N, int H, int t, const float* h_prev,
 int vc_lstm_step_bwd_f32(void* stream, int N, int H, int t, int first, const float* dG_next, const float* Wh,
                          const int32_t* lens_eff, const float* dh_ext, float* dH_run, float* dC_run, const float* act,
                          const float* c_prev, const float* c_cur, float* dG);
-/* Sequence drivers, process-wide switch for A/B measurements (identical arithmetic up to fp32 summation order):
- * 2 (default) = auto: the wide fused forward step kernel (8 waves split K, operands straight to registers, gates in the
- * epilogue) for N <= 640 rows when H % 512 == 0, otherwise 1; 1 = recurrent GEMM via vc_gemm_f32 (split-K) + element-wise
- * gate kernels; 3 = wide fused kernels for forward AND backward wherever supported; 0 = the round-1 fused step kernels. */
+/* Sequence drivers, process-wide switch for A/B measurements (identical arithmetic up to fp32 summation order and, in the
+ * recurrence kernels, sigmoid / tanh built from v_exp_f32 + v_rcp_f32, |error| < 3e-7):
+ * 2 (default) = auto: the register-operand recurrence step kernels (one workgroup per CU, four waves split K, Wh slice packed
+ * in MFMA-operand order, 16x16x4 tiles, gate math in the epilogue) when H == 512 -- forward up to 640 rows, backward any N --
+ * otherwise 1; 1 = recurrent GEMM via vc_gemm_f32 (split-K) + element-wise gate kernels; 3 = recurrence kernels wherever
+ * supported; 0 = the round-1 fused step kernels. */
 int vc_lstm_set_mode(int split);
 size_t vc_lstm_seq_workspace_bytes(int T, int N, int E, int H);
 int vc_lstm_seq_fwd_f32(void* stream, int T, int N, int E, int H, const float* X, const float* W, const float* b,

@@ -116,19 +116,31 @@ def _lstm_case(T, N, E, H, seed, full_len=False):
 
 @pytest.mark.parametrize("dims", [(6, 70, 32, 64, False), (4, 700, 48, 96, False), (3, 1280, 256, 512, True), (5, 330, 64, 512, True),
                                   (4, 650, 32, 1024, True)],
-                         ids=["small", "mid-128rows", "cfg2-shape", "cfg4-rows-ragged-wide-kernels", "H1024-wide-kernels"])
+                         ids=["small", "mid-128rows", "cfg2-shape", "cfg4-rows-ragged", "H1024"])
 def test_lstm_seq_fwd_bwd(lib, dims):
     T, N, E, H, full = dims
-    lib.vc_lstm_set_mode(3 if H % 512 == 0 else 2)  # 3: the wide fused kernels for forward AND backward (auto uses only the forward one)
+    lib.vc_lstm_set_mode(2)  # auto: the recurrence kernels at H = 512 (forward up to 640 rows), the split form elsewhere
     try:
         _lstm_seq_check(lib, T, N, E, H)
     finally:
         lib.vc_lstm_set_mode(2)
 
 
+@pytest.mark.parametrize("dims", [(3, 320, 64, 512), (2, 1280, 32, 512), (4, 37, 32, 512), (3, 650, 48, 512), (2, 5, 16, 512), (3, 161, 16, 512)],
+                         ids=["cfg4-rows", "cfg2-rows-4-passes", "37-rows", "650-rows", "5-rows", "161-rows"])
+def test_lstm_recurrence_kernels(lib, dims):
+    """mode 3: the register-operand recurrence kernels (16x16x4 MFMA, K split over four waves) forward AND backward, on whole and
+    ragged row blocks, one and several passes per workgroup"""
+    lib.vc_lstm_set_mode(3)
+    try:
+        _lstm_seq_check(lib, *dims)
+    finally:
+        lib.vc_lstm_set_mode(2)
+
+
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_lstm_sequence_modes_agree_with_oracle(lib, mode):
-    """every driver mode (round-1 fused kernels, GEMM + gate kernels, auto) on the cfg4 row count at H = 512"""
+    """every other driver mode (round-1 fused kernels, GEMM + gate kernels, auto) on the cfg4 row count at H = 512"""
     lib.vc_lstm_set_mode(mode)
     try:
         _lstm_seq_check(lib, 3, 320, 64, 512)

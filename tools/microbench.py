@@ -161,24 +161,33 @@ def convw():
 
 
 def lstm():
-  for mode in (2, 1):
-    lib.vc_lstm_set_mode(mode)
-    print("lstm mode", mode, "(2 = wide fused step kernels, 1 = gemm + gate kernels, 0 = round-1 fused step kernels)")
-    for N in (160, 320, 1280):
-        H, E, T = 512, 256, 22
-        X, W, b = rnd(T, N, E), rnd(E + H, 4 * H) * 0.05, rnd(4 * H) * 0.1
-        lens = torch.full((N,), T, dtype=torch.int32, device="cuda")
-        act, cs, hs = torch.empty(T, N, 4 * H, device="cuda"), torch.zeros(T + 1, N, H, device="cuda"), torch.zeros(T + 1, N, H, device="cuda")
-        ws = torch.empty(lib.vc_lstm_seq_workspace_bytes(T, N, E, H) // 4 + 4, device="cuda")
-        med, _ = timeit(lambda: lib.vc_lstm_seq_fwd_f32(st(), T, N, E, H, P(X), P(W), P(b), P(lens), P(act), P(cs), P(hs), P(ws), ws.numel() * 4), reps=5)
-        fl = 2e-9 * T * N * (E + H) * 4 * H
-        print("lstm fwd seq N=%4d T=%d: %8.3f ms (%.1f us/step) %6.1f TFLOP/s" % (N, T, med, 1e3 * med / T, fl / med))
-        dhs = rnd(T + 1, N, H) * 0.1
-        dH, dC, dG = torch.zeros(N, H, device="cuda"), torch.zeros(N, H, device="cuda"), torch.empty(T, N, 4 * H, device="cuda")
-        dX, dW, db = torch.empty(T, N, E, device="cuda"), torch.empty(E + H, 4 * H, device="cuda"), torch.empty(4 * H, device="cuda")
-        med, _ = timeit(lambda: lib.vc_lstm_seq_bwd_f32(st(), T, N, E, H, P(X), P(W), P(lens), P(act), P(cs), P(hs), P(dhs), P(dH), P(dC), P(dG), P(dX), P(dW), P(db), P(ws), ws.numel() * 4), reps=5)
-        print("lstm bwd seq N=%4d T=%d: %8.3f ms (%.1f us/step) %6.1f TFLOP/s" % (N, T, med, 1e3 * med / T, 2 * fl / med))
-  lib.vc_lstm_set_mode(2)
+    """marginal cost of one recurrence step = (sequence of T=42) - (sequence of T=2), / 40: the input projection and the
+    weight-gradient GEMMs of the sequence drivers scale with T too, so they are timed separately with mode 1 and N fixed ... no:
+    they are linear in T as well; the recurrent step kernels are isolated by timing the SAME driver in two modes and reporting both."""
+    import os
+    modes = [int(m) for m in os.environ.get("VC_LSTM_MODES", "3,1").split(",")]
+    names = {3: "register-operand recurrence kernels", 2: "auto", 1: "gemm + gate kernels", 0: "round-1 fused step kernels"}
+    H, E = 512, 256
+    for N in (160, 320, 640, 1280):
+        res = {}
+        for mode in modes:
+            lib.vc_lstm_set_mode(mode)
+            t = {}
+            for T in (2, 42):
+                X, W, b = rnd(T, N, E), rnd(E + H, 4 * H) * 0.05, rnd(4 * H) * 0.1
+                lens = torch.full((N,), T, dtype=torch.int32, device="cuda")
+                act, cs, hs = torch.empty(T, N, 4 * H, device="cuda"), torch.zeros(T + 1, N, H, device="cuda"), torch.zeros(T + 1, N, H, device="cuda")
+                ws = torch.empty(lib.vc_lstm_seq_workspace_bytes(T, N, E, H) // 4 + 4, device="cuda")
+                f, _ = timeit(lambda: lib.vc_lstm_seq_fwd_f32(st(), T, N, E, H, P(X), P(W), P(b), P(lens), P(act), P(cs), P(hs), P(ws), ws.numel() * 4), reps=5)
+                dhs = rnd(T + 1, N, H) * 0.1
+                dH, dC, dG = torch.zeros(N, H, device="cuda"), torch.zeros(N, H, device="cuda"), torch.empty(T, N, 4 * H, device="cuda")
+                dX, dW, db = torch.empty(T, N, E, device="cuda"), torch.empty(E + H, 4 * H, device="cuda"), torch.empty(4 * H, device="cuda")
+                bw, _ = timeit(lambda: lib.vc_lstm_seq_bwd_f32(st(), T, N, E, H, P(X), P(W), P(lens), P(act), P(cs), P(hs), P(dhs), P(dH), P(dC), P(dG), P(dX), P(dW), P(db), P(ws), ws.numel() * 4), reps=5)
+                t[T] = (f, bw)
+            res[mode] = ((t[42][0] - t[2][0]) / 40 * 1e3, (t[42][1] - t[2][1]) / 40 * 1e3, t[42][0], t[42][1])
+            print("lstm N=%4d mode %d (%s): T=42 sequence fwd %.3f ms bwd %.3f ms; marginal per step (incl. its share of the T-linear GEMMs) fwd %.1f us bwd %.1f us"
+                  % (N, mode, names[mode], res[mode][2], res[mode][3], res[mode][0], res[mode][1]), flush=True)
+    lib.vc_lstm_set_mode(2)
 
 
 def mid():

@@ -210,14 +210,6 @@ __global__ __launch_bounds__(256) void lstm_gates_bwd_kernel(const float* __rest
     }
 }
 
-// ---- wide fused step kernels (default for H % 512 == 0) ----------------------------------------------------------------
-// One launch per time step, no LDS staging and no barrier in the contraction: a workgroup of EIGHT waves owns a
-// (TM*32 rows) x (16 hidden units x 4 gates) block of the step and splits K eight ways; every wave loads its A fragments
-// (rows of h_{t-1}, 64 contiguous bytes per lane) and B fragments (Wh pre-packed [k/4][4H][4], so that a lane's four
-// consecutive k of one gate column are ONE 16-byte load) straight into registers -- all of a wave's loads are in flight
-// before its first MFMA -- and the eight partial tiles meet in LDS, where the gate math runs on the (row, unit) pairs.
-// 320 workgroups at N = 320 (the split form needed a split-K GEMM launch + a gate launch per step: 23 / 35 us per
-// forward / backward step; the round-1 fused kernel had 50 workgroups of four waves marching through K = 512 serially).
 typedef unsigned int lstm_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 lbuf(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     lstm_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
@@ -225,223 +217,420 @@ __device__ __forceinline__ float4 lbuf(__amdgpu_buffer_rsrc_t r, unsigned voff, 
 }
 __device__ __forceinline__ float lcomp(const float4& v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
 
-// Wh [H, 4H] row-major -> [H/4][4H][4]
-__global__ __launch_bounds__(256) void lstm_pack_wh_kernel(const float* __restrict__ Wh, int H, float4* __restrict__ out) {
-    const long total = (long)(H >> 2) * 4 * H;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int col = (int)(i % (4 * H));
-        const long kq = i / (4 * H);
-        const float* s = Wh + kq * 4 * 4 * H + col;
+// ---- register-operand recurrence kernels (H = 512) ------------------------------------------------------------------------
+// One launch per time step, ONE workgroup per CU: workgroup (ug, rg) owns a narrow column slice of the step -- forward: 8 hidden
+// units x 4 gates = 32 gate columns, backward: 16 hidden units -- for a block of rows, and its four waves split K.  The slice of Wh
+// a wave needs is pre-packed in MFMA-operand order (one 16-byte load per lane and four k) and sits in registers: forward, the whole
+// [128 k x 32 columns] quarter stays resident for the launch (64 VGPRs); backward, [128 k x 16 units] blocks stream through a
+// two-slot register ring.  The other operand (rows of h_{t-1}, or of dG[t+1]) is the one with many bytes: each wave streams ITS K
+// range of 16-row tiles global -> registers (coalesced 512-byte row segments) -> a wave-private LDS tile -> MFMA fragments, software
+// pipelined one tile ahead, with no workgroup barrier in the contraction (DS operations of one wave execute in order).  Tiles are
+// 16 x 16 (v_mfma_f32_16x16x4_f32): 320 rows / 4 row groups = 80 rows = five whole tiles, where 32 x 32 tiles would pad to 96.
+// The four K-partial tiles meet in LDS (each wave re-uses its own staging area) and the gate math runs on (row, unit) pairs.
+//
+// k order inside a 128-deep block: lane group kq = lane >> 4 of the 16x16x4 operand layout takes floats kbase(kq) + 4 j + e
+// (j = 0..7 the 16-byte read, e its element), kbase = {0, 64, 32, 96}: the two lane groups a ds_read_b128 services together then
+// differ by 64 floats = the same banks, and the 16 rows (pitch 132 floats) spread over all 64 banks -> conflict-free fragment reads.
+__device__ __forceinline__ int rec_kbase(int kq) { return ((kq & 1) << 6) | ((kq >> 1) << 5); }
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// tools/probes/rec_trace.hip compiles this file with VC_REC_TRACE: wave 0.. of every workgroup stamps s_memtime at phase edges
+#ifdef VC_REC_TRACE
+__device__ unsigned long long* g_rec_trace = nullptr;  // [workgroups][4 waves][32 stamps]
+#define REC_STAMP(k)                                                                                                          \
+    do {                                                                                                                      \
+        if (g_rec_trace && (threadIdx.x & 63) == 0)                                                                           \
+            g_rec_trace[((blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)) * 32 + (k)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define REC_STAMP(k)
+#endif
+
+constexpr int REC_PITCH = 132;                       // floats per staged row (128 k + 4 pad)
+constexpr int REC_TILE = 16 * REC_PITCH;             // one 16-row tile
+constexpr int REC_LDS_BYTES = 4 * 2 * REC_TILE * 4;  // 4 waves x 2 tiles = 67 584 B
+
+// forward: out[(((ug*4 + w)*2 + ct)*8 + j)*64 + lane] = Wh[k .. k+3][col], k = 128 w + kbase(lane>>4) + 4 j,
+// col = gate*H + 8 ug + unit with (gate, unit) = ((16 ct + (lane&15)) >> 3, & 7)
+__global__ __launch_bounds__(256) void lstm_rec_pack_fwd_kernel(const float* __restrict__ Wh, int H, float4* __restrict__ out) {
+    const int total = (H / 8) * 4 * 2 * 8 * 64;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int lane = i & 63, j = (i >> 6) & 7, ct = (i >> 9) & 1, w = (i >> 10) & 3, ug = i >> 12;
+        const int lc = ct * 16 + (lane & 15);
+        const int col = (lc >> 3) * H + ug * 8 + (lc & 7);
+        const int k = 128 * w + rec_kbase(lane >> 4) + 4 * j;
+        const float* s = Wh + (long)k * 4 * H + col;
         out[i] = make_float4(s[0], s[4L * H], s[8L * H], s[12L * H]);
     }
 }
 
-template <int TM>
-__global__ __launch_bounds__(512, 1) void lstm_wide_fwd_kernel(LstmFwdArgs a, const float* __restrict__ whp) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];  // [8 waves][2][32 rows][32 cols] = 64 KB
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
-    const int m0 = blockIdx.x * (TM * 32), u0 = blockIdx.y * 16;
-    const int H = a.H, N = a.N;
-    const int KW = H >> 3;          // K range of a wave
-    const int kb0 = wave * KW;
-    const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc((void*)a.h_prev, 0, N * H * 4, 0x00020000);  // rows >= N read as 0
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)whp, 0, H * 4 * H * 4, 0x00020000);
-    // B: column of lane li in tile tn = gate (2 tn + (li >> 4)), unit u0 + (li & 15); k quad (kb0 + 32 b + 16 lh + 4 q) / 4
-    unsigned vb[2];
-#pragma unroll
-    for (int tn = 0; tn < 2; ++tn) vb[tn] = (unsigned)((((long)(kb0 >> 2) + 4 * lh) * 4 * H + (2 * tn + (li >> 4)) * H + u0 + (li & 15)) * 16);
-    unsigned va[TM];
-#pragma unroll
-    for (int t = 0; t < TM; ++t) va[t] = (unsigned)(((long)(m0 + t * 32 + li) * H + kb0 + 16 * lh) * 4);
-    constexpr int NB = 2;  // 32-deep K blocks per wave at H = 512 (KW = 64); general: KW / 32, handled by the loop below
-    f32x16 acc[TM][2];
-#pragma unroll
-    for (int t = 0; t < TM; ++t)
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
-    for (int kb = 0; kb < KW; kb += 32 * NB) {
-        float4 fa[NB][TM][4], fb[NB][2][4];
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-#pragma unroll
-            for (int t = 0; t < TM; ++t)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) fa[b][t][q] = lbuf(rh, va[t], (unsigned)((kb + 32 * b + 4 * q) * 4));
-#pragma unroll
-            for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) fb[b][tn][q] = lbuf(rw, vb[tn], (unsigned)(((kb + 32 * b) / 4 + q) * 4 * H * 16));
-        }
-        __builtin_amdgcn_sched_barrier(0);  // every load of the K range is in flight before the first MFMA
-#pragma unroll
-        for (int b = 0; b < NB; ++b)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int t = 0; t < TM; ++t)
-#pragma unroll
-                        for (int tn = 0; tn < 2; ++tn)
-                            acc[t][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(lcomp(fa[b][t][q], e), lcomp(fb[b][tn][q], e), acc[t][tn], 0, 0, 0);
-    }
-    // partial tiles -> LDS, one 32-row tile at a time (64 KB): red[wave][tn][row][col]; then the gate math on its (row, unit) pairs
-    float* red = smem + wave * 2048;
-#pragma unroll
-    for (int t = 0; t < TM; ++t) {
-    if (t) __syncthreads();
-#pragma unroll
-    for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) red[tn * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + li] = acc[t][tn][r];
-    __syncthreads();
-    {
-        const int p = tid;  // 32 rows x 16 units = 512 pairs = one per thread
-        const int r32 = p >> 4, un = p & 15;
-        const int row = m0 + t * 32 + r32;
-        if (row >= N) continue;
-        float g4[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float sum = 0.f;
-#pragma unroll
-            for (int w = 0; w < 8; ++w) sum += smem[w * 2048 + (g >> 1) * 1024 + r32 * 32 + (g & 1) * 16 + un];  // fixed order
-            g4[g] = sum;
-        }
-        const int u = u0 + un;
-        float* gp = a.gact + (long)row * 4 * H + u;
-        const float gi = g4[0] + gp[0], gj = g4[1] + gp[H], gf = g4[2] + gp[2 * H], go = g4[3] + gp[3 * H];
-        const float i = sigmoidf_(gi), j = tanhf(gj), f = sigmoidf_(gf + 1.0f), o = sigmoidf_(go);
-        const long si = (long)row * H + u;
-        const float cp = a.c_prev[si];
-        const float c = f * cp + i * j;
-        const float h = o * tanhf(c);
-        gp[0] = i; gp[H] = j; gp[2 * H] = f; gp[3 * H] = o;
-        const bool active = a.t < a.lens[row];
-        a.c_out[si] = active ? c : cp;
-        a.h_out[si] = active ? h : a.h_prev[si];
-    }
+// backward: out[(((ug*4 + w)*4 + sb)*8 + j)*64 + lane] = Wh[16 ug + (lane&15)][k .. k+3], k = 512 w + 128 sb + kbase(lane>>4) + 4 j
+__global__ __launch_bounds__(256) void lstm_rec_pack_bwd_kernel(const float* __restrict__ Wh, int H, float4* __restrict__ out) {
+    const int total = (H / 16) * 4 * 4 * 8 * 64;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int lane = i & 63, j = (i >> 6) & 7, sb = (i >> 9) & 3, w = (i >> 11) & 3, ug = i >> 13;
+        const int k = 512 * w + 128 * sb + rec_kbase(lane >> 4) + 4 * j;
+        out[i] = *reinterpret_cast<const float4*>(Wh + (long)(ug * 16 + (lane & 15)) * 4 * H + k);
     }
 }
 
-// backward step: (dG[t+1] . Wh^T)[row, u] = sum_k dG[row, k] Wh[u, k], k over the 4H gate columns: both operands are
-// K-contiguous in memory (no packing); block = TM*32 rows x 32 units, eight waves split K = 4H, register ring of two
-// 64-deep K ranges per wave (the next range's loads fly under the current range's 32*TM MFMAs).
-template <int TM>
-__global__ __launch_bounds__(512, 1) void lstm_wide_bwd_kernel(LstmBwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];  // [8 waves][TM][32][32]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
-    const int m0 = blockIdx.x * (TM * 32), n0 = blockIdx.y * 32;
-    const int H = a.H, N = a.N, K = 4 * H;
-    const int KW = K >> 3, kb0 = wave * KW;
-    f32x16 acc[TM];
+// Row tile slot i of a workgroup works on row tile (i + rot) % RT of the pass, rot = its column-slice index % RT: the 64 (32)
+// workgroups that share a row block then walk its tiles in different orders instead of all asking L2 for the same lines at once.
+template <int RT>
+__device__ __forceinline__ int rec_rot(int i, int rot) {
+    const int r = i + rot;
+    return r >= RT ? r - RT : r;
+}
+
+// The contraction of one pass: acc[i][ct] += A[row0 + 16 i .., wave K range] . B, units u = sb*RT + i in order.
+// A: buffer resource over the row-major operand (rows past its end read as zeros), `pitch` bytes per row, kofs = byte offset of the
+// wave's K range in a row.  B: NSB == 1: resident fragments bres; else streamed from bp (1 KB per (sb, j), lane-linear).
+template <int NSB, int CT, int RT>
+__device__ __forceinline__ void rec_contract(f32x4 (&acc)[RT][CT], const __amdgpu_buffer_rsrc_t ra, const unsigned pitch, const int row0,
+                                             const unsigned kofs, const float4 (&bres)[CT][8], const float4* __restrict__ bp, float* As,
+                                             const int lane, const int rot) {
+    constexpr int U = NSB * RT;
+    const int rsub = lane >> 5, seg = lane & 31;
+    const unsigned v0 = (unsigned)(row0 + rsub) * pitch + kofs + seg * 16;
+    float* wr = As + rsub * REC_PITCH + seg * 4;
+    const float* rd = As + (lane & 15) * REC_PITCH + rec_kbase(lane >> 4);
+    float4 g[2][8], fr[2][8], bs[2][CT][8];
+    auto gload = [&](int u) {  // unit u's 16 rows x 128 k: two rows (2 x 512 contiguous bytes) per wave instruction
+        const int sb = u / RT, i = u % RT;
 #pragma unroll
-    for (int t = 0; t < TM; ++t)
+        for (int q = 0; q < 8; ++q) g[u & 1][q] = lbuf(ra, v0 + (unsigned)(16 * rec_rot<RT>(i, rot) + 2 * q) * pitch + sb * 512, 0);
+    };
+    auto stage = [&](int u) {  // registers -> this wave's LDS tile (u & 1)
+        float* w = wr + (u & 1) * REC_TILE;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    if (!a.first) {
-        const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)a.dG_next, 0, N * K * 4, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.Wh, 0, H * K * 4, 0x00020000);
-        unsigned va[TM];
+        for (int q = 0; q < 8; ++q) *reinterpret_cast<float4*>(w + 2 * q * REC_PITCH) = g[u & 1][q];
+    };
+    auto frags = [&](int u) {
+        const float* r = rd + (u & 1) * REC_TILE;
 #pragma unroll
-        for (int t = 0; t < TM; ++t) va[t] = (unsigned)(((long)(m0 + t * 32 + li) * K + kb0 + 16 * lh) * 4);
-        const unsigned vb = (unsigned)(((long)(n0 + li) * K + kb0 + 16 * lh) * 4);
-        float4 fa[2][2][TM][4], fb[2][2][4];  // [ring slot][32-deep block][..]
-        auto issue = [&](int slot, int kb) {
+        for (int j = 0; j < 8; ++j) fr[u & 1][j] = *reinterpret_cast<const float4*>(r + 4 * j);
+    };
+    auto bload = [&](int sb) {
+        if constexpr (NSB > 1) {
 #pragma unroll
-            for (int b = 0; b < 2; ++b) {
+            for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-                for (int t = 0; t < TM; ++t)
+                for (int j = 0; j < 8; ++j) bs[sb & 1][ct][j] = bp[((sb * CT + ct) * 8 + j) * 64];
+        }
+    };
+    // software pipeline: global loads run TWO units ahead of the MFMAs, the LDS round trip one unit ahead
+    REC_STAMP(1);
+    gload(0);
+    bload(0);
+    if (U > 1) gload(1);
+    __builtin_amdgcn_sched_barrier(0);
+    stage(0);
+    if (U > 2) gload(2);
+    frags(0);
+    __builtin_amdgcn_sched_barrier(0);
+    REC_STAMP(2);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) fa[slot][b][t][q] = lbuf(rg, va[t], (unsigned)((kb + 32 * b + 4 * q) * 4));
+    for (int u = 0; u < U; ++u) {
+        const int sb = u / RT, i = u % RT;
+        const bool nextb = NSB > 1 && i == 0 && sb + 1 < NSB;
+        if (u + 1 < U) {
+            stage(u + 1);
+            if (u + 3 < U) gload(u + 3);  // into the registers stage(u + 1) has just emptied
+            frags(u + 1);
+        }
+        if (nextb) bload(sb + 1);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) fb[slot][b][q] = lbuf(rw, vb, (unsigned)((kb + 32 * b + 4 * q) * 4));
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const float bv = NSB > 1 ? lcomp(bs[sb & 1][ct][j], e) : lcomp(bres[ct][j], e);
+                    acc[i][ct] = mfma16(lcomp(fr[u & 1][j], e), bv, acc[i][ct]);
+                }
+        // One wave per SIMD: nothing else fills the matrix pipe while this wave issues its LDS / memory instructions, so they are
+        // spread between the unit's MFMAs (CT MFMAs, then one of: 8 LDS writes, 8 LDS reads, 8 global loads, 8 CT B loads).
+        if (u + 1 < U) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, CT, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
             }
-        };
-        auto compute = [&](int slot) {
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
+            for (int q = 0; q < 8; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, CT, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            if (u + 3 < U) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
+                for (int q = 0; q < 8; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, CT, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+            }
+        }
+        if (nextb) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-#pragma unroll
-                        for (int t = 0; t < TM; ++t)
-                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(lcomp(fa[slot][b][t][q], e), lcomp(fb[slot][b][q], e), acc[t], 0, 0, 0);
-        };
-        issue(0, 0);
-        if (KW > 64) issue(1, 64);
+            for (int q = 0; q < 8 * CT; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);
-        for (int kb = 0; kb < KW; kb += 128) {
-            compute(0);
-            if (kb + 128 < KW) issue(0, kb + 128);
-            __builtin_amdgcn_sched_barrier(0);
-            if (kb + 64 < KW) compute(1);
-            if (kb + 192 < KW) issue(1, kb + 192);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        float* red = smem + wave * (TM * 1024);
-#pragma unroll
-        for (int t = 0; t < TM; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) red[t * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + li] = acc[t][r];
-    }
-    __syncthreads();
-    for (int p = tid; p < TM * 32 * 32; p += 512) {
-        const int rr = p >> 5, un = p & 31;
-        const int row = m0 + rr, u = n0 + un;
-        if (row >= N || u >= H) continue;
-        const long si = (long)row * H + u;
-        const int len = a.lens[row];
-        float dh = a.dH_run[si];
-        if (!a.first && (a.t + 1 < len)) {  // step t+1 was active: its recurrent gradient replaces the carried one
-            float sum = 0.f;
-#pragma unroll
-            for (int w = 0; w < 8; ++w) sum += smem[w * (TM * 1024) + (rr >> 5) * 1024 + (rr & 31) * 32 + un];
-            dh = sum;
-        }
-        if (a.dh_ext) dh += a.dh_ext[si];
-        a.dH_run[si] = dh;
-        const float* ac = a.act + (long)row * 4 * H + u;
-        float* dg = a.dG + (long)row * 4 * H + u;
-        if (a.t < len) {
-            const float i = ac[0], j = ac[H], f = ac[2 * H], o = ac[3 * H];
-            const float tc = tanhf(a.c_cur[si]);
-            const float dct = a.dC_run[si] + dh * o * (1.f - tc * tc);
-            dg[0] = dct * j * i * (1.f - i);
-            dg[H] = dct * i * (1.f - j * j);
-            dg[2 * H] = dct * a.c_prev[si] * f * (1.f - f);
-            dg[3 * H] = dh * tc * o * (1.f - o);
-            a.dC_run[si] = dct * f;
-        } else {
-            dg[0] = 0.f; dg[H] = 0.f; dg[2 * H] = 0.f; dg[3 * H] = 0.f;
-        }
+        REC_STAMP(3 + u);
     }
 }
 
-// 2 (default) = auto: wide fused FORWARD step kernel for N <= 640 rows where H % 512 == 0, else the split form; 3: wide kernels
-// wherever supported (forward and backward); 1: split-K GEMM + gate kernels; 0: round-1 fused kernels
+// K-partial tiles of a wave -> its own LDS area: red[row][RP], row = 16 i + 4 (lane >> 4) + v, column = 16 ct + (lane & 15)
+template <int CT, int RT, int RP>
+__device__ __forceinline__ void rec_spill(const f32x4 (&acc)[RT][CT], float* red, const int lane, const int rot) {
+    float* p = red + (4 * (lane >> 4)) * RP + (lane & 15);
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+        float* pi = p + 16 * rec_rot<RT>(i, rot) * RP;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) pi[v * RP + 16 * ct] = acc[i][ct][v];
+    }
+}
+
+// sigmoid / tanh of the recurrence kernels: v_exp_f32 + v_rcp_f32 (1 ulp each; |error| < 3e-7 absolute, saturating correctly)
+__device__ __forceinline__ float rsigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float rtanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float& at(float4& v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
+__device__ __forceinline__ float at(const float4& v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
+
+// Gate math of both kernels: one thread per (row, four consecutive units) item, every global operand of the item is loaded BEFORE
+// the contraction (none depends on it), so the step's tail is LDS reads, arithmetic and 16-byte stores only.
+template <int RT>
+__global__ __launch_bounds__(256, 1) void lstm_rec_fwd_kernel(LstmFwdArgs a, const float4* __restrict__ whp, int rows_wg) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int RP = 36;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ug = blockIdx.x, N = a.N, rot = ug % RT;
+    constexpr int H = 512;
+    const int rbeg = blockIdx.y * rows_wg, rend = min(N, rbeg + rows_wg);
+    REC_STAMP(0);
+    float4 bres[2][8];
+    {
+        const float4* bp = whp + (size_t)(ug * 4 + wave) * (2 * 8 * 64) + lane;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bres[ct][j] = bp[(ct * 8 + j) * 64];
+    }
+    const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc((void*)a.h_prev, 0, N * H * 4, 0x00020000);
+    float* As = smem + wave * (2 * REC_TILE);
+    const int rr = tid >> 1, hf = tid & 1;  // item: row rr of the pass, units 8 ug + 4 hf .. + 3  (32 RT items <= 160 threads)
+    for (int row0 = rbeg; row0 < rend; row0 += 16 * RT) {
+        const int row = row0 + rr;
+        const bool has = tid < 32 * RT && row < rend;
+        const int rowc = min(row, N - 1);  // (threads without an item load a valid row too: no branch, no copies behind the loads)
+        float4 gx[4];
+        const long si = (long)rowc * H + ug * 8 + 4 * hf;
+        float* gp = a.gact + (long)rowc * 4 * H + ug * 8 + 4 * hf;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gx[g] = ld4(gp + g * H);
+        const float4 cp = ld4(a.c_prev + si), hp = ld4(a.h_prev + si);
+        const int len = a.lens[rowc];
+        f32x4 acc[RT][2];
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) acc[i][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (row0 != rbeg) __syncthreads();  // the previous pass's gate math has read every wave's partials
+        rec_contract<1, 2, RT>(acc, rh, H * 4, row0, wave * 512, bres, nullptr, As, lane, rot);
+        rec_spill<2, RT, RP>(acc, As, lane, rot);
+        REC_STAMP(28);
+        __syncthreads();
+        REC_STAMP(29);
+        if (has) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 s = f4zero();
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {  // fixed order
+                    const float4 v = ld4(smem + w * (2 * REC_TILE) + rr * RP + g * 8 + 4 * hf);
+                    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+                }
+                gx[g].x += s.x; gx[g].y += s.y; gx[g].z += s.z; gx[g].w += s.w;
+            }
+            float4 c4, h4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float i = rsigmoid(at(gx[0], e)), j = rtanh(at(gx[1], e)), f = rsigmoid(at(gx[2], e) + 1.0f), o = rsigmoid(at(gx[3], e));
+                const float c = f * at(cp, e) + i * j;
+                const float h = o * rtanh(c);
+                at(gx[0], e) = i; at(gx[1], e) = j; at(gx[2], e) = f; at(gx[3], e) = o;
+                const bool active = a.t < len;  // dynamic_rnn: state copied through past the length
+                at(c4, e) = active ? c : at(cp, e);
+                at(h4, e) = active ? h : at(hp, e);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) st4(gp + g * H, gx[g]);
+            st4(a.c_out + si, c4);
+            st4(a.h_out + si, h4);
+        }
+        REC_STAMP(30);
+    }
+}
+
+template <int RT>
+__global__ __launch_bounds__(256, 1) void lstm_rec_bwd_kernel(LstmBwdArgs a, const float4* __restrict__ whp, int rows_wg) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int RP = 20;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ug = blockIdx.x, N = a.N, rot = ug % RT;
+    constexpr int H = 512, K = 4 * H;
+    constexpr int ITEMS = 64 * RT, ITERS = (ITEMS + 255) / 256;  // item: (row of the pass, four consecutive units of the 16)
+    const int rbeg = blockIdx.y * rows_wg, rend = min(N, rbeg + rows_wg);
+    REC_STAMP(0);
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)a.dG_next, 0, a.first ? 0 : N * K * 4, 0x00020000);
+    const float4* bp = whp + (size_t)(ug * 4 + wave) * (4 * 8 * 64) + lane;
+    float* As = smem + wave * (2 * REC_TILE);
+    const float4 nob[1][8] = {};
+    struct Item {
+        float4 ac[4], cc, cpv, dc, dh, ext;
+        int len;
+    };
+    for (int row0 = rbeg; row0 < rend; row0 += 16 * RT) {
+        auto item_ok = [&](int it) { return tid + 256 * it < ITEMS && row0 + ((tid + 256 * it) >> 2) < rend; };
+        auto fetch = [&](int it, Item& m) {
+            const int p = tid + 256 * it, row = min(row0 + (p >> 2), N - 1);  // (clamped: threads without an item load a valid row)
+            const long si = (long)row * H + ug * 16 + 4 * (p & 3);
+            const float* ac = a.act + (long)row * 4 * H + ug * 16 + 4 * (p & 3);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) m.ac[g] = ld4(ac + g * H);
+            m.cc = ld4(a.c_cur + si);
+            m.cpv = ld4(a.c_prev + si);
+            m.dc = ld4(a.dC_run + si);
+            m.dh = ld4(a.dH_run + si);
+            m.ext = ld4((a.dh_ext ? a.dh_ext : a.dH_run) + si);  // (used only when dh_ext is given)
+            m.len = a.lens[row];
+        };
+        auto finish = [&](int it, Item& m) {
+            const int p = tid + 256 * it, rr = p >> 2, row = row0 + rr;
+            const long si = (long)row * H + ug * 16 + 4 * (p & 3);
+            float4 dh = m.dh;
+            if (!a.first && (a.t + 1 < m.len)) {  // step t+1 was active: its recurrent gradient replaces the carried one
+                float4 s = f4zero();
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {  // fixed order
+                    const float4 v = ld4(smem + w * (2 * REC_TILE) + rr * RP + 4 * (p & 3));
+                    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+                }
+                dh = s;
+            }
+            if (a.dh_ext) { dh.x += m.ext.x; dh.y += m.ext.y; dh.z += m.ext.z; dh.w += m.ext.w; }
+            st4(a.dH_run + si, dh);
+            float4 dg[4], dcn = m.dc;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) dg[g] = f4zero();
+            if (a.t < m.len) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float i = at(m.ac[0], e), j = at(m.ac[1], e), f = at(m.ac[2], e), o = at(m.ac[3], e);
+                    const float tc = rtanh(at(m.cc, e));
+                    const float dhe = at(dh, e);
+                    const float dct = at(m.dc, e) + dhe * o * (1.f - tc * tc);
+                    at(dg[0], e) = dct * j * i * (1.f - i);
+                    at(dg[1], e) = dct * i * (1.f - j * j);
+                    at(dg[2], e) = dct * at(m.cpv, e) * f * (1.f - f);
+                    at(dg[3], e) = dhe * tc * o * (1.f - o);
+                    at(dcn, e) = dct * f;
+                }
+                st4(a.dC_run + si, dcn);
+            }
+            float* dgp = a.dG + (long)row * 4 * H + ug * 16 + 4 * (p & 3);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) st4(dgp + g * H, dg[g]);
+        };
+        Item m0;
+        const bool ok0 = item_ok(0);
+        fetch(0, m0);
+        if (!a.first) {
+            f32x4 acc[RT][1];
+#pragma unroll
+            for (int i = 0; i < RT; ++i) acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (row0 != rbeg) __syncthreads();
+            rec_contract<4, 1, RT>(acc, rg, K * 4, row0, wave * 2048, nob, bp, As, lane, rot);
+            rec_spill<1, RT, RP>(acc, As, lane, rot);
+            REC_STAMP(28);
+            __syncthreads();
+            REC_STAMP(29);
+        }
+        if (ok0) finish(0, m0);
+#pragma unroll
+        for (int it = 1; it < ITERS; ++it)
+            if (item_ok(it)) {
+                Item m;
+                fetch(it, m);
+                finish(it, m);
+            }
+        REC_STAMP(30);
+    }
+}
+
+// Step kernel choice (vc_lstm_set_mode): 2 (default) = auto -- the register-operand recurrence kernels where H == 512 (forward up
+// to rec_fwd_auto rows, backward any N), else the split form; 3: recurrence kernels wherever supported; 1: split-K GEMM + gate
+// kernels; 0: round-1 fused kernels.  Measured per step at H = 512 (marginal cost inside the sequence drivers, tools/microbench.py
+// lstm; N = 160 / 320 / 640 / 1280): forward 11.6 / 17.0 / 31.7 / 58.9 us against 18.4 / 22.0 / 32.6 / 55.3 us for the split form,
+// backward 18.4 / 25.1 / 42.5 / 80.3 against 24.3 / 33.7 / 50.9 / 88.7 us (the step kernels alone, rocprofv3: 13.0 us forward and
+// 11.8 us backward at N = 320, where round 2 started from a 13.4 us split-K GEMM + 8.2 us gate kernel backward).
 static int g_lstm_mode = 2;
-static bool wide_ok(int N, int H) { return H % 512 == 0 && (long)N * 4 * H * 4 < 0x7fffffffL; }  // (a wave's K range = H/8 = whole 64-deep blocks)
+static bool rec_ok(int N, int H) { return H == 512 && (long)(N + 96) * 4 * H * 4 < 0x7fffffffL; }
+static bool rec_fwd_auto(int N) { return N <= 640; }  // above: four passes per workgroup, the split-K GEMM + gate kernels are level or ahead
+constexpr size_t REC_PACK_BYTES = (size_t)512 * 2048 * sizeof(float);
 
-static int wide_fwd(hipStream_t st, const LstmFwdArgs& a, const float* whp) {
-    if (a.N > 640)
-        hipLaunchKernelGGL(lstm_wide_fwd_kernel<2>, dim3(cdiv(a.N, 64), a.H / 16), dim3(512), 8 * 2 * 1024 * 4, st, a, whp);
-    else
-        hipLaunchKernelGGL(lstm_wide_fwd_kernel<1>, dim3(cdiv(a.N, 32), a.H / 16), dim3(512), 8 * 2 * 1024 * 4, st, a, whp);
-    return launch_status("lstm wide fwd");
+static int rec_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 256;
+        cus = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+    }
+    return cus;
 }
 
-static int wide_bwd(hipStream_t st, const LstmBwdArgs& a) {
-    if (a.N > 640)
-        hipLaunchKernelGGL(lstm_wide_bwd_kernel<2>, dim3(cdiv(a.N, 64), a.H / 32), dim3(512), 8 * 2 * 1024 * 4, st, a);
-    else
-        hipLaunchKernelGGL(lstm_wide_bwd_kernel<1>, dim3(cdiv(a.N, 32), a.H / 32), dim3(512), 8 * 1024 * 4, st, a);
-    return launch_status("lstm wide bwd");
+template <class K>
+static int rec_lds(K kern) {  // 66 KB of dynamic LDS: above the 64 KB a kernel may use without opting in
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, REC_LDS_BYTES);
+    return e == hipSuccess ? 0 : fail((int)e, "%s: hipFuncSetAttribute failed", "lstm recurrence kernel");
 }
 
+// row groups: as many as keep one workgroup per CU (UG column slices x RG <= CUs), at least 16 rows each
+static int rec_row_groups(int N, int UG) {
+    int rg = rec_cus() / UG;
+    if (rg < 1) rg = 1;
+    const int cap = cdiv(N, 16);
+    return rg < cap ? rg : cap;
+}
+
+static int rec_fwd(hipStream_t st, const LstmFwdArgs& a, const float* whp) {
+    static int once = rec_lds(lstm_rec_fwd_kernel<5>) | rec_lds(lstm_rec_fwd_kernel<3>);
+    if (once) return once;
+    const int RG = rec_row_groups(a.N, 64), rows = cdiv(a.N, RG);
+    if (rows > 48)
+        hipLaunchKernelGGL(lstm_rec_fwd_kernel<5>, dim3(64, RG), dim3(256), REC_LDS_BYTES, st, a, (const float4*)whp, rows);
+    else
+        hipLaunchKernelGGL(lstm_rec_fwd_kernel<3>, dim3(64, RG), dim3(256), REC_LDS_BYTES, st, a, (const float4*)whp, rows);
+    return launch_status("lstm rec fwd");
+}
+
+static int rec_bwd(hipStream_t st, const LstmBwdArgs& a, const float* whp) {
+    static int once = rec_lds(lstm_rec_bwd_kernel<5>) | rec_lds(lstm_rec_bwd_kernel<3>);
+    if (once) return once;
+    const int RG = rec_row_groups(a.N, 32), rows = cdiv(a.N, RG);
+    if (rows > 48)
+        hipLaunchKernelGGL(lstm_rec_bwd_kernel<5>, dim3(32, RG), dim3(256), REC_LDS_BYTES, st, a, (const float4*)whp, rows);
+    else
+        hipLaunchKernelGGL(lstm_rec_bwd_kernel<3>, dim3(32, RG), dim3(256), REC_LDS_BYTES, st, a, (const float4*)whp, rows);
+    return launch_status("lstm rec bwd");
+}
 
 using FwdCfg128 = TileCfg<4, 1, 1, 4>;  // 128 rows x (4 gates x 32 units), 256 threads
 using FwdCfg64 = TileCfg<2, 1, 1, 4>;   //  64 rows,                       128 threads
@@ -506,7 +695,7 @@ extern "C" size_t vc_lstm_seq_workspace_bytes(int T, int N, int E, int H) {
     size_t w4 = vc_gemm_workspace_bytes(T * N, 4 * H, E);
     size_t w5 = vc_colsum_workspace_bytes(T * N, 4 * H);
     size_t m = w;
-    const size_t wp = (size_t)H * 4 * H * sizeof(float);  // packed Wh of the wide fused step kernels
+    const size_t wp = (size_t)H * 4 * H * sizeof(float);  // Wh in operand order for the recurrence kernels
     if (wp > m) m = wp;
     if (w2 > m) m = w2;
     if (w3 > m) m = w3;
@@ -529,19 +718,17 @@ extern "C" int vc_lstm_seq_fwd_f32(void* stream, int T, int N, int E, int H, con
     if (rc) return rc;
     const long NH = (long)N * H;
     const int eg = (int)((NH + 255) / 256) < 2048 ? (int)((NH + 255) / 256) : 2048;
-    // auto (2): the wide forward kernel up to 640 rows (measured, H = 512: N = 160 8.6 us vs 18.6 us per step for GEMM + gates,
-    // N = 320 17 vs 23 us; at N = 1280 both ~55 us: every workgroup re-reads its 128 KB slice of Wh from L2 each step)
-    const bool wide = (g_lstm_mode == 3 || (g_lstm_mode == 2 && N <= 640)) && wide_ok(N, H) && ws && ws_bytes >= (size_t)H * 4 * H * sizeof(float);
-    if (wide) {  // Wh in the MFMA-operand layout, once per sequence (4 MB at H = 512)
-        hipLaunchKernelGGL(lstm_pack_wh_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, Wh, H, (float4*)ws);
+    const bool rec = (g_lstm_mode == 3 || (g_lstm_mode == 2 && rec_fwd_auto(N))) && rec_ok(N, H) && ws && ws_bytes >= REC_PACK_BYTES;
+    if (rec) {  // Wh in the MFMA-operand layout of the step kernel, once per sequence (4 MB at H = 512)
+        hipLaunchKernelGGL(lstm_rec_pack_fwd_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, Wh, H, (float4*)ws);
         rc = launch_status(__func__);
         if (rc) return rc;
     }
     for (int t = 0; t < T; ++t) {
         float* g = act + (long)t * N * 4 * H;
-        if (wide) {
+        if (rec) {
             LstmFwdArgs a{hs + t * NH, cs + t * NH, Wh, g, lens_eff, cs + (t + 1) * NH, hs + (t + 1) * NH, N, H, t};
-            rc = wide_fwd((hipStream_t)stream, a, ws);
+            rc = rec_fwd((hipStream_t)stream, a, ws);
         } else if (g_lstm_mode) {
             int ns = 1;  // recurrent product as split-K partials in ws; the gate kernel sums them (no separate reduce launch)
             rc = gemm_partials_f32((hipStream_t)stream, 0, 0, N, 4 * H, H, hs + t * NH, H, Wh, 4 * H, ws, ws_bytes, 8, &ns);
@@ -575,13 +762,19 @@ extern "C" int vc_lstm_seq_bwd_f32(void* stream, int T, int N, int E, int H, con
     const int eg = (int)((NH + 255) / 256) < 2048 ? (int)((NH + 255) / 256) : 2048;
     // split form: the recurrent product dG[t+1].Wh^T as split-K partials in ws, summed by the gate kernel
     const float* rec = ws;
+    const bool recb = (g_lstm_mode == 3 || g_lstm_mode == 2) && rec_ok(N, H) && ws && ws_bytes >= REC_PACK_BYTES;
+    if (recb) {  // Wh^T slices in operand order; ws is free again for the GEMMs below once the step loop has run
+        hipLaunchKernelGGL(lstm_rec_pack_bwd_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, Wh, H, (float4*)ws);
+        rc = launch_status(__func__);
+        if (rc) return rc;
+    }
     for (int t = T - 1; t >= 0; --t) {
         const int first = (t == T - 1);
         const float* ext = dhs_ext ? dhs_ext + (t + 1) * NH : nullptr;
-        if (g_lstm_mode == 3 && wide_ok(N, H)) {  // (the wide backward kernel is not faster than GEMM + gates: 22.8 vs 21 us at N = 320, 71 vs 45 us at N = 1280)
+        if (recb) {
             LstmBwdArgs a{first ? nullptr : dG + (t + 1) * NG, Wh, lens_eff, ext, dH_run, dC_run, act + t * NG, cs + t * NH, cs + (t + 1) * NH,
                           dG + t * NG, N, H, t, first};
-            rc = wide_bwd((hipStream_t)stream, a);
+            rc = rec_bwd((hipStream_t)stream, a, ws);
         } else if (g_lstm_mode) {
             int ns = 1;
             if (!first) {
