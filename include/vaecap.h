@@ -258,6 +258,19 @@ size_t vc_conv3x3_wgrad_patch_workspace_bytes(int B, int H, int W, int Cin, int 
 int vc_conv3x3_wgrad_patch_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const float* dy, float* dw,
                                float* db, int accumulate, float* ws, size_t ws_bytes);
 
+/* conv1_1 (utils/image_embeddings.py:36-48: 3 -> 64 channels), csrc/conv_first.hip: the layer is HBM-bound (it writes / re-reads
+ * the [B,H,W,64] activation, 822 MB at 64 images, for 0.6 % of the multiply-adds), so it has its own kernels: the forward makes
+ * the 64 output channels the M dimension of the MFMA so that every lane stores 16-byte vectors of consecutive channels straight
+ * from its accumulators; the weight gradient contracts 27 patch rows + one row of ones (= the bias gradient) against dy and
+ * reduces per-workgroup partials in a fixed order.  x4: [B,H,W,4] from vc_vgg_preprocess_f32 (fourth channel ignored);
+ * w / dw: [3,3,3,64] HWIO (no padding to 4 channels); W % 32 == 0 (ask vc_conv1_supported, else use vc_conv3x3_*_f32 on the
+ * zero-padded weights).  There is no data gradient: the images are not trained. */
+int vc_conv1_supported(int B, int H, int W);
+size_t vc_conv1_wgrad_workspace_bytes(void);
+int vc_conv1_fwd_f32(void* stream, int B, int H, int W, const float* x4, const float* w, const float* bias, float* y, int relu);
+int vc_conv1_wgrad_f32(void* stream, int B, int H, int W, const float* x4, const float* dy, float* dw, float* db, int accumulate,
+                       float* ws, size_t ws_bytes);
+
 /* ------------------------------------------------------------------------------------
  * Beam-search bookkeeping after one decoder step, on device, one thread per image: the loop body of
  * vae_model/decoder.py:254-293 with utils/top_n.py's TopN (heapq min-heap keyed by score; ties resolved by

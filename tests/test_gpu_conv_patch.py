@@ -198,3 +198,46 @@ def test_fused_maxpool_epilogue_equals_separate_pool(lib, case):
     with pytest.raises(VaecapError):  # FLAT tiling: no fused pool
         lib.vc_conv3x3_fwd_pool_packed_f32(stream(), 2, 14, 14, 32, 64, P(zeros(2, 14, 14, 32)), P(zeros(9 * 32 * 64)), None, P(zeros(2, 14, 14, 64)),
                                            P(zeros(2, 7, 7, 64)), 1, None, 0)
+
+
+# ----------------------------------------------------------------------------- conv1_1 (csrc/conv_first.hip)
+@pytest.mark.parametrize("case", [(2, 5, 32), (1, 7, 96), (3, 16, 64), (2, 224, 224)], ids=lambda c: "x".join(map(str, c)))
+def test_conv1_fwd_wgrad_match_oracle(lib, case):
+    """The first layer's own kernels (3 -> 64 channels; channels as the MFMA's M dimension, 16-byte stores from the accumulators;
+    weight gradient with the bias gradient as a 28th contraction row): image borders, several row segments, batch edges, the
+    VGG geometry; accumulate flag; the fourth input channel must be ignored."""
+    B, H, W = case
+    assert lib.vc_conv1_supported(B, H, W) == 1 and lib.vc_conv1_supported(B, H, W + 8) == 0
+    rng = np.random.default_rng(B + H + W)
+    x = rng.standard_normal((B, H, W, 3), dtype=np.float32)
+    w = rng.standard_normal((3, 3, 3, 64), dtype=np.float32) * np.float32(0.2)
+    b = rng.standard_normal(64, dtype=np.float32)
+    dy = rng.standard_normal((B, H, W, 64), dtype=np.float32)
+    x4 = np.concatenate([x, rng.standard_normal((B, H, W, 1), dtype=np.float32)], axis=3)  # garbage in the pad channel
+    x64, w64 = x.astype(np.float64), w.astype(np.float64)
+    pre = OV.conv3x3_fwd(x64, w64, b.astype(np.float64))
+    tx4, tw, tb, tdy = dev(x4), dev(w), dev(b), dev(dy)
+    y = zeros(B, H, W, 64)
+    lib.vc_conv1_fwd_f32(stream(), B, H, W, P(tx4), P(tw), P(tb), P(y), 1)
+    assert_close(host(y), np.maximum(pre, 0), 2e-6 * np.sqrt(27), msg="conv1 forward + ReLU")
+    lib.vc_conv1_fwd_f32(stream(), B, H, W, P(tx4), P(tw), P(tb), P(y), 0)
+    assert_close(host(y), pre, 2e-6 * np.sqrt(27), msg="conv1 forward, no ReLU")
+    _, dw_ref, db_ref = OV.conv3x3_bwd(x64, w64, dy.astype(np.float64), need_dx=False)
+    ws = empty_bytes(lib.vc_conv1_wgrad_workspace_bytes())
+    dw0 = rng.standard_normal((3, 3, 3, 64), dtype=np.float32)
+    db0 = rng.standard_normal(64, dtype=np.float32)
+    dw, db = dev(dw0), dev(db0)
+    lib.vc_conv1_wgrad_f32(stream(), B, H, W, P(tx4), P(tdy), P(dw), P(db), 0, P(ws), ws.numel() * 4)
+    tol = 2e-6 * np.sqrt(B * H * W)
+    assert_close(host(dw), dw_ref, tol, msg="conv1 weight gradient")
+    assert_close(host(db), db_ref, tol, msg="conv1 bias gradient")
+    first = host(dw).copy()
+    lib.vc_conv1_wgrad_f32(stream(), B, H, W, P(tx4), P(tdy), P(dw), P(db), 0, P(ws), ws.numel() * 4)
+    assert np.array_equal(host(dw), first), "weight gradient is not bit-reproducible"
+    dw, db = dev(dw0), dev(db0)
+    lib.vc_conv1_wgrad_f32(stream(), B, H, W, P(tx4), P(tdy), P(dw), P(db), 1, P(ws), ws.numel() * 4)
+    assert_close(host(dw), dw_ref + dw0, tol, msg="conv1 weight gradient, accumulate")
+    assert_close(host(db), db_ref + db0, tol, msg="conv1 bias gradient, accumulate")
+    from vae_captioning_amd.abi import VaecapError
+    with pytest.raises(VaecapError):
+        lib.vc_conv1_wgrad_f32(stream(), B, H, W, P(tx4), P(tdy), P(dw), P(db), 0, None, 0)

@@ -63,6 +63,31 @@ def test_gemm_flags_and_ldc(lib):
     assert_close(host(C), ref, 2e-5, msg="gemm relu+accumulate, ldc > N (padding untouched)")
 
 
+@pytest.mark.parametrize("ta,flags,shape", [(0, 0, (4224, 2052, 96)), (1, 3, (4100, 2052, 100)), (0, 1, (6880, 10000, 512)), (1, 2, (512, 10000, 6880)),
+                                            (0, 3, (1000, 2048, 2560)), (1, 0, (256, 2048, 6880))],
+                         ids=["unsplit-ragged-N", "KM-ragged-M-K", "logits-fwd", "logits-wgrad-splitK", "splitK-flags", "dWx-splitK"])
+def test_gemm_training_shapes(lib, ta, flags, shape):
+    """the tb = 0 products of a training step (logits forward / weight gradient, input projections) and ragged M / N / K edges in
+    both A storage orders: split-K through the workspace, bias / ReLU / accumulate, ldc > N."""
+    M, N, K = shape
+    rng = np.random.default_rng(M + N + K + flags)
+    A = rng.standard_normal((M, K), dtype=np.float32)
+    B = rng.standard_normal((K, N), dtype=np.float32)
+    bias = rng.standard_normal(N, dtype=np.float32)
+    C0 = rng.standard_normal((M, N + 4), dtype=np.float32)
+    ref = C0.astype(np.float64).copy()
+    prod = A.astype(np.float64) @ B.astype(np.float64) + bias
+    if flags & 2:
+        prod = prod + C0[:, :N]
+    if flags & 1:
+        prod = np.maximum(prod, 0)
+    ref[:, :N] = prod
+    dA, dB, C = dev(A.T if ta else A), dev(B), dev(C0)
+    ws = empty_bytes(lib.vc_gemm_workspace_bytes(M, N, K))
+    lib.vc_gemm_f32(stream(), ta, 0, M, N, K, P(dA), M if ta else K, P(dB), N, P(C), N + 4, P(dev(bias)), flags, P(ws), ws.numel() * 4)
+    assert_close(host(C), ref, 2e-6 * np.sqrt(K) + 2e-6, msg="gemm ta=%d flags=%d %s (padding column untouched)" % (ta, flags, shape))
+
+
 @pytest.mark.parametrize("ta,tb,flags", [(0, 0, 0), (0, 1, 1), (1, 0, 2), (1, 1, 3)])
 def test_gemm_whole_rounds_tail(lib, ta, tb, flags):
     """776 tiles of 128 x 128 = one round of 768 resident workgroups + one tile row: that row runs as a K-split second

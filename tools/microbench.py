@@ -45,6 +45,43 @@ def gemm():
         print("gemm NN %6d x %6d x %6d: %8.3f ms  %6.1f TFLOP/s (best %.1f)" % (M, N, K, med, 2e-9 * M * N * K / med, 2e-9 * M * N * K / mn))
 
 
+def conv1():
+    """conv1_1's own kernels (csrc/conv_first.hip) against the general 3x3 kernels on the zero-padded 4-channel form; both are
+    HBM-bound on the [B,224,224,64] activation (822 MB at B = 64: ~0.14 ms at 6.3 TB/s)"""
+    B, H = 64, 224
+    x4 = rnd(B, H, H, 4)
+    w, bias = rnd(3, 3, 3, 64), rnd(64)
+    w4 = torch.zeros(3, 3, 4, 64, device="cuda")
+    w4[:, :, :3] = w
+    y, dy = torch.empty(B, H, H, 64, device="cuda"), rnd(B, H, H, 64)
+    dw, db, dw4 = torch.empty(3, 3, 3, 64, device="cuda"), torch.empty(64, device="cuda"), torch.empty(3, 3, 4, 64, device="cuda")
+    ws = torch.empty(max(lib.vc_conv1_wgrad_workspace_bytes(), lib.vc_conv3x3_wgrad_workspace_bytes(B, H, H, 4, 64)) // 4 + 4, device="cuda")
+    gb = 1e-9 * B * H * H * (64 + 4) * 4
+    for nm, fn in (("conv1 fwd", lambda: lib.vc_conv1_fwd_f32(st(), B, H, H, P(x4), P(w), P(bias), P(y), 1)),
+                   ("3x3 fwd (Cin 4)", lambda: lib.vc_conv3x3_fwd_f32(st(), B, H, H, 4, 64, P(x4), P(w4), P(bias), P(y), 1, None, 0)),
+                   ("conv1 wgrad", lambda: lib.vc_conv1_wgrad_f32(st(), B, H, H, P(x4), P(dy), P(dw), P(db), 0, P(ws), ws.numel() * 4)),
+                   ("3x3 wgrad (Cin 4)", lambda: lib.vc_conv3x3_wgrad_f32(st(), B, H, H, 4, 64, P(x4), P(dy), P(dw4), P(db), 0, P(ws), ws.numel() * 4))):
+        med, mn = timeit(fn, reps=10)
+        print("%-18s B=%d: %7.3f ms  %5.2f TB/s (activation once + input once)" % (nm, B, med, gb / med), flush=True)
+
+
+def gemmtrain():
+    """the tb = 0 products of a training step (cfg4: 6880 rows, cfg2: 27520 rows).  Round 2 measured a register-B variant on these
+    (B rows straight to registers as the operand of four interleaved MFMA tiles, 128 x 256 tiles, two workgroups per CU):
+    116.5 / 107.2 / 118.0 TFLOP/s against 119.6 / 119.4 / 124.9 of this kernel on 27520x10000x512 / 27520x2048x512 /
+    512x10000x27520 (only 8192^3 gained, 136.6 vs 133.3) -- per-tile prologue / epilogue with 16 K-tiles, not the main loop,
+    bounds these shapes, and three to four resident workgroups hide it better than two; not adopted."""
+    for (ta, M, N, K) in [(0, 6880, 10000, 512), (0, 27520, 10000, 512), (0, 6880, 2048, 512), (0, 27520, 2048, 512), (0, 6880, 2048, 256),
+                          (1, 512, 10000, 6880), (1, 512, 10000, 27520), (1, 512, 2048, 6880), (1, 512, 2048, 27520), (1, 256, 2048, 27520),
+                          (0, 64, 4096, 25088), (1, 25088, 4096, 64), (0, 64, 4096, 4096), (0, 8192, 8192, 8192)]:
+        A = rnd(K, M) if ta else rnd(M, K)
+        B = rnd(K, N)
+        C = torch.empty(M, N, device="cuda")
+        ws = torch.empty(max(lib.vc_gemm_workspace_bytes(M, N, K), 16) // 4 + 4, device="cuda")
+        med, mn = timeit(lambda: lib.vc_gemm_f32(st(), ta, 0, M, N, K, P(A), M if ta else K, P(B), N, P(C), N, None, 0, P(ws), ws.numel() * 4), reps=5)
+        print("gemm ta=%d tb=0 %6d x %6d x %6d: %8.3f ms  %6.1f TFLOP/s" % (ta, M, N, K, med, 2e-9 * M * N * K / med), flush=True)
+
+
 def gemmt():
     """transposed-operand forms at conv-wgrad-like and dense-backward shapes"""
     for (ta, tb, M, N, K) in [(0, 0, 8192, 8192, 8192), (0, 1, 8192, 8192, 8192), (1, 0, 8192, 8192, 8192), (1, 1, 8192, 8192, 8192), (0, 0, 2304, 256, 200704), (1, 0, 2304, 256, 200704), (0, 1, 200704, 256, 2304), (1, 0, 512, 10000, 25600), (0, 1, 25600, 512, 10000)]:

@@ -173,8 +173,10 @@ class VggEngine(object):
         self.B = B
         x = self._b("x0", (B, H, W, 4))
         lib.vc_vgg_preprocess_f32(st, P(images), B, H, W, P(x))
+        c1 = bool(self.use_patch and lib.vc_conv1_supported(B, H, W))  # conv1_1 through csrc/conv_first.hip (unpadded weights)
         w4 = self._b("w1_4", (3, 3, 4, 64))
-        lib.vc_pad_dim_f32(st, P(S.param("cnn/conv1_1/weights")), 9, 3, 4, 64, P(w4))
+        if not c1:
+            lib.vc_pad_dim_f32(st, P(S.param("cnn/conv1_1/weights")), 9, 3, 4, 64, P(w4))
         packed, waited = self._pack_weights(self.train), set()
         self.acts = []  # (layer name, input tensor, H, W, Cin_eff, Cout, weights used)
         # The conv / pool chain of one image is independent of every other image: with two streams the
@@ -196,7 +198,10 @@ class VggEngine(object):
                 tws = self._chain_ws(ch, nb)
                 with torch.cuda.stream(strm):
                     sh = _stream()
-                    if self._patch_ok(nb, H, W, cie, co, 0):
+                    if ci == 3 and c1:  # conv1_1: its own HBM-bound kernel, unpadded weights
+                        self._timed("conv_fwd", 2.0 * nb * H * W * 9 * ci * co,
+                                    lambda: lib.vc_conv1_fwd_f32(sh, nb, H, W, P(x[b0:]), P(S.param(wn)), P(S.param(bn)), P(y[b0:]), 1))
+                    elif self._patch_ok(nb, H, W, cie, co, 0):
                         if packed is not None and ch not in waited:
                             torch.cuda.current_stream().wait_event(packed)
                             waited.add(ch)
@@ -279,8 +284,9 @@ class VggEngine(object):
         if after_fc is not None:
             after_fc()
         dw4 = self._b("dw1_4", (3, 3, 4, 64))
-        self._need_ws(max(max(lib.vc_conv3x3_wgrad_workspace_bytes(B, a[2], a[3], a[4], a[5]), lib.vc_conv3x3_wgrad_patch_workspace_bytes(B, a[2], a[3], a[4], a[5]))
-                          for a in self.acts if a[0] != "P"))
+        self._need_ws(max(lib.vc_conv1_wgrad_workspace_bytes(),
+                          max(max(lib.vc_conv3x3_wgrad_workspace_bytes(B, a[2], a[3], a[4], a[5]), lib.vc_conv3x3_wgrad_patch_workspace_bytes(B, a[2], a[3], a[4], a[5]))
+                              for a in self.acts if a[0] != "P")))
         main = torch.cuda.current_stream()
         side, side2 = self.side, self.side2
         # streams: with 3, the data-gradient chain runs as two half-batch chains (main, side) and every
@@ -305,7 +311,9 @@ class VggEngine(object):
 
             def wgrad(x=x, d=d, wn=wn, bn=bn, ci=ci, co=co, H=H, W=W, fl=fl):
                 sw = _stream()
-                if ci == 4:
+                if ci == 4 and self.use_patch and lib.vc_conv1_supported(B, H, W):
+                    self._timed("conv_wgrad", fl, lambda: lib.vc_conv1_wgrad_f32(sw, B, H, W, P(x), P(d), P(S.grad(wn)), P(S.grad(bn)), 0, P(self.ws), self.ws_bytes))
+                elif ci == 4:
                     self._timed("conv_wgrad", fl, lambda: lib.vc_conv3x3_wgrad_f32(sw, B, H, W, ci, co, P(x), P(d), P(dw4), P(S.grad(bn)), 0, P(self.ws), self.ws_bytes))
                     lib.vc_pad_dim_f32(sw, P(dw4), 9, 4, 3, 64, P(S.grad(wn)))
                 elif self.use_patch and lib.vc_conv3x3_wgrad_patch_supported(B, H, W, ci, co):
