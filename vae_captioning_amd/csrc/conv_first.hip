@@ -176,20 +176,26 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(Conv1Args a) {
     for (int i = tid; i < 28 * 64; i += 256) o[i] = ((red[0][i] + red[1][i]) + red[2][i]) + red[3][i];  // fixed order
 }
 
+// ws[parts][1792] -> dw / db: a block owns 32 outputs, its eight waves-halves sum every eighth partial and meet in LDS; all in a
+// fixed order (deterministic)
 __global__ __launch_bounds__(256) void conv1_wgrad_reduce_kernel(const float* __restrict__ ws, int parts, float* __restrict__ dw,
                                                                  float* __restrict__ db, int accumulate) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= 28 * 64) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // four interleaved chains, combined in a fixed order
-    int p = 0;
-    for (; p + 3 < parts; p += 4) {
+    __shared__ float part[8][32];
+    const int o = threadIdx.x & 31, pg = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + o;  // < 1792 = 56 blocks x 32
+    float s0 = 0.f, s1 = 0.f;
+    int p = pg;
+    for (; p + 8 < parts; p += 16) {
         s0 += ws[(long)p * 1792 + i];
-        s1 += ws[(long)(p + 1) * 1792 + i];
-        s2 += ws[(long)(p + 2) * 1792 + i];
-        s3 += ws[(long)(p + 3) * 1792 + i];
+        s1 += ws[(long)(p + 8) * 1792 + i];
     }
-    for (; p < parts; ++p) s0 += ws[(long)p * 1792 + i];
-    const float s = (s0 + s1) + (s2 + s3);
+    if (p < parts) s0 += ws[(long)p * 1792 + i];
+    part[pg][o] = s0 + s1;
+    __syncthreads();
+    if (pg) return;
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += part[k][o];
     if (i < 27 * 64) dw[i] = accumulate ? dw[i] + s : s;
     else if (db) db[i - 27 * 64] = accumulate ? db[i - 27 * 64] + s : s;
 }
@@ -236,6 +242,6 @@ extern "C" int vc_conv1_wgrad_f32(void* stream, int B, int H, int W, const float
     hipLaunchKernelGGL(conv1_wgrad_kernel, dim3(wgs), dim3(256), 0, (hipStream_t)stream, a);
     int rc = launch_status(__func__);
     if (rc) return rc;
-    hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3(7), dim3(256), 0, (hipStream_t)stream, ws, wgs, dw, db, accumulate);
+    hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3(56), dim3(256), 0, (hipStream_t)stream, ws, wgs, dw, db, accumulate);
     return launch_status(__func__);
 }

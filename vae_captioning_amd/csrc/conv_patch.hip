@@ -688,12 +688,34 @@ __global__ __launch_bounds__(256, 2) void wgrad_patch_kernel(WgradPatchArgs a) {
     }
 }
 
+// dw = sum over the K splits of ws[split][MN] (fixed order; 16-byte accesses, MN % 4 == 0); the last block does the same for the
+// bias gradient's partials (Cout floats per split) when db is given -- one launch per layer
 __global__ __launch_bounds__(256) void wgrad_patch_reduce_kernel(const float* __restrict__ ws, int splits, long MN, float* __restrict__ dw,
+                                                                 const float* __restrict__ bias_ws, int Cout, float* __restrict__ db,
                                                                  int accumulate) {
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < MN; i += (long)gridDim.x * 256) {
-        float v = 0.f;
-        for (int z = 0; z < splits; ++z) v += ws[(long)z * MN + i];
-        dw[i] = accumulate ? dw[i] + v : v;
+    if (db && blockIdx.x == gridDim.x - 1) {
+        for (int i = threadIdx.x; i < Cout; i += 256) {
+            float v = 0.f;
+            for (int z = 0; z < splits; ++z) v += bias_ws[(long)z * Cout + i];
+            db[i] = accumulate ? db[i] + v : v;
+        }
+        return;
+    }
+    const long Q = MN >> 2;
+    const int nb = db ? gridDim.x - 1 : gridDim.x;
+    const float4* w4 = reinterpret_cast<const float4*>(ws);
+    float4* o4 = reinterpret_cast<float4*>(dw);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < Q; i += (long)nb * 256) {
+        float4 v = w4[i];
+        for (int z = 1; z < splits; ++z) {
+            const float4 t = w4[(long)z * Q + i];
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        if (accumulate) {
+            const float4 t = o4[i];
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        o4[i] = v;
     }
 }
 
@@ -966,13 +988,10 @@ extern "C" int vc_conv3x3_wgrad_patch_f32(void* stream, int B, int H, int W, int
     else
         hipLaunchKernelGGL(wgrad_patch_kernel, dim3(p.tiles, p.splits), dim3(256), (WG_XP + 32 * 64) * 4, (hipStream_t)stream, a);
     VC_LAUNCH_CHECK();
-    int grid = (int)((MN + 255) / 256);
+    int grid = (int)((MN / 4 + 255) / 256);
     if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(wgrad_patch_reduce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, ws, p.splits, MN, dw, accumulate);
+    hipLaunchKernelGGL(wgrad_patch_reduce_kernel, dim3(grid + (db ? 1 : 0)), dim3(256), 0, (hipStream_t)stream, ws, p.splits, MN, dw,
+                       a.bias_ws, Cout, db, accumulate);
     VC_LAUNCH_CHECK();
-    if (db) {
-        hipLaunchKernelGGL(wgrad_patch_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a.bias_ws, p.splits, (long)Cout, db, accumulate);
-        VC_LAUNCH_CHECK();
-    }
     return 0;
 }
