@@ -20,15 +20,15 @@ def family(name):
         k = re.search(r">,\s*(\d)\s*>\(", name)
         kinds = {"0": "fwd", "1": "dgrad", "2": "wgrad"}
         return "conv_kernel<%s>" % kinds.get(k.group(1) if k else "?", "?")
-    if "conv_patch_kernel" in name:  # conv_patch_kernel<TN, SCHEME, KIND>
-        k = re.search(r"conv_patch_kernel<\s*\d+,\s*\d+,\s*(\d)\s*>", name)
+    if "conv_patch_kernel" in name:  # conv_patch_kernel<TN, SCHEME, KIND, POOL>
+        k = re.search(r"conv_patch_kernel<\s*\d+,\s*\d+,\s*(\d)\s*(?:,\s*\w+\s*)?>", name)
         return "conv_patch_kernel<%s>" % {"0": "fwd", "1": "dgrad"}.get(k.group(1) if k else "?", "?")
     if "wgrad_flat_kernel" in name or "wgrad_patch_kernel" in name:
         return "wgrad_patch/flat_kernel"
     return base
 
 
-CONV_FAMILY = ("conv_kernel", "conv_patch_kernel", "wgrad_patch", "conv_tail_reduce", "patch_tail_reduce", "wgrad_reduce", "wgrad_patch_reduce")
+CONV_FAMILY = ("conv_kernel", "conv1_", "conv_patch_kernel", "wgrad_patch", "conv_tail_reduce", "patch_tail_reduce", "wgrad_reduce", "wgrad_patch_reduce")
 
 
 def main(root):
