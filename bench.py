@@ -357,7 +357,7 @@ def roofline_from_timer(timer, fine_tune):
     per = {t: dict(launches=sm[t]["launches"], avg_us=round(1e6 * sm[t]["seconds"] / sm[t]["launches"], 2),
                    tflops=round(sm[t]["flops"] / sm[t]["seconds"] / 1e12, 2)) for t in tags}
     return {"bound": "mfma",
-            "kernel": "vc::conv_patch_kernel / vc::wgrad_patch_kernel / vc::wgrad_flat_kernel (+ vc::conv_kernel for conv1_1)" if fine_tune
+            "kernel": "vc::conv_patch_kernel / vc::wgrad_patch_kernel (+ vc::conv1_fwd_kernel / vc::conv1_wgrad_kernel for conv1_1)" if fine_tune
                       else "vc::gemm_kernel<128x128,MK,KM> (logits)",
             "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
             "frac_union": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "frac_serial": round(fl / ser / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),

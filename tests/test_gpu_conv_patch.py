@@ -123,10 +123,11 @@ def test_patch_whole_rounds_tail_split_and_old_kernel(lib, case):
 
 
 # ---- weight gradient ------------------------------------------------------------------------------------------------
-# 4 x 8 sub-tile kernel (W % 8 == 0, H % 4 == 0), then the FLAT kernels of the 28- and 14-wide layers (K-tiles that straddle image
-# rows and images, a ragged last K-tile when B*H*W % 32 != 0)
+# 4 x 8 K-tiles (W % 8 == 0, H % 4 == 0), then 4 x 7 (W % 7 == 0, H % 4 == 0: the 28-wide layers) and 2 x 14 (W % 14 == 0, H % 2 == 0:
+# the 14-wide layers; also 28-wide images whose height is no multiple of 4)
 WG_CASES = [(2, 8, 8, 64, 64), (3, 4, 8, 64, 128), (2, 12, 16, 128, 64), (1, 56, 56, 64, 64), (2, 28, 40, 128, 192), (5, 8, 16, 64, 64),
-            (2, 28, 28, 64, 128), (1, 28, 28, 128, 256), (3, 14, 14, 128, 128), (5, 14, 14, 64, 256), (3, 20, 14, 64, 128), (2, 9, 28, 64, 128)]
+            (2, 28, 28, 64, 128), (1, 28, 28, 128, 256), (3, 14, 14, 128, 128), (5, 14, 14, 64, 256), (3, 20, 14, 64, 128), (2, 8, 28, 64, 128),
+            (3, 6, 28, 64, 64), (2, 4, 7, 64, 64), (1, 2, 14, 64, 64)]
 
 
 @pytest.mark.parametrize("case", WG_CASES, ids=lambda c: "x".join(map(str, c)))
@@ -165,8 +166,9 @@ def test_patch_wgrad_large_matches_implicit_gemm_and_is_reproducible(lib):
 
 
 def test_patch_wgrad_unsupported_shapes(lib):
-    assert lib.vc_conv3x3_wgrad_patch_supported(2, 28, 20, 256, 512) == 0   # neither W % 8 == 0 nor one of the FLAT widths
-    assert lib.vc_conv3x3_wgrad_patch_supported(2, 28, 28, 256, 64) == 0    # FLAT kernels: 128 output channels per workgroup
+    assert lib.vc_conv3x3_wgrad_patch_supported(2, 28, 20, 256, 512) == 0   # W is no multiple of 8, 7 or 14
+    assert lib.vc_conv3x3_wgrad_patch_supported(2, 29, 28, 256, 512) == 0   # 4 x 7 tiles need H % 4 == 0, 2 x 14 tiles H % 2 == 0
+    assert lib.vc_conv3x3_wgrad_patch_supported(2, 28, 28, 256, 64) == 1    # 4 x 7 K-tiles, 64 output channels per workgroup
     assert lib.vc_conv3x3_wgrad_patch_supported(2, 224, 224, 4, 64) == 0    # conv1_1
     assert lib.vc_conv3x3_wgrad_patch_supported(2, 56, 56, 96, 64) == 0     # Cin % 64
 

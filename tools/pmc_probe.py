@@ -1,5 +1,5 @@
 """Workload for SQ-counter probes (rocprofv3 --pmc ...): conv3_2-shaped forward / data gradient / weight gradient at
-64 images -- the implicit-GEMM kernels of conv.hip and the patch-staged kernels of conv_patch.hip -- the conv4_2-shaped FLAT weight
+64 images -- the implicit-GEMM kernels of conv.hip and the patch-staged kernels of conv_patch.hip -- the conv4_2-shaped (4 x 7 K-tile) weight
 gradient and the 8192^3 GEMM, three launches each.  Summarise with tools/pmc_probe_summary.py."""
 import os
 import sys
@@ -26,7 +26,7 @@ wp, wpt = torch.empty(9 * ci * co, device="cuda"), torch.empty(9 * ci * co, devi
 lib.vc_conv3x3_pack_f32(st(), ci, co, P(w), 0, P(wp))
 lib.vc_conv3x3_pack_f32(st(), ci, co, P(w), 1, P(wpt))
 tw = torch.empty(max(lib.vc_conv3x3_packed_workspace_bytes(B, H, H, ci, co, 0), 16) // 4 + 4, device="cuda")
-# conv4_2 shape for the FLAT weight-gradient kernel
+# conv4_2 shape: the 4 x 7 K-tile weight-gradient kernel
 x4 = torch.rand(B, 28, 28, 512, device="cuda") * 2 - 1
 dy4 = torch.rand(B, 28, 28, 512, device="cuda") * 2 - 1
 dw4 = torch.empty(3, 3, 512, 512, device="cuda")

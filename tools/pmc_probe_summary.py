@@ -18,9 +18,8 @@ for f in sorted(glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive
             if "tail" not in n and m2:
                 k = "patch_" + {"0": "fwd", "1": "dgrad"}[m2.group(1)]
         elif "wgrad_patch_kernel" in n:
-            k = "patch_wgrad(4x8)"
-        elif "wgrad_flat_kernel" in n:
-            k = "patch_wgrad(flat28)"
+            m3 = re.search(r"wgrad_patch_kernel<\s*(\d+),\s*(\d+)\s*>", n)
+            k = "patch_wgrad(%sx%s)" % (m3.group(1), m3.group(2)) if m3 else "patch_wgrad"
         elif "gemm_kernel" in n:
             k = "gemm"
         if k:

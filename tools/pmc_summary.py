@@ -23,8 +23,8 @@ def family(name):
     if "conv_patch_kernel" in name:  # conv_patch_kernel<TN, SCHEME, KIND, POOL>
         k = re.search(r"conv_patch_kernel<\s*\d+,\s*\d+,\s*(\d)\s*(?:,\s*\w+\s*)?>", name)
         return "conv_patch_kernel<%s>" % {"0": "fwd", "1": "dgrad"}.get(k.group(1) if k else "?", "?")
-    if "wgrad_flat_kernel" in name or "wgrad_patch_kernel" in name:
-        return "wgrad_patch/flat_kernel"
+    if "wgrad_patch_kernel" in name:
+        return "wgrad_patch_kernel<4x8 | 4x7 | 2x14>"
     return base
 
 

@@ -30,7 +30,7 @@ def main(path, top=40):
 # kernel families of the roofline report (substring match on the mangled kernel name)
 FAMILIES = [
     ("3x3 convolution (fwd + dgrad + wgrad, incl. K-split tails and split reduces)",
-     ["conv_kernel", "conv1_", "conv_patch_kernel", "wgrad_patch_kernel", "wgrad_flat_kernel", "conv_tail_reduce", "patch_tail_reduce",
+     ["conv_kernel", "conv1_", "conv_patch_kernel", "wgrad_patch_kernel", "conv_tail_reduce", "patch_tail_reduce",
       "wgrad_reduce_kernel", "wgrad_patch_reduce"]),
     ("GEMM (vc::gemm_kernel + split-K reduce)", ["gemm_kernel", "splitk_reduce"]),
     ("LSTM recurrence (step / gate kernels)", ["lstm_"]),

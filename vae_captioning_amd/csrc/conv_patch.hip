@@ -541,8 +541,11 @@ static int dispatch_patch(hipStream_t st, const PatchPlan& p, PatchArgs& a, floa
 // Weight gradient with LDS-staged patches:  dW[tap][ci][co] = sum_p x[p + off(tap)][ci] * dy[p][co]
 //   M = (tap, ci), N = co, K = pixels.  A workgroup owns 64 input channels x ALL NINE taps x 64 output channels
 //   (36 MFMA tiles of 32 x 32: wave w = (ci half w >> 1, co half w & 1) keeps the nine taps of its 32 x 32 block in
-//   nine accumulators) and walks a range of 4 x 8 pixel sub-tiles (K-tiles of 32 pixels).  Per K-tile it stages the
-//   6 x 10 halo patch of x (60 pixels x 64 channels) and the dy tile (32 x 64) ONCE and issues 9 x 16 MFMAs per wave:
+//   nine accumulators) and walks a range of TR x TC pixel sub-tiles = K-tiles: 4 x 8 for the 224 / 112 / 56-wide layers, 4 x 7 for
+//   the 28-wide and 2 x 14 for the 14-wide ones (round 2 first gave those a FLAT kernel -- 32 consecutive pixels of the flattened
+//   order with a row-pitched patch of 180 pixels and a per-k-step index table: 124-127 TFLOP/s; the 6 x 9 / 4 x 16 patches of an
+//   exact 2-D tiling reach 139-141 / 134 and that kernel was deleted).  Per K-tile it stages the (TR+2) x (TC+2) halo patch of x
+//   (60 pixels x 64 channels for 4 x 8) and the dy tile (TR*TC x 64) ONCE and issues 9 x TR*TC/2 MFMAs per wave:
 //   2.25 x the MFMAs per barrier pair of the implicit-GEMM weight gradient (whose M-tile is one tap: every tap re-stages
 //   its shifted copy of x), with 6 instead of 8 loads per thread and every LDS address = lane base + immediate.
 //   The nine taps read the SAME patch, so x travels global -> LDS once per (pixel, co-tile) instead of nine times.
@@ -561,12 +564,25 @@ struct WgradPatchArgs {
     int subs_per_split;
 };
 
-constexpr int WG_XP = 60 * 64;  // floats of the x patch
+// K-tile = TR x TC pixels (4 x 8 for the 224 / 112 / 56-wide layers, 4 x 7 for the 28-wide, 2 x 14 for the 14-wide ones): lane half
+// lh covers the TR/2 rows starting at row (TR/2) lh, TR*TC/2 MFMA k-steps per tile
+template <int TR, int TC>
+struct WgTile {
+    static constexpr int PW = TC + 2, PP = (TR + 2) * PW;  // patch row pitch / pixels
+    static constexpr int NP = TR * TC, KS = NP / 2;        // pixels / k-steps per K-tile
+    static constexpr int XP = ((PP * 16 + 255) / 256) * 256 * 4;  // floats of the x patch area (every staging slot has a home)
+    static constexpr int NVX = (PP * 16 + 255) / 256;
+    static constexpr int LDS_BYTES = (XP + 32 * 64) * 4;
+    static_assert(TR % 2 == 0 && NP <= 32 && NVX <= 4, "tile shape");
+};
 
+template <int TR, int TC>
 __global__ __launch_bounds__(256, 2) void wgrad_patch_kernel(WgradPatchArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Xp = smem;            // [60][64]
-    float* Dy = smem + WG_XP;    // [32][64]
+    using G = WgTile<TR, TC>;
+    constexpr int WG_XP = G::XP;
+    float* Xp = smem;            // [(TR+2)(TC+2)][64]
+    float* Dy = smem + WG_XP;    // [32][64] (rows >= TR*TC stay zero)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int cit = blockIdx.x / a.tiles_co, cot = blockIdx.x - cit * a.tiles_co;
@@ -576,26 +592,26 @@ __global__ __launch_bounds__(256, 2) void wgrad_patch_kernel(WgradPatchArgs a) {
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)(P * Cin * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, (int)(P * Cout * 4), 0x00020000);
 
-    // staging slots: x patch 60 px x 16 channel quads = 960 float4 (4 per thread, the last one partial), dy 32 x 16 = 512 (2)
-    int cx[4], fl[4];
+    // staging slots: x patch PP px x 16 channel quads (up to 4 float4 per thread, slots past the patch load zeros), dy 32 x 16 (2)
+    int cx[G::NVX], fl[G::NVX];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < G::NVX; ++u) {
         const int f = tid + 256 * u, pix = f >> 4, q = f & 15;
-        const int py = pix / 10, px = pix - py * 10;
+        const int py = pix / G::PW, px = pix - py * G::PW;
         cx[u] = (((py - 1) * W + (px - 1)) * Cin + ci0 + q * 4) * 4;
-        fl[u] = (py == 0 ? 1 : 0) | (py == 5 ? 2 : 0) | (px == 0 ? 4 : 0) | (px == 9 ? 8 : 0) | (pix >= 60 ? 16 : 0);
+        fl[u] = (py == 0 ? 1 : 0) | (py == TR + 1 ? 2 : 0) | (px == 0 ? 4 : 0) | (px == TC + 1 ? 8 : 0) | (pix >= G::PP ? 16 : 0);
     }
     unsigned cd[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int f = tid + 256 * u, pix = f >> 4, q = f & 15;
-        cd[u] = (unsigned)((((pix >> 3) * W + (pix & 7)) * Cout + co0 + q * 4) * 4);
+        cd[u] = pix < G::NP ? (unsigned)((((pix / TC) * W + (pix % TC)) * Cout + co0 + q * 4) * 4) : OOB;
     }
     const int xst = tid * 4;  // LDS float index of x slot 0 (slot u: + 1024 u), dy slot 0 (slot u: + 1024 u)
 
-    // fragment bases (bytes): A = x patch, row i = ci, lane half lh covers pixels 16 lh .. 16 lh + 15 of the sub-tile
-    const int abase = ((2 * lh * 10) * 64 + (wave >> 1) * 32 + li) * 4;
-    const int bbase = ((16 * lh) * 64 + (wave & 1) * 32 + li) * 4 + WG_XP * 4;
+    // fragment bases (bytes): A = x patch, row i = ci, lane half lh covers pixels KS lh .. KS lh + KS - 1 (TR/2 rows) of the K-tile
+    const int abase = (((TR / 2) * lh * G::PW) * 64 + (wave >> 1) * 32 + li) * 4;
+    const int bbase = ((G::KS * lh) * 64 + (wave & 1) * 32 + li) * 4 + WG_XP * 4;
 
     f32x16 acc[9];
 #pragma unroll
@@ -609,13 +625,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_patch_kernel(WgradPatchArgs a) {
     int b = (int)(s / subs_img), rem = (int)(s - (long)b * subs_img);
     int sy = rem / a.subs_x, sx = rem - sy * a.subs_x;
 
-    float4 pr[4], dr[2];
+    float4 pr[G::NVX], dr[2];
     auto issue = [&]() {
-        const int pb = (b * a.H + sy * 4) * W + sx * 8;  // first pixel of the sub-tile
+        const int pb = (b * a.H + sy * TR) * W + sx * TC;  // first pixel of the sub-tile
         const int em = 16 | (sy == 0 ? 1 : 0) | (sy == a.subs_y - 1 ? 2 : 0) | (sx == 0 ? 4 : 0) | (sx == a.subs_x - 1 ? 8 : 0);
         const int pbx = pb * Cin * 4;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) pr[u] = bufload(rx, (fl[u] & em) ? OOB : (unsigned)(cx[u] + pbx), 0);
+        for (int u = 0; u < G::NVX; ++u) pr[u] = bufload(rx, (fl[u] & em) ? OOB : (unsigned)(cx[u] + pbx), 0);
         const unsigned pbd = (unsigned)pb * (unsigned)Cout * 4u;
 #pragma unroll
         for (int u = 0; u < 2; ++u) dr[u] = bufload(rd, cd[u], pbd);
@@ -633,8 +649,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_patch_kernel(WgradPatchArgs a) {
     while (s < s_end) {
         __syncthreads();  // every wave is done with the previous tile
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (u < 3 || tid < 192) *reinterpret_cast<float4*>(&Xp[xst + 1024 * u]) = pr[u];
+        for (int u = 0; u < G::NVX; ++u) *reinterpret_cast<float4*>(&Xp[xst + 1024 * u]) = pr[u];
 #pragma unroll
         for (int u = 0; u < 2; ++u) *reinterpret_cast<float4*>(&Dy[xst + 1024 * u]) = dr[u];
         if (do_bias) {
@@ -643,7 +658,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_patch_kernel(WgradPatchArgs a) {
         __syncthreads();
         advance();
         if (s < s_end) issue();  // next tile's loads fly under this tile's 144 MFMAs
-        // 16 k-steps: k-step ks covers pixel 16 lh + ks of the sub-tile = (row 2 lh + (ks >> 3), column ks & 7)
+        // KS k-steps: k-step ks covers pixel KS lh + ks of the K-tile = (row (TR/2) lh + ks / TC, column ks % TC)
         float fa[2][9], fb[2];
         auto frag = [&](int ks, int buf) {
             const char* sm = reinterpret_cast<const char*>(smem);
@@ -651,14 +666,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_patch_kernel(WgradPatchArgs a) {
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int dyy = t / 3 - 1, dxx = t % 3 - 1;
-                fa[buf][t] = *reinterpret_cast<const float*>(sm + abase + ((((ks >> 3) + 1 + dyy) * 10 + (ks & 7) + 1 + dxx) * 64) * 4);
+                fa[buf][t] = *reinterpret_cast<const float*>(sm + abase + (((ks / TC + 1 + dyy) * G::PW + ks % TC + 1 + dxx) * 64) * 4);
             }
         };
         frag(0, 0);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-            if (ks + 1 < 16) frag(ks + 1, (ks + 1) & 1);
+        for (int ks = 0; ks < G::KS; ++ks) {
+            if (ks + 1 < G::KS) frag(ks + 1, (ks + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ks & 1][t], fb[ks & 1], acc[t], 0, 0, 0);
@@ -719,182 +734,31 @@ __global__ __launch_bounds__(256) void wgrad_patch_reduce_kernel(const float* __
     }
 }
 
-// ---- FLAT variant for the narrow layers (W = 28 / 14: no 4 x 8 tiling of the image exists) -----------------------------
-// K-tile = 32 consecutive pixels of the flattened [B*H*W] order; the patch holds every image row they touch +-1 with row
-// pitch W + 2 and one zero row between two images (as in the forward FLAT tiling).  A workgroup owns 32 input channels x
-// nine taps x 128 output channels (wave w = output channels 32 w ..), so the patch is 32 channels deep.  W is a template
-// parameter: the tap offsets stay immediates; the patch index of a k-step's pixel is a few VALU instructions per 9 MFMAs.
-template <int W>
-struct FlatGeom {
-    static constexpr int PW = W + 2;
-    static constexpr int RC = (W - 1 + 31) / W;        // most row crossings inside a 32-pixel K-tile
-    static constexpr int R = RC + 1 + 3;               // rows + halo above / below + the zero row between images
-    static constexpr int NPIX = R * PW;
-    static constexpr int NVX = (NPIX * 8 + 255) / 256; // float4 patch slots per thread (32 channels = 8 quads per pixel)
-    static constexpr int XP = NVX * 32 * 32;           // floats (every slot has a home: the stores are unconditional)
-    static_assert(NPIX <= 255, "patch pixel indices travel as bytes");
-};
-
-template <int W>
-__global__ __launch_bounds__(256, 2) void wgrad_flat_kernel(WgradPatchArgs a) {
-    using G = FlatGeom<W>;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Xp = smem;             // [NPIX][32]
-    float* Dy = smem + G::XP;     // [32][128]
-    unsigned char* tab = reinterpret_cast<unsigned char*>(smem + G::XP + 32 * 128);  // [32] patch pixel of K-tile pixel q
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 31, lh = lane >> 5;
-    const int cit = blockIdx.x / a.tiles_co, cot = blockIdx.x - cit * a.tiles_co;
-    const int ci0 = cit * 32, co0 = cot * 128;
-    const int H = a.H, Cin = a.Cin, Cout = a.Cout;
-    const long P = (long)a.B * H * W;
-    const int BH = a.B * H;
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)(P * Cin * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, (int)(P * Cout * 4), 0x00020000);
-
-    // x patch slots: slot u = (patch pixel (tid >> 3) + 32 u, channel quad tid & 7); its row slot / column never change
-    int prs[G::NVX], pcx[G::NVX];
-#pragma unroll
-    for (int u = 0; u < G::NVX; ++u) {
-        const int pix = (tid >> 3) + 32 * u;
-        prs[u] = pix < G::NPIX ? pix / G::PW : -1;
-        const int c = pix - (pix / G::PW) * G::PW;
-        if (c == 0 || c == G::PW - 1) prs[u] = -1;           // the halo columns are always zero
-        pcx[u] = ((c - 1) * Cin + ci0 + (tid & 7) * 4) * 4;  // byte offset inside the image row
-        asm volatile("" : "+v"(prs[u]), "+v"(pcx[u]));       // opaque: keep them in registers (hipcc re-derived them per K-tile through a decision tree)
-    }
-    // dy slots: slot u = (pixel (tid >> 5) + 8 u, column quad tid & 31)
-    const unsigned cd0 = (unsigned)(((tid >> 5) * Cout + co0 + (tid & 31) * 4) * 4);
-
-    const int abase = li * 4;                                                  // + patch pixel * 128
-    const int bbase = ((16 * lh) * 128 + wave * 32 + li) * 4 + G::XP * 4;      // + ks * 512
-
-    f32x16 acc[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-
-    long kt = (long)blockIdx.y * a.subs_per_split;
-    const long kt_end = kt + a.subs_per_split < a.nsubs ? kt + a.subs_per_split : a.nsubs;
-    // position of the K-tile's first pixel: global row g0 (image row y0 = g0 % H), column x0
-    int g0 = (int)((kt * 32) / W), x0 = (int)(kt * 32 - (long)g0 * W);
-    int y0 = g0 % H;
-
-    float4 pr[G::NVX], dr[4];
-    auto issue = [&]() {
-        const int nb0 = H - y0;
-#pragma unroll
-        for (int u = 0; u < G::NVX; ++u) {  // (bitwise logic: short-circuit && / ?: made hipcc branch around every load)
-            const int rs = prs[u];
-            const int first = rs <= nb0 ? 1 : 0;
-            const int gr = g0 + rs - 2 + first;  // row slots 1 .. nb0 are image b0's rows, nb0 + 2 .. the next image's
-            const int ok = (rs >= 0 ? 1 : 0) & ((first & ((rs != 0 ? 1 : 0) | (y0 != 0 ? 1 : 0))) |
-                                                ((first ^ 1) & (rs != nb0 + 1 ? 1 : 0) & (gr < BH ? 1 : 0)));
-            pr[u] = bufload(rx, (unsigned)(gr * (W * Cin * 4) + pcx[u]) | ((unsigned)(ok ^ 1) << 31), 0);  // bit 31 = the OOB marker
-        }
-        const unsigned pbd = (unsigned)(g0 * W + x0) * (unsigned)Cout * 4u;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) dr[u] = bufload(rd, cd0 + (unsigned)(8 * u * Cout * 4), pbd);  // beyond the tensor: zeros
-    };
-    auto advance = [&]() {
-        ++kt;
-        x0 += 32;
-        while (x0 >= W) { x0 -= W; ++g0; if (++y0 == H) y0 = 0; }
-    };
-    const bool do_bias = a.bias_ws != nullptr && cit == 0;
-    float4 csum = f4zero();
-
-    if (kt < kt_end) issue();
-    while (kt < kt_end) {
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < G::NVX; ++u) *reinterpret_cast<float4*>(&Xp[tid * 4 + 1024 * u]) = pr[u];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) *reinterpret_cast<float4*>(&Dy[((tid >> 5) + 8 * u) * 128 + (tid & 31) * 4]) = dr[u];
-        if (do_bias) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { csum.x += dr[u].x; csum.y += dr[u].y; csum.z += dr[u].z; csum.w += dr[u].w; }
-        }
-        if (tid < 32) {  // patch pixel of K-tile pixel q = tid: row slot = rows crossed + 1 (+ 1 behind the zero row of an image boundary)
-            const int t = x0 + tid, nb0 = H - y0;
-            int rc = t >= W ? 1 : 0;
-            if (G::RC >= 2) rc += t >= 2 * W ? 1 : 0;
-            if (G::RC >= 3) rc += t >= 3 * W ? 1 : 0;
-            tab[tid] = (unsigned char)((rc + (rc >= nb0 ? 1 : 0)) * G::PW + (t - rc * W));  // its TOP-LEFT neighbour: tap offsets stay >= 0 (immediates)
-        }
-        __syncthreads();
-        advance();
-        if (kt < kt_end) issue();
-        // the 16 patch pixels of this lane half (k-step ks covers pixel 16 lh + ks), one byte each: 2 VALU per k-step in the MFMA stream
-        const uint4 tq = *reinterpret_cast<const uint4*>(tab + 16 * lh);
-        float fa[2][9], fb[2];
-        auto frag = [&](int ks, int buf) {
-            const char* sm = reinterpret_cast<const char*>(smem);
-            fb[buf] = *reinterpret_cast<const float*>(sm + bbase + ks * 512);
-            const unsigned word = (ks >> 2) == 0 ? tq.x : (ks >> 2) == 1 ? tq.y : (ks >> 2) == 2 ? tq.z : tq.w;
-            const int pidx = (int)((word >> (8 * (ks & 3))) & 255u);
-            const char* pa = sm + abase + pidx * 128;
-#pragma unroll
-            for (int tp = 0; tp < 9; ++tp)
-                fa[buf][tp] = *reinterpret_cast<const float*>(pa + ((tp / 3) * G::PW + (tp % 3)) * 128);
-        };
-        frag(0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-            if (ks + 1 < 16) frag(ks + 1, (ks + 1) & 1);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ks & 1][t], fb[ks & 1], acc[t], 0, 0, 0);
-        }
-    }
-
-    float* out = a.ws + (long)blockIdx.y * 9 * Cin * Cout;
-    const int col = co0 + wave * 32 + li;
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int ci = ci0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            out[((long)t * Cin + ci) * Cout + col] = acc[t][r];
-        }
-    if (do_bias) {
-        __syncthreads();
-        *reinterpret_cast<float4*>(&smem[tid * 4]) = csum;  // [pixel group tid >> 5][column 4 (tid & 31) + e]
-        __syncthreads();
-        if (tid < 128) {
-            float t = 0.f;
-#pragma unroll
-            for (int g = 0; g < 8; ++g) t += smem[g * 128 + tid];
-            a.bias_ws[(long)blockIdx.y * Cout + co0 + tid] = t;
-        }
-    }
-}
-
 struct WgradPatchPlan {
     bool ok;
-    int flat;        // 0: 4 x 8 sub-tiles (64 ci x 64 co per workgroup); 28 / 14: FLAT kernel of that width (32 ci x 128 co)
+    int tr, tc;      // K-tile shape: 4 x 8, 4 x 7 (28-wide layers) or 2 x 14 (14-wide layers)
     int splits, sps, tiles;
     long nsubs;      // K-tiles
 };
 
 static WgradPatchPlan plan_wgrad_patch(int B, int H, int W, int Cin, int Cout) {
     WgradPatchPlan p;
-    p.ok = false; p.flat = 0; p.splits = 0; p.sps = 0; p.tiles = 0; p.nsubs = 0;
+    p.ok = false; p.splits = 0; p.sps = 0; p.tiles = 0; p.nsubs = 0; p.tr = 4; p.tc = 8;
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % 64 || Cout % 64) return p;
     const long P = (long)B * H * W;
     if (P * (long)(Cin > Cout ? Cin : Cout) * 4 > 0x7fffffffL) return p;
     if (W % 8 == 0 && H % 4 == 0) {
         p.nsubs = (long)B * (H / 4) * (W / 8);
-        p.tiles = (Cin / 64) * (Cout / 64);
-    } else if ((W == 28 || W == 14) && Cout % 128 == 0 && (long)H * W >= 64 + W) {  // (a K-tile crosses at most one image boundary)
-        p.flat = W;
-        p.nsubs = (P + 31) / 32;
-        p.tiles = (Cin / 32) * (Cout / 128);
+    } else if (W % 7 == 0 && H % 4 == 0) {   // 28 x 28: 4 x 7 K-tiles (6 x 9 patch)
+        p.tr = 4; p.tc = 7;
+        p.nsubs = (long)B * (H / 4) * (W / 7);
+    } else if (W % 14 == 0 && H % 2 == 0) {  // 14 x 14: 2 x 14 K-tiles (4 x 16 patch)
+        p.tr = 2; p.tc = 14;
+        p.nsubs = (long)B * (H / 2) * (W / 14);
     } else {
         return p;
     }
+    p.tiles = (Cin / 64) * (Cout / 64);
     long slots = 512;                        // two workgroups per CU
     if (const char* e = getenv("VC_WGRAD_SLOTS")) slots = atol(e) > 0 ? atol(e) : 512;  // experiments only
     long splits = slots / p.tiles;
@@ -980,13 +844,13 @@ extern "C" int vc_conv3x3_wgrad_patch_f32(void* stream, int B, int H, int W, int
     WgradPatchArgs a;
     a.x = x; a.dy = dy; a.ws = ws; a.bias_ws = db ? ws + (size_t)p.splits * MN : nullptr;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
-    a.subs_x = W / 8; a.subs_y = H / 4; a.nsubs = p.nsubs; a.tiles_co = p.flat ? Cout / 128 : Cout / 64; a.subs_per_split = p.sps;
-    if (p.flat == 28)
-        hipLaunchKernelGGL(wgrad_flat_kernel<28>, dim3(p.tiles, p.splits), dim3(256), (FlatGeom<28>::XP + 32 * 128 + 8) * 4, (hipStream_t)stream, a);
-    else if (p.flat == 14)
-        hipLaunchKernelGGL(wgrad_flat_kernel<14>, dim3(p.tiles, p.splits), dim3(256), (FlatGeom<14>::XP + 32 * 128 + 8) * 4, (hipStream_t)stream, a);
+    a.subs_x = W / p.tc; a.subs_y = H / p.tr; a.nsubs = p.nsubs; a.tiles_co = Cout / 64; a.subs_per_split = p.sps;
+    if (p.tc == 7)
+        hipLaunchKernelGGL((wgrad_patch_kernel<4, 7>), dim3(p.tiles, p.splits), dim3(256), (WgTile<4, 7>::LDS_BYTES), (hipStream_t)stream, a);
+    else if (p.tc == 14)
+        hipLaunchKernelGGL((wgrad_patch_kernel<2, 14>), dim3(p.tiles, p.splits), dim3(256), (WgTile<2, 14>::LDS_BYTES), (hipStream_t)stream, a);
     else
-        hipLaunchKernelGGL(wgrad_patch_kernel, dim3(p.tiles, p.splits), dim3(256), (WG_XP + 32 * 64) * 4, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((wgrad_patch_kernel<4, 8>), dim3(p.tiles, p.splits), dim3(256), (WgTile<4, 8>::LDS_BYTES), (hipStream_t)stream, a);
     VC_LAUNCH_CHECK();
     int grid = (int)((MN / 4 + 255) / 256);
     if (grid > 4096) grid = 4096;
