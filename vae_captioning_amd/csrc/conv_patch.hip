@@ -130,6 +130,14 @@ __device__ __forceinline__ float4 bufload(__amdgpu_buffer_rsrc_t r, unsigned vof
 
 __device__ __forceinline__ float comp(const float4& v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
 
+// value of lane ^ 1 (quad_perm [1,0,3,2]) / of lane ^ 8 (rotation by 8 inside the 16-lane DPP row): VALU modifiers, no LDS
+__device__ __forceinline__ float dpp_xor1(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_ror8(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));
+}
+
 template <int TN>
 using PatchCfg = TileCfg<2, 2, 2, TN>;  // 4 waves, wave tile 64 x (TN*32): block 128 x (TN*64)
 
@@ -144,7 +152,7 @@ struct PatchLds {
 };
 
 template <int TN, int SCHEME, int KIND, bool POOL = false>
-__global__ __launch_bounds__(256, (POOL && TN == 1) ? 3 : 2) void conv_patch_kernel(PatchArgs a) {
+__global__ __launch_bounds__(256, TN == 1 ? 3 : 2) void conv_patch_kernel(PatchArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using CFG = PatchCfg<TN>;
     constexpr int NVP = PatchLds<SCHEME>::NVP;
@@ -227,7 +235,7 @@ __global__ __launch_bounds__(256, (POOL && TN == 1) ? 3 : 2) void conv_patch_ker
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int u = 0; u < TN; ++u)
-                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c & 1][t][e], comp(b[u][c], e), acc[t][u], 0, 0, 0);
+                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(b[u][c], e), fa[c & 1][t][e], acc[t][u], 0, 0, 0);
         }
     };
     const int PWp = (SCHEME == PATCH_SUB ? 10 : g.PW) * PITCH;  // floats per patch row (SUB: compile-time -> immediate offsets)
@@ -261,59 +269,73 @@ __global__ __launch_bounds__(256, (POOL && TN == 1) ? 3 : 2) void conv_patch_ker
 #pragma unroll
                 for (int q = 0; q < 4; ++q) b0[t][q] = b1[t][q];
             __syncthreads();
+        } else {
+            // (hipcc 7.2 has scheduled register copies of a loop exit straight behind the last 16-pass MFMA without its wait states,
+            //  see gemm notes in DESIGN.md: the epilogue below reads the accumulators right away)
+            asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
         }
     }
 
+    // The weights are the MFMA's A operand, the patch its B operand: acc[t][u][r] = D[output column 32 u + (r&3) + 8 (r>>2) + 4 lh]
+    // [tile row (pixel) 32 t + li] -- a lane owns ONE pixel and, in every group of four accumulator registers, four CONSECUTIVE
+    // output columns: bias / ReLU / ReLU mask and the 16-byte stores come straight from the accumulators, with no LDS transposition and
+    // no workgroup barrier (round 2's first version transposed through LDS: ~8 % of a 64-channel tile).
     if (a.tail_ws) {  // raw partial sums of this split: [split][tail tile][128][BN]
         float* o = a.tail_ws + ((long)blockIdx.y * a.ntiles + (id - a.tile0)) * (128 * CFG::BN);
-        epilogue_rows<CFG>(acc, smem, [&](int r, int cc, float4 v) { *reinterpret_cast<float4*>(o + r * CFG::BN + cc) = v; });
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int u = 0; u < TN; ++u)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(o + ((wm * 2 + t) * 32 + li) * CFG::BN + (wn * TN + u) * 32 + 8 * q + 4 * lh) =
+                        make_float4(acc[t][u][4 * q], acc[t][u][4 * q + 1], acc[t][u][4 * q + 2], acc[t][u][4 * q + 3]);
         return;
     }
-    // epilogue: each call handles 4 consecutive columns of one tile row
-    epilogue_rows<CFG>(acc, smem, [&](int r, int cc, float4 v) {
-        const long p = map.out_pixel(r);
-        if (p < 0) return;
-        const int col = n0 + cc;
-        if (KIND == PK_FWD) {
-            if (a.aux) {
-                const float4 bv = *reinterpret_cast<const float4*>(a.aux + col);
-                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-            }
-            if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        } else if (a.aux) {  // ReluGrad of the layer that produced this convolution's input
-            const float4 m = *reinterpret_cast<const float4*>(a.aux + p * N + col);
-            if (!(m.x > 0.f)) v.x = 0.f;
-            if (!(m.y > 0.f)) v.y = 0.f;
-            if (!(m.z > 0.f)) v.z = 0.f;
-            if (!(m.w > 0.f)) v.w = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const long p = map.out_pixel((wm * 2 + t) * 32 + li);
+        const bool live = p >= 0;
+        const long pc = live ? p : 0;
+        float* pool_row = nullptr;
+        bool pool_lane = false;
+        if (POOL) {
+            // 2x2 / stride 2 max-pool (utils/image_embeddings.py:59-63 ...): the 32 pixels of this MFMA tile are one 4 x 8 sub-tile, pixel
+            // li = 8 row + column, so a pooling window is the lanes {li, li ^ 1, li ^ 8}: two DPP max steps; max commutes with the bias
+            // add and the ReLU (both monotone)
+            const long prow = pc / g.W;                      // b*H + y (H even): the pooled row is prow / 2
+            const int px = (int)(pc - prow * g.W) >> 1;
+            pool_row = a.pool + ((prow >> 1) * (g.W >> 1) + px) * N;
+            pool_lane = live && (li & 9) == 0;
         }
-        *reinterpret_cast<float4*>(a.out + p * N + col) = v;
-    }, [&](int tm, const float* T, int LD) {
-        // fused 2x2 / stride 2 max-pool (utils/image_embeddings.py:59-63 ...): the 32 rows of the strip are one 4 x 8 sub-tile, i.e.
-        // eight complete pooling windows per column; max commutes with the bias add and the ReLU (both monotone)
-        if (!POOL) return;
-        constexpr int QPR = TN * 8;
-        const int sub_row0 = (wm * 2 + tm) * 32;
-        for (int it = lane; it < 8 * QPR; it += 64) {
-            const int pq = it / QPR, cq = it - pq * QPR;
-            const int r0 = (pq >> 2) * 16 + (pq & 3) * 2;  // window rows r0, r0+1 (x+1), r0+8 (y+1), r0+9
-            const long p = map.out_pixel(sub_row0 + r0);
-            if (p < 0) continue;
-            const float4 q0 = *reinterpret_cast<const float4*>(&T[r0 * LD + cq * 4]), q1 = *reinterpret_cast<const float4*>(&T[(r0 + 1) * LD + cq * 4]);
-            const float4 q2 = *reinterpret_cast<const float4*>(&T[(r0 + 8) * LD + cq * 4]), q3 = *reinterpret_cast<const float4*>(&T[(r0 + 9) * LD + cq * 4]);
-            float4 v = make_float4(fmaxf(fmaxf(q0.x, q1.x), fmaxf(q2.x, q3.x)), fmaxf(fmaxf(q0.y, q1.y), fmaxf(q2.y, q3.y)),
-                                   fmaxf(fmaxf(q0.z, q1.z), fmaxf(q2.z, q3.z)), fmaxf(fmaxf(q0.w, q1.w), fmaxf(q2.w, q3.w)));
-            const int col = n0 + wn * TN * 32 + cq * 4;
-            if (a.aux) {
-                const float4 bv = *reinterpret_cast<const float4*>(a.aux + col);
-                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+#pragma unroll
+        for (int u = 0; u < TN; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int col = n0 + (wn * TN + u) * 32 + 8 * q + 4 * lh;
+                float4 v = make_float4(acc[t][u][4 * q], acc[t][u][4 * q + 1], acc[t][u][4 * q + 2], acc[t][u][4 * q + 3]);
+                if (KIND == PK_FWD) {
+                    if (a.aux) {
+                        const float4 bv = *reinterpret_cast<const float4*>(a.aux + col);
+                        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                    }
+                    if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                } else if (a.aux) {  // ReluGrad of the layer that produced this convolution's input
+                    const float4 m = *reinterpret_cast<const float4*>(a.aux + pc * N + col);
+                    if (!(m.x > 0.f)) v.x = 0.f;
+                    if (!(m.y > 0.f)) v.y = 0.f;
+                    if (!(m.z > 0.f)) v.z = 0.f;
+                    if (!(m.w > 0.f)) v.w = 0.f;
+                }
+                if (live) *reinterpret_cast<float4*>(a.out + p * N + col) = v;
+                if (POOL) {
+                    float4 m = v;
+                    m.x = fmaxf(m.x, dpp_xor1(m.x)); m.y = fmaxf(m.y, dpp_xor1(m.y)); m.z = fmaxf(m.z, dpp_xor1(m.z)); m.w = fmaxf(m.w, dpp_xor1(m.w));
+                    m.x = fmaxf(m.x, dpp_ror8(m.x)); m.y = fmaxf(m.y, dpp_ror8(m.y)); m.z = fmaxf(m.z, dpp_ror8(m.z)); m.w = fmaxf(m.w, dpp_ror8(m.w));
+                    if (pool_lane) *reinterpret_cast<float4*>(pool_row + col) = m;
+                }
             }
-            if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            const long prow = p / g.W;                       // b*H + y with y even (and H even): the pooled row is prow / 2
-            const int px = (int)(p - prow * g.W) >> 1;
-            *reinterpret_cast<float4*>(a.pool + ((prow >> 1) * (g.W >> 1) + px) * N + col) = v;
-        }
-    });
+    }
 }
 
 // Sum of the tail launch's K splits (fixed order) + the epilogue of the main launch.
