@@ -185,8 +185,42 @@ __global__ __launch_bounds__(256, TN == 1 ? 3 : 2) void conv_patch_kernel(PatchA
     for (int t = 0; t < TN; ++t) voffb[t] = (unsigned)(((long)(4 * lh) * N + n0 + (wn * TN + t) * 32 + li) * 16);
     const unsigned qstride = (unsigned)N * 16u;  // bytes between channel quads
 
+    // Accumulators start at the BIAS of their output column (forward, main launch: the K-split tail launch writes raw partial sums
+    // and its reduce kernel adds the bias); the data gradient packs the ReLU mask of its rows into one bit per accumulator element
+    // here, while the first patch is in flight -- the epilogue then has no load on its critical path.
     f32x16 acc[2][TN];
     acc_zero<CFG>(acc);
+    unsigned mbits[TN];
+#pragma unroll
+    for (int u = 0; u < TN; ++u) mbits[u] = 0xffffffffu;
+    if (!a.tail_ws && a.aux) {
+        if (KIND == PK_FWD) {
+#pragma unroll
+            for (int u = 0; u < TN; ++u)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 bv = *reinterpret_cast<const float4*>(a.aux + n0 + (wn * TN + u) * 32 + 8 * q + 4 * lh);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) { acc[t][u][4 * q] = bv.x; acc[t][u][4 * q + 1] = bv.y; acc[t][u][4 * q + 2] = bv.z; acc[t][u][4 * q + 3] = bv.w; }
+                }
+        } else {
+#pragma unroll
+            for (int u = 0; u < TN; ++u) mbits[u] = 0u;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const long p = map.out_pixel((wm * 2 + t) * 32 + li);
+                const long pc = p >= 0 ? p : 0;
+#pragma unroll
+                for (int u = 0; u < TN; ++u)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 m = *reinterpret_cast<const float4*>(a.aux + pc * N + n0 + (wn * TN + u) * 32 + 8 * q + 4 * lh);
+                        const unsigned bits = (m.x > 0.f ? 1u : 0u) | (m.y > 0.f ? 2u : 0u) | (m.z > 0.f ? 4u : 0u) | (m.w > 0.f ? 8u : 0u);
+                        mbits[u] |= bits << (16 * t + 4 * q);
+                    }
+            }
+        }
+    }
 
     int cb = 0, ce = a.nchunks;
     if (a.tail_ws) {
@@ -314,18 +348,14 @@ __global__ __launch_bounds__(256, TN == 1 ? 3 : 2) void conv_patch_kernel(PatchA
             for (int q = 0; q < 4; ++q) {
                 const int col = n0 + (wn * TN + u) * 32 + 8 * q + 4 * lh;
                 float4 v = make_float4(acc[t][u][4 * q], acc[t][u][4 * q + 1], acc[t][u][4 * q + 2], acc[t][u][4 * q + 3]);
-                if (KIND == PK_FWD) {
-                    if (a.aux) {
-                        const float4 bv = *reinterpret_cast<const float4*>(a.aux + col);
-                        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-                    }
+                if (KIND == PK_FWD) {  // (the bias is already in the accumulators)
                     if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                } else if (a.aux) {  // ReluGrad of the layer that produced this convolution's input
-                    const float4 m = *reinterpret_cast<const float4*>(a.aux + pc * N + col);
-                    if (!(m.x > 0.f)) v.x = 0.f;
-                    if (!(m.y > 0.f)) v.y = 0.f;
-                    if (!(m.z > 0.f)) v.z = 0.f;
-                    if (!(m.w > 0.f)) v.w = 0.f;
+                } else {               // ReluGrad of the layer that produced this convolution's input (mask bits packed before the main loop)
+                    const unsigned mb = mbits[u] >> (16 * t + 4 * q);
+                    if (!(mb & 1u)) v.x = 0.f;
+                    if (!(mb & 2u)) v.y = 0.f;
+                    if (!(mb & 4u)) v.z = 0.f;
+                    if (!(mb & 8u)) v.w = 0.f;
                 }
                 if (live) *reinterpret_cast<float4*>(a.out + p * N + col) = v;
                 if (POOL) {
