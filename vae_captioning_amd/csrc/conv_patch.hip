@@ -151,6 +151,18 @@ struct PatchLds {
     }
 };
 
+// tools/probes/patch_trace.hip compiles this file with VC_PATCH_TRACE: every wave stamps s_memtime at phase edges
+#ifdef VC_PATCH_TRACE
+__device__ unsigned long long* g_patch_trace = nullptr;  // [workgroups][4 waves][8 stamps]
+#define PATCH_STAMP(k)                                                                                              \
+    do {                                                                                                            \
+        if (g_patch_trace && (threadIdx.x & 63) == 0)                                                               \
+            g_patch_trace[((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (k)] = __builtin_readcyclecounter();    \
+    } while (0)
+#else
+#define PATCH_STAMP(k)
+#endif
+
 template <int TN, int SCHEME, int KIND, bool POOL = false>
 __global__ __launch_bounds__(256, TN == 1 ? 3 : 2) void conv_patch_kernel(PatchArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -159,6 +171,7 @@ __global__ __launch_bounds__(256, TN == 1 ? 3 : 2) void conv_patch_kernel(PatchA
     const PatchGeom& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+    PATCH_STAMP(0);
     const int id = a.tile0 + xcd_remap(blockIdx.x, a.ntiles);
     const int tmi = id / a.tiles_n, n0 = (id - tmi * a.tiles_n) * CFG::BN;
     const TileMap<SCHEME> map(g, tmi);
@@ -275,12 +288,15 @@ __global__ __launch_bounds__(256, TN == 1 ? 3 : 2) void conv_patch_kernel(PatchA
     const int PWp = (SCHEME == PATCH_SUB ? 10 : g.PW) * PITCH;  // floats per patch row (SUB: compile-time -> immediate offsets)
     auto tapoff = [&](int tap) { return (tap / 3 - 1) * PWp + (tap % 3 - 1) * PITCH; };
 
+    PATCH_STAMP(1);
     if (cb < ce) {
         pload(cb);
         bload(b0, 0, cb);
         pstore();
+        PATCH_STAMP(2);
         __syncthreads();
     }
+    PATCH_STAMP(3);
     for (int ch = cb; ch < ce; ++ch) {
         const bool more = ch + 1 < ce;
         bload(b1, 1, ch); compute(b0, tapoff(0));
@@ -310,6 +326,7 @@ __global__ __launch_bounds__(256, TN == 1 ? 3 : 2) void conv_patch_kernel(PatchA
         }
     }
 
+    PATCH_STAMP(4);
     // The weights are the MFMA's A operand, the patch its B operand: acc[t][u][r] = D[output column 32 u + (r&3) + 8 (r>>2) + 4 lh]
     // [tile row (pixel) 32 t + li] -- a lane owns ONE pixel and, in every group of four accumulator registers, four CONSECUTIVE
     // output columns: bias / ReLU / ReLU mask and the 16-byte stores come straight from the accumulators, with no LDS transposition and
@@ -366,6 +383,7 @@ __global__ __launch_bounds__(256, TN == 1 ? 3 : 2) void conv_patch_kernel(PatchA
                 }
             }
     }
+    PATCH_STAMP(5);
 }
 
 // Sum of the tail launch's K splits (fixed order) + the epilogue of the main launch.
