@@ -695,18 +695,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_patch_kernel(WgradPatchArgs a) {
     int b = (int)(s / subs_img), rem = (int)(s - (long)b * subs_img);
     int sy = rem / a.subs_x, sx = rem - sy * a.subs_x;
 
-    float4 pr[G::NVX], dr[2];
-    auto issue = [&]() {
+    // staging registers of TWO K-tiles: the loads run two tiles ahead of the MFMAs (the 64-channel layers stream x and dy from HBM
+    // with no re-use between workgroups; one tile ahead = 9216 MFMA cycles did not always cover that latency)
+    float4 pr[2][G::NVX], dr[2][2];
+    auto issue = [&](int h) {
         const int pb = (b * a.H + sy * TR) * W + sx * TC;  // first pixel of the sub-tile
         const int em = 16 | (sy == 0 ? 1 : 0) | (sy == a.subs_y - 1 ? 2 : 0) | (sx == 0 ? 4 : 0) | (sx == a.subs_x - 1 ? 8 : 0);
         const int pbx = pb * Cin * 4;
 #pragma unroll
-        for (int u = 0; u < G::NVX; ++u) pr[u] = bufload(rx, (fl[u] & em) ? OOB : (unsigned)(cx[u] + pbx), 0);
+        for (int u = 0; u < G::NVX; ++u) pr[h][u] = bufload(rx, (fl[u] & em) ? OOB : (unsigned)(cx[u] + pbx), 0);
         const unsigned pbd = (unsigned)pb * (unsigned)Cout * 4u;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) dr[u] = bufload(rd, cd[u], pbd);
+        for (int u = 0; u < 2; ++u) dr[h][u] = bufload(rd, cd[u], pbd);
     };
-    auto advance = [&]() {
+    auto advance = [&]() {  // the ISSUE cursor (s, b, sy, sx)
         ++s;
         if (++sx == a.subs_x) { sx = 0; if (++sy == a.subs_y) { sy = 0; ++b; } }
     };
@@ -715,38 +717,44 @@ __global__ __launch_bounds__(256, 2) void wgrad_patch_kernel(WgradPatchArgs a) {
     const bool do_bias = a.bias_ws != nullptr && cit == 0;
     float4 csum = f4zero();
 
-    if (s < s_end) issue();
-    while (s < s_end) {
-        __syncthreads();  // every wave is done with the previous tile
+    long todo = s_end - s;  // K-tiles of this split
+    if (s < s_end) { issue(0); advance(); }
+    if (s < s_end) { issue(1); advance(); }
+    while (todo > 0) {
 #pragma unroll
-        for (int u = 0; u < G::NVX; ++u) *reinterpret_cast<float4*>(&Xp[xst + 1024 * u]) = pr[u];
+        for (int h = 0; h < 2; ++h) {  // (register set h holds the tile that is consumed now; it is refilled with the tile two ahead)
+            if (todo <= 0) break;
+            --todo;
+            __syncthreads();  // every wave is done with the previous tile
 #pragma unroll
-        for (int u = 0; u < 2; ++u) *reinterpret_cast<float4*>(&Dy[xst + 1024 * u]) = dr[u];
-        if (do_bias) {
-            csum.x += dr[0].x + dr[1].x; csum.y += dr[0].y + dr[1].y; csum.z += dr[0].z + dr[1].z; csum.w += dr[0].w + dr[1].w;
-        }
-        __syncthreads();
-        advance();
-        if (s < s_end) issue();  // next tile's loads fly under this tile's 144 MFMAs
-        // KS k-steps: k-step ks covers pixel KS lh + ks of the K-tile = (row (TR/2) lh + ks / TC, column ks % TC)
-        float fa[2][9], fb[2];
-        auto frag = [&](int ks, int buf) {
-            const char* sm = reinterpret_cast<const char*>(smem);
-            fb[buf] = *reinterpret_cast<const float*>(sm + bbase + ks * 256);
+            for (int u = 0; u < G::NVX; ++u) *reinterpret_cast<float4*>(&Xp[xst + 1024 * u]) = pr[h][u];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int dyy = t / 3 - 1, dxx = t % 3 - 1;
-                fa[buf][t] = *reinterpret_cast<const float*>(sm + abase + (((ks / TC + 1 + dyy) * G::PW + ks % TC + 1 + dxx) * 64) * 4);
+            for (int u = 0; u < 2; ++u) *reinterpret_cast<float4*>(&Dy[xst + 1024 * u]) = dr[h][u];
+            if (do_bias) {
+                csum.x += dr[h][0].x + dr[h][1].x; csum.y += dr[h][0].y + dr[h][1].y; csum.z += dr[h][0].z + dr[h][1].z; csum.w += dr[h][0].w + dr[h][1].w;
             }
-        };
-        frag(0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            if (s < s_end) { issue(h); advance(); }  // the tile two ahead: its loads fly under this tile's and the next tile's MFMAs
+            // KS k-steps: k-step ks covers pixel KS lh + ks of the K-tile = (row (TR/2) lh + ks / TC, column ks % TC)
+            float fa[2][9], fb[2];
+            auto frag = [&](int ks, int buf) {
+                const char* sm = reinterpret_cast<const char*>(smem);
+                fb[buf] = *reinterpret_cast<const float*>(sm + bbase + ks * 256);
 #pragma unroll
-        for (int ks = 0; ks < G::KS; ++ks) {
-            if (ks + 1 < G::KS) frag(ks + 1, (ks + 1) & 1);
+                for (int t = 0; t < 9; ++t) {
+                    const int dyy = t / 3 - 1, dxx = t % 3 - 1;
+                    fa[buf][t] = *reinterpret_cast<const float*>(sm + abase + (((ks / TC + 1 + dyy) * G::PW + ks % TC + 1 + dxx) * 64) * 4);
+                }
+            };
+            frag(0, 0);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ks & 1][t], fb[ks & 1], acc[t], 0, 0, 0);
+            for (int ks = 0; ks < G::KS; ++ks) {
+                if (ks + 1 < G::KS) frag(ks + 1, (ks + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ks & 1][t], fb[ks & 1], acc[t], 0, 0, 0);
+            }
         }
     }
 
