@@ -490,7 +490,7 @@ class CaptionEngine(object):
                     lambda: lib.vc_embedding_gather_f32(st, P(S.param("encoder/enc_embeddings")), P(self.buf["cap_enc_t"]), T * N, E, V, P(Xe[self.n_init_e])))
         act_e, cs_e, hs_e = self._b("act_e", (Te, N, 4 * He)), self._b("cs_e", (Te + 1, N, He)), self._b("hs_e", (Te + 1, N, He))
         self._need_ws(lib.vc_lstm_seq_workspace_bytes(Te, N, E, He))
-        cs_e[0].zero_(); hs_e[0].zero_()
+        # (cs_e[0] / hs_e[0] = the zero initial state: `_b` allocates zeros and nothing ever writes row 0)
         lib.vc_lstm_seq_fwd_f32(st, Te, N, E, He, P(Xe), P(S.param(spec.ENC_CELL + "kernel")), P(S.param(spec.ENC_CELL + "bias")),
                                 P(self.buf["lens_e"]), P(act_e), P(cs_e), P(hs_e), P(self.ws), self.ws_bytes)
         hT = hs_e[Te]
@@ -555,7 +555,7 @@ class CaptionEngine(object):
             lib.vc_dropout_f32(st, P(xw), P(self.buf["drop_in"]), p.dec_keep_rate, T * N * E, P(xw))
         act_d, cs_d, hs_d = self._b("act_d", (Td, N, 4 * Hd)), self._b("cs_d", (Td + 1, N, Hd)), self._b("hs_d", (Td + 1, N, Hd))
         self._need_ws(lib.vc_lstm_seq_workspace_bytes(Td, N, E, Hd))
-        cs_d[0].zero_(); hs_d[0].zero_()
+        # (cs_d[0] / hs_d[0]: zero initial state, as above)
         lib.vc_lstm_seq_fwd_f32(st, Td, N, E, Hd, P(Xd), P(S.param(spec.DEC_CELL + "kernel")), P(S.param(spec.DEC_CELL + "bias")),
                                 P(self.buf["lens_d"]), P(act_d), P(cs_d), P(hs_d), P(self.ws), self.ws_bytes)
         # outputs of the word steps.  (The reference zeroes outputs past the caption length; those rows
@@ -626,7 +626,9 @@ class CaptionEngine(object):
         self.gemm(0, 1, T * N, Hd, Vp, dlogits, Vp, S.param("decoder/rnn_logits/kernel"), Vp, douts, Hd)
         if p.dec_lstm_drop < 1:
             lib.vc_dropout_f32(st, P(douts), P(self.buf["drop_out"]), p.dec_lstm_drop, T * N * Hd, P(douts))
-        dH, dC = self._b("dH_d", (N, Hd), zero=True), self._b("dC_d", (N, Hd), zero=True)
+        # running state gradients of both LSTMs: one buffer, one fill ([dH_d | dC_d | dC_e])
+        dstate = self._b("dstate0", (N * (2 * Hd + He),), zero=True)
+        dH, dC = dstate[:N * Hd].view(N, Hd), dstate[N * Hd:2 * N * Hd].view(N, Hd)
         dG, dXd = self._b("dG_d", (Td, N, 4 * Hd)), self._b("dXd", (Td, N, E))
         lib.vc_lstm_seq_bwd_f32(st, Td, N, E, Hd, P(self.buf["Xd"]), P(S.param(spec.DEC_CELL + "kernel")), P(self.buf["lens_d"]),
                                 P(self.buf["act_d"]), P(self.buf["cs_d"]), P(self.buf["hs_d"]), P(dhs), P(dH), P(dC), P(dG), P(dXd),
@@ -677,7 +679,7 @@ class CaptionEngine(object):
                                          P(dmean), P(dstd), P(dheads))
                 self.dense_bwd_w(hT, N, He, 2 * K_CL * L, dheads, "encoder/heads/kernel", "encoder/heads/bias")
                 self.gemm(0, 1, N, He, 2 * K_CL * L, dheads, 2 * K_CL * L, S.param("encoder/heads/kernel"), 2 * K_CL * L, dhT, He)
-            dC = self._b("dC_e", (N, He), zero=True)
+            dC = self.buf["dstate0"][2 * N * Hd:].view(N, He)
             dG, dXe = self._b("dG_e", (Te, N, 4 * He)), self._b("dXe", (Te, N, E))
             lib.vc_lstm_seq_bwd_f32(st, Te, N, E, He, P(self.buf["Xe"]), P(S.param(spec.ENC_CELL + "kernel")), P(self.buf["lens_e"]),
                                     P(self.buf["act_e"]), P(self.buf["cs_e"]), P(self.buf["hs_e"]), None, P(dhT), P(dC), P(dG), P(dXe),
