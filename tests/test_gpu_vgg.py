@@ -129,6 +129,42 @@ def test_fine_tune_step_matches_oracle(lib):
         assert rel_l2(new[n] - PV[n], PVn[n] - PV[n]) < 2e-2, (n, rel_l2(new[n] - PV[n], PVn[n] - PV[n]), upd)
 
 
+def test_fallback_kernels_without_the_patch_path(lib, monkeypatch):
+    """VC_CONV_PATCH=0: every layer through the general implicit-GEMM kernels of csrc/conv.hip (conv1_1 on zero-padded 4-channel
+    weights, separate max-pool launches) -- the path taken for geometries the patch / conv1 kernels do not support: forward vs
+    the fp64 oracle, backward vs the oracle on the device's forward decisions, and close to the default path."""
+    p = Parameters()
+    p.fine_tune = True
+    rng = np.random.default_rng(21)
+    PV = spec.init_vgg_params(seed=6)
+    img = rng.integers(0, 256, size=(1, 224, 224, 3)).astype(np.float32)
+    dfc2 = rng.normal(size=(1, 4096)).astype(np.float32)
+    ones = np.ones((1, 4096), np.float32)
+    P64 = {k: v.astype(np.float64) for k, v in PV.items()}
+    fc2_ref, cache = ov.forward(P64, img.astype(np.float64), ones.astype(np.float64), ones.astype(np.float64), keep=0.5)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("VC_CONV_PATCH", mode)
+        eng = VggEngine(p, lib=lib)
+        assert eng.use_patch == (mode == "1")
+        eng.load_params(PV)
+        eng.set_masks(ones, ones)
+        fc2 = eng.forward(torch.from_numpy(img).cuda())
+        eng.backward(torch.from_numpy(dfc2).cuda())
+        torch.cuda.synchronize()
+        res[mode] = (fc2.clone(), eng.store.g.clone())
+        if mode == "0":
+            assert rel_l2(fc2.cpu().numpy(), fc2_ref) < 2e-5
+            for name, x, y in [c for c in cache["conv"] if c[0] != "P"]:
+                assert rel_l2(eng.buf["y_" + name].cpu().numpy(), y) < 2e-5, name
+            G = eng.grads_dict()
+            Gdev = ov.backward(P64, device_cache(eng, P64, 0.5), dfc2.astype(np.float64))
+            for n, ref in Gdev.items():
+                assert rel_l2(G[n], ref) < 1e-4, (n, rel_l2(G[n], ref))
+    assert (res["0"][0] - res["1"][0]).norm() <= 1e-5 * res["1"][0].norm()
+    assert (res["0"][1] - res["1"][1]).norm() <= 2e-3 * res["1"][1].norm()
+
+
 def test_half_batch_chains_on_three_streams(lib, monkeypatch):
     """B = 2: the default three-stream schedule (two half-batch conv/pool chains + weight gradients on a
     third stream, trainer.VggEngine) vs the fp64 oracle forward, vs the oracle backward on the device's
