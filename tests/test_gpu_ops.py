@@ -25,6 +25,8 @@ GEMM_SHAPES = [
     (64, 64, 32), (33, 47, 19), (100, 70, 50), (256, 384, 128), (1280, 2048, 256),
     (300, 256, 4096), (20, 10000, 512), (1280, 256, 15000), (768, 2048, 2560), (1, 4, 4),
     (129, 131, 37),
+    (64, 4096, 2048),     # 64-row fc shape: 64 x 128 tiles (plan_gemm skinny), split-K
+    (37, 390, 1100),      # skinny with ragged N (390 = 3 x 128 + 6) and K (1100 = 34 x 32 + 12)
     (3200, 512, 5000),    # 100 tiles of 128 x 128: one whole round through split-K (768 / tiles)
     (5000, 640, 2600),    # 200 tiles: below one round, K split into ~1200 workgroups
 ]

@@ -105,6 +105,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 struct GemmPlan {
     bool big;  // 128x128 tile, else 64x64
+    bool skinny;  // M <= 64: 64 x 128 tiles (four waves of 64 x 32) -- a 128-row tile would spend half its MFMAs on zero rows, and the
+                  // 64-row fc products (13 GFLOP over 411 MB of weights) are then MFMA-bound at twice their HBM time
     int splits, kchunk, tiles_m, tiles_n;
     // whole rounds (128x128 tiles, no global split-K): the tile rows beyond the last full round of 768 resident workgroups
     // run as a second launch with K split `tail_splits` ways (see conv.hip launch_rounds for the measurement behind it)
@@ -113,6 +115,20 @@ struct GemmPlan {
 
 static GemmPlan plan_gemm(int M, int N, int K) {
     GemmPlan p;
+    p.skinny = false;
+    if (M <= 64 && N >= 256 && K >= 512) {
+        p.skinny = true; p.big = false;
+        p.tiles_m = 1; p.tiles_n = cdiv(N, 128);
+        long sa = 768 / p.tiles_n;           // one round of resident workgroups
+        const long maxs = K / 256;           // >= 8 K-tiles per split
+        if (sa > maxs) sa = maxs;
+        if (sa > 64) sa = 64;
+        if (sa < 1) sa = 1;
+        p.kchunk = cdiv(cdiv(K, (int)sa), 32) * 32;
+        p.splits = cdiv(K, p.kchunk);
+        p.main_m = 1; p.tail_splits = 1; p.tail_kchunk = 0;
+        return p;
+    }
     // Measured on MI355X (tools/microbench.py): 128x128 tiles win when there are >= 1.5 per CU, and for
     // small outputs with a deep K (weight gradients) when K is split into chunks of >= 512 so that every
     // CU gets 2-3 of them; in between (e.g. 512 x 10000 x 25600) 64x64 tiles with ~5 workgroups per CU
@@ -193,6 +209,7 @@ static void dispatch_modes(hipStream_t st, const GemmArgs& g, int ta, int tb) {
 
 using Cfg128 = TileCfg<2, 2, 2, 2>;
 using Cfg64 = TileCfg<2, 2, 1, 1>;
+using CfgSkinny = TileCfg<1, 4, 2, 1>;  // 64 x 128: four waves side by side, each 64 rows x 32 columns
 
 // Split-K partial products only (no reduce, no bias): ws[s][M][N] = op(A) op(B) over the s-th K range, 64 x 64 tiles.
 // For consumers that sum the partials themselves (the LSTM gate kernels).  Returns the number of splits written
@@ -278,7 +295,9 @@ extern "C" int vc_gemm_f32(void* stream, int ta, int tb, int M, int N, int K, co
     const long tail_row0 = (long)p.main_m * 128;
     const bool tail = p.tail_splits > 1 && ws && ws_bytes >= (size_t)p.tail_splits * (M - tail_row0) * N * sizeof(float);
     if (tail) g.ntiles = p.main_m * p.tiles_n;  // whole rounds; the remaining tile rows follow as a K-split launch
-    if (p.big) {
+    if (p.skinny) {
+        if (vec) dispatch_modes<CfgSkinny, true>(st, g, ta, tb); else dispatch_modes<CfgSkinny, false>(st, g, ta, tb);
+    } else if (p.big) {
         if (vec) dispatch_modes<Cfg128, true>(st, g, ta, tb); else dispatch_modes<Cfg128, false>(st, g, ta, tb);
     } else {
         if (vec) dispatch_modes<Cfg64, true>(st, g, ta, tb); else dispatch_modes<Cfg64, false>(st, g, ta, tb);
