@@ -103,6 +103,46 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
+// the same with 16-byte accesses (N % 4 == 0, ldc % 4 == 0, 16-byte aligned C / bias / ws): same summation order per element
+__global__ __launch_bounds__(256) void splitk_reduce4_kernel(const float4* __restrict__ ws, int splits, long Q, int NQ,
+                                                            float* __restrict__ C, long ldc, const float* __restrict__ bias,
+                                                            int flags) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < Q; i += (long)gridDim.x * 256) {
+        float4 v = ws[i];
+        for (int z = 1; z < splits; ++z) {
+            const float4 t = ws[(long)z * Q + i];
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        const int cq = (int)(i % NQ);
+        const long row = i / NQ;
+        if (bias) {
+            const float4 b = *reinterpret_cast<const float4*>(bias + cq * 4);
+            v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+        }
+        float4* p = reinterpret_cast<float4*>(C + row * ldc + cq * 4);
+        if (flags & VC_GEMM_ACCUMULATE) {
+            const float4 o = *p;
+            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        }
+        if (flags & VC_GEMM_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *p = v;
+    }
+}
+
+static void launch_splitk_reduce(hipStream_t st, const float* ws, int splits, long MN, int N, float* C, long ldc, const float* bias, int flags) {
+    auto al = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+    if ((N & 3) == 0 && (ldc & 3) == 0 && al(ws) && al(C) && (!bias || al(bias))) {
+        const long Q = MN >> 2;
+        int blocks = cdiv(Q, 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(splitk_reduce4_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float4*>(ws), splits, Q, N >> 2, C, ldc, bias, flags);
+        return;
+    }
+    int blocks = cdiv(MN, 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws, splits, MN, N, C, ldc, bias, flags);
+}
+
 struct GemmPlan {
     bool big;  // 128x128 tile, else 64x64
     bool skinny;  // M <= 64: 64 x 128 tiles (four waves of 64 x 32) -- a 128-row tile would spend half its MFMAs on zero rows, and the
@@ -304,10 +344,7 @@ extern "C" int vc_gemm_f32(void* stream, int ta, int tb, int M, int N, int K, co
     }
     VC_LAUNCH_CHECK();
     if (p.splits > 1) {
-        const long MN = (long)M * N;
-        int blocks = cdiv(MN, 256);
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws, p.splits, MN, N, C, ldc, bias, flags);
+        launch_splitk_reduce(st, ws, p.splits, (long)M * N, N, C, ldc, bias, flags);
         VC_LAUNCH_CHECK();
     }
     if (tail) {
@@ -318,10 +355,7 @@ extern "C" int vc_gemm_f32(void* stream, int ta, int tb, int M, int N, int K, co
         t.ws_row0 = tail_row0; t.ws_rows = M - tail_row0;
         if (vec) dispatch_modes<Cfg128, true>(st, t, ta, tb); else dispatch_modes<Cfg128, false>(st, t, ta, tb);
         VC_LAUNCH_CHECK();
-        const long MN = t.ws_rows * N;
-        int blocks = cdiv(MN, 256);
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws, t.splits, MN, N, C + tail_row0 * ldc, ldc, bias, flags);
+        launch_splitk_reduce(st, ws, t.splits, t.ws_rows * N, N, C + tail_row0 * ldc, ldc, bias, flags);
         VC_LAUNCH_CHECK();
     }
     return 0;
