@@ -249,6 +249,13 @@ int vc_conv3x3_fwd_pool_packed_f32(void* stream, int B, int H, int W, int Cin, i
                                    const float* bias, float* y, float* ypool, int relu, float* ws, size_t ws_bytes);
 int vc_conv3x3_dgrad_packed_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* dy, const float* wpt,
                                 const float* relu_src, float* dx, float* ws, size_t ws_bytes);
+/* The same data gradient for a convolution that sits BEHIND a 2x2 max-pool, with MaxPoolGrad + the ReluGrad of the pool's
+ * producer fused into the epilogue: the gradient w.r.t. the pooled tensor [B,H,W,Cin] is never written; each value goes to the
+ * first maximum (row-major scan) of its 2x2 window of y_prepool [B,2H,2W,Cin] unless that maximum is <= 0, the other three
+ * positions get zeros: dx_prepool [B,2H,2W,Cin] == vc_maxpool2x2_bwd_f32(y_prepool, vc_conv3x3_dgrad_packed_f32(...), relu_grad = 1)
+ * bit for bit (tests/test_gpu_conv_patch.py). */
+int vc_conv3x3_dgrad_unpool_packed_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* dy, const float* wpt,
+                                       const float* y_prepool, float* dx_prepool, float* ws, size_t ws_bytes);
 /* Patch-staged weight gradient: a workgroup owns 64 input channels x all nine taps x 64 output channels and stages the
  * halo patch of every 4 x 8 pixel sub-tile once (the nine taps share it).  Same contract as conv3x3_wgrad (split-K into the
  * workspace, deterministic reduce, db != NULL also returns the bias gradient).  Shapes: Cin % 64 == 0, Cout % 64 == 0,

@@ -243,3 +243,29 @@ def test_conv1_fwd_wgrad_match_oracle(lib, case):
     from vae_captioning_amd.abi import VaecapError
     with pytest.raises(VaecapError):
         lib.vc_conv1_wgrad_f32(stream(), B, H, W, P(tx4), P(tdy), P(dw), P(db), 0, None, 0)
+
+
+# ----------------------------------------------------------------------------- MaxPoolGrad fused into the data gradient
+@pytest.mark.parametrize("case", [(2, 8, 8, 64, 64), (3, 12, 16, 64, 128), (1, 56, 56, 64, 128), (2, 28, 28, 128, 256), (3, 14, 14, 128, 64),
+                                  (2, 112, 112, 64, 128)], ids=lambda c: "x".join(map(str, c)))
+def test_dgrad_with_fused_unpool_equals_dgrad_then_maxpool_bwd(lib, case):
+    """vc_conv3x3_dgrad_unpool_packed_f32 == vc_maxpool2x2_bwd_f32(y, vc_conv3x3_dgrad_packed_f32(dy), relu_grad = 1) bit for bit:
+    both tilings, both tile widths, with and without the K-split tail launch; ties and non-positive maxima occur in y."""
+    B, H, W, Ci, Co = case            # the convolution behind the pool: input [B,H,W,Ci] = the pooled tensor
+    rng = np.random.default_rng(B * H + Co)
+    w = torch.from_numpy(rng.standard_normal((3, 3, Ci, Co), dtype=np.float32) * np.float32(1 / np.sqrt(9 * Co))).cuda()
+    dy = torch.from_numpy(rng.standard_normal((B, H, W, Co), dtype=np.float32)).cuda()
+    ypre = np.maximum(rng.standard_normal((B, 2 * H, 2 * W, Ci), dtype=np.float32), 0)   # ReLU output: many zeros, hence ties
+    ypre[0, :4, :4] = 1.5                                                                 # a constant patch: four-way ties
+    ypre = torch.from_numpy(ypre).cuda()
+    wpt = _pack(lib, w, 1)
+    nb = lib.vc_conv3x3_packed_workspace_bytes(B, H, W, Ci, Co, 1)
+    ws = empty_bytes(nb)
+    for use_ws in ([False, True] if nb > 0 else [False]):
+        wsp, wsb = (P(ws), ws.numel() * 4) if use_ws else (None, 0)
+        dpool = zeros(B, H, W, Ci)
+        ref, got = zeros(B, 2 * H, 2 * W, Ci), torch.full((B, 2 * H, 2 * W, Ci), 7.0, device="cuda")
+        lib.vc_conv3x3_dgrad_packed_f32(stream(), B, H, W, Ci, Co, P(dy), P(wpt), None, P(dpool), wsp, wsb)
+        lib.vc_maxpool2x2_bwd_f32(stream(), B, 2 * H, 2 * W, Ci, P(ypre), P(dpool), P(ref), 1)
+        lib.vc_conv3x3_dgrad_unpool_packed_f32(stream(), B, H, W, Ci, Co, P(dy), P(wpt), P(ypre), P(got), wsp, wsb)
+        assert torch.equal(ref, got), "fused unpool differs (workspace %s)" % use_ws

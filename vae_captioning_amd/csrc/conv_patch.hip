@@ -53,7 +53,32 @@ struct PatchArgs {
     int chunks_per_split;
     float* tail_ws;
     float* pool;       // forward, SUB tiling only: also write max_pool2x2(out) [B, H/2, W/2, N] (null: no pooling)
+    // data gradient of the convolution BEHIND a 2x2 max-pool: the result is the gradient w.r.t. the pooled tensor; with up_y / up_dx
+    // set it is routed straight to the arg-max positions of the pool's input up_y [B, 2H, 2W, N] (+ its ReLU gradient) and written
+    // to up_dx [B, 2H, 2W, N] -- MaxPoolGrad + ReluGrad without their own launch and without materialising the pooled gradient
+    const float* up_y;
+    float* up_dx;
 };
+
+// MaxPoolGrad (first maximum in (dy,dx) scan order wins; TF-sem.) fused with the ReluGrad of the convolution that produced the
+// window a, b (row 0), c, d (row 1): the same rule as conv.hip's maxpool_bwd_kernel
+__device__ __forceinline__ void unpool_route(float a, float b, float c, float d, float g, float& oa, float& ob, float& oc, float& od) {
+    const float m = fmaxf(fmaxf(a, b), fmaxf(c, d));
+    const int w = (a == m) ? 0 : (b == m) ? 1 : (c == m) ? 2 : 3;
+    const float v = !(m > 0.f) ? 0.f : g;
+    oa = w == 0 ? v : 0.f; ob = w == 1 ? v : 0.f; oc = w == 2 ? v : 0.f; od = w == 3 ? v : 0.f;
+}
+__device__ __forceinline__ void unpool_store(const float* __restrict__ yb, float* __restrict__ db, long rowstride, int N, const float4& g) {
+    const float4 a = *reinterpret_cast<const float4*>(yb), b = *reinterpret_cast<const float4*>(yb + N);
+    const float4 c = *reinterpret_cast<const float4*>(yb + rowstride), d = *reinterpret_cast<const float4*>(yb + rowstride + N);
+    float4 oa, ob, oc, od;
+    unpool_route(a.x, b.x, c.x, d.x, g.x, oa.x, ob.x, oc.x, od.x);
+    unpool_route(a.y, b.y, c.y, d.y, g.y, oa.y, ob.y, oc.y, od.y);
+    unpool_route(a.z, b.z, c.z, d.z, g.z, oa.z, ob.z, oc.z, od.z);
+    unpool_route(a.w, b.w, c.w, d.w, g.w, oa.w, ob.w, oc.w, od.w);
+    *reinterpret_cast<float4*>(db) = oa; *reinterpret_cast<float4*>(db + N) = ob;
+    *reinterpret_cast<float4*>(db + rowstride) = oc; *reinterpret_cast<float4*>(db + rowstride + N) = od;
+}
 
 // ---- tile geometry ------------------------------------------------------------------------------
 template <int SCHEME>
@@ -163,7 +188,7 @@ __device__ unsigned long long* g_patch_trace = nullptr;  // [workgroups][4 waves
 #define PATCH_STAMP(k)
 #endif
 
-template <int TN, int SCHEME, int KIND, bool POOL = false>
+template <int TN, int SCHEME, int KIND, bool POOL = false, bool UNPOOL = false>
 __global__ __launch_bounds__(256, TN == 1 ? 3 : 2) void conv_patch_kernel(PatchArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using CFG = PatchCfg<TN>;
@@ -350,6 +375,16 @@ __global__ __launch_bounds__(256, TN == 1 ? 3 : 2) void conv_patch_kernel(PatchA
         const long pc = live ? p : 0;
         float* pool_row = nullptr;
         bool pool_lane = false;
+        const float* up_y = nullptr;
+        float* up_dx = nullptr;
+        long up_stride = 0;
+        if (UNPOOL) {  // top-left pixel of this (pooled) pixel's window in the [B, 2H, 2W, N] tensors
+            const long prow = pc / g.W;                      // b*H + y
+            const long base = ((2 * prow) * (2L * g.W) + 2 * (pc - prow * g.W)) * N;
+            up_y = a.up_y + base;
+            up_dx = a.up_dx + base;
+            up_stride = 2L * g.W * N;
+        }
         if (POOL) {
             // 2x2 / stride 2 max-pool (utils/image_embeddings.py:59-63 ...): the 32 pixels of this MFMA tile are one 4 x 8 sub-tile, pixel
             // li = 8 row + column, so a pooling window is the lanes {li, li ^ 1, li ^ 8}: two DPP max steps; max commutes with the bias
@@ -358,6 +393,38 @@ __global__ __launch_bounds__(256, TN == 1 ? 3 : 2) void conv_patch_kernel(PatchA
             const int px = (int)(pc - prow * g.W) >> 1;
             pool_row = a.pool + ((prow >> 1) * (g.W >> 1) + px) * N;
             pool_lane = live && (li & 9) == 0;
+        }
+        if (UNPOOL) {
+            // all sixteen window loads of a 32-column strip in flight together (the registers of the weight / patch pipeline are free
+            // here), then route + store: one memory latency per strip instead of one per register quad
+#pragma unroll
+            for (int u = 0; u < TN; ++u) {
+                float4 wa[4], wb[4], wc[4], wd[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float* yq = up_y + n0 + (wn * TN + u) * 32 + 8 * q + 4 * lh;
+                    wa[q] = live ? *reinterpret_cast<const float4*>(yq) : f4zero();
+                    wb[q] = live ? *reinterpret_cast<const float4*>(yq + N) : f4zero();
+                    wc[q] = live ? *reinterpret_cast<const float4*>(yq + up_stride) : f4zero();
+                    wd[q] = live ? *reinterpret_cast<const float4*>(yq + up_stride + N) : f4zero();
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float* dq = up_dx + n0 + (wn * TN + u) * 32 + 8 * q + 4 * lh;
+                    const float4 gv = make_float4(acc[t][u][4 * q], acc[t][u][4 * q + 1], acc[t][u][4 * q + 2], acc[t][u][4 * q + 3]);
+                    float4 oa, ob, oc, od;
+                    unpool_route(wa[q].x, wb[q].x, wc[q].x, wd[q].x, gv.x, oa.x, ob.x, oc.x, od.x);
+                    unpool_route(wa[q].y, wb[q].y, wc[q].y, wd[q].y, gv.y, oa.y, ob.y, oc.y, od.y);
+                    unpool_route(wa[q].z, wb[q].z, wc[q].z, wd[q].z, gv.z, oa.z, ob.z, oc.z, od.z);
+                    unpool_route(wa[q].w, wb[q].w, wc[q].w, wd[q].w, gv.w, oa.w, ob.w, oc.w, od.w);
+                    if (live) {
+                        *reinterpret_cast<float4*>(dq) = oa; *reinterpret_cast<float4*>(dq + N) = ob;
+                        *reinterpret_cast<float4*>(dq + up_stride) = oc; *reinterpret_cast<float4*>(dq + up_stride + N) = od;
+                    }
+                }
+            }
+            continue;
         }
 #pragma unroll
         for (int u = 0; u < TN; ++u)
@@ -387,7 +454,7 @@ __global__ __launch_bounds__(256, TN == 1 ? 3 : 2) void conv_patch_kernel(PatchA
 }
 
 // Sum of the tail launch's K splits (fixed order) + the epilogue of the main launch.
-template <int SCHEME, int KIND>
+template <int SCHEME, int KIND, bool UNPOOL = false>
 __global__ __launch_bounds__(256) void patch_tail_reduce_kernel(PatchArgs a, int splits, int BN) {
     const PatchGeom& g = a.g;
     const int qpr = BN >> 2;                         // float4 per tile row
@@ -420,6 +487,12 @@ __global__ __launch_bounds__(256) void patch_tail_reduce_kernel(PatchArgs a, int
             if (!(m.y > 0.f)) v.y = 0.f;
             if (!(m.z > 0.f)) v.z = 0.f;
             if (!(m.w > 0.f)) v.w = 0.f;
+        }
+        if (UNPOOL) {
+            const long prow = p / g.W;
+            const long base = ((2 * prow) * (2L * g.W) + 2 * (p - prow * g.W)) * g.N + col;
+            unpool_store(a.up_y + base, a.up_dx + base, 2L * g.W * g.N, g.N, v);
+            continue;
         }
         *reinterpret_cast<float4*>(a.out + p * g.N + col) = v;
         if (KIND == PK_FWD && SCHEME == PATCH_SUB && a.pool && !(r & 1) && !(r & 8)) {  // top-left pixel of a pooling window
@@ -568,7 +641,7 @@ static size_t patch_workspace(const PatchPlan& p) {
     return t.tail_tiles ? (size_t)t.splits * t.tail_tiles * 128 * (p.TN * 64) * sizeof(float) : 0;
 }
 
-template <int TN, int SCHEME, int KIND, bool POOL = false>
+template <int TN, int SCHEME, int KIND, bool POOL = false, bool UNPOOL = false>
 static int launch_patch(hipStream_t st, const PatchPlan& p, PatchArgs& a, float* ws, size_t ws_bytes) {
     const PatchTail t = plan_patch_tail(p);
     constexpr int smem = PatchLds<SCHEME>::template bytes<TN>();
@@ -578,27 +651,32 @@ static int launch_patch(hipStream_t st, const PatchPlan& p, PatchArgs& a, float*
     const size_t need = (size_t)t.splits * t.tail_tiles * 128 * (TN * 64) * sizeof(float);
     if (t.tail_tiles == 0 || !ws || ws_bytes < need) {
         a.ntiles = p.tiles_m * p.tiles_n;
-        hipLaunchKernelGGL((conv_patch_kernel<TN, SCHEME, KIND, POOL>), dim3(a.ntiles, 1), dim3(256), smem, st, a);
+        hipLaunchKernelGGL((conv_patch_kernel<TN, SCHEME, KIND, POOL, UNPOOL>), dim3(a.ntiles, 1), dim3(256), smem, st, a);
         return launch_status("conv patch");
     }
     if (t.main_tiles > 0) {
         a.ntiles = t.main_tiles;
-        hipLaunchKernelGGL((conv_patch_kernel<TN, SCHEME, KIND, POOL>), dim3(a.ntiles, 1), dim3(256), smem, st, a);
+        hipLaunchKernelGGL((conv_patch_kernel<TN, SCHEME, KIND, POOL, UNPOOL>), dim3(a.ntiles, 1), dim3(256), smem, st, a);
         if (int e = launch_status("conv patch")) return e;
     }
     PatchArgs d = a;
     d.tile0 = t.main_tiles; d.ntiles = t.tail_tiles; d.chunks_per_split = t.cps; d.tail_ws = ws;
-    hipLaunchKernelGGL((conv_patch_kernel<TN, SCHEME, KIND>), dim3(d.ntiles, t.splits), dim3(256), smem, st, d);
+    hipLaunchKernelGGL((conv_patch_kernel<TN, SCHEME, KIND, false, false>), dim3(d.ntiles, t.splits), dim3(256), smem, st, d);
     if (int e = launch_status("conv patch tail")) return e;
     const long items = (long)t.tail_tiles * 128 * (TN * 16);
     int grid = (int)((items + 255) / 256);
     if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL((patch_tail_reduce_kernel<SCHEME, KIND>), dim3(grid), dim3(256), 0, st, d, t.splits, TN * 64);
+    hipLaunchKernelGGL((patch_tail_reduce_kernel<SCHEME, KIND, UNPOOL>), dim3(grid), dim3(256), 0, st, d, t.splits, TN * 64);
     return launch_status("conv patch tail reduce");
 }
 
 template <int KIND>
 static int dispatch_patch(hipStream_t st, const PatchPlan& p, PatchArgs& a, float* ws, size_t ws_bytes) {
+    if (KIND == PK_DGRAD && a.up_y) {  // MaxPoolGrad + ReluGrad fused into the data gradient's epilogue
+        if (p.scheme == PATCH_SUB)
+            return p.TN == 2 ? launch_patch<2, PATCH_SUB, PK_DGRAD, false, true>(st, p, a, ws, ws_bytes) : launch_patch<1, PATCH_SUB, PK_DGRAD, false, true>(st, p, a, ws, ws_bytes);
+        return p.TN == 2 ? launch_patch<2, PATCH_FLAT, PK_DGRAD, false, true>(st, p, a, ws, ws_bytes) : launch_patch<1, PATCH_FLAT, PK_DGRAD, false, true>(st, p, a, ws, ws_bytes);
+    }
     if (KIND == PK_FWD && a.pool)  // fused 2x2 max-pool: 4 x 8 sub-tile tiling only (checked by the caller)
         return p.TN == 2 ? launch_patch<2, PATCH_SUB, PK_FWD, true>(st, p, a, ws, ws_bytes) : launch_patch<1, PATCH_SUB, PK_FWD, true>(st, p, a, ws, ws_bytes);
     if (p.scheme == PATCH_SUB)
@@ -878,7 +956,7 @@ extern "C" int vc_conv3x3_fwd_packed_f32(void* stream, int B, int H, int W, int 
     const PatchPlan p = plan_patch(B, H, W, Cin, Cout);
     if (p.scheme < 0) return fail(VC_EINVAL, "%s: shape not supported by the patch kernel (vc_conv3x3_patch_supported)", __func__);
     PatchArgs a;
-    a.g = p.g; a.x = x; a.wp = wp; a.out = y; a.aux = bias; a.relu = relu; a.pool = nullptr;
+    a.g = p.g; a.x = x; a.wp = wp; a.out = y; a.aux = bias; a.relu = relu; a.pool = nullptr; a.up_y = nullptr; a.up_dx = nullptr;
     return dispatch_patch<PK_FWD>((hipStream_t)stream, p, a, ws, ws_bytes);
 }
 
@@ -888,7 +966,7 @@ extern "C" int vc_conv3x3_fwd_pool_packed_f32(void* stream, int B, int H, int W,
     const PatchPlan p = plan_patch(B, H, W, Cin, Cout);
     if (p.scheme != PATCH_SUB) return fail(VC_EINVAL, "%s: the fused max-pool needs the 4 x 8 sub-tile tiling (W %% 8 == 0, H %% 4 == 0, Cin %% 32 == 0, Cout %% 64 == 0)", __func__);
     PatchArgs a;
-    a.g = p.g; a.x = x; a.wp = wp; a.out = y; a.aux = bias; a.relu = relu; a.pool = ypool;
+    a.g = p.g; a.x = x; a.wp = wp; a.out = y; a.aux = bias; a.relu = relu; a.pool = ypool; a.up_y = nullptr; a.up_dx = nullptr;
     return dispatch_patch<PK_FWD>((hipStream_t)stream, p, a, ws, ws_bytes);
 }
 
@@ -898,7 +976,19 @@ extern "C" int vc_conv3x3_dgrad_packed_f32(void* stream, int B, int H, int W, in
     const PatchPlan p = plan_patch(B, H, W, Cout, Cin);
     if (p.scheme < 0) return fail(VC_EINVAL, "%s: shape not supported by the patch kernel (vc_conv3x3_patch_supported)", __func__);
     PatchArgs a;
-    a.g = p.g; a.x = dy; a.wp = wpt; a.out = dx; a.aux = relu_src; a.relu = 0; a.pool = nullptr;
+    a.g = p.g; a.x = dy; a.wp = wpt; a.out = dx; a.aux = relu_src; a.relu = 0; a.pool = nullptr; a.up_y = nullptr; a.up_dx = nullptr;
+    return dispatch_patch<PK_DGRAD>((hipStream_t)stream, p, a, ws, ws_bytes);
+}
+
+extern "C" int vc_conv3x3_dgrad_unpool_packed_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* dy, const float* wpt,
+                                                  const float* y_prepool, float* dx_prepool, float* ws, size_t ws_bytes) {
+    VC_CHECK_ARG(dy && wpt && y_prepool && dx_prepool, "null pointer");
+    VC_CHECK_ARG((((uintptr_t)y_prepool | (uintptr_t)dx_prepool) & 15) == 0, "y_prepool / dx_prepool must be 16-byte aligned");
+    const PatchPlan p = plan_patch(B, H, W, Cout, Cin);
+    if (p.scheme < 0) return fail(VC_EINVAL, "%s: shape not supported by the patch kernel (vc_conv3x3_patch_supported)", __func__);
+    if ((long)B * 4 * H * W * Cin * 4 > 0x7fffffffL * 4L) return fail(VC_EINVAL, "%s: pre-pool tensor too large", __func__);
+    PatchArgs a;
+    a.g = p.g; a.x = dy; a.wp = wpt; a.out = nullptr; a.aux = nullptr; a.relu = 0; a.pool = nullptr; a.up_y = y_prepool; a.up_dx = dx_prepool;
     return dispatch_patch<PK_DGRAD>((hipStream_t)stream, p, a, ws, ws_bytes);
 }
 

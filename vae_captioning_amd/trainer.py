@@ -56,6 +56,10 @@ class VggEngine(object):
         # patch-staged forward / data-gradient kernels (csrc/conv_patch.hip) wherever the layer shape allows; VC_CONV_PATCH=0
         # keeps every layer on the implicit-GEMM kernels of csrc/conv.hip (A/B runs)
         self.use_patch = os.environ.get("VC_CONV_PATCH", "1") != "0"
+        # MaxPoolGrad + ReluGrad inside the next data gradient's epilogue (vc_conv3x3_dgrad_unpool_packed_f32): measured 49.22 / 49.32
+        # vs 49.40 / 49.38 ms per step -- the four pool-gradient launches (0.55 ms at 5.9 TB/s) disappear but their 3.5 GB of traffic
+        # leaves the four data gradients as 32-byte pieces from the accumulator epilogue (+0.4 ms): off by default
+        self.fuse_unpool = os.environ.get("VC_FUSE_UNPOOL", "0") == "1"
         nstreams = int(os.environ.get("VC_VGG_STREAMS", "1"))
         self.side = torch.cuda.Stream() if nstreams >= 2 else None
         self.side2 = torch.cuda.Stream() if nstreams >= 3 else None
@@ -296,9 +300,13 @@ class VggEngine(object):
         halves = [(0, B // 2, main), (B // 2, B // 2, side)] if split else [(0, B, main)]
         if split:
             side.wait_stream(main)
+        fused_pool = False  # the previous data gradient already wrote this pool's input gradient (MaxPoolGrad fused into its epilogue)
         for li in range(len(self.acts) - 1, -1, -1):
             name, x, H, W, ci, co, w = self.acts[li]
             if name == "P":
+                if fused_pool:
+                    fused_pool = False
+                    continue
                 dx = self._b("dx_%d" % li, (B, H, W, co))
                 for b0, nb, strm in halves:
                     with torch.cuda.stream(strm):  # + ReluGrad of the conv that made x
@@ -334,6 +342,20 @@ class VggEngine(object):
                     after_layer[1]()
             if li > 0:
                 prev_is_pool = self.acts[li - 1][0] == "P"
+                fuse = (prev_is_pool and self.fuse_unpool and self._patch_ok(B // max(len(halves), 1), H, W, ci, co, 1)
+                        and ("wpt_" + name) in self.buf)
+                if fuse:  # MaxPoolGrad + ReluGrad of the pool in front of this layer ride in the data gradient's epilogue
+                    ypre = self.acts[li - 1][1]                                   # the pool's input [B, 2H, 2W, ci]
+                    dx = self._b("dx_%d" % (li - 1), (B, 2 * H, 2 * W, ci))
+                    for ch, (b0, nb, strm) in enumerate(halves):
+                        tws = self._chain_ws(ch, nb)
+                        with torch.cuda.stream(strm):
+                            sh = _stream()
+                            self._timed("conv_dgrad", fl * nb / B, lambda: lib.vc_conv3x3_dgrad_unpool_packed_f32(
+                                sh, nb, H, W, ci, co, P(d[b0:]), P(self.buf["wpt_" + name]), P(ypre[b0:]), P(dx[b0:]), P(tws), tws.numel() * 4))
+                    d = dx
+                    fused_pool = True
+                    continue
                 dx = self._b("dx_%d" % li, (B, H, W, ci))
                 for ch, (b0, nb, strm) in enumerate(halves):
                     tws = self._chain_ws(ch, nb)
