@@ -14,7 +14,7 @@ for f in sorted(glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive
         if m:
             k = "conv_" + {"0": "fwd", "1": "dgrad", "2": "wgrad"}[m.group(1)]
         elif "conv_patch_kernel" in n:
-            m2 = re.search(r"conv_patch_kernel<\s*\d+,\s*\d+,\s*(\d)\s*(?:,\s*\w+\s*)?>", n)
+            m2 = re.search(r"conv_patch_kernel<\s*\d+,\s*\d+,\s*(\d)\s*(?:,\s*\w+\s*)*>", n)
             if "tail" not in n and m2:
                 k = "patch_" + {"0": "fwd", "1": "dgrad"}[m2.group(1)]
         elif "wgrad_patch_kernel" in n:

@@ -21,7 +21,7 @@ def family(name):
         kinds = {"0": "fwd", "1": "dgrad", "2": "wgrad"}
         return "conv_kernel<%s>" % kinds.get(k.group(1) if k else "?", "?")
     if "conv_patch_kernel" in name:  # conv_patch_kernel<TN, SCHEME, KIND, POOL>
-        k = re.search(r"conv_patch_kernel<\s*\d+,\s*\d+,\s*(\d)\s*(?:,\s*\w+\s*)?>", name)
+        k = re.search(r"conv_patch_kernel<\s*\d+,\s*\d+,\s*(\d)\s*(?:,\s*\w+\s*)*>", name)
         return "conv_patch_kernel<%s>" % {"0": "fwd", "1": "dgrad"}.get(k.group(1) if k else "?", "?")
     if "wgrad_patch_kernel" in name:
         return "wgrad_patch_kernel<4x8 | 4x7 | 2x14>"
