@@ -63,17 +63,23 @@ def test_beam_search_matches_oracle(lib, kw, beam):
         np.testing.assert_allclose([sc for _, sc in got[b]], scores, rtol=1e-4, atol=1e-5)
 
 
-def test_topk_is_a_stable_descending_sort_prefix(lib):
+@pytest.mark.parametrize("k,cols,ld", [(9, 300, 300), (5, 300, 300), (8, 1003, 1004), (5, 10000, 10000), (3, 257, 259), (1, 40, 40), (5, 6, 8)],
+                         ids=["k9-k-pass-kernel", "k5", "k8-ragged-vector-tail", "k5-vocab", "k3-unaligned-pitch", "k1", "k5-of-6"])
+def test_topk_is_a_stable_descending_sort_prefix(lib, k, cols, ld):
+    """(value descending, index ascending) = the first k entries of a STABLE sort on -p (decoder.py:273-276), with many ties;
+    k <= 8 runs the single-pass kernel (16-byte loads when the pitch allows, per-thread sorted lists merged through LDS)."""
     import torch
     from .gpu_util import P, dev, host, stream
-    rng = np.random.default_rng(0)
-    x = rng.integers(0, 6, size=(7, 300)).astype(np.float32)  # many ties
-    k = 9
-    tv = torch.empty((7, k), dtype=torch.float32, device="cuda")
-    ti = torch.empty((7, k), dtype=torch.int32, device="cuda")
-    lib.vc_topk_rows_f32(stream(), P(dev(x)), 7, 300, 300, k, P(tv), P(ti))
-    for r in range(7):
-        ref = sorted(enumerate(x[r]), key=lambda t: -t[1])[:k]  # Python's sort is stable (decoder.py:273-276)
+    rng = np.random.default_rng(k * 1000 + cols)
+    R = 7
+    x = np.full((R, ld), 99.0, np.float32)  # (the padding columns hold a LARGER value: they must never be selected)
+    x[:, :cols] = rng.integers(0, 6, size=(R, cols)).astype(np.float32)
+    x[0, :cols] = 2.0                       # a constant row: the answer is indices 0 .. k-1
+    tv = torch.empty((R, k), dtype=torch.float32, device="cuda")
+    ti = torch.empty((R, k), dtype=torch.int32, device="cuda")
+    lib.vc_topk_rows_f32(stream(), P(dev(x)), R, cols, ld, k, P(tv), P(ti))
+    for r in range(R):
+        ref = sorted(enumerate(x[r, :cols]), key=lambda t: -t[1])[:k]  # Python's sort is stable
         assert host(ti)[r].tolist() == [i for i, _ in ref]
         assert host(tv)[r].tolist() == [float(v) for _, v in ref]
 
