@@ -94,6 +94,13 @@ int vc_lstm_step_bwd_f32(void* stream, int N, int H, int t, int first, const flo
  * otherwise 1; 1 = recurrent GEMM via vc_gemm_f32 (split-K) + element-wise gate kernels; 3 = recurrence kernels wherever
  * supported; 0 = the round-1 fused step kernels. */
 int vc_lstm_set_mode(int split);
+/* Single steps on the recurrence kernel for callers that advance one token at a time with fixed weights (generation: greedy /
+ * sampling / beam search, vae_model/decoder.py:145-320): pack Wh [H,4H] once into whp (H * 4H floats), then step with the same
+ * arguments as vc_lstm_step_fwd_f32.  H == 512 only: ask vc_lstm_step_packed_supported. */
+int vc_lstm_step_packed_supported(int N, int H);
+int vc_lstm_pack_wh_f32(void* stream, int H, const float* Wh, float* whp);
+int vc_lstm_step_fwd_packed_f32(void* stream, int N, int H, int t, const float* h_prev, const float* c_prev, const float* whp,
+                                float* gact, const int32_t* lens_eff, float* c_out, float* h_out);
 size_t vc_lstm_seq_workspace_bytes(int T, int N, int E, int H);
 int vc_lstm_seq_fwd_f32(void* stream, int T, int N, int E, int H, const float* X, const float* W, const float* b,
                         const int32_t* lens_eff, float* act, float* cs, float* hs, float* ws, size_t ws_bytes);

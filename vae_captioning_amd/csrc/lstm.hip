@@ -679,6 +679,29 @@ extern "C" int vc_lstm_step_bwd_f32(void* stream, int N, int H, int t, int first
     return step_bwd((hipStream_t)stream, a);
 }
 
+// Single steps on the recurrence kernel (generation: the decoder advances one token at a time and Wh does not change between
+// steps): pack Wh once, then step.  H == 512 only (ask vc_lstm_step_packed_supported); whp: H * 4H floats.
+extern "C" int vc_lstm_step_packed_supported(int N, int H) { return vc::rec_ok(N, H) ? 1 : 0; }
+
+extern "C" int vc_lstm_pack_wh_f32(void* stream, int H, const float* Wh, float* whp) {
+    using namespace vc;
+    VC_CHECK_ARG(H == 512 && Wh && whp, "H == 512 required (vc_lstm_step_packed_supported)");
+    VC_CHECK_ARG(aligned16(Wh) && aligned16(whp), "Wh / whp must be 16-byte aligned");
+    hipLaunchKernelGGL(lstm_rec_pack_fwd_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, Wh, H, (float4*)whp);
+    return launch_status(__func__);
+}
+
+extern "C" int vc_lstm_step_fwd_packed_f32(void* stream, int N, int H, int t, const float* h_prev, const float* c_prev, const float* whp,
+                                           float* gact, const int32_t* lens_eff, float* c_out, float* h_out) {
+    using namespace vc;
+    VC_CHECK_ARG(N > 0 && rec_ok(N, H), "unsupported shape (vc_lstm_step_packed_supported)");
+    VC_CHECK_ARG(h_prev && c_prev && whp && gact && lens_eff && c_out && h_out, "null pointer");
+    VC_CHECK_ARG(aligned16(h_prev) && aligned16(c_prev) && aligned16(whp) && aligned16(gact) && aligned16(c_out) && aligned16(h_out),
+                 "state / gate buffers must be 16-byte aligned");
+    LstmFwdArgs a{h_prev, c_prev, nullptr, gact, lens_eff, c_out, h_out, N, H, t};
+    return rec_fwd((hipStream_t)stream, a, whp);
+}
+
 extern "C" int vc_lstm_set_mode(int split) {
     vc::g_lstm_mode = (split < 0 || split > 3) ? 2 : split;
     return 0;

@@ -29,6 +29,9 @@ class CaptionGenerator(object):
         self.p = engine.p
         self.lib = engine.lib
         self.buf = {}
+        self._ones = {}
+        self._whp = None        # decoder Wh in the recurrence kernel's operand order
+        self._whp_fresh = False  # re-packed at the start of every init_state (the weights may have been trained in between)
 
     def _b(self, name, shape, dtype=torch.float32):
         t = self.buf.get(name)
@@ -65,6 +68,7 @@ class CaptionGenerator(object):
         """State after image -> (c_v) -> z (decoder.py:96-114), batched over B images.
         eps: [S, B, L] N(0,1) draws (generated on device when None)."""
         e, p, lib, st, S = self.e, self.p, self.lib, _stream(), self.e.store
+        self._whp_fresh = False  # a new generation call: re-pack Wh on the first step (5 us)
         feats = self._dev(features, np.float32)
         B = feats.shape[0]
         E, Hd, L, Sm, F = p.embed_size, p.decoder_hidden, p.latent_size, p.gen_z_samples, p.cnn_feature_size
@@ -111,8 +115,18 @@ class CaptionGenerator(object):
         gact = torch.empty((M, 4 * Hd), dtype=torch.float32, device=e.dev)
         e.gemm(0, 0, M, 4 * Hd, E, x, E, W, 4 * Hd, gact, 4 * Hd, S.param(spec.DEC_CELL + "bias"))
         c2, h2 = torch.empty_like(c), torch.empty_like(h)
-        ones = torch.ones((M,), dtype=torch.int32, device=e.dev)
-        lib.vc_lstm_step_fwd_f32(st, M, Hd, 0, P(h), P(c), W.data_ptr() + E * 4 * Hd * 4, P(gact), P(ones), P(c2), P(h2))
+        ones = self._ones.get(M)
+        if ones is None:
+            ones = self._ones[M] = torch.ones((M,), dtype=torch.int32, device=e.dev)
+        if lib.vc_lstm_step_packed_supported(M, Hd):  # the recurrence step kernel on Wh packed once per weight version
+            if not self._whp_fresh:
+                if self._whp is None or self._whp.numel() != Hd * 4 * Hd:
+                    self._whp = torch.empty(Hd * 4 * Hd, dtype=torch.float32, device=e.dev)
+                lib.vc_lstm_pack_wh_f32(st, Hd, W.data_ptr() + E * 4 * Hd * 4, P(self._whp))
+                self._whp_fresh = True
+            lib.vc_lstm_step_fwd_packed_f32(st, M, Hd, 0, P(h), P(c), P(self._whp), P(gact), P(ones), P(c2), P(h2))
+        else:
+            lib.vc_lstm_step_fwd_f32(st, M, Hd, 0, P(h), P(c), W.data_ptr() + E * 4 * Hd * 4, P(gact), P(ones), P(c2), P(h2))
         logits = torch.empty((M, V), dtype=torch.float32, device=e.dev)
         e._timed("logits_gemm", 2.0 * M * V * Hd,
                  lambda: e.gemm(0, 0, M, V, Hd, h2, Hd, S.param("decoder/rnn_logits/kernel"), e.Vp, logits, V, S.param("decoder/rnn_logits/bias")))
