@@ -98,13 +98,13 @@ struct TileMap {
     }
     // output pixel of tile row r (-1: beyond the tensor)
     __device__ __forceinline__ long out_pixel(int r) const {
-        if (SCHEME == PATCH_SUB) {
-            const long s = (long)tm * 4 + (r >> 5);
-            if (s >= g.nsubs) return -1;
-            const int b = (int)(s / g.subs_img), rem = (int)(s - (long)b * g.subs_img);
-            const int sy = rem / g.subs_x, sx = rem - sy * g.subs_x;
-            const int y = sy * 4 + ((r & 31) >> 3), x = sx * 8 + (r & 7);
-            return ((long)b * g.H + y) * g.W + x;
+        if (SCHEME == PATCH_SUB) {  // (32-bit unsigned arithmetic: sub-tile and pixel counts are < 2^31; 64-bit divisions cost ~100 VALU each)
+            const unsigned s = (unsigned)tm * 4u + (unsigned)(r >> 5);
+            if (s >= (unsigned)g.nsubs) return -1;
+            const unsigned b = s / (unsigned)g.subs_img, rem = s - b * (unsigned)g.subs_img;
+            const unsigned sy = rem / (unsigned)g.subs_x, sx = rem - sy * (unsigned)g.subs_x;
+            const unsigned y = sy * 4u + ((unsigned)(r & 31) >> 3), x = sx * 8u + (unsigned)(r & 7);
+            return (long)((b * (unsigned)g.H + y) * (unsigned)g.W + x);
         } else {
             const long p = p0 + r;
             return p < g.P ? p : -1;
@@ -128,13 +128,13 @@ struct TileMap {
             if (pix >= 240) return -1;
             const int j = pix / 60, r60 = pix - j * 60;
             const int py = r60 / 10, px = r60 - py * 10;
-            const long s = (long)tm * 4 + j;
-            if (s >= g.nsubs) return -1;
-            const int b = (int)(s / g.subs_img), rem = (int)(s - (long)b * g.subs_img);
-            const int sy = rem / g.subs_x, sx = rem - sy * g.subs_x;
-            const int y = sy * 4 + py - 1, x = sx * 8 + px - 1;
+            const unsigned s = (unsigned)tm * 4u + (unsigned)j;
+            if (s >= (unsigned)g.nsubs) return -1;
+            const unsigned b = s / (unsigned)g.subs_img, rem = s - b * (unsigned)g.subs_img;
+            const unsigned sy = rem / (unsigned)g.subs_x, sx = rem - sy * (unsigned)g.subs_x;
+            const int y = (int)(sy * 4u) + py - 1, x = (int)(sx * 8u) + px - 1;
             if ((unsigned)y >= (unsigned)g.H || (unsigned)x >= (unsigned)g.W) return -1;
-            return ((long)b * g.H + y) * g.W + x;
+            return (long)((b * (unsigned)g.H + (unsigned)y) * (unsigned)g.W + (unsigned)x);
         } else {
             const int rs = pix / g.PW, x = pix - rs * g.PW - 1;
             if (rs >= g.R || (unsigned)x >= (unsigned)g.W) return -1;
