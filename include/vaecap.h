@@ -90,13 +90,13 @@ int vc_lstm_step_bwd_f32(void* stream, int N, int H, int t, int first, const flo
 /* Sequence drivers, process-wide switch for A/B measurements (identical arithmetic up to fp32 summation order and, in the
  * recurrence kernels, sigmoid / tanh built from v_exp_f32 + v_rcp_f32, |error| < 3e-7):
  * 2 (default) = auto: the register-operand recurrence step kernels (one workgroup per CU, four waves split K, Wh slice packed
- * in MFMA-operand order, 16x16x4 tiles, gate math in the epilogue) when H == 512 -- forward up to 640 rows, backward any N --
- * otherwise 1; 1 = recurrent GEMM via vc_gemm_f32 (split-K) + element-wise gate kernels; 3 = recurrence kernels wherever
+ * in MFMA-operand order, 16x16x4 tiles, gate math in the epilogue; above 400 rows the forward uses eight waves on 16-unit slices)
+ * when H == 512, otherwise 1; 1 = recurrent GEMM via vc_gemm_f32 (split-K) + element-wise gate kernels; 3 = recurrence kernels wherever
  * supported; 0 = the round-1 fused step kernels. */
 int vc_lstm_set_mode(int split);
 /* Single steps on the recurrence kernel for callers that advance one token at a time with fixed weights (generation: greedy /
- * sampling / beam search, vae_model/decoder.py:145-320): pack Wh [H,4H] once into whp (H * 4H floats), then step with the same
- * arguments as vc_lstm_step_fwd_f32.  H == 512 only: ask vc_lstm_step_packed_supported. */
+ * sampling / beam search, vae_model/decoder.py:145-320): pack Wh [H,4H] once into whp (2 * H * 4H floats: the operand orders of
+ * both step kernels, chosen by N), then step with the same arguments as vc_lstm_step_fwd_f32.  H == 512 only: ask vc_lstm_step_packed_supported. */
 int vc_lstm_step_packed_supported(int N, int H);
 int vc_lstm_pack_wh_f32(void* stream, int H, const float* Wh, float* whp);
 int vc_lstm_step_fwd_packed_f32(void* stream, int N, int H, int t, const float* h_prev, const float* c_prev, const float* whp,

@@ -574,15 +574,188 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_bwd_kernel(LstmBwdArgs a, con
     }
 }
 
-// Step kernel choice (vc_lstm_set_mode): 2 (default) = auto -- the register-operand recurrence kernels where H == 512 (forward up
-// to rec_fwd_auto rows, backward any N), else the split form; 3: recurrence kernels wherever supported; 1: split-K GEMM + gate
+// ---- forward recurrence for many rows (N > 640): eight waves, 16 hidden units x 4 gates per workgroup ---------------------------
+// Above ~640 rows the four-wave kernel needs several passes per workgroup and re-reads the h rows once per 8-unit column slice
+// (64 slices).  This variant halves that: 32 column slices of 16 units (64 gate columns, four 16-wide MFMA column tiles: a patch
+// fragment feeds four MFMAs), EIGHT waves split K (64 k each, so the resident Wh fragments still fit: 4 x 4 float4 = 64 VGPRs),
+// 32 x 8 workgroups of 160 rows at N = 1280 = two passes of five 16-row tiles.  The eight partial tiles meet in LDS in two halves
+// (gates i, j then f, o: 8 x 80 x 36 floats = 92 KB each).
+constexpr int R8_PITCH = 68;                 // floats per staged row (64 k + 4 pad)
+constexpr int R8_TILE = 16 * R8_PITCH;       // one 16-row tile
+constexpr int R8_WAVE = 80 * 36;             // floats per wave: its partial half tile (>= its two staging tiles)
+constexpr int R8_LDS_BYTES = 8 * R8_WAVE * 4;
+
+// out[((((ug*8 + w)*4 + ct)*4 + j)*64 + lane] = Wh[k .. k+3][col], k = 64 w + 16 (lane>>4) + 4 j, col = ct*H + 16 ug + (lane&15)
+__global__ __launch_bounds__(256) void lstm_rec8_pack_kernel(const float* __restrict__ Wh, int H, float4* __restrict__ out) {
+    const int total = (H / 16) * 8 * 4 * 4 * 64;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int lane = i & 63, j = (i >> 6) & 3, ct = (i >> 8) & 3, w = (i >> 10) & 7, ug = i >> 13;
+        const int col = ct * H + ug * 16 + (lane & 15);
+        const int k = 64 * w + 16 * (lane >> 4) + 4 * j;
+        const float* s = Wh + (long)k * 4 * H + col;
+        out[i] = make_float4(s[0], s[4L * H], s[8L * H], s[12L * H]);
+    }
+}
+
+__global__ __launch_bounds__(512, 1) void lstm_rec8_fwd_kernel(LstmFwdArgs a, const float4* __restrict__ whp, int rows_wg) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int RT = 5, H = 512, RP = 36;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ug = blockIdx.x, N = a.N, rot = ug % RT;
+    const int rbeg = blockIdx.y * rows_wg, rend = min(N, rbeg + rows_wg);
+    float4 bres[4][4];
+    {
+        const float4* bp = whp + (size_t)(ug * 8 + wave) * (4 * 4 * 64) + lane;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bres[ct][j] = bp[(ct * 4 + j) * 64];
+    }
+    const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc((void*)a.h_prev, 0, N * H * 4, 0x00020000);
+    float* As = smem + wave * R8_WAVE;
+    // staging: lane -> (row lane >> 4 of a group of four, 16-byte segment lane & 15); fragments: lane -> (row lane & 15, k group lane >> 4)
+    const int rsub = lane >> 4, seg = lane & 15;
+    float* wr = As + rsub * R8_PITCH + seg * 4;
+    const float* rd = As + (lane & 15) * R8_PITCH + 16 * (lane >> 4);
+    const int rr = tid >> 2, quad = tid & 3;  // gate item: row rr of the pass, units 16 ug + 4 quad .. + 3 (320 items)
+    for (int row0 = rbeg; row0 < rend; row0 += 16 * RT) {
+        const int row = row0 + rr;
+        const bool has = tid < 64 * RT && row < rend;
+        const int rowc = min(row, N - 1);
+        float4 gx[4];
+        const long si = (long)rowc * H + ug * 16 + 4 * quad;
+        float* gp = a.gact + (long)rowc * 4 * H + ug * 16 + 4 * quad;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gx[g] = ld4(gp + g * H);
+        const float4 cp = ld4(a.c_prev + si), hp = ld4(a.h_prev + si);
+        const int len = a.lens[rowc];
+        f32x4 acc[RT][4];
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[i][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (row0 != rbeg) __syncthreads();  // the previous pass's gate math has read every wave's partials
+        // contraction: tile slot i works on row tile (i + rot) % RT; loads two tiles ahead, LDS round trip one tile ahead
+        const unsigned v0 = (unsigned)(row0 + rsub) * (H * 4) + wave * 256 + seg * 16;
+        float4 g[2][4], fr[2][4];
+        auto gload = [&](int u) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) g[u & 1][q] = lbuf(rh, v0 + (unsigned)(16 * rec_rot<RT>(u, rot) + 4 * q) * (H * 4), 0);
+        };
+        auto stage = [&](int u) {
+            float* w = wr + (u & 1) * R8_TILE;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(w + 4 * q * R8_PITCH) = g[u & 1][q];
+        };
+        auto frags = [&](int u) {
+            const float* r = rd + (u & 1) * R8_TILE;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fr[u & 1][j] = *reinterpret_cast<const float4*>(r + 4 * j);
+        };
+        gload(0);
+        gload(1);
+        __builtin_amdgcn_sched_barrier(0);
+        stage(0);
+        gload(2);
+        frags(0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < RT; ++u) {
+            if (u + 1 < RT) {
+                stage(u + 1);
+                if (u + 3 < RT) gload(u + 3);
+                frags(u + 1);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) acc[u][ct] = mfma16(lcomp(fr[u & 1][j], e), lcomp(bres[ct][j], e), acc[u][ct]);
+            if (u + 1 < RT) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                if (u + 3 < RT) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // the eight K-partial tiles meet in LDS, gates (i, j) first, then (f, o): red[wave][row][36], column = 16 (gate & 1) + unit
+        float4 sums[4];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            if (half) __syncthreads();
+            {
+                float* p = As + (4 * (lane >> 4)) * RP + (lane & 15);
+#pragma unroll
+                for (int i = 0; i < RT; ++i) {
+                    float* pi = p + 16 * rec_rot<RT>(i, rot) * RP;
+#pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) pi[v * RP + 16 * c2] = acc[i][2 * half + c2][v];
+                }
+            }
+            __syncthreads();
+            if (has) {
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) {
+                    float4 s = f4zero();
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) {  // fixed order
+                        const float4 v = ld4(smem + w * R8_WAVE + rr * RP + 16 * c2 + 4 * quad);
+                        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+                    }
+                    sums[2 * half + c2] = s;
+                }
+            }
+        }
+        if (has) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { gx[g].x += sums[g].x; gx[g].y += sums[g].y; gx[g].z += sums[g].z; gx[g].w += sums[g].w; }
+            float4 c4, h4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float i = rsigmoid(at(gx[0], e)), j = rtanh(at(gx[1], e)), f = rsigmoid(at(gx[2], e) + 1.0f), o = rsigmoid(at(gx[3], e));
+                const float c = f * at(cp, e) + i * j;
+                const float h = o * rtanh(c);
+                at(gx[0], e) = i; at(gx[1], e) = j; at(gx[2], e) = f; at(gx[3], e) = o;
+                const bool active = a.t < len;
+                at(c4, e) = active ? c : at(cp, e);
+                at(h4, e) = active ? h : at(hp, e);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) st4(gp + g * H, gx[g]);
+            st4(a.c_out + si, c4);
+            st4(a.h_out + si, h4);
+        }
+    }
+}
+
+// Step kernel choice (vc_lstm_set_mode): 2 (default) = auto -- the register-operand recurrence kernels where H == 512 (forward:
+// the four-wave 8-unit kernel up to 400 rows, the eight-wave 16-unit kernel above; backward any N), else the split form; 3: the
+// same (kept for callers of round 2's first half, when auto still took the split form above 640 rows); 1: split-K GEMM + gate
 // kernels; 0: round-1 fused kernels.  Measured per step at H = 512 (marginal cost inside the sequence drivers, tools/microbench.py
-// lstm; N = 160 / 320 / 640 / 1280): forward 11.6 / 17.0 / 31.7 / 58.9 us against 18.4 / 22.0 / 32.6 / 55.3 us for the split form,
-// backward 18.4 / 25.1 / 42.5 / 80.3 against 24.3 / 33.7 / 50.9 / 88.7 us (the step kernels alone, rocprofv3: 13.0 us forward and
-// 11.8 us backward at N = 320, where round 2 started from a 13.4 us split-K GEMM + 8.2 us gate kernel backward).
+// lstm; N = 160 / 320 / 640 / 1280): forward 11.5 / 17.1 / 26.2 / 47.9 us against 18.4 / 22.0 / 32.6 / 55.3 us for the split form
+// (four-wave kernel alone: 31.9 / 58.9 at 640 / 1280), backward 18.4 / 25.1 / 42.5 / 80.3 against 24.3 / 33.7 / 50.9 / 88.7 us (the
+// step kernels alone, rocprofv3: 13.0 us forward and 11.8 us backward at N = 320, where round 2 started from a 13.4 us split-K
+// GEMM + 8.2 us gate kernel backward).
 static int g_lstm_mode = 2;
 static bool rec_ok(int N, int H) { return H == 512 && (long)(N + 96) * 4 * H * 4 < 0x7fffffffL; }
-static bool rec_fwd_auto(int N) { return N <= 640; }  // above: four passes per workgroup, the split-K GEMM + gate kernels are level or ahead
+static bool rec8_rows(int N) { return N > 400; }  // forward: the eight-wave 16-unit kernel above (19.7 vs 17.1 us at 320 rows, 26.2 vs 31.9 at 640, 47.9 vs 58.9 at 1280)
 constexpr size_t REC_PACK_BYTES = (size_t)512 * 2048 * sizeof(float);
 
 static int rec_cus() {
@@ -619,6 +792,17 @@ static int rec_fwd(hipStream_t st, const LstmFwdArgs& a, const float* whp) {
     else
         hipLaunchKernelGGL(lstm_rec_fwd_kernel<3>, dim3(64, RG), dim3(256), REC_LDS_BYTES, st, a, (const float4*)whp, rows);
     return launch_status("lstm rec fwd");
+}
+
+static int rec8_fwd(hipStream_t st, const LstmFwdArgs& a, const float* whp) {
+    static int once = [] {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_rec8_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, R8_LDS_BYTES);
+        return e == hipSuccess ? 0 : fail((int)e, "%s: hipFuncSetAttribute failed", "lstm rec8 kernel");
+    }();
+    if (once) return once;
+    const int RG = rec_row_groups(a.N, 32), rows = cdiv(a.N, RG);
+    hipLaunchKernelGGL(lstm_rec8_fwd_kernel, dim3(32, RG), dim3(512), R8_LDS_BYTES, st, a, (const float4*)whp, rows);
+    return launch_status("lstm rec8 fwd");
 }
 
 static int rec_bwd(hipStream_t st, const LstmBwdArgs& a, const float* whp) {
@@ -680,7 +864,8 @@ extern "C" int vc_lstm_step_bwd_f32(void* stream, int N, int H, int t, int first
 }
 
 // Single steps on the recurrence kernel (generation: the decoder advances one token at a time and Wh does not change between
-// steps): pack Wh once, then step.  H == 512 only (ask vc_lstm_step_packed_supported); whp: H * 4H floats.
+// steps): pack Wh once, then step.  H == 512 only (ask vc_lstm_step_packed_supported); whp: 2 * H * 4H floats (the operand
+// orders of the four-wave and of the eight-wave kernel; the step picks by N).
 extern "C" int vc_lstm_step_packed_supported(int N, int H) { return vc::rec_ok(N, H) ? 1 : 0; }
 
 extern "C" int vc_lstm_pack_wh_f32(void* stream, int H, const float* Wh, float* whp) {
@@ -688,6 +873,7 @@ extern "C" int vc_lstm_pack_wh_f32(void* stream, int H, const float* Wh, float* 
     VC_CHECK_ARG(H == 512 && Wh && whp, "H == 512 required (vc_lstm_step_packed_supported)");
     VC_CHECK_ARG(aligned16(Wh) && aligned16(whp), "Wh / whp must be 16-byte aligned");
     hipLaunchKernelGGL(lstm_rec_pack_fwd_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, Wh, H, (float4*)whp);
+    hipLaunchKernelGGL(lstm_rec8_pack_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, Wh, H, (float4*)(whp + (size_t)H * 4 * H));
     return launch_status(__func__);
 }
 
@@ -699,7 +885,7 @@ extern "C" int vc_lstm_step_fwd_packed_f32(void* stream, int N, int H, int t, co
     VC_CHECK_ARG(aligned16(h_prev) && aligned16(c_prev) && aligned16(whp) && aligned16(gact) && aligned16(c_out) && aligned16(h_out),
                  "state / gate buffers must be 16-byte aligned");
     LstmFwdArgs a{h_prev, c_prev, nullptr, gact, lens_eff, c_out, h_out, N, H, t};
-    return rec_fwd((hipStream_t)stream, a, whp);
+    return rec8_rows(N) ? rec8_fwd((hipStream_t)stream, a, whp + (size_t)H * 4 * H) : rec_fwd((hipStream_t)stream, a, whp);
 }
 
 extern "C" int vc_lstm_set_mode(int split) {
@@ -741,9 +927,11 @@ extern "C" int vc_lstm_seq_fwd_f32(void* stream, int T, int N, int E, int H, con
     if (rc) return rc;
     const long NH = (long)N * H;
     const int eg = (int)((NH + 255) / 256) < 2048 ? (int)((NH + 255) / 256) : 2048;
-    const bool rec = (g_lstm_mode == 3 || (g_lstm_mode == 2 && rec_fwd_auto(N))) && rec_ok(N, H) && ws && ws_bytes >= REC_PACK_BYTES;
+    const bool rec = (g_lstm_mode == 3 || g_lstm_mode == 2) && rec_ok(N, H) && ws && ws_bytes >= REC_PACK_BYTES;
+    const bool rec8 = rec && rec8_rows(N);
     if (rec) {  // Wh in the MFMA-operand layout of the step kernel, once per sequence (4 MB at H = 512)
-        hipLaunchKernelGGL(lstm_rec_pack_fwd_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, Wh, H, (float4*)ws);
+        if (rec8) hipLaunchKernelGGL(lstm_rec8_pack_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, Wh, H, (float4*)ws);
+        else hipLaunchKernelGGL(lstm_rec_pack_fwd_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, Wh, H, (float4*)ws);
         rc = launch_status(__func__);
         if (rc) return rc;
     }
@@ -751,7 +939,7 @@ extern "C" int vc_lstm_seq_fwd_f32(void* stream, int T, int N, int E, int H, con
         float* g = act + (long)t * N * 4 * H;
         if (rec) {
             LstmFwdArgs a{hs + t * NH, cs + t * NH, Wh, g, lens_eff, cs + (t + 1) * NH, hs + (t + 1) * NH, N, H, t};
-            rc = rec_fwd((hipStream_t)stream, a, ws);
+            rc = rec8 ? rec8_fwd((hipStream_t)stream, a, ws) : rec_fwd((hipStream_t)stream, a, ws);
         } else if (g_lstm_mode) {
             int ns = 1;  // recurrent product as split-K partials in ws; the gate kernel sums them (no separate reduce launch)
             rc = gemm_partials_f32((hipStream_t)stream, 0, 0, N, 4 * H, H, hs + t * NH, H, Wh, 4 * H, ws, ws_bytes, 8, &ns);

@@ -120,8 +120,8 @@ class CaptionGenerator(object):
             ones = self._ones[M] = torch.ones((M,), dtype=torch.int32, device=e.dev)
         if lib.vc_lstm_step_packed_supported(M, Hd):  # the recurrence step kernel on Wh packed once per weight version
             if not self._whp_fresh:
-                if self._whp is None or self._whp.numel() != Hd * 4 * Hd:
-                    self._whp = torch.empty(Hd * 4 * Hd, dtype=torch.float32, device=e.dev)
+                if self._whp is None or self._whp.numel() != 2 * Hd * 4 * Hd:
+                    self._whp = torch.empty(2 * Hd * 4 * Hd, dtype=torch.float32, device=e.dev)
                 lib.vc_lstm_pack_wh_f32(st, Hd, W.data_ptr() + E * 4 * Hd * 4, P(self._whp))
                 self._whp_fresh = True
             lib.vc_lstm_step_fwd_packed_f32(st, M, Hd, 0, P(h), P(c), P(self._whp), P(gact), P(ones), P(c2), P(h2))
