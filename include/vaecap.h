@@ -272,6 +272,20 @@ size_t vc_conv3x3_wgrad_patch_workspace_bytes(int B, int H, int W, int Cin, int 
 int vc_conv3x3_wgrad_patch_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const float* dy, float* dw,
                                float* db, int accumulate, float* ws, size_t ws_bytes);
 
+/* Winograd F(2x2, 3x3) forward / data gradient (csrc/conv_wino.hip): the same convolution in fp32 with 2.25x fewer multiplications.
+ * Input transform, sixteen position products on MFMA and output transform in one kernel; a wave owns up to 32 tiles (2x2 output
+ * pixels each) x 32 output columns x all sixteen positions.  The weights are transformed and packed once per optimiser step
+ * (wp: 16 * Cin * Cout floats; transpose 0 = forward, 1 = flipped taps + transposed channels for the data gradient).  Results agree
+ * with conv3x3_fwd / conv3x3_dgrad to fp32 rounding of a different summation (tests/test_gpu_conv_wino.py: same fp64 oracle, same
+ * tolerance class).  ypool != NULL also writes max_pool2x2(y) (a pooling window is one Winograd tile).  Shapes: H, W even, gathered
+ * channels % 16 == 0, output channels % 32 == 0; ask vc_conv3x3_wino_supported. */
+int vc_conv3x3_wino_supported(int B, int H, int W, int Cin, int Cout, int dgrad);
+int vc_conv3x3_wino_pack_f32(void* stream, int Cin, int Cout, const float* w, int transpose, float* wp);
+int vc_conv3x3_wino_fwd_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const float* wp,
+                            const float* bias, float* y, float* ypool, int relu);
+int vc_conv3x3_wino_dgrad_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* dy, const float* wpt,
+                              const float* relu_src, float* dx);
+
 /* conv1_1 (utils/image_embeddings.py:36-48: 3 -> 64 channels), csrc/conv_first.hip: the layer is HBM-bound (it writes / re-reads
  * the [B,H,W,64] activation, 822 MB at 64 images, for 0.6 % of the multiply-adds), so it has its own kernels: the forward makes
  * the 64 output channels the M dimension of the MFMA so that every lane stores 16-byte vectors of consecutive channels straight

@@ -159,6 +159,38 @@ def convp():
             print("conv%s B=%d speed-up fwd %.3f dgrad %.3f" % (name, B, res["fwd"] / res["fwd-patch"], res["dgrad"] / res["dgrad-patch"]), flush=True)
 
 
+def wino():
+    """Winograd F(2x2,3x3) forward / data gradient (conv_wino.hip) against the patch-staged direct kernels, VGG16 layer shapes at 64 images;
+    TFLOP/s are ALGORITHMIC (direct-convolution flops / time)"""
+    B = 64
+    for (name, H, ci, co) in [("1_2", 224, 64, 64), ("2_1", 112, 64, 128), ("2_2", 112, 128, 128), ("3_1", 56, 128, 256), ("3_2", 56, 256, 256),
+                              ("4_1", 28, 256, 512), ("4_2", 28, 512, 512), ("5_2", 14, 512, 512)]:
+        x, w, bias = rnd(B, H, H, ci), rnd(3, 3, ci, co), rnd(co)
+        y, dx = torch.empty(B, H, H, co, device="cuda"), torch.empty(B, H, H, ci, device="cuda")
+        yp = torch.empty(B, H // 2, H // 2, co, device="cuda")
+        dy = rnd(B, H, H, co)
+        wp, wpt = torch.empty(9 * ci * co, device="cuda"), torch.empty(9 * ci * co, device="cuda")
+        vp, vpt = torch.empty(16 * ci * co, device="cuda"), torch.empty(16 * ci * co, device="cuda")
+        lib.vc_conv3x3_pack_f32(st(), ci, co, P(w), 0, P(wp))
+        lib.vc_conv3x3_pack_f32(st(), ci, co, P(w), 1, P(wpt))
+        lib.vc_conv3x3_wino_pack_f32(st(), ci, co, P(w), 0, P(vp))
+        lib.vc_conv3x3_wino_pack_f32(st(), ci, co, P(w), 1, P(vpt))
+        tw = torch.empty(max(lib.vc_conv3x3_packed_workspace_bytes(B, H, H, ci, co, 0), lib.vc_conv3x3_packed_workspace_bytes(B, H, H, ci, co, 1), 16) // 4 + 4, device="cuda")
+        tb = tw.numel() * 4
+        fl = 2e-9 * B * H * H * 9 * ci * co
+        res = {}
+        for nm, fn in (("fwd-patch", lambda: lib.vc_conv3x3_fwd_packed_f32(st(), B, H, H, ci, co, P(x), P(wp), P(bias), P(y), 1, P(tw), tb)),
+                       ("fwd-wino", lambda: lib.vc_conv3x3_wino_fwd_f32(st(), B, H, H, ci, co, P(x), P(vp), P(bias), P(y), None, 1)),
+                       ("fwd-wino-pool", lambda: lib.vc_conv3x3_wino_fwd_f32(st(), B, H, H, ci, co, P(x), P(vp), P(bias), P(y), P(yp), 1)),
+                       ("dgrad-patch", lambda: lib.vc_conv3x3_dgrad_packed_f32(st(), B, H, H, ci, co, P(dy), P(wpt), P(x), P(dx), P(tw), tb)),
+                       ("dgrad-wino", lambda: lib.vc_conv3x3_wino_dgrad_f32(st(), B, H, H, ci, co, P(dy), P(vpt), P(x), P(dx))),
+                       ("wino-pack", lambda: lib.vc_conv3x3_wino_pack_f32(st(), ci, co, P(w), 1, P(vpt)))):
+            med, mn = timeit(fn, reps=5)
+            res[nm] = med
+            print("conv%s %-13s B=%d H=%3d %3d->%3d: %8.3f ms  %6.1f TFLOP/s" % (name, nm, B, H, ci, co, med, fl / med), flush=True)
+        print("conv%s speed-up fwd %.3f dgrad %.3f" % (name, res["fwd-patch"] / res["fwd-wino"], res["dgrad-patch"] / res["dgrad-wino"]), flush=True)
+
+
 def convsweep():
     """tile-count sweep of the patch forward kernel (conv4_2 / conv3_2 shapes, batch varied): how launch time depends on
     tiles / resident workgroups, with (tail) and without (single) the K-split tail launch"""

@@ -56,6 +56,9 @@ class VggEngine(object):
         # patch-staged forward / data-gradient kernels (csrc/conv_patch.hip) wherever the layer shape allows; VC_CONV_PATCH=0
         # keeps every layer on the implicit-GEMM kernels of csrc/conv.hip (A/B runs)
         self.use_patch = os.environ.get("VC_CONV_PATCH", "1") != "0"
+        # Winograd F(2x2,3x3) forward / data gradient (csrc/conv_wino.hip: 2.25x fewer multiplications, fp32) wherever the shape allows
+        # (every 3x3 layer but conv1_1); VC_CONV_WINO=0 keeps the direct kernels (A/B runs, tests of the direct path)
+        self.use_wino = self.use_patch and os.environ.get("VC_CONV_WINO", "1") != "0"
         # MaxPoolGrad + ReluGrad inside the next data gradient's epilogue (vc_conv3x3_dgrad_unpool_packed_f32): measured 49.22 / 49.32
         # vs 49.40 / 49.38 ms per step -- the four pool-gradient launches (0.55 ms at 5.9 TB/s) disappear but their 3.5 GB of traffic
         # leaves the four data gradients as 32-byte pieces from the accumulator epilogue (+0.4 ms): off by default
@@ -130,12 +133,20 @@ class VggEngine(object):
                 lib.vc_conv3x3_pack_f32(sh, ci, co, P(w), 0, P(self._b("wp_" + name, (9 * ci * co,))))
                 if backward:
                     lib.vc_conv3x3_pack_f32(sh, ci, co, P(w), 1, P(self._b("wpt_" + name, (9 * ci * co,))))
+                if self.use_wino and ci % 16 == 0 and co % 32 == 0:   # G g G^T of every filter, in the Winograd kernel's operand order
+                    lib.vc_conv3x3_wino_pack_f32(sh, ci, co, P(w), 0, P(self._b("vp_" + name, (16 * ci * co,))))
+                    if backward and ci % 32 == 0 and co % 16 == 0:
+                        lib.vc_conv3x3_wino_pack_f32(sh, ci, co, P(w), 1, P(self._b("vpt_" + name, (16 * ci * co,))))
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
         return ev
 
     def _patch_ok(self, nb, H, W, ci, co, dgrad):
         return self.use_patch and ci % 32 == 0 and bool(self.lib.vc_conv3x3_patch_supported(nb, H, W, ci, co, dgrad))
+
+    def _wino_ok(self, name, nb, H, W, ci, co, dgrad):
+        return (self.use_wino and (("vpt_" if dgrad else "vp_") + name) in self.buf
+                and bool(self.lib.vc_conv3x3_wino_supported(nb, H, W, ci, co, dgrad)))
 
     def colsum(self, x, rows, cols, out):
         self._need_ws(self.lib.vc_colsum_workspace_bytes(rows, cols))
@@ -209,6 +220,11 @@ class VggEngine(object):
                         if packed is not None and ch not in waited:
                             torch.cuda.current_stream().wait_event(packed)
                             waited.add(ch)
+                        if self._wino_ok(name, nb, H, W, cie, co, 0):   # Winograd; the 2x2 max-pool is register math in its epilogue
+                            self._timed("conv_fwd", 2.0 * nb * H * W * 9 * ci * co,
+                                        lambda: lib.vc_conv3x3_wino_fwd_f32(sh, nb, H, W, cie, co, P(x[b0:]), P(self.buf["vp_" + name]), P(S.param(bn)),
+                                                                            P(y[b0:]), P(yp[b0:]) if pooled else None, 1))
+                            continue
                         wp = self.buf["wp_" + name]
                         if pooled and W % 8 == 0 and H % 4 == 0:  # 2x2 max-pool fused into the epilogue (4 x 8 sub-tile tiling)
                             self._timed("conv_fwd", 2.0 * nb * H * W * 9 * ci * co,
@@ -361,7 +377,10 @@ class VggEngine(object):
                     tws = self._chain_ws(ch, nb)
                     with torch.cuda.stream(strm):
                         sh = _stream()
-                        if self._patch_ok(nb, H, W, ci, co, 1) and ("wpt_" + name) in self.buf:
+                        if self._wino_ok(name, nb, H, W, ci, co, 1):
+                            self._timed("conv_dgrad", fl * nb / B, lambda: lib.vc_conv3x3_wino_dgrad_f32(
+                                sh, nb, H, W, ci, co, P(d[b0:]), P(self.buf["vpt_" + name]), None if prev_is_pool else P(x[b0:]), P(dx[b0:])))
+                        elif self._patch_ok(nb, H, W, ci, co, 1) and ("wpt_" + name) in self.buf:
                             wpt = self.buf["wpt_" + name]
                             self._timed("conv_dgrad", fl * nb / B, lambda: lib.vc_conv3x3_dgrad_packed_f32(
                                 sh, nb, H, W, ci, co, P(d[b0:]), P(wpt), None if prev_is_pool else P(x[b0:]), P(dx[b0:]), P(tws), tws.numel() * 4))
