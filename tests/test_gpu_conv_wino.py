@@ -34,8 +34,9 @@ def test_wino_pack_is_G_g_Gt(lib):
         g = w.astype(np.float64) if not transpose else w[::-1, ::-1].transpose(0, 1, 3, 2).astype(np.float64)
         C, N = g.shape[2], g.shape[3]
         V = np.einsum("ak,klcn,bl->abcn", G, g, G).reshape(16, C, N)                        # [p][c][n]
-        got = host(_pack(lib, dev(w), transpose)).reshape(N // 32, C // 16, 16, 4, 32, 4)  # [nt][chunk][p][quad][nl][e]
-        ref = V.reshape(16, C // 16, 4, 4, N // 32, 32).transpose(4, 1, 0, 2, 5, 3)
+        # packed [nt][chunk][half][p][lane half][nl][e], channel = 16 chunk + 8 half + 4 lane half + e
+        got = host(_pack(lib, dev(w), transpose)).reshape(N // 32, C // 16, 2, 16, 2, 32, 4)
+        ref = V.reshape(16, C // 16, 2, 2, 4, N // 32, 32).transpose(5, 1, 2, 0, 3, 6, 4)
         np.testing.assert_allclose(got, ref, rtol=0, atol=1e-6)
 
 

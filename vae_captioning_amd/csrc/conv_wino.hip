@@ -30,8 +30,8 @@ constexpr int WCH = 16;                          // channels per chunk
 constexpr int WPITCH = WCH + 4;                  // floats per patch pixel in LDS
 constexpr int WPIX = 180;                        // patch pixels per block: (2 TBH + 2)(2 TBW + 2) <= 180
 constexpr int WBLK = WPIX * WPITCH;              // floats per block patch
-constexpr int WSLOTS = 12;                       // float4 patch slots per thread: 4 blocks x 180 pixels x 4 channel quads <= 256 x 12
-constexpr int WV_FLOATS = 16 * 4 * 32 * 4;       // one chunk of transformed weights: [p 16][quad 4][n 32][e 4]
+constexpr int WSLOTS = 6;                        // float4 patch slots per thread and half: 4 blocks x 180 pixels x 2 channel quads <= 256 x 6
+constexpr int WV_FLOATS = 2 * 16 * 2 * 32 * 4;   // one chunk of transformed weights: [half 2][p 16][lane half 2][n 32][e 4]
 constexpr int WP_OFF = WV_FLOATS;                // LDS: weights first (their ds_read offsets stay below the 64 KB immediate range), then the patches
 constexpr int WINO_LDS_BYTES = (WP_OFF + 4 * WBLK) * 4;
 constexpr unsigned WOOB = 0x80000000u;
@@ -48,13 +48,12 @@ struct WinoGeom {
 struct WinoArgs {
     WinoGeom g;
     const float* x;     // [P, C]
-    const float* wp;    // packed [N/32][C/16][16][4][32][4]
+    const float* wp;    // packed [N/32][C/16][2][16][2][32][4]
     float* out;         // [P, N]
     const float* aux;   // fwd: bias [N] or null; dgrad: ReLU source [P, N] or null
     float* pool;        // fwd: also max_pool2x2(out) [B, H/2, W/2, N] (null: none)
     int relu;
     int tiles_n, ntiles, nchunks;
-    int dbg;            // experiments (VC_WINO_DBG): 1 = no global loads in the loop, 2 = no LDS restaging, 4 = no MFMAs
 };
 
 __device__ __forceinline__ float4 wbufload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
@@ -77,132 +76,37 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(WinoArgs a) {
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)((long)g.B * g.H * g.W * C * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, 16 * C * N * 4, 0x00020000);
 
-    // patch slots of this thread: slot s = tid + 256 i = (block s / 720, patch pixel (s % 720) / 4, channel quad s % 4)
+    // A chunk (16 channels) is staged as two HALVES: half q = channels [8 q, 8 q + 8) of every patch pixel + the weights of those
+    // channels (lane half lh works on channel quad 2 q + lh).  While the MFMAs of one half run, the other half's region of the LDS is
+    // refilled for the next half-phase, so that LDS writes, global loads and MFMAs overlap all the time; one barrier per half-phase.
+    // patch slots of this thread: slot s = tid + 256 i = (patch pixel s / 2 of the workgroup's 4 x 180, quad 2 q + (s & 1))
     unsigned voff[WSLOTS];
 #pragma unroll
     for (int i = 0; i < WSLOTS; ++i) {
-        const int s = tid + 256 * i;
-        const int blk = s / (4 * WPIX), r = s - blk * (4 * WPIX), pix = r >> 2, quad = r & 3;
-        const int gb = tm * 4 + blk;
+        const unsigned pl = (unsigned)(tid >> 1) + 128u * i;
+        const unsigned blk = pl / WPIX, pix = pl - blk * WPIX;   // (32-bit unsigned divisions: a signed or 64-bit one costs ~100 VALU)
+        const unsigned gb = (unsigned)tm * 4u + blk;
         voff[i] = WOOB;
-        if (blk < 4 && gb < g.nblocks && pix < g.PH * g.PW) {
-            const int b = gb / g.blocks_img, rem = gb - b * g.blocks_img;
-            const int by = rem / g.bx_n, bx = rem - by * g.bx_n;
-            const int py = pix / g.PW, px = pix - py * g.PW;
-            const int y = by * 2 * g.TBH - 1 + py, x = bx * 2 * g.TBW - 1 + px;
+        if (blk < 4 && gb < (unsigned)g.nblocks && pix < (unsigned)(g.PH * g.PW)) {
+            const unsigned b = gb / (unsigned)g.blocks_img, rem = gb - b * (unsigned)g.blocks_img;
+            const unsigned by = rem / (unsigned)g.bx_n, bx = rem - by * (unsigned)g.bx_n;
+            const unsigned py = pix / (unsigned)g.PW, px = pix - py * (unsigned)g.PW;
+            const int y = (int)(by * 2u * g.TBH + py) - 1, x = (int)(bx * 2u * g.TBW + px) - 1;
             if ((unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W)
-                voff[i] = (unsigned)((((long)(b * g.H + y) * g.W + x) * C + quad * 4) * 4);
+                voff[i] = (((b * (unsigned)g.H + (unsigned)y) * (unsigned)g.W + (unsigned)x) * (unsigned)C + (unsigned)(tid & 1) * 4u) * 4u;
         }
     }
-    const int pst = WP_OFF + (tid >> 2) * WPITCH + (tid & 3) * 4;   // LDS float index of slot 0; slot i is 64 pixels = 64 * WPITCH floats further
-    const unsigned vsrc = (unsigned)(((long)nt * a.nchunks) * WV_FLOATS * 4) + (unsigned)tid * 16u;  // weights: chunk c at + c * 32 KB, piece i at + i * 4 KB
+    const int pst = WP_OFF + (tid >> 1) * WPITCH + (tid & 1) * 4;   // LDS float index of slot 0 of half 0; slot i is 128 pixels further, half 1 eight floats
+    const unsigned vsrc = (unsigned)(((long)nt * a.nchunks) * WV_FLOATS * 4) + (unsigned)tid * 16u;  // weights: half-phase h at + h * 16 KB, piece i at + i * 4 KB
 
     // this lane's tile inside its wave's block, its 4 x 4 patch origin in LDS, its weight fragment origin
     const int ntl = g.TBH * g.TBW;
     const int jt = li < ntl ? li : 0;
     const int tyl = jt / g.TBW, txl = jt - tyl * g.TBW;
-    const int abase = WP_OFF + wave * WBLK + ((2 * tyl) * g.PW + 2 * txl) * WPITCH + lh * 8;   // + q * 4 + (i * PW + j) * WPITCH
+    const int abase = WP_OFF + wave * WBLK + ((2 * tyl) * g.PW + 2 * txl) * WPITCH + lh * 4;   // + q * 8 + (i * PW + j) * WPITCH
     const int rowp = g.PW * WPITCH;
-    const int vbase = (2 * lh * 32 + li) * 4;                               // + (p * 4 + q) * 128
+    const int vbase = (lh * 32 + li) * 4;                                                      // + q * 4096 + p * 256
 
-    f32x16 acc[16];
-#pragma unroll
-    for (int p = 0; p < 16; ++p)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
-
-    float4 pr[WSLOTS], vr[8];
-    auto gload = [&](int ch) {
-#pragma unroll
-        for (int i = 0; i < WSLOTS; ++i) pr[i] = wbufload(rx, voff[i], (unsigned)ch * (WCH * 4));
-#pragma unroll
-        for (int i = 0; i < 8; ++i) vr[i] = wbufload(rw, vsrc + (unsigned)i * 4096u, (unsigned)ch * (WV_FLOATS * 4));
-    };
-    auto lstore = [&]() {
-#pragma unroll
-        for (int i = 0; i < WSLOTS; ++i)
-            if (i < WSLOTS - 1 || tid + 256 * i < 4 * 4 * WPIX) *reinterpret_cast<float4*>(&smem[pst + i * 64 * WPITCH]) = pr[i];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(&smem[(tid + 256 * i) * 4]) = vr[i];
-    };
-
-    // unit (q, xi): position row xi of channel quad q.  U[xi][nu] = (B^T d B)[xi][nu], B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1].
-    // The software pipeline is written out and pinned with sched_barriers (hipcc otherwise sinks the LDS reads next to their first
-    // use and batches the MFMAs behind the additions): while the sixteen MFMAs of unit u run, the twelve ds_read_b128 of unit u + 1
-    // are issued first and its 32 additions follow one quad per MFMA.
-    // Units run in the order xi = 0, 2, 1, 3 so that every patch row is read once per channel quad: rows 0 and 2 for xi = 0, row 1 for
-    // xi = 2, nothing for xi = 1, row 3 for xi = 3 (sixteen patch reads + sixteen weight reads per 64 MFMAs).
-    float4 ur[2][4], vf[2][4];
-    float4 dr[4][4], tt[4];
-    auto rd = [&](int u, int buf) {   // the patch rows unit u is the first to need (four pixels each) + its four weight fragments
-        const int q = u >> 2, xi = (u & 3) == 1 ? 2 : (u & 3) == 2 ? 1 : (u & 3);
-        const float* pq = &smem[abase + q * 4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (xi == 0) { dr[0][j] = *reinterpret_cast<const float4*>(pq + j * WPITCH); dr[2][j] = *reinterpret_cast<const float4*>(pq + 2 * rowp + j * WPITCH); }
-            if (xi == 2) dr[1][j] = *reinterpret_cast<const float4*>(pq + rowp + j * WPITCH);
-            if (xi == 3) dr[3][j] = *reinterpret_cast<const float4*>(pq + 3 * rowp + j * WPITCH);
-        }
-#pragma unroll
-        for (int nu = 0; nu < 4; ++nu) vf[buf][nu] = *reinterpret_cast<const float4*>(&smem[vbase + ((xi * 4 + nu) * 4 + q) * 128]);
-    };
-    auto tstep = [&](int u, int buf, int k) {   // eight steps of four additions
-        const int xi = (u & 3) == 1 ? 2 : (u & 3) == 2 ? 1 : (u & 3);
-        if (k < 4) tt[k] = xi == 0 ? f4sub(dr[0][k], dr[2][k]) : xi == 1 ? f4add(dr[1][k], dr[2][k]) : xi == 2 ? f4sub(dr[2][k], dr[1][k]) : f4sub(dr[1][k], dr[3][k]);
-        if (k == 4) ur[buf][0] = f4sub(tt[0], tt[2]);
-        if (k == 5) ur[buf][1] = f4add(tt[1], tt[2]);
-        if (k == 6) ur[buf][2] = f4sub(tt[2], tt[1]);
-        if (k == 7) ur[buf][3] = f4sub(tt[1], tt[3]);
-    };
-    auto mf = [&](int u, int buf, int m) {
-        const int xi = (u & 3) == 1 ? 2 : (u & 3) == 2 ? 1 : (u & 3), e = m >> 2, nu = m & 3;
-        acc[xi * 4 + nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcomp(vf[buf][nu], e), wcomp(ur[buf][nu], e), acc[xi * 4 + nu], 0, 0, 0);
-    };
-#define WSB() __builtin_amdgcn_sched_barrier(0)
-
-    gload(0);
-    lstore();
-    __syncthreads();
-    for (int ch = 0; ch < a.nchunks; ++ch) {
-        const bool more = ch + 1 < a.nchunks;
-        if (more && !(a.dbg & 1)) gload(ch + 1);
-        rd(0, 0);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) tstep(0, 0, k);
-        WSB();
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int b = u & 1, nb = b ^ 1;
-            if (u + 1 < 8) {
-                rd(u + 1, nb);
-                WSB();
-                mf(u, b, 0); mf(u, b, 1);
-                WSB();
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    tstep(u + 1, nb, k);
-                    WSB();
-                    mf(u, b, 2 + k);
-                    WSB();
-                }
-#pragma unroll
-                for (int m = 10; m < 16; ++m) mf(u, b, m);
-            } else {
-#pragma unroll
-                for (int m = 0; m < 16; ++m) mf(u, b, m);
-            }
-            WSB();
-        }
-        if (more && !(a.dbg & 2)) {
-            __syncthreads();
-            lstore();
-            __syncthreads();
-        }
-    }
-#undef WSB
-    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
-
-    // ---- output transform + epilogue: acc[p][r] = M_p[column n0 + 8 (r >> 2) + 4 lh + (r & 3)][tile li]
     const int gb = tm * 4 + wave;
     const bool blk_ok = gb < g.nblocks && li < ntl;
     const int gbc = gb < g.nblocks ? gb : 0;
@@ -212,6 +116,120 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(WinoArgs a) {
     const bool ok00 = blk_ok && y0 < g.H && x0 < g.W, ok01 = ok00 && x0 + 1 < g.W, ok10 = ok00 && y0 + 1 < g.H, ok11 = ok10 && x0 + 1 < g.W;
     const long p00 = ((long)(b * g.H + y0) * g.W + x0) * N;
     const long rowN = (long)g.W * N;
+    unsigned mbits[2] = {0xffffffffu, 0xffffffffu};
+    f32x16 acc[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+
+    float4 st[WSLOTS + 4];           // staging registers: six patch slots + four weight pieces of ONE half
+    auto gload1 = [&](int hp, int i) {   // the i-th of the ten global loads of half-phase hp's data
+        if (i < WSLOTS) st[i] = wbufload(rx, voff[i], (unsigned)hp * 32u);
+        else st[i] = wbufload(rw, vsrc + (unsigned)(i - WSLOTS) * 4096u, (unsigned)hp * 16384u);
+    };
+    auto lstore = [&](int q, int i) {    // the i-th of the ten LDS writes of a half
+        if (i < WSLOTS) {
+            if (i < WSLOTS - 1 || tid + 256 * i < 2 * 4 * WPIX) *reinterpret_cast<float4*>(&smem[pst + q * 8 + i * 128 * WPITCH]) = st[i];
+        } else {
+            *reinterpret_cast<float4*>(&smem[q * 4096 + (tid + 256 * (i - WSLOTS)) * 4]) = st[i];
+        }
+    };
+
+    // unit (q, xi): position row xi of half q.  U[xi][nu] = (B^T d B)[xi][nu], B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1].
+    // Units run in the order xi = 0, 2, 1, 3 so that every patch row is read once per half: rows 0 and 2 for xi = 0, row 1 for
+    // xi = 2, nothing for xi = 1, row 3 for xi = 3 (sixteen patch reads + sixteen weight reads per 64 MFMAs).
+    // One wave per SIMD: nothing else feeds the matrix pipe while this wave issues anything that is not an MFMA, so the software
+    // pipeline is written out gap by gap and pinned with sched_barriers -- consecutive MFMAs go to DIFFERENT accumulators (k-step
+    // outer, column inner), every gap between two MFMAs carries at most five other instructions (MI355X_MICROARCH.md: what a
+    // single wave hides per MFMA), the additions stay scalar (-fno-slp-vectorize: packed fp32 adds cost more beside MFMAs).
+    float4 ur[2][4], vf[2][4];
+    float4 dr[4][4], tt[4];
+    auto xi_of = [](int u4) { return u4 == 1 ? 2 : u4 == 2 ? 1 : u4; };
+    auto rdp = [&](int q, int u4, int j) {   // pixel j of the patch rows unit u4 is the first to need
+        const int xi = xi_of(u4);
+        const float* pq = &smem[abase + q * 8 + j * WPITCH];
+        if (xi == 0) { dr[0][j] = *reinterpret_cast<const float4*>(pq); dr[2][j] = *reinterpret_cast<const float4*>(pq + 2 * rowp); }
+        if (xi == 2) dr[1][j] = *reinterpret_cast<const float4*>(pq + rowp);
+        if (xi == 3) dr[3][j] = *reinterpret_cast<const float4*>(pq + 3 * rowp);
+    };
+    auto rdv = [&](int q, int u4, int buf, int nu) { vf[buf][nu] = *reinterpret_cast<const float4*>(&smem[vbase + q * 4096 + (xi_of(u4) * 4 + nu) * 256]); };
+    auto tstep = [&](int u4, int buf, int k) {   // eight steps of four additions
+        const int xi = xi_of(u4);
+        if (k < 4) tt[k] = xi == 0 ? f4sub(dr[0][k], dr[2][k]) : xi == 1 ? f4add(dr[1][k], dr[2][k]) : xi == 2 ? f4sub(dr[2][k], dr[1][k]) : f4sub(dr[1][k], dr[3][k]);
+        if (k == 4) ur[buf][0] = f4sub(tt[0], tt[2]);
+        if (k == 5) ur[buf][1] = f4add(tt[1], tt[2]);
+        if (k == 6) ur[buf][2] = f4sub(tt[2], tt[1]);
+        if (k == 7) ur[buf][3] = f4sub(tt[1], tt[3]);
+    };
+    auto mf = [&](int u4, int buf, int m) {
+        const int xi = xi_of(u4), e = m >> 2, nu = m & 3;
+        acc[xi * 4 + nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcomp(vf[buf][nu], e), wcomp(ur[buf][nu], e), acc[xi * 4 + nu], 0, 0, 0);
+    };
+#define WSB() __builtin_amdgcn_sched_barrier(0)
+    // one half-phase = the four units of half q of the current chunk; the data of the NEXT half-phase (the other half's LDS region) is
+    // loaded from global memory during unit 0 and written to the LDS during unit 2; the barrier at the head of unit 3 closes both this
+    // half's last reads and those writes, so unit 3 already prepares the first unit of the next half-phase.
+    auto half = [&](int q, bool more, int nexthp) {
+#pragma unroll
+        for (int u4 = 0; u4 < 4; ++u4) {
+            const int b = u4 & 1, nb = b ^ 1;
+            const bool nxt = u4 < 3 || more;
+            const int nq = u4 < 3 ? q : q ^ 1, nu4 = (u4 + 1) & 3;
+            if (u4 == 3 && more) __syncthreads();
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                mf(u4, b, m);
+                WSB();
+                if (nxt) {
+                    if (m < 4) rdp(nq, nu4, m);                       // gaps 0..3: one patch pixel each (two rows for xi = 0)
+                    else if (m < 6) { rdv(nq, nu4, nb, 2 * (m - 4)); rdv(nq, nu4, nb, 2 * (m - 4) + 1); }
+                    else if (m < 14) tstep(nu4, nb, m - 6);           // gaps 6..13: four additions each
+                }
+                if (more && m < 10) {                                 // staging of the next half-phase: one operation per gap
+                    if (u4 == 0) gload1(nexthp, m);
+                    if (u4 == 2) lstore(q ^ 1, m);
+                }
+                WSB();
+            }
+        }
+    };
+
+#pragma unroll
+    for (int i = 0; i < WSLOTS + 4; ++i) gload1(0, i);
+    // data gradient: the ReLU mask of this lane's 2 x 2 pixels x 16 columns as 64 bits, loaded while the first patch is in flight
+    if (KIND == WK_DGRAD && a.aux) {
+        mbits[0] = mbits[1] = 0u;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+            for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb) {
+                    const bool ok = aa == 0 ? (bb == 0 ? ok00 : ok01) : (bb == 0 ? ok10 : ok11);
+                    const float4 m = ok ? *reinterpret_cast<const float4*>(a.aux + p00 + aa * rowN + bb * N + n0 + 8 * rg + 4 * lh) : f4zero();
+                    const unsigned bits = (m.x > 0.f ? 1u : 0u) | (m.y > 0.f ? 2u : 0u) | (m.z > 0.f ? 4u : 0u) | (m.w > 0.f ? 8u : 0u);
+                    mbits[rg >> 1] |= bits << (16 * (rg & 1) + 8 * aa + 4 * bb);
+                }
+    }
+#pragma unroll
+    for (int i = 0; i < WSLOTS + 4; ++i) lstore(0, i);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rdp(0, 0, j);
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu) rdv(0, 0, 0, nu);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tstep(0, 0, k);
+    WSB();
+    for (int ch = 0; ch < a.nchunks; ++ch) {
+        half(0, true, 2 * ch + 1);
+        half(1, ch + 1 < a.nchunks, 2 * ch + 2);
+    }
+#undef WSB
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+
+    // ---- output transform + epilogue: acc[p][r] = M_p[column n0 + 8 (r >> 2) + 4 lh + (r & 3)][tile li]
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
         const int col = n0 + 8 * rg + 4 * lh;
@@ -256,13 +274,12 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(WinoArgs a) {
             for (int aa = 0; aa < 2; ++aa)
 #pragma unroll
                 for (int bb = 0; bb < 2; ++bb) {
-                    const bool ok = aa == 0 ? (bb == 0 ? ok00 : ok01) : (bb == 0 ? ok10 : ok11);
-                    const float4 m = ok ? *reinterpret_cast<const float4*>(a.aux + p00 + aa * rowN + bb * N + col) : f4zero();
+                    const unsigned mb = mbits[rg >> 1] >> (16 * (rg & 1) + 8 * aa + 4 * bb);
                     float4& v = Y[aa][bb];
-                    if (!(m.x > 0.f)) v.x = 0.f;
-                    if (!(m.y > 0.f)) v.y = 0.f;
-                    if (!(m.z > 0.f)) v.z = 0.f;
-                    if (!(m.w > 0.f)) v.w = 0.f;
+                    if (!(mb & 1u)) v.x = 0.f;
+                    if (!(mb & 2u)) v.y = 0.f;
+                    if (!(mb & 4u)) v.z = 0.f;
+                    if (!(mb & 8u)) v.w = 0.f;
                 }
         }
         if (ok00) *reinterpret_cast<float4*>(a.out + p00 + col) = Y[0][0];
@@ -280,7 +297,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(WinoArgs a) {
     }
 }
 
-// w [3][3][Ci][Co] (HWIO) -> V = G g G^T, G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1], packed [N/32][C/16][p 16][quad 4][n 32][e 4]:
+// w [3][3][Ci][Co] (HWIO) -> V = G g G^T, G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1], packed [N/32][C/16][half 2][p 16][lane half 2][n 32][e 4] (channel = 16 chunk + 8 half + 4 lane half + e):
 //   transpose 0 (forward):        C = Ci, N = Co, g[ky][kx] = w[ky][kx][c][n]
 //   transpose 1 (data gradient):  C = Co, N = Ci, g[ky][kx] = w[2 - ky][2 - kx][n][c]
 __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict__ w, int Ci, int Co, int transpose, float* __restrict__ out) {
@@ -304,15 +321,15 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict_
             t[2][kx] = 0.5f * (gk[0][kx] - gk[1][kx] + gk[2][kx]);
             t[3][kx] = gk[2][kx];
         }
-        const int nt = n >> 5, nl = n & 31, ch = c / WCH, quad = (c % WCH) >> 2, e = c & 3;
-        float* o = out + ((long)nt * nchunks + ch) * WV_FLOATS + (quad * 32 + nl) * 4 + e;
+        const int nt = n >> 5, nl = n & 31, ch = c / WCH, quad = (c % WCH) >> 2, e = c & 3;   // quad = 2 * half + lane half
+        float* o = out + ((long)nt * nchunks + ch) * WV_FLOATS + (quad >> 1) * 4096 + ((quad & 1) * 32 + nl) * 4 + e;
 #pragma unroll
         for (int xi = 0; xi < 4; ++xi) {
             const float v0 = t[xi][0], v1 = 0.5f * (t[xi][0] + t[xi][1] + t[xi][2]), v2 = 0.5f * (t[xi][0] - t[xi][1] + t[xi][2]), v3 = t[xi][2];
-            o[(xi * 4 + 0) * 512] = v0;
-            o[(xi * 4 + 1) * 512] = v1;
-            o[(xi * 4 + 2) * 512] = v2;
-            o[(xi * 4 + 3) * 512] = v3;
+            o[(xi * 4 + 0) * 256] = v0;
+            o[(xi * 4 + 1) * 256] = v1;
+            o[(xi * 4 + 2) * 256] = v2;
+            o[(xi * 4 + 3) * 256] = v3;
         }
     }
 }
@@ -367,8 +384,6 @@ static int launch_wino(hipStream_t st, WinoArgs& a) {
     a.tiles_n = a.g.N / 32;
     a.nchunks = a.g.C / WCH;
     a.ntiles = cdiv(a.g.nblocks, 4) * a.tiles_n;
-    static const int dbg = getenv("VC_WINO_DBG") ? atoi(getenv("VC_WINO_DBG")) : 0;
-    a.dbg = dbg;
     hipLaunchKernelGGL((conv_wino_kernel<KIND, POOL>), dim3(a.ntiles), dim3(256), WINO_LDS_BYTES, st, a);
     return launch_status("conv wino");
 }
