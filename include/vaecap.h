@@ -286,6 +286,15 @@ int vc_conv3x3_wino_fwd_f32(void* stream, int B, int H, int W, int Cin, int Cout
 int vc_conv3x3_wino_dgrad_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* dy, const float* wpt,
                               const float* relu_src, float* dx);
 
+/* Winograd F(3x3, 2x2) weight gradient (csrc/conv_wino.hip): both operands transformed in registers, the contraction runs over the
+ * 2x2-pixel tiles; raw position sums per K split in the workspace, a reduce kernel sums the splits in fixed order and applies the
+ * output transform.  Same contract as conv3x3_wgrad (db != NULL also returns the bias gradient, accumulate adds to dw / db); the
+ * workspace is REQUIRED.  Shapes: H, W even, H >= 4, Cin % 64 == 0, Cout % 64 == 0; ask vc_conv3x3_wino_wgrad_supported. */
+int vc_conv3x3_wino_wgrad_supported(int B, int H, int W, int Cin, int Cout);
+size_t vc_conv3x3_wino_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+int vc_conv3x3_wino_wgrad_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const float* dy, float* dw,
+                              float* db, int accumulate, float* ws, size_t ws_bytes);
+
 /* conv1_1 (utils/image_embeddings.py:36-48: 3 -> 64 channels), csrc/conv_first.hip: the layer is HBM-bound (it writes / re-reads
  * the [B,H,W,64] activation, 822 MB at 64 images, for 0.6 % of the multiply-adds), so it has its own kernels: the forward makes
  * the 64 output channels the M dimension of the MFMA so that every lane stores 16-byte vectors of consecutive channels straight

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from .gpu_util import P, assert_close, dev, host, stream, zeros
+from .gpu_util import P, assert_close, dev, empty_bytes, host, stream, zeros
 
 pytestmark = pytest.mark.gpu
 
@@ -92,3 +92,37 @@ def test_wino_unsupported_shapes_are_refused(lib):
     x, wp, y = zeros(2, 7, 8, 32), zeros(16 * 32 * 64), zeros(2, 7, 8, 64)
     with pytest.raises(VaecapError):
         lib.vc_conv3x3_wino_fwd_f32(stream(), 2, 7, 8, 32, 64, P(x), P(wp), None, P(y), None, 0)
+
+
+# (B, H, W, Cin, Cout): block shapes 4x8 / 4x7 / 2x14, ragged blocks at the image border (H, W not multiples of the block), a ragged
+# last K split, several channel blocks, more workgroups than blocks per split
+WG_CASES = [(2, 8, 16, 64, 64), (1, 56, 56, 64, 64), (2, 28, 28, 64, 128), (3, 14, 14, 128, 64), (2, 12, 20, 64, 64), (5, 4, 6, 64, 192), (1, 224, 224, 64, 64)]
+
+
+@pytest.mark.parametrize("case", WG_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_wino_wgrad_matches_oracle(lib, case):
+    B, H, W, Ci, Co = case
+    assert lib.vc_conv3x3_wino_wgrad_supported(B, H, W, Ci, Co) == 1
+    rng = np.random.default_rng(sum(case) + 1)
+    x = np.maximum(rng.standard_normal((B, H, W, Ci), dtype=np.float32), 0)
+    dy = rng.standard_normal((B, H, W, Co), dtype=np.float32)
+    w0 = np.zeros((3, 3, Ci, Co))
+    if B * H * W <= 20000:
+        _, dwref, dbref = OV.conv3x3_bwd(x.astype(np.float64), w0, dy.astype(np.float64))
+    else:   # the 224 x 224 case: torch fp64 on the device as the reference of the reference (same contraction)
+        tx64, tdy64 = torch.from_numpy(x).cuda().double().permute(0, 3, 1, 2), torch.from_numpy(dy).cuda().double().permute(0, 3, 1, 2)
+        dwref = torch.nn.grad.conv2d_weight(tx64, (Co, Ci, 3, 3), tdy64, padding=1).permute(2, 3, 1, 0).cpu().numpy()
+        dbref = dy.astype(np.float64).sum(axis=(0, 1, 2))
+    ws = empty_bytes(lib.vc_conv3x3_wino_wgrad_workspace_bytes(B, H, W, Ci, Co))
+    dw, db = zeros(3, 3, Ci, Co), zeros(Co)
+    lib.vc_conv3x3_wino_wgrad_f32(stream(), B, H, W, Ci, Co, P(dev(x)), P(dev(dy)), P(dw), P(db), 0, P(ws), ws.numel() * 4)
+    tol = 3e-6 * np.sqrt(B * H * W) + 1e-6
+    assert_close(host(dw), dwref, tol, msg="wino wgrad")
+    assert_close(host(db), dbref, tol, msg="wino wgrad: bias gradient")
+    first = host(dw).copy()
+    lib.vc_conv3x3_wino_wgrad_f32(stream(), B, H, W, Ci, Co, P(dev(x)), P(dev(dy)), P(dw), P(db), 1, P(ws), ws.numel() * 4)
+    assert_close(host(dw), 2 * dwref, tol, msg="wino wgrad (accumulate)")
+    assert_close(host(db), 2 * dbref, tol, msg="wino wgrad (accumulate): bias gradient")
+    dw2 = zeros(3, 3, Ci, Co)
+    lib.vc_conv3x3_wino_wgrad_f32(stream(), B, H, W, Ci, Co, P(dev(x)), P(dev(dy)), P(dw2), None, 0, P(ws), ws.numel() * 4)
+    assert np.array_equal(host(dw2), first), "not bit-reproducible"

@@ -191,6 +191,24 @@ def wino():
         print("conv%s speed-up fwd %.3f dgrad %.3f" % (name, res["fwd-patch"] / res["fwd-wino"], res["dgrad-patch"] / res["dgrad-wino"]), flush=True)
 
 
+def winow():
+    """Winograd F(3x3,2x2) weight gradient against the patch-staged direct kernel, VGG16 layer shapes at 64 images (algorithmic TFLOP/s)"""
+    B = 64
+    for (name, H, ci, co) in [("1_2", 224, 64, 64), ("2_1", 112, 64, 128), ("2_2", 112, 128, 128), ("3_1", 56, 128, 256), ("3_2", 56, 256, 256),
+                              ("4_1", 28, 256, 512), ("4_2", 28, 512, 512), ("5_2", 14, 512, 512)]:
+        x, dy, bias = rnd(B, H, H, ci), rnd(B, H, H, co), rnd(co)
+        dw = torch.empty(3, 3, ci, co, device="cuda")
+        ws = torch.empty(max(lib.vc_conv3x3_wgrad_patch_workspace_bytes(B, H, H, ci, co), lib.vc_conv3x3_wino_wgrad_workspace_bytes(B, H, H, ci, co)) // 4 + 4, device="cuda")
+        fl = 2e-9 * B * H * H * 9 * ci * co
+        res = {}
+        for nm, fn in (("wgrad-patch", lambda: lib.vc_conv3x3_wgrad_patch_f32(st(), B, H, H, ci, co, P(x), P(dy), P(dw), P(bias), 0, P(ws), ws.numel() * 4)),
+                       ("wgrad-wino", lambda: lib.vc_conv3x3_wino_wgrad_f32(st(), B, H, H, ci, co, P(x), P(dy), P(dw), P(bias), 0, P(ws), ws.numel() * 4))):
+            med, mn = timeit(fn, reps=5)
+            res[nm] = med
+            print("conv%s %-12s B=%d H=%3d %3d->%3d: %8.3f ms  %6.1f TFLOP/s" % (name, nm, B, H, ci, co, med, fl / med), flush=True)
+        print("conv%s speed-up wgrad %.3f" % (name, res["wgrad-patch"] / res["wgrad-wino"]), flush=True)
+
+
 def convsweep():
     """tile-count sweep of the patch forward kernel (conv4_2 / conv3_2 shapes, batch varied): how launch time depends on
     tiles / resident workgroups, with (tail) and without (single) the K-split tail launch"""

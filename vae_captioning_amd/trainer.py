@@ -148,6 +148,9 @@ class VggEngine(object):
         return (self.use_wino and (("vpt_" if dgrad else "vp_") + name) in self.buf
                 and bool(self.lib.vc_conv3x3_wino_supported(nb, H, W, ci, co, dgrad)))
 
+    def _wino_wgrad_ok(self, B, H, W, ci, co):
+        return self.use_wino and ci % 64 == 0 and co % 64 == 0 and bool(self.lib.vc_conv3x3_wino_wgrad_supported(B, H, W, ci, co))
+
     def colsum(self, x, rows, cols, out):
         self._need_ws(self.lib.vc_colsum_workspace_bytes(rows, cols))
         self.lib.vc_colsum_f32(_stream(), P(x), rows, cols, cols, P(out), 0, P(self.ws), self.ws_bytes)
@@ -305,7 +308,8 @@ class VggEngine(object):
             after_fc()
         dw4 = self._b("dw1_4", (3, 3, 4, 64))
         self._need_ws(max(lib.vc_conv1_wgrad_workspace_bytes(),
-                          max(max(lib.vc_conv3x3_wgrad_workspace_bytes(B, a[2], a[3], a[4], a[5]), lib.vc_conv3x3_wgrad_patch_workspace_bytes(B, a[2], a[3], a[4], a[5]))
+                          max(max(lib.vc_conv3x3_wgrad_workspace_bytes(B, a[2], a[3], a[4], a[5]), lib.vc_conv3x3_wgrad_patch_workspace_bytes(B, a[2], a[3], a[4], a[5]),
+                                  lib.vc_conv3x3_wino_wgrad_workspace_bytes(B, a[2], a[3], a[4], a[5]) if self._wino_wgrad_ok(B, a[2], a[3], a[4], a[5]) else 0)
                               for a in self.acts if a[0] != "P")))
         main = torch.cuda.current_stream()
         side, side2 = self.side, self.side2
@@ -340,6 +344,8 @@ class VggEngine(object):
                 elif ci == 4:
                     self._timed("conv_wgrad", fl, lambda: lib.vc_conv3x3_wgrad_f32(sw, B, H, W, ci, co, P(x), P(d), P(dw4), P(S.grad(bn)), 0, P(self.ws), self.ws_bytes))
                     lib.vc_pad_dim_f32(sw, P(dw4), 9, 4, 3, 64, P(S.grad(wn)))
+                elif self._wino_wgrad_ok(B, H, W, ci, co):   # Winograd F(3x3,2x2): both operands transformed in registers, K = the 2x2 tiles
+                    self._timed("conv_wgrad", fl, lambda: lib.vc_conv3x3_wino_wgrad_f32(sw, B, H, W, ci, co, P(x), P(d), P(S.grad(wn)), P(S.grad(bn)), 0, P(self.ws), self.ws_bytes))
                 elif self.use_patch and lib.vc_conv3x3_wgrad_patch_supported(B, H, W, ci, co):
                     self._timed("conv_wgrad", fl, lambda: lib.vc_conv3x3_wgrad_patch_f32(sw, B, H, W, ci, co, P(x), P(d), P(S.grad(wn)), P(S.grad(bn)), 0, P(self.ws), self.ws_bytes))
                 else:
