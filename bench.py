@@ -240,7 +240,7 @@ def main():
             tr.vgg.timer = timer
         for _ in range(max(2, args.steps // 4)):
             tr._step()
-    roof = roofline_from_timer(timer, tr.vgg is not None)
+    roof = roofline_from_timer(timer, tr.vgg is not None, B)
     roof["instrumented_pass"] = instrumented_pass
     roof["hbm_kernels"] = hbm_from_timer(timer)
     # HBM-side bytes per launch of the same kernels, from the rocprofv3 --pmc passes of this command
@@ -339,14 +339,50 @@ def hbm_from_timer(timer):
     return out
 
 
-def roofline_from_timer(timer, fine_tune):
+def _cdiv(a, b):
+    return (a + b - 1) // b
+
+
+def wino_executed_ratio(images):
+    """Executed MFMA FLOPs / algorithmic FLOPs of one cfg4 step's 3x3 convolution calls when the Winograd kernels run (default):
+    F(2x2,3x3) / F(3x3,2x2) multiply 16 times per 2x2 tile and channel pair where the direct form multiplies 36 times; tile blocks
+    that stick out of the image (csrc/conv_wino.hip plan_wino / plan_wino_wgrad: 32 tile slots per block) add padding work.
+    conv1_1 (3 input channels) stays on its direct HBM-bound kernels."""
+    from vae_captioning_amd import spec
+    H = 224
+    alg = ex = 0.0
+    for name, ci, co in spec.VGG_CONV:
+        th = tw = H // 2
+        fl = 2.0 * images * H * H * 9 * ci * co
+        if ci == 3:
+            alg += 2 * fl
+            ex += 2 * fl
+        else:
+            best = 0.0   # forward / data gradient: the block shape with the fewest empty slots (TBH = min(32 // TBW, 8))
+            for tbw in range(1, min(16, tw) + 1):
+                tbh = min(32 // tbw, 8, th)
+                if (2 * tbh + 2) * (2 * tbw + 2) > 180:
+                    continue
+                best = max(best, tw * th / (_cdiv(tw, tbw) * _cdiv(th, tbh) * 32.0))
+            effw = max(tw * th / (_cdiv(tw, bw) * _cdiv(th, bh) * float(bh * bw)) for bh, bw in ((4, 8), (4, 7), (2, 14)))
+            alg += 3 * fl
+            ex += 2 * fl * (16.0 / 36.0) / best + fl * (16.0 / 36.0) / effw
+        if name in spec.VGG_POOL_AFTER:
+            H //= 2
+    return ex / alg
+
+
+def roofline_from_timer(timer, fine_tune, images=0):
     """Dominant kernel family: cfg4 = the 3x3 convolution calls (forward, data gradient, weight gradient; a call = its main
-    launch + K-split tail launch + split reduce); caption-only workloads = the [T*N, H] x [H, V] logits GEMM.
-      achieved / frac        = algorithmic FLOPs / UNION of the calls' HIP-event intervals (= frac_union)
+    launch + split reduce); caption-only workloads = the [T*N, H] x [H, V] logits GEMM.
+      achieved / frac        = ALGORITHMIC (direct-convolution) FLOPs / UNION of the calls' HIP-event intervals (= frac_union)
       frac_serial            = algorithmic FLOPs / SUM of the calls' durations
-    With the default single VGG stream nothing overlaps and the two coincide; both are recomputable from the tracked rocprofv3
-    summary of the same command (profiles/*_kernel_stats.md ends with the family's summed and union dispatch time,
-    tools/rocpd_stats.py)."""
+      executed / mfma_util   = the FLOPs the MFMAs actually execute (Winograd: 16 multiplications where the direct form has 36, plus
+                               block padding) / the same time, and that rate over the fp32 MFMA peak
+    With the Winograd kernels `frac` exceeds 1: they do the algorithm's work with 2.25x fewer multiplications (fp32 throughout);
+    `mfma_util` is the matrix-pipe utilisation.  With the default single VGG stream nothing overlaps and union = serial; both are
+    recomputable from the tracked rocprofv3 summary of the same command (profiles/*_kernel_stats.md ends with the family's summed
+    and union dispatch time, tools/rocpd_stats.py)."""
     tags = ["conv_fwd", "conv_dgrad", "conv_wgrad"] if fine_tune else ["logits_gemm"]
     sm = timer.summary(family=tags)
     fl = sum(sm[t]["flops"] for t in tags)
@@ -356,16 +392,26 @@ def roofline_from_timer(timer, fine_tune):
     ach = fl / sec / 1e12
     per = {t: dict(launches=sm[t]["launches"], avg_us=round(1e6 * sm[t]["seconds"] / sm[t]["launches"], 2),
                    tflops=round(sm[t]["flops"] / sm[t]["seconds"] / 1e12, 2)) for t in tags}
-    return {"bound": "mfma",
-            "kernel": "vc::conv_patch_kernel / vc::wgrad_patch_kernel (+ vc::conv1_fwd_kernel / vc::conv1_wgrad_kernel for conv1_1)" if fine_tune
-                      else "vc::gemm_kernel<128x128,MK,KM> (logits)",
+    wino = fine_tune and os.environ.get("VC_CONV_PATCH", "1") != "0" and os.environ.get("VC_CONV_WINO", "1") != "0"
+    ratio = wino_executed_ratio(images) if (wino and images) else 1.0
+    if not fine_tune:
+        kern = "vc::gemm_kernel<128x128,MK,KM> (logits)"
+    elif wino:
+        kern = ("vc::conv_wino_kernel (Winograd F(2x2,3x3) forward / data gradient) / vc::wino_wgrad_kernel (F(3x3,2x2) weight gradient) "
+                "(+ vc::conv1_fwd_kernel / vc::conv1_wgrad_kernel for conv1_1)")
+    else:
+        kern = "vc::conv_patch_kernel / vc::wgrad_patch_kernel (+ vc::conv1_fwd_kernel / vc::conv1_wgrad_kernel for conv1_1)"
+    return {"bound": "mfma", "kernel": kern,
             "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
             "frac_union": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "frac_serial": round(fl / ser / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+            "executed": round(ach * ratio, 2), "mfma_util": round(ach * ratio / PEAK_F32_MFMA_TFLOPS, 4), "executed_over_algorithmic": round(ratio, 4),
             "family_flops": fl, "family_seconds_union": round(sec, 6), "family_seconds_serial": round(ser, 6),
             "traffic": None, "launches": n, "avg_launch_us": round(1e6 * sec / n, 2), "per_kernel": per,
             "streams": int(os.environ.get("VC_VGG_STREAMS", "1")) if fine_tune else 1,
-            "note": "achieved = algorithmic FLOPs of the family's calls in the timed region / union of their HIP-event intervals "
-                    "(events recorded on the stream each call is launched on)"}
+            "note": "achieved = ALGORITHMIC (direct-convolution) FLOPs of the family's calls in the timed region / union of their HIP-event "
+                    "intervals (events recorded on the stream each call is launched on); executed = the FLOPs the MFMAs perform "
+                    "(Winograd F(2x2,3x3) / F(3x3,2x2), fp32: 16 multiplications per tile where the direct form has 36, + block padding): "
+                    "frac > 1 means fewer multiplications than the direct algorithm, mfma_util is the matrix-pipe utilisation"}
 
 
 if __name__ == "__main__":

@@ -26,6 +26,7 @@ done
 python tools/pmc_summary.py /tmp/pmc $OUT/${TAG}_traffic_cfg4.json > $OUT/${TAG}_cfg4_pmc.md
 # 4. comparison points: the implicit-GEMM kernels of round 1 (VC_CONV_PATCH=0), the three-stream schedule of round 1
 VC_CONV_PATCH=0 python bench.py --no-cpu-baseline > $OUT/${TAG}_bench_nopatch.json 2>/dev/null
+VC_CONV_WINO=0 python bench.py --no-cpu-baseline > $OUT/${TAG}_bench_nowino.json 2>/dev/null
 VC_VGG_STREAMS=3 python bench.py --no-cpu-baseline > $OUT/${TAG}_bench_3streams.json 2>/dev/null
 # 5. the step a user runs: fresh host batches through set_batch inside the timed region
 python bench.py --no-cpu-baseline --fresh-batch 4 > $OUT/${TAG}_bench_fresh_cfg4.json 2>/dev/null
@@ -38,3 +39,5 @@ python bench.py --no-cpu-baseline --workload cfg2 --num-captions 1 > $OUT/${TAG}
 python bench.py --no-cpu-baseline --workload cfg1 > $OUT/${TAG}_bench_cfg1.json 2>/dev/null
 python bench.py --no-cpu-baseline --workload cfg3 > $OUT/${TAG}_bench_cfg3.json 2>/dev/null
 python bench.py --no-cpu-baseline --workload cfg5 --steps 5 --warmup 1 > $OUT/${TAG}_bench_cfg5.json 2>/dev/null
+# 7. per-layer tables: Winograd kernels against the direct patch kernels (forward / data gradient, weight gradient)
+python tools/microbench.py wino winow > $OUT/${TAG}_wino_layers.txt 2>/dev/null

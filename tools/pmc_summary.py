@@ -25,10 +25,16 @@ def family(name):
         return "conv_patch_kernel<%s>" % {"0": "fwd", "1": "dgrad"}.get(k.group(1) if k else "?", "?")
     if "wgrad_patch_kernel" in name:
         return "wgrad_patch_kernel<4x8 | 4x7 | 2x14>"
+    if "conv_wino_kernel" in name:  # conv_wino_kernel<KIND, POOL>
+        k = re.search(r"conv_wino_kernel<\s*(\d)", name)
+        return "conv_wino_kernel<%s>" % {"0": "fwd", "1": "dgrad"}.get(k.group(1) if k else "?", "?")
+    if "wino_wgrad_kernel" in name:
+        return "wino_wgrad_kernel<4x8 | 4x7 | 2x14>"
     return base
 
 
-CONV_FAMILY = ("conv_kernel", "conv1_", "conv_patch_kernel", "wgrad_patch", "conv_tail_reduce", "patch_tail_reduce", "wgrad_reduce", "wgrad_patch_reduce")
+CONV_FAMILY = ("conv_kernel", "conv1_", "conv_patch_kernel", "wgrad_patch", "conv_tail_reduce", "patch_tail_reduce", "wgrad_reduce", "wgrad_patch_reduce",
+               "conv_wino_kernel", "wino_wgrad")
 
 
 def main(root):

@@ -405,7 +405,6 @@ struct WinoWgArgs {
     const float* dy;     // [P, N]
     float* ws;           // [split][16][C][N] position sums, then [split][N] bias partials
     int ncb, nnb, nsplit, cps;
-    int dbg;
 };
 
 template <int TBH, int TBW>
@@ -558,10 +557,10 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(WinoWgArgs a) {
                         if (k2 < per && m * per + k2 < total) prep(nbuf, sn, nob, m * per + k2);
                 }
                 if (more && m < 10) {   // the next block's data: two batches of ten slots, loaded early, written a few steps later
-                    if (s == 0 && !(a.dbg & 1)) gload1(m, m);
-                    if (s == NS / 2 - 2 && !(a.dbg & 2)) lstore1(buf ^ 1, m, m);
-                    if (s == NS / 2 - 1 && !(a.dbg & 1)) gload1(10 + m, m);
-                    if (s == NS - 3 && !(a.dbg & 2)) lstore1(buf ^ 1, 10 + m, m);
+                    if (s == 0) gload1(m, m);
+                    if (s == NS / 2 - 2) lstore1(buf ^ 1, m, m);
+                    if (s == NS / 2 - 1) gload1(10 + m, m);
+                    if (s == NS - 3) lstore1(buf ^ 1, 10 + m, m);
                 }
                 WSB();
             }
@@ -737,8 +736,6 @@ extern "C" int vc_conv3x3_wino_wgrad_f32(void* stream, int B, int H, int W, int 
     if (ws_bytes < wino_wgrad_ws(p)) return fail(VC_EWORKSPACE, "%s: workspace too small (%ld < %ld bytes)", __func__, (long)ws_bytes, (long)wino_wgrad_ws(p));
     WinoWgArgs a;
     a.g = p.g; a.x = x; a.dy = dy; a.ws = ws; a.ncb = p.ncb; a.nnb = p.nnb; a.nsplit = p.nsplit; a.cps = p.cps;
-    static const int dbg = getenv("VC_WINO_DBG") ? atoi(getenv("VC_WINO_DBG")) : 0;
-    a.dbg = dbg;
     int rc = p.shape == 0 ? launch_wino_wgrad<4, 8>((hipStream_t)stream, a) : p.shape == 1 ? launch_wino_wgrad<4, 7>((hipStream_t)stream, a)
                                                                                            : launch_wino_wgrad<2, 14>((hipStream_t)stream, a);
     if (rc) return rc;
