@@ -33,7 +33,16 @@ dw4 = torch.empty(3, 3, 512, 512, device="cuda")
 A = torch.rand(8192, 8192, device="cuda") * 2 - 1
 Bm = torch.rand(8192, 8192, device="cuda") * 2 - 1
 C = torch.empty(8192, 8192, device="cuda")
+vp, vpt = torch.empty(16 * ci * co, device="cuda"), torch.empty(16 * ci * co, device="cuda")
+lib.vc_conv3x3_wino_pack_f32(st(), ci, co, P(w), 0, P(vp))
+lib.vc_conv3x3_wino_pack_f32(st(), ci, co, P(w), 1, P(vpt))
+wws = torch.empty(max(lib.vc_conv3x3_wino_wgrad_workspace_bytes(B, H, H, ci, co), lib.vc_conv3x3_wino_wgrad_workspace_bytes(B, 28, 28, 512, 512)) // 4 + 4, device="cuda")
 for _ in range(3):
+    # Winograd kernels (csrc/conv_wino.hip): conv3_2-shaped forward / data gradient / weight gradient, conv4_2-shaped weight gradient
+    lib.vc_conv3x3_wino_fwd_f32(st(), B, H, H, ci, co, P(x), P(vp), P(bias), P(y), None, 1)
+    lib.vc_conv3x3_wino_dgrad_f32(st(), B, H, H, ci, co, P(dy), P(vpt), P(x), P(dx))
+    lib.vc_conv3x3_wino_wgrad_f32(st(), B, H, H, ci, co, P(x), P(dy), P(dw), None, 0, P(wws), wws.numel() * 4)
+    lib.vc_conv3x3_wino_wgrad_f32(st(), B, 28, 28, 512, 512, P(x4), P(dy4), P(dw4), None, 0, P(wws), wws.numel() * 4)
     lib.vc_conv3x3_fwd_f32(st(), B, H, H, ci, co, P(x), P(w), P(bias), P(y), 1, None, 0)
     lib.vc_conv3x3_dgrad_f32(st(), B, H, H, ci, co, P(dy), P(w), P(x), P(dx), None, 0)
     lib.vc_conv3x3_wgrad_f32(st(), B, H, H, ci, co, P(x), P(dy), P(dw), None, 0, P(ws), ws.numel() * 4)

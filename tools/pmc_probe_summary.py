@@ -20,6 +20,12 @@ for f in sorted(glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive
         elif "wgrad_patch_kernel" in n:
             m3 = re.search(r"wgrad_patch_kernel<\s*(\d+),\s*(\d+)\s*>", n)
             k = "patch_wgrad(%sx%s)" % (m3.group(1), m3.group(2)) if m3 else "patch_wgrad"
+        elif "conv_wino_kernel" in n:
+            m4 = re.search(r"conv_wino_kernel<\s*(\d)", n)
+            k = "wino_" + {"0": "fwd", "1": "dgrad"}.get(m4.group(1) if m4 else "?", "?")
+        elif "wino_wgrad_kernel" in n:
+            m5 = re.search(r"wino_wgrad_kernel<\s*(\d+),\s*(\d+)\s*>", n)
+            k = "wino_wgrad(%sx%s)" % (m5.group(1), m5.group(2)) if m5 else "wino_wgrad"
         elif "gemm_kernel" in n:
             k = "gemm"
         if k:

@@ -1,0 +1,27 @@
+// Shared by conv_wino.hip (forward / data gradient) and conv_wino_wgrad.hip (weight gradient): tile-block geometry and the buffer load.
+#pragma once
+#include "gemm_core.h"
+#include "vaecap.h"
+
+namespace vc {
+
+typedef unsigned int wu32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned WOOB = 0x80000000u;   // buffer voffset that always fails the bounds check (tensors are < 2 GiB): loads 0
+
+struct WinoGeom {
+    int B, H, W, C, N;
+    int TBH, TBW;          // tiles per block (rows, columns); TBH * TBW <= 32
+    int PW, PH;            // halo patch of a block in pixels: 2 TBW + 2, 2 TBH + 2
+    int bx_n, by_n;        // blocks per image row / column
+    int blocks_img;
+    int nblocks;           // B * blocks_img
+};
+
+__device__ __forceinline__ float4 wbufload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    wu32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+    return *reinterpret_cast<float4*>(&v);
+}
+
+static inline bool waligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+}  // namespace vc

@@ -89,7 +89,23 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         vv = beta2 * vv + (1.f - beta2) * gg * gg;
         pp -= lr * mm / (sqrtf(vv) + eps);
     };
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    // two independent 16-byte groups per thread and iteration: eight loads in flight before the first use (HBM-bound: 28 B / parameter)
+    const long stride = (long)gridDim.x * 256;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    for (; i + stride < n4; i += 2 * stride) {
+        const long j = i + stride;
+        float4 pa = p4[i], ma = m4[i], va = v4[i];
+        const float4 ga = g4[i];
+        float4 pb = p4[j], mb = m4[j], vb = v4[j];
+        const float4 gb = g4[j];
+        upd(pa.x, ga.x, ma.x, va.x); upd(pa.y, ga.y, ma.y, va.y);
+        upd(pa.z, ga.z, ma.z, va.z); upd(pa.w, ga.w, ma.w, va.w);
+        upd(pb.x, gb.x, mb.x, vb.x); upd(pb.y, gb.y, mb.y, vb.y);
+        upd(pb.z, gb.z, mb.z, vb.z); upd(pb.w, gb.w, mb.w, vb.w);
+        p4[i] = pa; m4[i] = ma; v4[i] = va;
+        p4[j] = pb; m4[j] = mb; v4[j] = vb;
+    }
+    if (i < n4) {
         float4 pp = p4[i], mm = m4[i], vv = v4[i];
         const float4 gg = g4[i];
         upd(pp.x, gg.x, mm.x, vv.x); upd(pp.y, gg.y, mm.y, vv.y);

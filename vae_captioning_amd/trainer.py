@@ -113,7 +113,7 @@ class VggEngine(object):
         else:
             fn()
 
-    def _pack_weights(self, backward):
+    def _pack_weights(self, backward, H=224, W=224):
         """[tap][C/4][N][4] copies of the 3x3 kernels for the patch-staged convolutions (forward layout, and the flipped
         + transposed one of the data gradient when a backward pass follows).  Runs on the weight-gradient stream, which is
         idle during the forward pass; returns the event the convolution chains wait for (conv1_1 does not need it)."""
@@ -127,16 +127,20 @@ class VggEngine(object):
         with torch.cuda.stream(st):
             sh = _stream()
             for name, ci, co in spec.VGG_CONV:
-                if ci % 32:
-                    continue
-                w = S.param(spec.vgg_var_names(name)[0])
-                lib.vc_conv3x3_pack_f32(sh, ci, co, P(w), 0, P(self._b("wp_" + name, (9 * ci * co,))))
-                if backward:
-                    lib.vc_conv3x3_pack_f32(sh, ci, co, P(w), 1, P(self._b("wpt_" + name, (9 * ci * co,))))
-                if self.use_wino and ci % 16 == 0 and co % 32 == 0:   # G g G^T of every filter, in the Winograd kernel's operand order
-                    lib.vc_conv3x3_wino_pack_f32(sh, ci, co, P(w), 0, P(self._b("vp_" + name, (16 * ci * co,))))
-                    if backward and ci % 32 == 0 and co % 16 == 0:
+                if ci % 32 == 0:
+                    w = S.param(spec.vgg_var_names(name)[0])
+                    wf = self.use_wino and bool(lib.vc_conv3x3_wino_supported(1, H, W, ci, co, 0))
+                    wb = self.use_wino and bool(lib.vc_conv3x3_wino_supported(1, H, W, ci, co, 1))
+                    if wf:   # G g G^T of every filter, in the Winograd kernel's operand order
+                        lib.vc_conv3x3_wino_pack_f32(sh, ci, co, P(w), 0, P(self._b("vp_" + name, (16 * ci * co,))))
+                    else:    # direct patch kernels: [tap][C/4][N][4]
+                        lib.vc_conv3x3_pack_f32(sh, ci, co, P(w), 0, P(self._b("wp_" + name, (9 * ci * co,))))
+                    if backward and wb:
                         lib.vc_conv3x3_wino_pack_f32(sh, ci, co, P(w), 1, P(self._b("vpt_" + name, (16 * ci * co,))))
+                    elif backward:
+                        lib.vc_conv3x3_pack_f32(sh, ci, co, P(w), 1, P(self._b("wpt_" + name, (9 * ci * co,))))
+                if name in spec.VGG_POOL_AFTER:
+                    H, W = H // 2, W // 2
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
         return ev
@@ -195,7 +199,7 @@ class VggEngine(object):
         w4 = self._b("w1_4", (3, 3, 4, 64))
         if not c1:
             lib.vc_pad_dim_f32(st, P(S.param("cnn/conv1_1/weights")), 9, 3, 4, 64, P(w4))
-        packed, waited = self._pack_weights(self.train), set()
+        packed, waited = self._pack_weights(self.train, H, W), set()
         self.acts = []  # (layer name, input tensor, H, W, Cin_eff, Cout, weights used)
         # The conv / pool chain of one image is independent of every other image: with two streams the
         # batch is pushed through as two half-batch chains so that the tail of each kernel (its last partial
@@ -228,7 +232,14 @@ class VggEngine(object):
                                         lambda: lib.vc_conv3x3_wino_fwd_f32(sh, nb, H, W, cie, co, P(x[b0:]), P(self.buf["vp_" + name]), P(S.param(bn)),
                                                                             P(y[b0:]), P(yp[b0:]) if pooled else None, 1))
                             continue
-                        wp = self.buf["wp_" + name]
+                        wp = self.buf.get("wp_" + name)
+                        if wp is None:   # (not packed: the layer was expected on the Winograd path) general kernel
+                            self._timed("conv_fwd", 2.0 * nb * H * W * 9 * ci * co,
+                                        lambda: lib.vc_conv3x3_fwd_f32(sh, nb, H, W, cie, co, P(x[b0:]), P(w), P(S.param(bn)), P(y[b0:]), 1,
+                                                                       P(tws), tws.numel() * 4))
+                            if pooled:
+                                lib.vc_maxpool2x2_fwd_f32(sh, nb, H, W, co, P(y[b0:]), P(yp[b0:]))
+                            continue
                         if pooled and W % 8 == 0 and H % 4 == 0:  # 2x2 max-pool fused into the epilogue (4 x 8 sub-tile tiling)
                             self._timed("conv_fwd", 2.0 * nb * H * W * 9 * ci * co,
                                         lambda: lib.vc_conv3x3_fwd_pool_packed_f32(sh, nb, H, W, cie, co, P(x[b0:]), P(wp), P(S.param(bn)), P(y[b0:]),
