@@ -286,6 +286,16 @@ int vc_conv3x3_wino_fwd_f32(void* stream, int B, int H, int W, int Cin, int Cout
 int vc_conv3x3_wino_dgrad_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* dy, const float* wpt,
                               const float* relu_src, float* dx);
 
+/* The same Winograd forward / data gradient on 16x16x4 MFMA tiles (csrc/conv_wino16.hip): a wave owns up to sixteen 2x2 tiles x 64 output
+ * channels, so that one transformed input value feeds four MFMAs (half the transform instructions per MFMA) and 4x4-tile blocks fit the
+ * 56-wide layers exactly.  Own packed layout (same size: 16 * Cin * Cout floats).  Shapes: H, W even, gathered channels % 16 == 0,
+ * output channels % 64 == 0; ask vc_conv3x3_wino16_supported. */
+int vc_conv3x3_wino16_supported(int B, int H, int W, int Cin, int Cout, int dgrad);
+int vc_conv3x3_wino16_pack_f32(void* stream, int Cin, int Cout, const float* w, int transpose, float* wp);
+int vc_conv3x3_wino16_fwd_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const float* wp,
+                              const float* bias, float* y, float* ypool, int relu);
+int vc_conv3x3_wino16_dgrad_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* dy, const float* wpt,
+                                const float* relu_src, float* dx);
 /* Winograd F(3x3, 2x2) weight gradient (csrc/conv_wino.hip): both operands transformed in registers, the contraction runs over the
  * 2x2-pixel tiles; raw position sums per K split in the workspace, a reduce kernel sums the splits in fixed order and applies the
  * output transform.  Same contract as conv3x3_wgrad (db != NULL also returns the bias gradient, accumulate adds to dw / db); the

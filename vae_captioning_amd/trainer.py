@@ -59,6 +59,9 @@ class VggEngine(object):
         # Winograd F(2x2,3x3) forward / data gradient (csrc/conv_wino.hip: 2.25x fewer multiplications, fp32) wherever the shape allows
         # (every 3x3 layer but conv1_1); VC_CONV_WINO=0 keeps the direct kernels (A/B runs, tests of the direct path)
         self.use_wino = self.use_patch and os.environ.get("VC_CONV_WINO", "1") != "0"
+        # experimental (off): the 16x16x4-tile Winograd forward / data gradient (csrc/conv_wino16.hip) on the layers whose tile grid its
+        # 4 x 4 blocks fit exactly while the 32-tile blocks do not (the 56-wide layers): -0.3 ms per step; its MFMAs are inline asm
+        self.use_wino16 = self.use_wino and os.environ.get("VC_CONV_WINO16", "0") == "1"
         # MaxPoolGrad + ReluGrad inside the next data gradient's epilogue (vc_conv3x3_dgrad_unpool_packed_f32): measured 49.22 / 49.32
         # vs 49.40 / 49.38 ms per step -- the four pool-gradient launches (0.55 ms at 5.9 TB/s) disappear but their 3.5 GB of traffic
         # leaves the four data gradients as 32-byte pieces from the accumulator epilogue (+0.4 ms): off by default
@@ -131,11 +134,21 @@ class VggEngine(object):
                     w = S.param(spec.vgg_var_names(name)[0])
                     wf = self.use_wino and bool(lib.vc_conv3x3_wino_supported(1, H, W, ci, co, 0))
                     wb = self.use_wino and bool(lib.vc_conv3x3_wino_supported(1, H, W, ci, co, 1))
-                    if wf:   # G g G^T of every filter, in the Winograd kernel's operand order
+                    if self._wino16_layer(H, W, ci, co, 0):
+                        lib.vc_conv3x3_wino16_pack_f32(sh, ci, co, P(w), 0, P(self._b("up_" + name, (16 * ci * co,))))
+                        wf = None
+                    if backward and self._wino16_layer(H, W, ci, co, 1):
+                        lib.vc_conv3x3_wino16_pack_f32(sh, ci, co, P(w), 1, P(self._b("upt_" + name, (16 * ci * co,))))
+                        wb = None
+                    if wf is None:
+                        pass
+                    elif wf:   # G g G^T of every filter, in the Winograd kernel's operand order
                         lib.vc_conv3x3_wino_pack_f32(sh, ci, co, P(w), 0, P(self._b("vp_" + name, (16 * ci * co,))))
                     else:    # direct patch kernels: [tap][C/4][N][4]
                         lib.vc_conv3x3_pack_f32(sh, ci, co, P(w), 0, P(self._b("wp_" + name, (9 * ci * co,))))
-                    if backward and wb:
+                    if wb is None:
+                        pass
+                    elif backward and wb:
                         lib.vc_conv3x3_wino_pack_f32(sh, ci, co, P(w), 1, P(self._b("vpt_" + name, (16 * ci * co,))))
                     elif backward:
                         lib.vc_conv3x3_pack_f32(sh, ci, co, P(w), 1, P(self._b("wpt_" + name, (9 * ci * co,))))
@@ -151,6 +164,14 @@ class VggEngine(object):
     def _wino_ok(self, name, nb, H, W, ci, co, dgrad):
         return (self.use_wino and (("vpt_" if dgrad else "vp_") + name) in self.buf
                 and bool(self.lib.vc_conv3x3_wino_supported(nb, H, W, ci, co, dgrad)))
+
+    def _wino16_layer(self, H, W, ci, co, dgrad):
+        """the 16-tile variant only where its 4 x 4 blocks tile the image exactly and the 32-tile blocks (4x8 / 8x4 / 2x14 / 4x7) do not"""
+        if not self.use_wino16 or not self.lib.vc_conv3x3_wino16_supported(1, H, W, ci, co, dgrad):
+            return False
+        th, tw = H // 2, W // 2
+        fits32 = any(th % a == 0 and tw % b == 0 for a, b in ((4, 8), (8, 4), (2, 16), (1, 16)))
+        return th % 4 == 0 and tw % 4 == 0 and not fits32
 
     def _wino_wgrad_ok(self, B, H, W, ci, co):
         return self.use_wino and ci % 64 == 0 and co % 64 == 0 and bool(self.lib.vc_conv3x3_wino_wgrad_supported(B, H, W, ci, co))
@@ -227,6 +248,11 @@ class VggEngine(object):
                         if packed is not None and ch not in waited:
                             torch.cuda.current_stream().wait_event(packed)
                             waited.add(ch)
+                        if ("up_" + name) in self.buf and self._wino16_layer(H, W, cie, co, 0):
+                            self._timed("conv_fwd", 2.0 * nb * H * W * 9 * ci * co,
+                                        lambda: lib.vc_conv3x3_wino16_fwd_f32(sh, nb, H, W, cie, co, P(x[b0:]), P(self.buf["up_" + name]), P(S.param(bn)),
+                                                                              P(y[b0:]), P(yp[b0:]) if pooled else None, 1))
+                            continue
                         if self._wino_ok(name, nb, H, W, cie, co, 0):   # Winograd; the 2x2 max-pool is register math in its epilogue
                             self._timed("conv_fwd", 2.0 * nb * H * W * 9 * ci * co,
                                         lambda: lib.vc_conv3x3_wino_fwd_f32(sh, nb, H, W, cie, co, P(x[b0:]), P(self.buf["vp_" + name]), P(S.param(bn)),
@@ -394,7 +420,10 @@ class VggEngine(object):
                     tws = self._chain_ws(ch, nb)
                     with torch.cuda.stream(strm):
                         sh = _stream()
-                        if self._wino_ok(name, nb, H, W, ci, co, 1):
+                        if ("upt_" + name) in self.buf and self._wino16_layer(H, W, ci, co, 1):
+                            self._timed("conv_dgrad", fl * nb / B, lambda: lib.vc_conv3x3_wino16_dgrad_f32(
+                                sh, nb, H, W, ci, co, P(d[b0:]), P(self.buf["upt_" + name]), None if prev_is_pool else P(x[b0:]), P(dx[b0:])))
+                        elif self._wino_ok(name, nb, H, W, ci, co, 1):
                             self._timed("conv_dgrad", fl * nb / B, lambda: lib.vc_conv3x3_wino_dgrad_f32(
                                 sh, nb, H, W, ci, co, P(d[b0:]), P(self.buf["vpt_" + name]), None if prev_is_pool else P(x[b0:]), P(dx[b0:])))
                         elif self._patch_ok(nb, H, W, ci, co, 1) and ("wpt_" + name) in self.buf:
