@@ -15,7 +15,11 @@ struct WinoGeom {
     int bx_n, by_n;        // blocks per image row / column
     int blocks_img;
     int nblocks;           // B * blocks_img
+    unsigned m_blocks_img, m_bx_n, m_pw, m_tbw;   // ceil(2^32 / d) of the kernel's divisors (wino_magic): n / d == __umulhi(n, m) while n * d < 2^32
 };
+
+static inline unsigned wino_magic(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ULL + (unsigned)d - 1) / (unsigned)d); }   // 0: divisor 1
+__device__ __forceinline__ unsigned wino_div(unsigned n, unsigned m) { return m ? __umulhi(n, m) : n; }
 
 __device__ __forceinline__ float4 wbufload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     wu32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);

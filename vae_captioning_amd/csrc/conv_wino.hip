@@ -49,11 +49,24 @@ __device__ __forceinline__ float wcomp(const float4& v, int e) { return e == 0 ?
 __device__ __forceinline__ float4 f4add(const float4& a, const float4& b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 f4sub(const float4& a, const float4& b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 
+// tools/probes/wino_trace.hip compiles this file with VC_WINO_TRACE: every wave stamps the cycle counter at phase edges
+#ifdef VC_WINO_TRACE
+__device__ unsigned long long* g_wino_trace = nullptr;  // [workgroups][4 waves][8 stamps]
+#define WINO_STAMP(k)                                                                                              \
+    do {                                                                                                           \
+        if (g_wino_trace && (threadIdx.x & 63) == 0)                                                               \
+            g_wino_trace[((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (k)] = __builtin_readcyclecounter();    \
+    } while (0)
+#else
+#define WINO_STAMP(k)
+#endif
+
 template <int KIND, bool POOL>
 __global__ __launch_bounds__(256, 1) void conv_wino_kernel(WinoArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const WinoGeom& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+    WINO_STAMP(0);
     const int id = xcd_remap(blockIdx.x, a.ntiles);
     const int tm = id / a.tiles_n, nt = id - tm * a.tiles_n, n0 = nt * 32;
     const int C = g.C, N = g.N;
@@ -73,9 +86,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(WinoArgs a) {
         const unsigned gb = (unsigned)tm * 4u + blk;
         voff[i] = WOOB;
         if (blk < 4 && gb < (unsigned)g.nblocks && pix < (unsigned)(g.PH * g.PW)) {
-            const unsigned b = gb / (unsigned)g.blocks_img, rem = gb - b * (unsigned)g.blocks_img;
-            const unsigned by = rem / (unsigned)g.bx_n, bx = rem - by * (unsigned)g.bx_n;
-            const unsigned py = pix / (unsigned)g.PW, px = pix - py * (unsigned)g.PW;
+            // (divisions by multiplication with the plan's reciprocals: a 32-bit division is ~35 instructions, 25 of them cost 3 000 cycles per tile)
+            const unsigned b = wino_div(gb, g.m_blocks_img), rem = gb - b * (unsigned)g.blocks_img;
+            const unsigned by = wino_div(rem, g.m_bx_n), bx = rem - by * (unsigned)g.bx_n;
+            const unsigned py = wino_div(pix, g.m_pw), px = pix - py * (unsigned)g.PW;
             const int y = (int)(by * 2u * g.TBH + py) - 1, x = (int)(bx * 2u * g.TBW + px) - 1;
             if ((unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W)
                 voff[i] = (((b * (unsigned)g.H + (unsigned)y) * (unsigned)g.W + (unsigned)x) * (unsigned)C + (((unsigned)tid ^ (py >> 1)) & 1u) * 4u) * 4u;
@@ -91,7 +105,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(WinoArgs a) {
     // this lane's tile inside its wave's block, its 4 x 4 patch origin in LDS, its weight fragment origin
     const int ntl = g.TBH * g.TBW;
     const int jt = li < ntl ? li : 0;
-    const int tyl = jt / g.TBW, txl = jt - tyl * g.TBW;
+    const int tyl = (int)wino_div((unsigned)jt, g.m_tbw), txl = jt - tyl * g.TBW;
     const int abase0 = WP_OFF + wave * WBLK + ((2 * tyl) * g.PW + 2 * txl) * WPITCH;           // + (i * PW + j) * WPITCH + slot * 4
     int aq[2][2];   // [half q][row pair i >> 1]: abase0 + 4 * slot of this lane's quad 2 q + lh in patch rows 2 tyl + i
 #pragma unroll
@@ -104,8 +118,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(WinoArgs a) {
     const int gb = tm * 4 + wave;
     const bool blk_ok = gb < g.nblocks && li < ntl;
     const int gbc = gb < g.nblocks ? gb : 0;
-    const int b = gbc / g.blocks_img, rem = gbc - b * g.blocks_img;
-    const int by = rem / g.bx_n, bx = rem - by * g.bx_n;
+    const int b = (int)wino_div((unsigned)gbc, g.m_blocks_img), rem = gbc - b * g.blocks_img;
+    const int by = (int)wino_div((unsigned)rem, g.m_bx_n), bx = rem - by * g.bx_n;
     const int y0 = (by * g.TBH + tyl) * 2, x0 = (bx * g.TBW + txl) * 2;
     const bool ok00 = blk_ok && y0 < g.H && x0 < g.W, ok01 = ok00 && x0 + 1 < g.W, ok10 = ok00 && y0 + 1 < g.H, ok11 = ok10 && x0 + 1 < g.W;
     const long p00 = ((long)(b * g.H + y0) * g.W + x0) * N;
@@ -116,6 +130,15 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(WinoArgs a) {
     for (int p = 0; p < 16; ++p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+    // forward: the bias rides in the accumulator of position (1, 1) -- A^T's column 1 is (1, 1), so A^T M A adds M_(1,1) to all four
+    // outputs of the tile; its loads overlap the first patch loads and the epilogue has no load left
+    if (KIND == WK_FWD && a.aux) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const float4 bv = *reinterpret_cast<const float4*>(a.aux + n0 + 8 * rg + 4 * lh);
+            acc[5][4 * rg] = bv.x; acc[5][4 * rg + 1] = bv.y; acc[5][4 * rg + 2] = bv.z; acc[5][4 * rg + 3] = bv.w;
+        }
+    }
 
     float4 st[WSLOTS + 4];           // staging registers: six patch slots + four weight pieces of ONE half
     auto gload1 = [&](int hp, int i) {   // the i-th of the ten global loads of half-phase hp's data
@@ -191,6 +214,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(WinoArgs a) {
         }
     };
 
+    WINO_STAMP(1);
 #pragma unroll
     for (int i = 0; i < WSLOTS + 4; ++i) gload1(0, i);
     // data gradient: the ReLU mask of this lane's 2 x 2 pixels x 16 columns as 64 bits, loaded while the first patch is in flight
@@ -210,7 +234,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(WinoArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < WSLOTS + 4; ++i) lstore(0, i);
+    WINO_STAMP(2);
     __syncthreads();
+    WINO_STAMP(3);
 #pragma unroll
     for (int j = 0; j < 4; ++j) rdp(0, 0, j);
 #pragma unroll
@@ -218,6 +244,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(WinoArgs a) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) tstep(0, 0, k);
     WSB();
+    WINO_STAMP(4);
     for (int ch = 0; ch < a.nchunks; ++ch) {
         const bool more = ch + 1 < a.nchunks;
         half(0, true, more, 2 * ch + 1);
@@ -225,6 +252,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(WinoArgs a) {
     }
 #undef WSB
     asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+    WINO_STAMP(5);
 
     // ---- output transform + epilogue: acc[p][r] = M_p[column n0 + 8 (r >> 2) + 4 lh + (r & 3)][tile li]
 #pragma unroll
@@ -249,14 +277,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(WinoArgs a) {
                 if (k == 3) { Y[aa][0].w = y0v; Y[aa][1].w = y1v; }
             }
         }
-        if (KIND == WK_FWD) {
-            if (a.aux) {
-                const float4 bv = *reinterpret_cast<const float4*>(a.aux + col);
-#pragma unroll
-                for (int aa = 0; aa < 2; ++aa)
-#pragma unroll
-                    for (int bb = 0; bb < 2; ++bb) Y[aa][bb] = f4add(Y[aa][bb], bv);
-            }
+        if (KIND == WK_FWD) {   // (the bias is already in the accumulators)
             if (a.relu) {
 #pragma unroll
                 for (int aa = 0; aa < 2; ++aa)
@@ -292,6 +313,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(WinoArgs a) {
             *reinterpret_cast<float4*>(a.pool + ((long)(b * (g.H >> 1) + (y0 >> 1)) * (g.W >> 1) + (x0 >> 1)) * N + col) = m;
         }
     }
+    WINO_STAMP(6);
 }
 
 // w [3][3][Ci][Co] (HWIO) -> V = G g G^T, G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1], packed [N/32][C/16][half 2][p 16][lane half 2][n 32][e 4] (channel = 16 chunk + 8 half + 4 lane half + e):
@@ -359,6 +381,8 @@ static bool plan_wino(int B, int H, int W, int C, int N, WinoGeom& g) {
     g.blocks_img = g.bx_n * g.by_n;
     if ((long)B * g.blocks_img > 0x3fffffffL) return false;
     g.nblocks = B * g.blocks_img;
+    if ((long)g.nblocks * g.blocks_img >= 0x100000000L) return false;   // the reciprocal divisions are exact below 2^32 / divisor
+    g.m_blocks_img = wino_magic(g.blocks_img); g.m_bx_n = wino_magic(g.bx_n); g.m_pw = wino_magic(g.PW); g.m_tbw = wino_magic(g.TBW);
     return true;
 }
 
