@@ -407,7 +407,7 @@ def roofline_from_timer(timer, fine_tune, images=0):
             "executed": round(ach * ratio, 2), "mfma_util": round(ach * ratio / PEAK_F32_MFMA_TFLOPS, 4), "executed_over_algorithmic": round(ratio, 4),
             "family_flops": fl, "family_seconds_union": round(sec, 6), "family_seconds_serial": round(ser, 6),
             "traffic": None, "launches": n, "avg_launch_us": round(1e6 * sec / n, 2), "per_kernel": per,
-            "streams": int(os.environ.get("VC_VGG_STREAMS", "1")) if fine_tune else 1,
+            "streams": int(os.environ.get("VC_VGG_STREAMS", "3")) if fine_tune else 1,
             "note": "achieved = ALGORITHMIC (direct-convolution) FLOPs of the family's calls in the timed region / union of their HIP-event "
                     "intervals (events recorded on the stream each call is launched on); executed = the FLOPs the MFMAs perform "
                     "(Winograd F(2x2,3x3) / F(3x3,2x2), fp32: 16 multiplications per tile where the direct form has 36, + block padding): "

@@ -10,24 +10,29 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 # 1. the driver's command (headline line incl. the CPU baseline leg)
 python bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/${TAG}_bench_default.err
-# 2. kernel traces of the same command (cfg4) and of cfg2: per-kernel table + per-family sum / union of dispatch intervals
+# 2. kernel traces of the same command (cfg4) and of cfg2: per-kernel table + per-family sum / union of dispatch intervals; cfg4 also
+#    with ONE VGG stream (VC_VGG_STREAMS=1: nothing overlaps, the per-kernel durations are the kernels' own)
 for WL in cfg4 cfg2; do
   rm -rf /tmp/kt_$WL
   (cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/kt_$WL -- python $ROOT/bench.py --workload $WL --no-cpu-baseline > $OUT/${TAG}_${WL}_kt.log 2>&1)
   DB=$(find /tmp/kt_$WL -name "*_results.db" | head -1)
   python tools/rocpd_stats.py "$DB" 60 > $OUT/${TAG}_${WL}_kernel_stats.md
 done
-# 3. PMC passes (each counter set in its own run, with --kernel-trace only)
+rm -rf /tmp/kt_1s
+(cd /tmp && VC_VGG_STREAMS=1 rocprofv3 --kernel-trace --stats -d /tmp/kt_1s -- python $ROOT/bench.py --no-cpu-baseline > $OUT/${TAG}_cfg4_1stream_kt.log 2>&1)
+python tools/rocpd_stats.py "$(find /tmp/kt_1s -name "*_results.db" | head -1)" 60 > $OUT/${TAG}_cfg4_kernel_stats_1stream.md
+# 3. PMC passes (each counter set in its own run, with --kernel-trace only; ONE VGG stream so that a kernel's counters are its own)
 rm -rf /tmp/pmc
 for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   D=/tmp/pmc/$(echo $C | tr ' ' '_')
-  (cd /tmp && rocprofv3 --pmc $C --kernel-trace --output-format csv -d $D -- python $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_pmc_$(echo $C | cut -d' ' -f1).log 2>&1)
+  (cd /tmp && VC_VGG_STREAMS=1 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $D -- python $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_pmc_$(echo $C | cut -d' ' -f1).log 2>&1)
 done
 python tools/pmc_summary.py /tmp/pmc $OUT/${TAG}_traffic_cfg4.json > $OUT/${TAG}_cfg4_pmc.md
-# 4. comparison points: the implicit-GEMM kernels of round 1 (VC_CONV_PATCH=0), the three-stream schedule of round 1
+# 4. comparison points: the implicit-GEMM kernels of round 1 (VC_CONV_PATCH=0), the direct patch kernels (VC_CONV_WINO=0), one stream, the 16x16x4 variant
 VC_CONV_PATCH=0 python bench.py --no-cpu-baseline > $OUT/${TAG}_bench_nopatch.json 2>/dev/null
 VC_CONV_WINO=0 python bench.py --no-cpu-baseline > $OUT/${TAG}_bench_nowino.json 2>/dev/null
-VC_VGG_STREAMS=3 python bench.py --no-cpu-baseline > $OUT/${TAG}_bench_3streams.json 2>/dev/null
+VC_VGG_STREAMS=1 python bench.py --no-cpu-baseline > $OUT/${TAG}_bench_1stream.json 2>/dev/null
+VC_CONV_WINO16=1 python bench.py --no-cpu-baseline > $OUT/${TAG}_bench_wino16.json 2>/dev/null
 # 5. the step a user runs: fresh host batches through set_batch inside the timed region
 python bench.py --no-cpu-baseline --fresh-batch 4 > $OUT/${TAG}_bench_fresh_cfg4.json 2>/dev/null
 python bench.py --no-cpu-baseline --workload cfg2 > $OUT/${TAG}_bench_cfg2.json 2>/dev/null

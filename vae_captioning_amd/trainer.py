@@ -66,7 +66,10 @@ class VggEngine(object):
         # vs 49.40 / 49.38 ms per step -- the four pool-gradient launches (0.55 ms at 5.9 TB/s) disappear but their 3.5 GB of traffic
         # leaves the four data gradients as 32-byte pieces from the accumulator epilogue (+0.4 ms): off by default
         self.fuse_unpool = os.environ.get("VC_FUSE_UNPOOL", "0") == "1"
-        nstreams = int(os.environ.get("VC_VGG_STREAMS", "1"))
+        # three streams (two half-batch convolution chains + the weight gradients on a third): the Winograd kernels run ONE workgroup per
+        # CU, so the tail of a launch leaves CUs idle that another stream's launch fills (36.0 -> 35.0 ms per step; with the direct
+        # kernels of the first half of round 2 -- three workgroups per CU -- one stream was as fast); VC_VGG_STREAMS=1 serialises
+        nstreams = int(os.environ.get("VC_VGG_STREAMS", "3"))
         self.side = torch.cuda.Stream() if nstreams >= 2 else None
         self.side2 = torch.cuda.Stream() if nstreams >= 3 else None
         self.part = torch.zeros(self.lib.vc_sumsq_blocks(), dtype=torch.float32, device=device)
