@@ -286,6 +286,15 @@ int vc_conv3x3_wino_fwd_f32(void* stream, int B, int H, int W, int Cin, int Cout
 int vc_conv3x3_wino_dgrad_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* dy, const float* wpt,
                               const float* relu_src, float* dx);
 
+/* ReLU mask as bits: the forward of a layer can leave (y > 0) of every lane's 2x2 pixels x 16 columns as 64 bits (vc_conv3x3_wino_mask_words
+ * (B, H, W, Cout) 32-bit words), and the data gradient of the NEXT 3x3 layer -- whose output has the same [B,H,W,Cout] shape, hence the
+ * same tiles and lanes -- reads those bits (one 8-byte load per lane) instead of relu_src (sixteen 16-byte loads + packing per lane:
+ * 6-17 % of a data-gradient call).  Results are bit-identical to vc_conv3x3_wino_dgrad_f32 with relu_src = that y. */
+size_t vc_conv3x3_wino_mask_words(int B, int H, int W, int C);
+int vc_conv3x3_wino_fwd_mask_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const float* wp,
+                                 const float* bias, float* y, int relu, uint32_t* mask_out);
+int vc_conv3x3_wino_dgrad_bits_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* dy, const float* wpt,
+                                   const uint32_t* mask_bits, float* dx);
 /* The same Winograd forward / data gradient on 16x16x4 MFMA tiles (csrc/conv_wino16.hip): a wave owns up to sixteen 2x2 tiles x 64 output
  * channels, so that one transformed input value feeds four MFMAs (half the transform instructions per MFMA) and 4x4-tile blocks fit the
  * 56-wide layers exactly.  Own packed layout (same size: 16 * Cin * Cout floats).  Shapes: H, W even, gathered channels % 16 == 0,

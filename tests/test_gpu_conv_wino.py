@@ -191,3 +191,31 @@ def test_wino16_fwd_dgrad_match_oracle(lib, case):
         assert_close(host(dx), dxref, told, msg="wino16 dgrad")
     else:
         assert Ci % 64 != 0
+
+
+@pytest.mark.parametrize("case", [(2, 8, 8, 32, 64), (1, 56, 56, 64, 64), (2, 28, 28, 64, 128), (3, 14, 14, 32, 64), (2, 12, 20, 32, 64)], ids=lambda c: "x".join(map(str, c)))
+def test_wino_relu_mask_as_bits(lib, case):
+    """forward of layer L leaves (y > 0) as bits; the data gradient of layer L + 1 (Cin = L's Cout, same H x W) reads them: bit-identical
+    to the data gradient that loads relu_src = y, and y itself is what the plain forward writes"""
+    B, H, W, Ci, Cm = case
+    Co = 64
+    rng = np.random.default_rng(sum(case) + 3)
+    x = dev(rng.standard_normal((B, H, W, Ci), dtype=np.float32))
+    w1 = dev(rng.standard_normal((3, 3, Ci, Cm), dtype=np.float32) * np.float32(0.1))
+    b1 = dev(rng.standard_normal(Cm, dtype=np.float32))
+    w2 = dev(rng.standard_normal((3, 3, Cm, Co), dtype=np.float32) * np.float32(0.1))
+    dy = dev(rng.standard_normal((B, H, W, Co), dtype=np.float32))
+    y, y0 = zeros(B, H, W, Cm), zeros(B, H, W, Cm)
+    nw = lib.vc_conv3x3_wino_mask_words(B, H, W, Cm)
+    assert nw > 0
+    bits = torch.zeros(nw, dtype=torch.int32, device="cuda")
+    wp1 = _pack(lib, w1, 0)
+    lib.vc_conv3x3_wino_fwd_f32(stream(), B, H, W, Ci, Cm, P(x), P(wp1), P(b1), P(y0), None, 1)
+    lib.vc_conv3x3_wino_fwd_mask_f32(stream(), B, H, W, Ci, Cm, P(x), P(wp1), P(b1), P(y), 1, P(bits))
+    assert np.array_equal(host(y), host(y0))
+    wpt2 = _pack(lib, w2, 1)
+    dx_ref, dx = zeros(B, H, W, Cm), zeros(B, H, W, Cm)
+    lib.vc_conv3x3_wino_dgrad_f32(stream(), B, H, W, Cm, Co, P(dy), P(wpt2), P(y), P(dx_ref))
+    lib.vc_conv3x3_wino_dgrad_bits_f32(stream(), B, H, W, Cm, Co, P(dy), P(wpt2), P(bits), P(dx))
+    assert np.array_equal(host(dx), host(dx_ref))
+    assert float(np.abs(host(dx_ref)).max()) > 0 and (host(dx_ref) == 0).mean() > 0.2   # the mask does mask

@@ -17,7 +17,7 @@ _CTYPES = {
     "void*": ctypes.c_void_p, "const void*": ctypes.c_void_p,
     "float*": ctypes.c_void_p, "const float*": ctypes.c_void_p,
     "int32_t*": ctypes.c_void_p, "const int32_t*": ctypes.c_void_p,
-    "uint32_t*": ctypes.c_void_p, "double*": ctypes.c_void_p, "const double*": ctypes.c_void_p, "double": ctypes.c_double,
+    "uint32_t*": ctypes.c_void_p, "const uint32_t*": ctypes.c_void_p, "double*": ctypes.c_void_p, "const double*": ctypes.c_void_p, "double": ctypes.c_double,
     "int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float,
     "size_t": ctypes.c_size_t, "uint64_t": ctypes.c_uint64,
     "const char*": ctypes.c_char_p,

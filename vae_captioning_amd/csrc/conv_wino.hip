@@ -41,6 +41,8 @@ struct WinoArgs {
     float* out;         // [P, N]
     const float* aux;   // fwd: bias [N] or null; dgrad: ReLU source [P, N] or null
     float* pool;        // fwd: also max_pool2x2(out) [B, H/2, W/2, N] (null: none)
+    unsigned* mask;     // [ntiles][256 threads][2]: (out > 0) of each lane's 2 x 2 pixels x 16 columns as 64 bits -- written by the forward
+                        // (null: not wanted), read by the data gradient of the NEXT layer instead of relu_src (same shape => same tiles / lanes)
     int relu;
     int tiles_n, ntiles, nchunks;
 };
@@ -218,7 +220,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(WinoArgs a) {
 #pragma unroll
     for (int i = 0; i < WSLOTS + 4; ++i) gload1(0, i);
     // data gradient: the ReLU mask of this lane's 2 x 2 pixels x 16 columns as 64 bits, loaded while the first patch is in flight
-    if (KIND == WK_DGRAD && a.aux) {
+    if (KIND == WK_DGRAD && a.mask) {   // the producer's forward left the mask as bits in this kernel's lane order: one 8-byte load
+        const uint2 mb = *reinterpret_cast<const uint2*>(a.mask + ((size_t)id * 256 + tid) * 2);
+        mbits[0] = mb.x; mbits[1] = mb.y;
+    } else if (KIND == WK_DGRAD && a.aux) {
         mbits[0] = mbits[1] = 0u;
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg)
@@ -255,6 +260,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(WinoArgs a) {
     WINO_STAMP(5);
 
     // ---- output transform + epilogue: acc[p][r] = M_p[column n0 + 8 (r >> 2) + 4 lh + (r & 3)][tile li]
+    unsigned obits[2] = {0u, 0u};
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
         const int col = n0 + 8 * rg + 4 * lh;
@@ -287,7 +293,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(WinoArgs a) {
                         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                     }
             }
-        } else if (a.aux) {
+        } else if (a.aux || a.mask) {
 #pragma unroll
             for (int aa = 0; aa < 2; ++aa)
 #pragma unroll
@@ -298,6 +304,16 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(WinoArgs a) {
                     if (!(mb & 2u)) v.y = 0.f;
                     if (!(mb & 4u)) v.z = 0.f;
                     if (!(mb & 8u)) v.w = 0.f;
+                }
+        }
+        if (KIND == WK_FWD && a.mask) {
+#pragma unroll
+            for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb) {
+                    const float4& v = Y[aa][bb];
+                    const unsigned bits = (v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u);
+                    obits[rg >> 1] |= bits << (16 * (rg & 1) + 8 * aa + 4 * bb);
                 }
         }
         if (ok00) *reinterpret_cast<float4*>(a.out + p00 + col) = Y[0][0];
@@ -313,6 +329,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(WinoArgs a) {
             *reinterpret_cast<float4*>(a.pool + ((long)(b * (g.H >> 1) + (y0 >> 1)) * (g.W >> 1) + (x0 >> 1)) * N + col) = m;
         }
     }
+    if (KIND == WK_FWD && a.mask) *reinterpret_cast<uint2*>(a.mask + ((size_t)id * 256 + tid) * 2) = make_uint2(obits[0], obits[1]);
     WINO_STAMP(6);
 }
 
@@ -435,8 +452,25 @@ extern "C" int vc_conv3x3_wino_fwd_f32(void* stream, int B, int H, int W, int Ci
     VC_CHECK_ARG(plan_wino(B, H, W, Cin, Cout, a.g), "unsupported shape (vc_conv3x3_wino_supported)");
     VC_CHECK_ARG(x && wp && y, "null pointer");
     VC_CHECK_ARG(waligned16(x) && waligned16(wp) && waligned16(y) && waligned16(bias) && waligned16(ypool), "pointers must be 16-byte aligned");
-    a.x = x; a.wp = wp; a.out = y; a.aux = bias; a.relu = relu; a.pool = ypool;
+    a.x = x; a.wp = wp; a.out = y; a.aux = bias; a.relu = relu; a.pool = ypool; a.mask = nullptr;
     return ypool ? launch_wino<WK_FWD, true>((hipStream_t)stream, a) : launch_wino<WK_FWD, false>((hipStream_t)stream, a);
+}
+
+extern "C" size_t vc_conv3x3_wino_mask_words(int B, int H, int W, int C) {
+    vc::WinoGeom g;
+    if (!vc::plan_wino(B, H, W, 16, C, g)) return 0;
+    return (size_t)vc::cdiv(g.nblocks, 4) * (C / 32) * 256 * 2;
+}
+
+extern "C" int vc_conv3x3_wino_fwd_mask_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const float* wp,
+                                            const float* bias, float* y, int relu, uint32_t* mask_out) {
+    using namespace vc;
+    WinoArgs a;
+    VC_CHECK_ARG(plan_wino(B, H, W, Cin, Cout, a.g), "unsupported shape (vc_conv3x3_wino_supported)");
+    VC_CHECK_ARG(x && wp && y && mask_out, "null pointer");
+    VC_CHECK_ARG(waligned16(x) && waligned16(wp) && waligned16(y) && waligned16(bias) && waligned16(mask_out), "pointers must be 16-byte aligned");
+    a.x = x; a.wp = wp; a.out = y; a.aux = bias; a.relu = relu; a.pool = nullptr; a.mask = mask_out;
+    return launch_wino<WK_FWD, false>((hipStream_t)stream, a);
 }
 
 extern "C" int vc_conv3x3_wino_dgrad_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* dy, const float* wpt,
@@ -446,6 +480,17 @@ extern "C" int vc_conv3x3_wino_dgrad_f32(void* stream, int B, int H, int W, int 
     VC_CHECK_ARG(plan_wino(B, H, W, Cout, Cin, a.g), "unsupported shape (vc_conv3x3_wino_supported)");
     VC_CHECK_ARG(dy && wpt && dx, "null pointer");
     VC_CHECK_ARG(waligned16(dy) && waligned16(wpt) && waligned16(dx) && waligned16(relu_src), "pointers must be 16-byte aligned");
-    a.x = dy; a.wp = wpt; a.out = dx; a.aux = relu_src; a.relu = 0; a.pool = nullptr;
+    a.x = dy; a.wp = wpt; a.out = dx; a.aux = relu_src; a.relu = 0; a.pool = nullptr; a.mask = nullptr;
+    return launch_wino<WK_DGRAD, false>((hipStream_t)stream, a);
+}
+
+extern "C" int vc_conv3x3_wino_dgrad_bits_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* dy, const float* wpt,
+                                              const uint32_t* mask_bits, float* dx) {
+    using namespace vc;
+    WinoArgs a;
+    VC_CHECK_ARG(plan_wino(B, H, W, Cout, Cin, a.g), "unsupported shape (vc_conv3x3_wino_supported)");
+    VC_CHECK_ARG(dy && wpt && dx && mask_bits, "null pointer");
+    VC_CHECK_ARG(waligned16(dy) && waligned16(wpt) && waligned16(dx) && waligned16(mask_bits), "pointers must be 16-byte aligned");
+    a.x = dy; a.wp = wpt; a.out = dx; a.aux = nullptr; a.relu = 0; a.pool = nullptr; a.mask = const_cast<uint32_t*>(mask_bits);
     return launch_wino<WK_DGRAD, false>((hipStream_t)stream, a);
 }

@@ -225,6 +225,7 @@ class VggEngine(object):
             lib.vc_pad_dim_f32(st, P(S.param("cnn/conv1_1/weights")), 9, 3, 4, 64, P(w4))
         packed, waited = self._pack_weights(self.train, H, W), set()
         self.acts = []  # (layer name, input tensor, H, W, Cin_eff, Cout, weights used)
+        self.mask_geom = {}  # layer name -> (images per launch, launches): forward launches that left their ReLU mask as bits
         # The conv / pool chain of one image is independent of every other image: with two streams the
         # batch is pushed through as two half-batch chains so that the tail of each kernel (its last partial
         # round of workgroups) overlaps the other chain's kernels.  Halves are contiguous NHWC slices.
@@ -255,6 +256,14 @@ class VggEngine(object):
                             self._timed("conv_fwd", 2.0 * nb * H * W * 9 * ci * co,
                                         lambda: lib.vc_conv3x3_wino16_fwd_f32(sh, nb, H, W, cie, co, P(x[b0:]), P(self.buf["up_" + name]), P(S.param(bn)),
                                                                               P(y[b0:]), P(yp[b0:]) if pooled else None, 1))
+                            continue
+                        if self._wino_ok(name, nb, H, W, cie, co, 0) and self.train and not pooled and not self.use_wino16:
+                            # the next layer is a convolution on this output: leave (y > 0) as bits in the lane order of ITS data gradient
+                            mk = self._b("mk_%s_%d" % (name, ch), (lib.vc_conv3x3_wino_mask_words(nb, H, W, co),), dtype=torch.int32)
+                            self.mask_geom[name] = (nb, len(halves))   # the bits are per tile of THIS launch geometry
+                            self._timed("conv_fwd", 2.0 * nb * H * W * 9 * ci * co,
+                                        lambda: lib.vc_conv3x3_wino_fwd_mask_f32(sh, nb, H, W, cie, co, P(x[b0:]), P(self.buf["vp_" + name]), P(S.param(bn)),
+                                                                                 P(y[b0:]), 1, P(mk)))
                             continue
                         if self._wino_ok(name, nb, H, W, cie, co, 0):   # Winograd; the 2x2 max-pool is register math in its epilogue
                             self._timed("conv_fwd", 2.0 * nb * H * W * 9 * ci * co,
@@ -426,6 +435,11 @@ class VggEngine(object):
                         if ("upt_" + name) in self.buf and self._wino16_layer(H, W, ci, co, 1):
                             self._timed("conv_dgrad", fl * nb / B, lambda: lib.vc_conv3x3_wino16_dgrad_f32(
                                 sh, nb, H, W, ci, co, P(d[b0:]), P(self.buf["upt_" + name]), None if prev_is_pool else P(x[b0:]), P(dx[b0:])))
+                        elif (self._wino_ok(name, nb, H, W, ci, co, 1) and not prev_is_pool
+                              and self.mask_geom.get(self.acts[li - 1][0]) == (nb, len(halves))):
+                            # ReluGrad from the bits the previous layer's forward left (one 8-byte load per lane instead of sixteen 16-byte ones)
+                            self._timed("conv_dgrad", fl * nb / B, lambda: lib.vc_conv3x3_wino_dgrad_bits_f32(
+                                sh, nb, H, W, ci, co, P(d[b0:]), P(self.buf["vpt_" + name]), P(self.buf["mk_%s_%d" % (self.acts[li - 1][0], ch)]), P(dx[b0:])))
                         elif self._wino_ok(name, nb, H, W, ci, co, 1):
                             self._timed("conv_dgrad", fl * nb / B, lambda: lib.vc_conv3x3_wino_dgrad_f32(
                                 sh, nb, H, W, ci, co, P(d[b0:]), P(self.buf["vpt_" + name]), None if prev_is_pool else P(x[b0:]), P(dx[b0:])))
