@@ -129,9 +129,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(WinoArgs a) {
     unsigned mbits[2] = {0xffffffffu, 0xffffffffu};
     f32x16 acc[16];
 #pragma unroll
-    for (int p = 0; p < 16; ++p)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[5][r] = 0.f;   // (the other fifteen start with a zero-addend MFMA, see mf)
     // forward: the bias rides in the accumulator of position (1, 1) -- A^T's column 1 is (1, 1), so A^T M A adds M_(1,1) to all four
     // outputs of the tile; its loads overlap the first patch loads and the epilogue has no load left
     if (KIND == WK_FWD && a.aux) {
@@ -182,16 +180,25 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(WinoArgs a) {
         if (k == 6) ur[buf][2] = f4sub(tt[2], tt[1]);
         if (k == 7) ur[buf][3] = f4sub(tt[1], tt[3]);
     };
-    auto mf = [&](int u4, int buf, int m) {
+    auto mf = [&](int u4, int buf, int m, bool first) {
         const int xi = xi_of(u4), e = m >> 2, nu = m & 3;
-        acc[xi * 4 + nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcomp(vf[buf][nu], e), wcomp(ur[buf][nu], e), acc[xi * 4 + nu], 0, 0, 0);
+        // the first MFMA of an accumulator (first half-phase of the tile, k-step 0) takes the constant 0 as its addend: no zero-fill of 240
+        // accumulator registers per tile (position (1, 1) starts at the bias instead)
+        if (first && e == 0 && xi * 4 + nu != 5) {
+            f32x16 z;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[r] = 0.f;
+            acc[xi * 4 + nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcomp(vf[buf][nu], e), wcomp(ur[buf][nu], e), z, 0, 0, 0);
+        } else {
+            acc[xi * 4 + nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcomp(vf[buf][nu], e), wcomp(ur[buf][nu], e), acc[xi * 4 + nu], 0, 0, 0);
+        }
     };
 #define WSB() __builtin_amdgcn_sched_barrier(0)
     // one half-phase = the four units of half q of the current chunk; the data of the NEXT half-phase (the other half's LDS region) sits
     // in the staging registers since the previous half-phase's unit 3 (three units = ~3000 cycles of load latency) and is written to
     // the LDS during unit 2; the barrier at the head of unit 3 closes both this half's last reads and those writes, so unit 3 already
     // prepares the first unit of the next half-phase and re-loads the staging registers.
-    auto half = [&](int q, bool more, bool more2, int nexthp) {
+    auto half = [&](int q, bool more, bool more2, int nexthp, bool first) {
 #pragma unroll
         for (int u4 = 0; u4 < 4; ++u4) {
             const int b = u4 & 1, nb = b ^ 1;
@@ -200,7 +207,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(WinoArgs a) {
             if (u4 == 3 && more) __syncthreads();
 #pragma unroll
             for (int m = 0; m < 16; ++m) {
-                mf(u4, b, m);
+                mf(u4, b, m, first);
                 WSB();
                 if (nxt) {
                     if (m < 4) rdp(nq, nu4, m);                       // gaps 0..3: one patch pixel each (two rows for xi = 0)
@@ -250,10 +257,15 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(WinoArgs a) {
     for (int k = 0; k < 8; ++k) tstep(0, 0, k);
     WSB();
     WINO_STAMP(4);
-    for (int ch = 0; ch < a.nchunks; ++ch) {
+    {   // chunk 0: its first half-phase starts the accumulators
+        const bool more = 1 < a.nchunks;
+        half(0, true, more, 1, true);
+        half(1, more, more, 2, false);
+    }
+    for (int ch = 1; ch < a.nchunks; ++ch) {
         const bool more = ch + 1 < a.nchunks;
-        half(0, true, more, 2 * ch + 1);
-        half(1, more, more, 2 * ch + 2);
+        half(0, true, more, 2 * ch + 1, false);
+        half(1, more, more, 2 * ch + 2, false);
     }
 #undef WSB
     asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
