@@ -86,16 +86,15 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(WinoArgs a) {
         const unsigned pl = (unsigned)(tid >> 1) + 128u * i;
         const unsigned blk = pl / WPIX, pix = pl - blk * WPIX;   // (32-bit unsigned divisions: a signed or 64-bit one costs ~100 VALU)
         const unsigned gb = (unsigned)tm * 4u + blk;
-        voff[i] = WOOB;
-        if (blk < 4 && gb < (unsigned)g.nblocks && pix < (unsigned)(g.PH * g.PW)) {
-            // (divisions by multiplication with the plan's reciprocals: a 32-bit division is ~35 instructions, 25 of them cost 3 000 cycles per tile)
-            const unsigned b = wino_div(gb, g.m_blocks_img), rem = gb - b * (unsigned)g.blocks_img;
-            const unsigned by = wino_div(rem, g.m_bx_n), bx = rem - by * (unsigned)g.bx_n;
-            const unsigned py = wino_div(pix, g.m_pw), px = pix - py * (unsigned)g.PW;
-            const int y = (int)(by * 2u * g.TBH + py) - 1, x = (int)(bx * 2u * g.TBW + px) - 1;
-            if ((unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W)
-                voff[i] = (((b * (unsigned)g.H + (unsigned)y) * (unsigned)g.W + (unsigned)x) * (unsigned)C + (((unsigned)tid ^ (py >> 1)) & 1u) * 4u) * 4u;
-        }
+        // (branch-free: the reciprocal divisions are cheap, and divergent branches here cost more than the arithmetic they skip)
+        const unsigned gbc = gb < (unsigned)g.nblocks ? gb : 0u;
+        const unsigned b = wino_div(gbc, g.m_blocks_img), rem = gbc - b * (unsigned)g.blocks_img;
+        const unsigned by = wino_div(rem, g.m_bx_n), bx = rem - by * (unsigned)g.bx_n;
+        const unsigned py = wino_div(pix, g.m_pw), px = pix - py * (unsigned)g.PW;
+        const int y = (int)(by * 2u * g.TBH + py) - 1, x = (int)(bx * 2u * g.TBW + px) - 1;
+        const bool ok = blk < 4 && gb < (unsigned)g.nblocks && pix < (unsigned)(g.PH * g.PW) && (unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W;
+        const unsigned off = (((b * (unsigned)g.H + (unsigned)y) * (unsigned)g.W + (unsigned)x) * (unsigned)C + (((unsigned)tid ^ (py >> 1)) & 1u) * 4u) * 4u;
+        voff[i] = ok ? off : WOOB;
     }
     // LDS patch layout: pixel pitch 20 floats = four channel quads + pad; in patch rows py with (py >> 1) odd the two quads of a half
     // are SWAPPED (done on the global side: the staging thread fetches the other quad, its LDS address stays uniform) -- this shifts
