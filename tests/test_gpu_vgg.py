@@ -165,6 +165,40 @@ def test_fallback_kernels_without_the_patch_path(lib, monkeypatch):
     assert (res["0"][1] - res["1"][1]).norm() <= 2e-3 * res["1"][1].norm()
 
 
+@pytest.mark.parametrize("env", [("VC_CONV_WINO", "0"), ("VC_CONV_WINO16", "1"), ("VC_VGG_STREAMS", "1")], ids=lambda e: "%s=%s" % e)
+def test_alternative_convolution_paths_match_the_oracle(lib, monkeypatch, env):
+    """The non-default convolution paths stay correct: VC_CONV_WINO=0 (direct patch kernels of the first half of round 2 on every layer),
+    VC_CONV_WINO16=1 (16x16x4-tile Winograd variant on the 56-wide layers), VC_VGG_STREAMS=1 (serial schedule; B = 2 so that the default
+    would have used half-batch chains and the ReLU-mask bits of both geometries are exercised): forward vs the fp64 oracle, backward vs
+    the oracle on the device's forward decisions."""
+    monkeypatch.setenv(*env)
+    p = Parameters()
+    p.fine_tune = True
+    rng = np.random.default_rng(33)
+    PV = spec.init_vgg_params(seed=8)
+    B = 2
+    img = rng.integers(0, 256, size=(B, 224, 224, 3)).astype(np.float32)
+    dfc2 = rng.normal(size=(B, 4096)).astype(np.float32)
+    ones = np.ones((B, 4096), np.float32)
+    P64 = {k: v.astype(np.float64) for k, v in PV.items()}
+    fc2_ref, cache = ov.forward(P64, img.astype(np.float64), ones.astype(np.float64), ones.astype(np.float64), keep=0.5)
+    eng = VggEngine(p, lib=lib)
+    assert eng.use_wino == (env != ("VC_CONV_WINO", "0")) and eng.use_wino16 == (env == ("VC_CONV_WINO16", "1"))
+    eng.load_params(PV)
+    eng.set_masks(ones, ones)
+    for _ in range(2):   # the first step allocates
+        fc2 = eng.forward(torch.from_numpy(img).cuda())
+        eng.backward(torch.from_numpy(dfc2).cuda())
+    torch.cuda.synchronize()
+    assert rel_l2(fc2.cpu().numpy(), fc2_ref) < 2e-5
+    for name, x, y in [c for c in cache["conv"] if c[0] != "P"]:
+        assert rel_l2(eng.buf["y_" + name].cpu().numpy(), y) < 2e-5, name
+    G = eng.grads_dict()
+    Gdev = ov.backward(P64, device_cache(eng, P64, 0.5), dfc2.astype(np.float64))
+    for n, ref in Gdev.items():
+        assert rel_l2(G[n], ref) < 1e-4, (n, rel_l2(G[n], ref))
+
+
 def test_half_batch_chains_on_three_streams(lib, monkeypatch):
     """B = 2: the default three-stream schedule (two half-batch conv/pool chains + weight gradients on a
     third stream, trainer.VggEngine) vs the fp64 oracle forward, vs the oracle backward on the device's
