@@ -157,8 +157,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(WinoArgs a) {
     // xi = 2, nothing for xi = 1, row 3 for xi = 3 (sixteen patch reads + sixteen weight reads per 64 MFMAs).
     // One wave per SIMD: nothing else feeds the matrix pipe while this wave issues anything that is not an MFMA, so the software
     // pipeline is written out gap by gap and pinned with sched_barriers -- consecutive MFMAs go to DIFFERENT accumulators (k-step
-    // outer, column inner), every gap between two MFMAs carries at most five other instructions (MI355X_MICROARCH.md: what a
-    // single wave hides per MFMA), the additions stay scalar (-fno-slp-vectorize: packed fp32 adds cost more beside MFMAs).
+    // outer, column inner), every gap between two MFMAs carries at most five other instructions.  tools/probes/mfma_fillers.hip
+    // measures what a lone wave hides beside this MFMA: LDS reads are free, every VALU instruction in a gap costs matrix-pipe time
+    // (0 / 1 / 2 / 4 adds per gap: 135 / 125 / 118 / 115 TFLOP/s), a packed v_pk_add_f32 costs as much as a scalar add -- so the
+    // float4 additions are left to the SLP vectoriser (two packed adds per float4).
     float4 ur[2][4], vf[2][4];
     float4 dr[4][4], tt[4];
     auto xi_of = [](int u4) { return u4 == 1 ? 2 : u4 == 2 ? 1 : u4; };
