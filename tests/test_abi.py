@@ -86,3 +86,26 @@ def test_product_code_never_touches_the_oracle_or_the_reference():
         uses = any(isinstance(n, (ast.Import, ast.ImportFrom)) and "oracle" in ast.dump(n) for n in ast.walk(node))
         if uses:
             assert isinstance(node, ast.FunctionDef) and "cpu_baseline" in node.name, getattr(node, "name", node)
+
+
+def test_bench_executed_ratio_of_the_winograd_kernels():
+    """bench.py prices the Winograd kernels' executed MFMA work as a fraction of the algorithmic (direct-convolution) FLOPs: 16 / 36 per
+    layer and pass, divided by the share of the 32 tile slots per block that hold real tiles (csrc/conv_wino.hip plan_wino /
+    plan_wino_wgrad); conv1_1 stays direct.  Hand-worked for the VGG16 shapes at 224 x 224."""
+    import bench
+    r = bench.wino_executed_ratio(64)
+    # per layer: efficiency of the forward / data-gradient blocks and of the weight-gradient blocks
+    eff = {224: (1.0, 1.0), 112: (1.0, 1.0), 56: (0.875, 1.0), 28: (0.875, 1.0), 14: (49.0 / 64.0, 0.875)}
+    layers = [(224, 3, 64), (224, 64, 64), (112, 64, 128), (112, 128, 128), (56, 128, 256), (56, 256, 256), (56, 256, 256),
+              (28, 256, 512), (28, 512, 512), (28, 512, 512), (14, 512, 512), (14, 512, 512), (14, 512, 512)]
+    alg = ex = 0.0
+    for H, ci, co in layers:
+        fl = H * H * 9.0 * ci * co
+        if ci == 3:
+            alg += 2 * fl
+            ex += 2 * fl
+        else:
+            alg += 3 * fl
+            ex += 2 * fl * (16.0 / 36.0) / eff[H][0] + fl * (16.0 / 36.0) / eff[H][1]
+    assert abs(r - ex / alg) < 1e-9
+    assert 0.47 < r < 0.50
