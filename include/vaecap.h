@@ -280,6 +280,9 @@ int vc_conv3x3_wgrad_patch_f32(void* stream, int B, int H, int W, int Cin, int C
  * tolerance class).  ypool != NULL also writes max_pool2x2(y) (a pooling window is one Winograd tile).  Shapes: H, W even, gathered
  * channels % 16 == 0, output channels % 32 == 0; ask vc_conv3x3_wino_supported. */
 int vc_conv3x3_wino_supported(int B, int H, int W, int Cin, int Cout, int dgrad);
+/* The kernels address a launch's tensors with 32-bit offsets: calls on more than 2 GiB per tensor are cut into launches over image
+ * ranges inside the library; 1 if [B,H,W,max(Cin,Cout)] floats fit one launch (the mask-bit variants below require it). */
+int vc_conv3x3_wino_single_launch_supported(int B, int H, int W, int Cin, int Cout);
 int vc_conv3x3_wino_pack_f32(void* stream, int Cin, int Cout, const float* w, int transpose, float* wp);
 int vc_conv3x3_wino_fwd_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const float* wp,
                             const float* bias, float* y, float* ypool, int relu);

@@ -219,3 +219,50 @@ def test_wino_relu_mask_as_bits(lib, case):
     lib.vc_conv3x3_wino_dgrad_bits_f32(stream(), B, H, W, Cm, Co, P(dy), P(wpt2), P(bits), P(dx))
     assert np.array_equal(host(dx), host(dx_ref))
     assert float(np.abs(host(dx_ref)).max()) > 0 and (host(dx_ref) == 0).mean() > 0.2   # the mask does mask
+
+
+def test_wino_calls_over_the_launch_limit_are_cut_into_image_ranges(tmp_path):
+    """The kernels address a launch's tensors with 32-bit offsets (< 2 GiB); a call on more images runs as several launches over image
+    ranges.  VC_WINO_MAX_BYTES forces that on a small shape (a fresh process: the limit is read once): forward / data gradient must
+    equal the single-launch results bit for bit, the weight gradient up to the summation order of the ranges."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "run.py"
+    script.write_text(
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from vae_captioning_amd import abi\n"
+        "from vae_captioning_amd.abi import ptr as P\n"
+        "lib = abi.load(); st = torch.cuda.current_stream().cuda_stream\n"
+        "B, H, W, Ci, Co = 5, 8, 16, 64, 64\n"
+        "g = torch.Generator(device='cuda').manual_seed(1)\n"
+        "x = torch.rand(B, H, W, Ci, device='cuda', generator=g); w = torch.rand(3, 3, Ci, Co, device='cuda', generator=g) - 0.5\n"
+        "dy = torch.rand(B, H, W, Co, device='cuda', generator=g) - 0.5; b = torch.rand(Co, device='cuda', generator=g)\n"
+        "vp = torch.empty(16 * Ci * Co, device='cuda'); vpt = torch.empty(16 * Ci * Co, device='cuda')\n"
+        "lib.vc_conv3x3_wino_pack_f32(st, Ci, Co, P(w), 0, P(vp)); lib.vc_conv3x3_wino_pack_f32(st, Ci, Co, P(w), 1, P(vpt))\n"
+        "y = torch.zeros(B, H, W, Co, device='cuda'); yp = torch.zeros(B, H // 2, W // 2, Co, device='cuda'); dx = torch.zeros(B, H, W, Ci, device='cuda')\n"
+        "dw = torch.zeros(3, 3, Ci, Co, device='cuda'); db = torch.zeros(Co, device='cuda')\n"
+        "ws = torch.empty(lib.vc_conv3x3_wino_wgrad_workspace_bytes(B, H, W, Ci, Co) // 4 + 4, device='cuda')\n"
+        "lib.vc_conv3x3_wino_fwd_f32(st, B, H, W, Ci, Co, P(x), P(vp), P(b), P(y), P(yp), 1)\n"
+        "lib.vc_conv3x3_wino_dgrad_f32(st, B, H, W, Ci, Co, P(dy), P(vpt), P(x), P(dx))\n"
+        "lib.vc_conv3x3_wino_wgrad_f32(st, B, H, W, Ci, Co, P(x), P(dy), P(dw), P(db), 0, P(ws), ws.numel() * 4)\n"
+        "torch.cuda.synchronize()\n"
+        "print(int(lib.vc_conv3x3_wino_single_launch_supported(B, H, W, Ci, Co)))\n"
+        "np.savez(sys.argv[1], y=y.cpu().numpy(), yp=yp.cpu().numpy(), dx=dx.cpu().numpy(), dw=dw.cpu().numpy(), db=db.cpu().numpy())\n" % root)
+    out = {}
+    for tag, cap in (("one", None), ("cut", str(2 * 8 * 16 * 64 * 4))):   # cut: two images per launch -> ranges of 2, 2, 1
+        env = dict(os.environ)
+        env.pop("VC_WINO_MAX_BYTES", None)
+        if cap:
+            env["VC_WINO_MAX_BYTES"] = cap
+        f = str(tmp_path / (tag + ".npz"))
+        r = subprocess.run([sys.executable, str(script), f], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert r.stdout.strip().splitlines()[-1] == ("1" if cap is None else "0")
+        out[tag] = np.load(f)
+    for k in ("y", "yp", "dx"):
+        assert np.array_equal(out["one"][k], out["cut"][k]), k
+    for k in ("dw", "db"):
+        assert np.abs(out["one"][k] - out["cut"][k]).max() <= 1e-5 * np.abs(out["one"][k]).max(), k

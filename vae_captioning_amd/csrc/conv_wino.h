@@ -1,5 +1,6 @@
 // Shared by conv_wino.hip (forward / data gradient) and conv_wino_wgrad.hip (weight gradient): tile-block geometry and the buffer load.
 #pragma once
+#include <stdlib.h>
 #include "gemm_core.h"
 #include "vaecap.h"
 
@@ -27,5 +28,15 @@ __device__ __forceinline__ float4 wbufload(__amdgpu_buffer_rsrc_t r, unsigned vo
 }
 
 static inline bool waligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+// The kernels address their tensors with 32-bit buffer offsets (< 2 GiB per launch): a call on more images is cut into launches
+// over image ranges.  Images per launch for [B, H, W, max(C, N)] floats (VC_WINO_MAX_BYTES: tests force the cut on small shapes).
+static inline int wino_images_per_launch(int B, int H, int W, int C, int N) {
+    static const long cap = getenv("VC_WINO_MAX_BYTES") ? atol(getenv("VC_WINO_MAX_BYTES")) : 0x7fffffffL;
+    const long per = (long)H * W * (long)(C > N ? C : N) * 4;
+    long n = per > 0 ? cap / per : 0;
+    if (n > B) n = B;
+    return (int)n;   // 0: one image alone is too large
+}
 
 }  // namespace vc

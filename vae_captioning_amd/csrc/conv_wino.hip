@@ -444,7 +444,12 @@ static int launch_wino(hipStream_t st, WinoArgs& a) {
 
 extern "C" int vc_conv3x3_wino_supported(int B, int H, int W, int Cin, int Cout, int dgrad) {
     vc::WinoGeom g;
-    return (dgrad ? vc::plan_wino(B, H, W, Cout, Cin, g) : vc::plan_wino(B, H, W, Cin, Cout, g)) ? 1 : 0;
+    const int nb = vc::wino_images_per_launch(B, H, W, Cin, Cout);
+    return nb > 0 && (dgrad ? vc::plan_wino(nb, H, W, Cout, Cin, g) : vc::plan_wino(nb, H, W, Cin, Cout, g)) ? 1 : 0;
+}
+
+extern "C" int vc_conv3x3_wino_single_launch_supported(int B, int H, int W, int Cin, int Cout) {
+    return vc::wino_images_per_launch(B, H, W, Cin, Cout) >= B ? 1 : 0;
 }
 
 extern "C" int vc_conv3x3_wino_pack_f32(void* stream, int Cin, int Cout, const float* w, int transpose, float* wp) {
@@ -461,12 +466,20 @@ extern "C" int vc_conv3x3_wino_pack_f32(void* stream, int Cin, int Cout, const f
 extern "C" int vc_conv3x3_wino_fwd_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const float* wp,
                                        const float* bias, float* y, float* ypool, int relu) {
     using namespace vc;
-    WinoArgs a;
-    VC_CHECK_ARG(plan_wino(B, H, W, Cin, Cout, a.g), "unsupported shape (vc_conv3x3_wino_supported)");
     VC_CHECK_ARG(x && wp && y, "null pointer");
     VC_CHECK_ARG(waligned16(x) && waligned16(wp) && waligned16(y) && waligned16(bias) && waligned16(ypool), "pointers must be 16-byte aligned");
-    a.x = x; a.wp = wp; a.out = y; a.aux = bias; a.relu = relu; a.pool = ypool; a.mask = nullptr;
-    return ypool ? launch_wino<WK_FWD, true>((hipStream_t)stream, a) : launch_wino<WK_FWD, false>((hipStream_t)stream, a);
+    const int per = wino_images_per_launch(B, H, W, Cin, Cout);
+    VC_CHECK_ARG(per > 0, "unsupported shape (vc_conv3x3_wino_supported)");
+    for (int b0 = 0; b0 < B; b0 += per) {   // image ranges of < 2 GiB (one launch for every VGG16 layer up to 160 images)
+        const int nb = B - b0 < per ? B - b0 : per;
+        WinoArgs a;
+        VC_CHECK_ARG(plan_wino(nb, H, W, Cin, Cout, a.g), "unsupported shape (vc_conv3x3_wino_supported)");
+        a.x = x + (size_t)b0 * H * W * Cin; a.wp = wp; a.out = y + (size_t)b0 * H * W * Cout; a.aux = bias; a.relu = relu; a.mask = nullptr;
+        a.pool = ypool ? ypool + (size_t)b0 * (H / 2) * (W / 2) * Cout : nullptr;
+        const int rc = ypool ? launch_wino<WK_FWD, true>((hipStream_t)stream, a) : launch_wino<WK_FWD, false>((hipStream_t)stream, a);
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 extern "C" size_t vc_conv3x3_wino_mask_words(int B, int H, int W, int C) {
@@ -479,7 +492,8 @@ extern "C" int vc_conv3x3_wino_fwd_mask_f32(void* stream, int B, int H, int W, i
                                             const float* bias, float* y, int relu, uint32_t* mask_out) {
     using namespace vc;
     WinoArgs a;
-    VC_CHECK_ARG(plan_wino(B, H, W, Cin, Cout, a.g), "unsupported shape (vc_conv3x3_wino_supported)");
+    VC_CHECK_ARG(wino_images_per_launch(B, H, W, Cin, Cout) >= B && plan_wino(B, H, W, Cin, Cout, a.g),
+                 "unsupported shape, or more images than one launch takes (vc_conv3x3_wino_single_launch_supported): the mask bits are per tile of ONE launch");
     VC_CHECK_ARG(x && wp && y && mask_out, "null pointer");
     VC_CHECK_ARG(waligned16(x) && waligned16(wp) && waligned16(y) && waligned16(bias) && waligned16(mask_out), "pointers must be 16-byte aligned");
     a.x = x; a.wp = wp; a.out = y; a.aux = bias; a.relu = relu; a.pool = nullptr; a.mask = mask_out;
@@ -489,19 +503,28 @@ extern "C" int vc_conv3x3_wino_fwd_mask_f32(void* stream, int B, int H, int W, i
 extern "C" int vc_conv3x3_wino_dgrad_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* dy, const float* wpt,
                                          const float* relu_src, float* dx) {
     using namespace vc;
-    WinoArgs a;
-    VC_CHECK_ARG(plan_wino(B, H, W, Cout, Cin, a.g), "unsupported shape (vc_conv3x3_wino_supported)");
     VC_CHECK_ARG(dy && wpt && dx, "null pointer");
     VC_CHECK_ARG(waligned16(dy) && waligned16(wpt) && waligned16(dx) && waligned16(relu_src), "pointers must be 16-byte aligned");
-    a.x = dy; a.wp = wpt; a.out = dx; a.aux = relu_src; a.relu = 0; a.pool = nullptr; a.mask = nullptr;
-    return launch_wino<WK_DGRAD, false>((hipStream_t)stream, a);
+    const int per = wino_images_per_launch(B, H, W, Cin, Cout);
+    VC_CHECK_ARG(per > 0, "unsupported shape (vc_conv3x3_wino_supported)");
+    for (int b0 = 0; b0 < B; b0 += per) {
+        const int nb = B - b0 < per ? B - b0 : per;
+        WinoArgs a;
+        VC_CHECK_ARG(plan_wino(nb, H, W, Cout, Cin, a.g), "unsupported shape (vc_conv3x3_wino_supported)");
+        a.x = dy + (size_t)b0 * H * W * Cout; a.wp = wpt; a.out = dx + (size_t)b0 * H * W * Cin;
+        a.aux = relu_src ? relu_src + (size_t)b0 * H * W * Cin : nullptr; a.relu = 0; a.pool = nullptr; a.mask = nullptr;
+        const int rc = launch_wino<WK_DGRAD, false>((hipStream_t)stream, a);
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 extern "C" int vc_conv3x3_wino_dgrad_bits_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* dy, const float* wpt,
                                               const uint32_t* mask_bits, float* dx) {
     using namespace vc;
     WinoArgs a;
-    VC_CHECK_ARG(plan_wino(B, H, W, Cout, Cin, a.g), "unsupported shape (vc_conv3x3_wino_supported)");
+    VC_CHECK_ARG(wino_images_per_launch(B, H, W, Cin, Cout) >= B && plan_wino(B, H, W, Cout, Cin, a.g),
+                 "unsupported shape, or more images than one launch takes (vc_conv3x3_wino_single_launch_supported)");
     VC_CHECK_ARG(dy && wpt && dx && mask_bits, "null pointer");
     VC_CHECK_ARG(waligned16(dy) && waligned16(wpt) && waligned16(dx) && waligned16(mask_bits), "pointers must be 16-byte aligned");
     a.x = dy; a.wp = wpt; a.out = dx; a.aux = nullptr; a.relu = 0; a.pool = nullptr; a.mask = const_cast<uint32_t*>(mask_bits);

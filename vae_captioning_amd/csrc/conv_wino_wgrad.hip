@@ -101,26 +101,39 @@ static size_t wino_wgrad_ws(const WinoWgPlan& p) {
 
 }  // namespace vc
 
-extern "C" int vc_conv3x3_wino_wgrad_supported(int B, int H, int W, int Cin, int Cout) { return vc::plan_wino_wgrad(B, H, W, Cin, Cout).ok ? 1 : 0; }
+extern "C" int vc_conv3x3_wino_wgrad_supported(int B, int H, int W, int Cin, int Cout) {
+    const int nb = vc::wino_images_per_launch(B, H, W, Cin, Cout);
+    return nb > 0 && vc::plan_wino_wgrad(nb, H, W, Cin, Cout).ok ? 1 : 0;
+}
 
 extern "C" size_t vc_conv3x3_wino_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
-    return vc::wino_wgrad_ws(vc::plan_wino_wgrad(B, H, W, Cin, Cout));
+    const int nb = vc::wino_images_per_launch(B, H, W, Cin, Cout);
+    return nb > 0 ? vc::wino_wgrad_ws(vc::plan_wino_wgrad(nb, H, W, Cin, Cout)) : 0;
 }
 
 extern "C" int vc_conv3x3_wino_wgrad_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const float* dy, float* dw,
                                          float* db, int accumulate, float* ws, size_t ws_bytes) {
     using namespace vc;
-    const WinoWgPlan p = plan_wino_wgrad(B, H, W, Cin, Cout);
-    VC_CHECK_ARG(p.ok, "unsupported shape (vc_conv3x3_wino_wgrad_supported)");
+    const int per = wino_images_per_launch(B, H, W, Cin, Cout);
+    VC_CHECK_ARG(per > 0 && plan_wino_wgrad(per, H, W, Cin, Cout).ok, "unsupported shape (vc_conv3x3_wino_wgrad_supported)");
     VC_CHECK_ARG(x && dy && dw && ws, "null pointer");
     VC_CHECK_ARG(waligned16(x) && waligned16(dy) && waligned16(ws), "pointers must be 16-byte aligned");
-    if (ws_bytes < wino_wgrad_ws(p)) return fail(VC_EWORKSPACE, "%s: workspace too small (%ld < %ld bytes)", __func__, (long)ws_bytes, (long)wino_wgrad_ws(p));
-    WinoWgArgs a;
-    a.g = p.g; a.x = x; a.dy = dy; a.ws = ws; a.ncb = p.ncb; a.nnb = p.nnb; a.nsplit = p.nsplit; a.cps = p.cps;
-    int rc = p.shape == 0 ? launch_wino_wgrad_4x8((hipStream_t)stream, a) : p.shape == 1 ? launch_wino_wgrad_4x7((hipStream_t)stream, a)
-                                                                                         : launch_wino_wgrad_2x14((hipStream_t)stream, a);
-    if (rc) return rc;
-    const int grid = (int)((long)Cin * Cout / 64);
-    hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(grid + (db ? 1 : 0)), dim3(256), 0, (hipStream_t)stream, ws, p.nsplit, Cin, Cout, dw, db, accumulate);
-    return launch_status(__func__);
+    for (int b0 = 0; b0 < B; b0 += per) {   // image ranges of < 2 GiB; the later ranges accumulate into dw / db
+        const int nbi = B - b0 < per ? B - b0 : per;
+        const WinoWgPlan p = plan_wino_wgrad(nbi, H, W, Cin, Cout);
+        VC_CHECK_ARG(p.ok, "unsupported shape (vc_conv3x3_wino_wgrad_supported)");
+        if (ws_bytes < wino_wgrad_ws(p)) return fail(VC_EWORKSPACE, "%s: workspace too small (%ld < %ld bytes)", __func__, (long)ws_bytes, (long)wino_wgrad_ws(p));
+        WinoWgArgs a;
+        a.g = p.g; a.x = x + (size_t)b0 * H * W * Cin; a.dy = dy + (size_t)b0 * H * W * Cout; a.ws = ws;
+        a.ncb = p.ncb; a.nnb = p.nnb; a.nsplit = p.nsplit; a.cps = p.cps;
+        int rc = p.shape == 0 ? launch_wino_wgrad_4x8((hipStream_t)stream, a) : p.shape == 1 ? launch_wino_wgrad_4x7((hipStream_t)stream, a)
+                                                                                             : launch_wino_wgrad_2x14((hipStream_t)stream, a);
+        if (rc) return rc;
+        const int grid = (int)((long)Cin * Cout / 64);
+        hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(grid + (db ? 1 : 0)), dim3(256), 0, (hipStream_t)stream, ws, p.nsplit, Cin, Cout, dw, db,
+                           accumulate || b0 > 0);
+        rc = launch_status(__func__);
+        if (rc) return rc;
+    }
+    return 0;
 }

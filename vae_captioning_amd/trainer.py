@@ -257,7 +257,8 @@ class VggEngine(object):
                                         lambda: lib.vc_conv3x3_wino16_fwd_f32(sh, nb, H, W, cie, co, P(x[b0:]), P(self.buf["up_" + name]), P(S.param(bn)),
                                                                               P(y[b0:]), P(yp[b0:]) if pooled else None, 1))
                             continue
-                        if self._wino_ok(name, nb, H, W, cie, co, 0) and self.train and not pooled and not self.use_wino16:
+                        if (self._wino_ok(name, nb, H, W, cie, co, 0) and self.train and not pooled and not self.use_wino16
+                                and lib.vc_conv3x3_wino_single_launch_supported(nb, H, W, cie, co)):
                             # the next layer is a convolution on this output: leave (y > 0) as bits in the lane order of ITS data gradient
                             mk = self._b("mk_%s_%d" % (name, ch), (lib.vc_conv3x3_wino_mask_words(nb, H, W, co),), dtype=torch.int32)
                             self.mask_geom[name] = (nb, len(halves))   # the bits are per tile of THIS launch geometry
@@ -436,7 +437,8 @@ class VggEngine(object):
                             self._timed("conv_dgrad", fl * nb / B, lambda: lib.vc_conv3x3_wino16_dgrad_f32(
                                 sh, nb, H, W, ci, co, P(d[b0:]), P(self.buf["upt_" + name]), None if prev_is_pool else P(x[b0:]), P(dx[b0:])))
                         elif (self._wino_ok(name, nb, H, W, ci, co, 1) and not prev_is_pool
-                              and self.mask_geom.get(self.acts[li - 1][0]) == (nb, len(halves))):
+                              and self.mask_geom.get(self.acts[li - 1][0]) == (nb, len(halves))
+                              and lib.vc_conv3x3_wino_single_launch_supported(nb, H, W, ci, co)):
                             # ReluGrad from the bits the previous layer's forward left (one 8-byte load per lane instead of sixteen 16-byte ones)
                             self._timed("conv_dgrad", fl * nb / B, lambda: lib.vc_conv3x3_wino_dgrad_bits_f32(
                                 sh, nb, H, W, ci, co, P(d[b0:]), P(self.buf["vpt_" + name]), P(self.buf["mk_%s_%d" % (self.acts[li - 1][0], ch)]), P(dx[b0:])))
