@@ -225,10 +225,10 @@ def main():
                    "buckets_bytes": [int((b - a) * 4) for a, b in bk] if (tr.buckets and tr.vgg is not None) else [int(tr.gall.numel() * 4)]}
         if tr.dp_stats:
             torch.cuda.synchronize()
-            w = {}
+            waits = {}
             for i, nbytes, e0, e1 in tr.dp_stats:
-                w.setdefault(i, []).append(e0.elapsed_time(e1))
-            dp_info["bucket_wait_ms"] = [round(float(np.mean(w[i])), 4) for i in sorted(w)]
+                waits.setdefault(i, []).append(e0.elapsed_time(e1))
+            dp_info["bucket_wait_ms"] = [round(float(np.mean(waits[i])), 4) for i in sorted(waits)]
 
     # ---- roofline of the dominant kernel family from the HIP events of the timed region
     instrumented_pass = False

@@ -150,6 +150,9 @@ def test_bench_two_ranks_through_torchrun_on_one_gpu(tmp_path):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert d["n_gpus"] == 2 and d["config"]["global_caption_rows"] == 20 and np.isfinite(d["final_losses"]["rec_loss"])
+    # the workload description survives the data-parallel statistics (a local of the bucket-wait summary once shadowed it)
+    assert d["config"]["workload"].startswith("cfg4: {") and '"fine_tune": true' in d["config"]["workload"]
+    assert len(d["data_parallel"]["bucket_wait_ms"]) == 4 and d["data_parallel"]["rccl_world_size"] == 2
 
 
 def test_gen_caption_cli_single_image(tmp_path, lib):
