@@ -67,6 +67,7 @@ int vc_embedding_grad_sorted_f32(void* stream, float* dtable, const int32_t* ord
  * for every id the range of its sub-segments.  ws: int32 scratch of vc_embedding_index_workspace_bytes. */
 size_t vc_embedding_index_workspace_bytes(long R, int vocab);
 size_t vc_embedding_index_max_subsegments(long R, int vocab, int chunk);
+int vc_embedding_index_max_vocab(void); /* larger vocabularies: build the index on the host (engine.embedding_grad_index) */
 int vc_embedding_grad_index(void* stream, const int32_t* ids, long R, int vocab, int chunk, int32_t* order, int32_t* seg1,
                             int32_t* seg2, int32_t* ws, size_t ws_bytes);
 int vc_mark_rows_f32(void* stream, float* touched, const int32_t* ids, long n, int vocab);

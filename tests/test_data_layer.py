@@ -241,6 +241,30 @@ def test_two_ranks_see_disjoint_examples_of_one_shuffle():
     assert seen == one                                  # and in the order a single rank with the global batch size would read them
 
 
+def test_ranks_pad_to_the_longest_caption_of_the_global_batch():
+    """Data-parallel ranks must step with the SAME T (kernel shapes, step time): each rank forms the captions of the global batch and
+    keeps its rows, so rank r's arrays are exactly rows [r*bs, (r+1)*bs) of the single-process batch of size world*bs -- also with
+    random_select (num_captions = 1), whose draws every rank repeats identically."""
+    rng = np.random.default_rng(5)
+    caps = {"im%03d" % i: [[1] + list(rng.integers(3, 50, size=14 if i == 7 else int(rng.integers(2, 6)))) + [2] for _ in range(int(rng.integers(1, 6)))] for i in range(48)}
+    caps = {k: [[int(t) for t in c] for c in v] for k, v in caps.items()}
+    feats = {k: np.full((1, 8), i, np.float32) for i, k in enumerate(caps)}
+    for nc in (1, 5):
+        ranks = [list(BatchGenerator(caps, feats, 4, seed=11, shard=(r, 3)).next_batch(num_captions=nc)) for r in range(3)]
+        whole = list(BatchGenerator(caps, feats, 12, seed=11).next_batch(num_captions=nc))
+        assert len(whole) == len(ranks[0]) == 4
+        Ts = set()
+        for k, g in enumerate(whole):
+            for r in range(3):
+                b = ranks[r][k]
+                assert b["cap_dec"].shape[1] == g["cap_dec"].shape[1]                      # the global T on every rank
+                for key in ("cap_dec", "cap_enc", "lengths"):
+                    np.testing.assert_array_equal(b[key], g[key][r * 4 * nc:(r + 1) * 4 * nc], err_msg="%s nc=%d" % (key, nc))
+                np.testing.assert_array_equal(b["features"], g["features"][r * 4:(r + 1) * 4])
+            Ts.add(g["cap_dec"].shape[1])
+        assert len(Ts) > 1   # (T does change from batch to batch in this data)
+
+
 def test_imagenet_npz_is_assigned_in_sorted_key_order(tmp_path):
     """utils/image_embeddings.py:240-246 (quirk Q18): the first 30 ALPHABETICALLY sorted arrays go to `parameters` in creation
     order, whatever order the archive stores them in; fc8_* (sorted last) are skipped."""

@@ -247,3 +247,94 @@ def test_gmm_component_is_drawn_on_device_from_softmax_of_the_cluster_vector(lib
     assert np.abs(freq - pr).max() < 0.03, (freq[[3, 17]], pr[[3, 17]])
     e.forward(train=True)                                # and the step runs end to end with the drawn components
     assert np.isfinite(e.out.cpu().numpy()).all()
+
+
+def _run_sequence(lib, p, V, P0, batches, synchronous, seed=7):
+    """`len(batches)` training steps on a fresh engine; synchronous=True drains the device after every call (no upload can
+    overlap a step), False leaves the two-stream pipeline of set_batch alone."""
+    eng = CaptionEngine(p, V, lib=lib, seed=seed)
+    eng.load_params(P0)
+    losses = []
+    for b in batches:
+        eng.set_batch(b)
+        if synchronous:
+            torch.cuda.synchronize()
+        eng.forward(); eng.backward(); eng.pack_tail(); eng.apply_gradients()
+        if synchronous:
+            torch.cuda.synchronize()
+            losses.append(eng.losses())
+    if not synchronous:
+        losses.append(eng.losses())
+    return losses, eng.state_dict(), eng
+
+
+def test_caption_length_changes_between_steps_equal_the_synchronous_upload(lib):
+    """Batch_Generator pads every batch to ITS longest caption, so T changes almost every step.  The staging / landing / index
+    buffers are sized to a high-water mark (engine._upload_pack): T_k == T_{k+2} != T_{k+1}, growth in the middle of the run and a
+    return to the small size must give bit-identical parameters to a run that drains the device around every call."""
+    p = small_params(prior="Normal", dec_keep_rate=0.9)
+    V, B = 203, 6
+    rng = np.random.default_rng(21)
+    P0 = spec.init_caption_params(p, V, seed=2)
+    Ts = [9, 6, 9, 6, 9, 14, 5, 14, 9, 6, 23, 6]
+    batches = [synth.make_batch(rng, B, p.num_captions, T, V, variable_len=True, feature_size=p.cnn_feature_size) for T in Ts]
+    la, Pa, ea = _run_sequence(lib, p, V, P0, batches, synchronous=False)
+    ls, Ps, _ = _run_sequence(lib, p, V, P0, batches, synchronous=True)
+    assert la[-1] == ls[-1]
+    for k in Pa:
+        np.testing.assert_array_equal(Pa[k], Ps[k], err_msg=k)
+    st = ea.pinned["__pack__"]
+    assert st["cap"] >= max(ea.buf[k].numel() * 4 for k in ("cap_dec_t", "cap_enc_t"))
+    assert len({d.data_ptr() for d in st["devs"]}) == 2 and not ea.retired   # losses() released what growth replaced
+
+
+def test_vocabulary_beyond_the_device_scan_builds_the_index_on_the_host(lib):
+    """vc_embedding_grad_index scans one LDS table (<= vc_embedding_index_max_vocab ids); larger vocabularies ship the host-built
+    index in the same upload: one training step equals the oracle."""
+    p = small_params(prior="Normal")
+    p.embed_size = 8
+    V = int(lib.vc_embedding_index_max_vocab()) + 37
+    B, T = 4, 5
+    P0, batch, noise = make_case(p, V, B, T, seed=5)
+    eng = CaptionEngine(p, V, lib=lib)
+    eng.load_params(P0)
+    eng.set_batch(batch, noise)
+    eng.forward(); eng.backward(); eng.pack_tail()
+    first, hist, _ = oracle_steps(p, P0, batch, noise, 1)
+    kld, rec, lb, ann = eng.losses()
+    assert abs(rec - hist[0][1]) <= 2e-4 * abs(hist[0][1])
+    G = eng.grads_dict()
+    for name in ("decoder/net/dec_embeddings", "encoder/enc_embeddings"):
+        ref = first.grads[name]
+        assert np.abs(G[name] - ref).max() <= 2e-4 * np.abs(ref).max(), name
+
+
+def test_set_batch_under_a_captured_graph_feeds_the_replayed_step(lib):
+    """Trainer.capture() makes the inputs persistent tensors (engine.fix_inputs): a later set_batch copies INTO them, so a replay
+    trains on the new batch -- same parameters as the eager run over the same batches -- and a batch of another shape is refused."""
+    from vae_captioning_amd.trainer import Trainer
+    p = small_params(prior="Normal")
+    V, B, T = 203, 4, 6
+    rng = np.random.default_rng(31)
+    P0 = spec.init_caption_params(p, V, seed=4)
+    batches = [synth.make_batch(rng, B, p.num_captions, T, V, variable_len=True, feature_size=p.cnn_feature_size) for _ in range(4)]
+    res = []
+    for graph in (False, True):
+        tr = Trainer(p, V, lib=lib, seed=9)
+        tr.load_state_dict(P0)
+        tr.set_batch(batches[0])
+        if graph:
+            tr.capture(warmup=1)
+            tr.cap.step.zero_()      # the warm-up ran the step once on batch 0: rewind to the same starting point
+            tr.load_state_dict(P0)
+            for s in tr.cap.store.slots.values():
+                s.zero_()
+        for b in batches:
+            tr.set_batch(b)
+            tr.train_step()
+        res.append((tr.losses(), tr.state_dict()))
+    assert res[0][0] == res[1][0]
+    for k in res[0][1]:
+        np.testing.assert_array_equal(res[0][1][k], res[1][1][k], err_msg=k)
+    with pytest.raises(ValueError):
+        tr.set_batch(synth.make_batch(rng, B, p.num_captions, T + 2, V, feature_size=p.cnn_feature_size))

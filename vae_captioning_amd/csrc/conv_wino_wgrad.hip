@@ -106,9 +106,21 @@ extern "C" int vc_conv3x3_wino_wgrad_supported(int B, int H, int W, int Cin, int
     return nb > 0 && vc::plan_wino_wgrad(nb, H, W, Cin, Cout).ok ? 1 : 0;
 }
 
+// the split count is not monotone in the block count (nsplit = cdiv(nblocks, cdiv(nblocks, ns))): the remainder launch of a call that
+// is cut into image ranges may need MORE workspace than the full ranges -- the reported size is the maximum over both plans
+static size_t wino_wgrad_ws_call(int B, int H, int W, int Cin, int Cout) {
+    const int per = vc::wino_images_per_launch(B, H, W, Cin, Cout);
+    if (per <= 0) return 0;
+    size_t need = vc::wino_wgrad_ws(vc::plan_wino_wgrad(per, H, W, Cin, Cout));
+    if (B % per) {
+        const size_t r = vc::wino_wgrad_ws(vc::plan_wino_wgrad(B % per, H, W, Cin, Cout));
+        if (r > need) need = r;
+    }
+    return need;
+}
+
 extern "C" size_t vc_conv3x3_wino_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
-    const int nb = vc::wino_images_per_launch(B, H, W, Cin, Cout);
-    return nb > 0 ? vc::wino_wgrad_ws(vc::plan_wino_wgrad(nb, H, W, Cin, Cout)) : 0;
+    return wino_wgrad_ws_call(B, H, W, Cin, Cout);
 }
 
 extern "C" int vc_conv3x3_wino_wgrad_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const float* dy, float* dw,
@@ -118,6 +130,10 @@ extern "C" int vc_conv3x3_wino_wgrad_f32(void* stream, int B, int H, int W, int 
     VC_CHECK_ARG(per > 0 && plan_wino_wgrad(per, H, W, Cin, Cout).ok, "unsupported shape (vc_conv3x3_wino_wgrad_supported)");
     VC_CHECK_ARG(x && dy && dw && ws, "null pointer");
     VC_CHECK_ARG(waligned16(x) && waligned16(dy) && waligned16(ws), "pointers must be 16-byte aligned");
+    // every image range is validated BEFORE the first launch: a failure must not leave dw / db half accumulated
+    VC_CHECK_ARG(B % per == 0 || plan_wino_wgrad(B % per, H, W, Cin, Cout).ok, "unsupported shape (vc_conv3x3_wino_wgrad_supported)");
+    if (ws_bytes < wino_wgrad_ws_call(B, H, W, Cin, Cout))
+        return fail(VC_EWORKSPACE, "%s: workspace too small (%ld < %ld bytes)", __func__, (long)ws_bytes, (long)wino_wgrad_ws_call(B, H, W, Cin, Cout));
     for (int b0 = 0; b0 < B; b0 += per) {   // image ranges of < 2 GiB; the later ranges accumulate into dw / db
         const int nbi = B - b0 < per ? B - b0 : per;
         const WinoWgPlan p = plan_wino_wgrad(nbi, H, W, Cin, Cout);

@@ -540,13 +540,17 @@ extern "C" size_t vc_embedding_index_max_subsegments(long R, int vocab, int chun
     return chunk > 0 ? (size_t)(R / chunk + vocab) : 0;
 }
 
+// largest vocabulary the single-workgroup scan takes (its LDS table: 8 bytes per id + 8 KB of the 160 KB); callers with more ids build
+// the index on the host (engine.embedding_grad_index) -- engine.set_batch does
+extern "C" int vc_embedding_index_max_vocab(void) { return (160 * 1024 - 8192) / 8; }
+
 extern "C" int vc_embedding_grad_index(void* stream, const int32_t* ids, long R, int vocab, int chunk, int32_t* order,
                                        int32_t* seg1, int32_t* seg2, int32_t* ws, size_t ws_bytes) {
     VC_CHECK_ARG(ids && order && seg1 && seg2 && R > 0 && vocab > 0 && chunk > 0 && R < (1L << 31), "bad argument");
     const int segs = embidx_segs(R);
     if (!ws || ws_bytes < ((size_t)segs + 3) * vocab * sizeof(int32_t))
         return fail(VC_EWORKSPACE, "%s: workspace too small (need vc_embedding_index_workspace_bytes)", __func__);
-    VC_CHECK_ARG((size_t)vocab * 8 + 8192 <= 160 * 1024, "vocabulary too large for the single-workgroup scan (<= 19456 ids)");
+    VC_CHECK_ARG(vocab <= vc_embedding_index_max_vocab(), "vocabulary too large for the single-workgroup scan (vc_embedding_index_max_vocab)");
     int32_t* tot = ws + (size_t)segs * vocab;
     int32_t* nsb = tot + vocab;
     int32_t* starts = nsb + vocab;
@@ -557,8 +561,10 @@ extern "C" int vc_embedding_grad_index(void* stream, const int32_t* ids, long R,
     VC_LAUNCH_CHECK();
     hipLaunchKernelGGL(embidx_totals_kernel, dim3(grid.x), dim3(256), 0, (hipStream_t)stream, ws, segs, vocab, chunk, tot, nsb);
     VC_LAUNCH_CHECK();
-    if ((size_t)vocab * 8 + 8192 > 64 * 1024)  // more than the default 64 KB of dynamic LDS
-        (void)hipFuncSetAttribute((const void*)embidx_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)vocab * 8 + 8192));
+    if ((size_t)vocab * 8 + 8192 > 64 * 1024) {  // more than the default 64 KB of dynamic LDS
+        const hipError_t e = hipFuncSetAttribute((const void*)embidx_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)vocab * 8 + 8192));
+        if (e != hipSuccess) return fail((int)e, "%s: hipFuncSetAttribute (%ld bytes of dynamic LDS) failed", __func__, (long)vocab * 8 + 8192);
+    }
     hipLaunchKernelGGL(embidx_scan_kernel, dim3(1), dim3(1024), (size_t)vocab * 8 + 8192, (hipStream_t)stream, tot, nsb, vocab, starts, seg2);
     VC_LAUNCH_CHECK();
     hipLaunchKernelGGL(embidx_finish_kernel, dim3(grid.x), dim3(256), 0, (hipStream_t)stream, ws, segs, vocab, R, chunk, nsub_max, tot, starts, seg1, seg2);

@@ -185,6 +185,9 @@ class CaptionEngine(object):
         self.n_dense = self.store.offset(emb[0]) if emb else self.store.n
         self.buf = {}
         self.pinned, self.copy_stream = {}, None
+        self.capbuf, self.retired = {}, []   # capacity-sized scratch (index buffers); buffers replaced by larger ones
+        self.fixed_inputs = False            # True once a hipGraph holds the input addresses (Trainer.capture)
+        self._main_stream = None
         self.gmm_draw = False
         self.ws = None
         self.ws_bytes = 0
@@ -314,7 +317,10 @@ class CaptionEngine(object):
         """Upload one batch (numpy, reference layout: cap_* are [N, T]).  Every host array of the batch (token ids, lengths,
         cluster vectors, features or images, injected noise) travels in ONE pinned staging buffer and ONE asynchronous H2D copy
         (ten separate copies cost a queue hand-off each: ~1 ms per step); the device buffers are typed views of the landing buffer.
-        extra: further (name, array, torch dtype) items for the same copy (the Trainer's images)."""
+        extra: further (name, array, torch dtype) items for the same copy (the Trainer's images).
+        T (and with it every size) may change from batch to batch -- form_captions_batch pads to the longest caption of each
+        batch: staging, landing and index buffers are sized to a high-water mark and only ever grow (tests/test_gpu_engine.py
+        alternates T and compares with a synchronous upload)."""
         p = self.p
         nc = p.num_captions if p.mode == "training" else 1
         items = list(extra)
@@ -331,6 +337,7 @@ class CaptionEngine(object):
         items += [("lens_e", lens + self.n_init_e, torch.int32), ("lens_d", lens + self.n_init_d, torch.int32)]
         if self.use_ci:
             items.append(("c_v", np.asarray(batch["c_v"], np.float32), torch.float32))
+        was_injected = self.inject
         self.inject = noise is not None
         self.gmm_draw = False
         if noise is not None:
@@ -339,35 +346,112 @@ class CaptionEngine(object):
                     items.append((k, np.asarray(noise[k], np.float32), torch.float32))
             if "gmm_idx" in noise:
                 items.append(("gmm_idx", np.asarray(noise["gmm_idx"], np.int32), torch.int32))
-        else:
-            for k in ("eps", "drop_in", "drop_out", "gmm_idx"):  # views of an earlier injected batch: device-generated noise gets its own buffers
+        elif was_injected and not self.fixed_inputs:
+            # views of an earlier injected batch: device-generated noise gets its own buffers (only then -- the device-noise
+            # buffers otherwise persist from step to step: no re-allocation, no zero-fill, addresses stable under a hipGraph)
+            for k in ("eps", "drop_in", "drop_out", "gmm_idx"):
                 self.buf.pop(k, None)
         if noise is None and self.enc and p.prior == "GMM":
             # encoder.py:72: tf.multinomial(c_i_ph, 1) -- the cluster vector used as LOGITS (Q15): drawn on device in _noise()
             # (Philox uniforms + inverse CDF of softmax(c_v); no host loop, no read-back of the step counter)
             self.gmm_draw = True
-        slot = self._upload_pack(items)
-        # inverted index of the token ids for the deterministic embedding gradient: stable counting sort ON DEVICE (it was a numpy
-        # argsort + bincount on the host in every set_batch; embedding_grad_index below is that host form, kept as the test reference).
-        # It runs on the copy stream right behind the upload, i.e. under the previous step, into the buffers of batch slot `slot`.
+        # inverted index of the token ids for the deterministic embedding gradient: stable counting sort ON DEVICE, on the copy stream
+        # right behind the upload (i.e. under the previous step), into the index buffers of batch slot `slot`.  Vocabularies beyond the
+        # single-workgroup scan of vc_embedding_grad_index (its LDS table: <= vc_embedding_index_max_vocab ids) build the same index on
+        # the host (embedding_grad_index below, bit-identical by tests/test_gpu_ops.py) and ship it in the same copy.
         lib = self.lib
-        nb = lib.vc_embedding_index_workspace_bytes(R, self.V)
         nsub = int(lib.vc_embedding_index_max_subsegments(R, self.V, 32))
+        host_index = self.V > int(lib.vc_embedding_index_max_vocab())
+        if host_index:
+            for key, ids in (("dec", cap_dec.T), ("enc", cap_enc.T)):
+                o, s1, s2 = embedding_grad_index(ids, self.V, 32)
+                s1p = np.full(nsub + 1, R, np.int32)   # sub-segments past the batch's real count are empty (seg1 == R)
+                s1p[:s1.size] = s1
+                items += [("order_" + key, o, torch.int32), ("seg1_" + key, s1p, torch.int32), ("seg2_" + key, s2, torch.int32)]
+        views, slot, done = self._upload_pack(items)
         main = torch.cuda.current_stream()
+        if self.fixed_inputs:
+            # a captured hipGraph holds the addresses of the step's inputs: copy from the landing buffer into persistent tensors
+            # (one device-to-device copy per item on the compute stream), build the index there as well
+            main.wait_event(done)
+            for name, v in views.items():
+                dst = self.buf.get(name)
+                if dst is None or self._is_landing_view(dst):
+                    dst = self.buf[name] = torch.empty_like(v)
+                if tuple(dst.shape) != tuple(v.shape) or dst.dtype != v.dtype:
+                    raise ValueError("set_batch under a captured hipGraph: %s changed from %s to %s (shapes are baked into the graph)"
+                                     % (name, tuple(dst.shape), tuple(v.shape)))
+                dst.copy_(v)
+            if not host_index:
+                self._build_index(R, nsub, "fixed", _stream())
+            return
+        self.buf.update(views)
+        if host_index:
+            main.wait_event(done)
+            return
         with torch.cuda.stream(self.copy_stream):
-            st = _stream()
-            iws = self._b("idx_ws", (nb // 4 + 16,), torch.int32)
-            for key in ("dec", "enc"):
-                o, s1, s2 = (self._b("%s_%s_%d" % (n, key, slot), shp, torch.int32) for n, shp in (("order", (R,)), ("seg1", (nsub + 1,)), ("seg2", (self.V + 1,))))
-                lib.vc_embedding_grad_index(st, P(self.buf["cap_%s_t" % key]), R, self.V, 32, P(o), P(s1), P(s2), P(iws), iws.numel() * 4)
-                self.buf["order_" + key], self.buf["seg1_" + key], self.buf["seg2_" + key] = o, s1, s2
+            self._build_index(R, nsub, slot, _stream())
             done = torch.cuda.Event()
             done.record(self.copy_stream)
         main.wait_event(done)
 
+    def _is_landing_view(self, t):
+        st = self.pinned.get("__pack__")
+        return st is not None and any(t.untyped_storage().data_ptr() == d.untyped_storage().data_ptr() for d in st["devs"])
+
+    def _build_index(self, R, nsub, slot, st):
+        """vc_embedding_grad_index for both token tables into the index buffers of `slot` (capacity = high-water mark; the views bound
+        to self.buf have this batch's exact sizes)."""
+        lib = self.lib
+        nb = lib.vc_embedding_index_workspace_bytes(R, self.V)
+        iws = self._cap_buf("idx_ws", nb // 4 + 16, torch.int32)
+        for key in ("dec", "enc"):
+            o = self._cap_buf("order_%s_%s" % (key, slot), R, torch.int32)[:R]
+            s1 = self._cap_buf("seg1_%s_%s" % (key, slot), nsub + 1, torch.int32)[:nsub + 1]
+            s2 = self._cap_buf("seg2_%s_%s" % (key, slot), self.V + 1, torch.int32)
+            lib.vc_embedding_grad_index(st, P(self.buf["cap_%s_t" % key]), R, self.V, 32, P(o), P(s1), P(s2), P(iws), iws.numel() * 4)
+            self.buf["order_" + key], self.buf["seg1_" + key], self.buf["seg2_" + key] = o, s1, s2
+
+    def _cap_buf(self, name, n, dtype):
+        """Flat scratch buffer `name` with capacity >= n elements (high-water mark + 25 %; growth is rare).  A replaced buffer is
+        RETIRED, not freed: queued work of either stream may still use it, and a block returned to the caching allocator could be
+        handed out again before that work has run (released at the next host synchronisation, `_release_retired`)."""
+        t = self.capbuf.get(name)
+        if t is None or t.numel() < n or t.dtype != dtype:
+            cur, main = torch.cuda.current_stream(), self._main_stream or torch.cuda.current_stream()
+            with torch.cuda.stream(main):
+                t = torch.empty(int(n * 1.25) + 64, dtype=dtype, device=self.dev)
+            if cur != main:
+                cur.wait_stream(main)   # the block's previous owner finished in the compute stream's order
+            if name in self.capbuf:
+                self.retired.append(self.capbuf[name])
+            self.capbuf[name] = t
+        return t
+
+    def _release_retired(self):
+        """Drop the buffers that growth replaced, after both streams have drained."""
+        if self.retired:
+            torch.cuda.current_stream().synchronize()
+            if self.copy_stream is not None:
+                self.copy_stream.synchronize()
+            self.retired = []
+
+    def fix_inputs(self):
+        """Make every input of the step a PERSISTENT tensor (called by Trainer.capture before the step is captured into a hipGraph):
+        later set_batch calls copy into these tensors instead of re-binding views of the alternating landing buffers."""
+        self.fixed_inputs = True
+        for name, t in list(self.buf.items()):
+            if self._is_landing_view(t):
+                self.buf[name] = t.clone()
+        if "cap_dec_t" in self.buf and self.V <= int(self.lib.vc_embedding_index_max_vocab()):
+            R = self.N * self.T
+            self._build_index(R, int(self.lib.vc_embedding_index_max_subsegments(R, self.V, 32)), "fixed", _stream())
+
     def _upload_pack(self, items):
-        """[(name, host array, torch dtype)] -> self.buf[name] device tensors, through one pinned staging buffer (a ring of
-        three, so the host may run two steps ahead of the device) and one asynchronous copy on the current stream."""
+        """[(name, host array, torch dtype)] -> ({name: device view}, landing slot, copy-done event), through one pinned staging buffer
+        (a ring of three, so the host may run two steps ahead of the device) and one asynchronous copy on the copy stream.  All buffers
+        have a CAPACITY (high-water mark of the packed size): a batch of another size re-uses them, so the ring position, the landing
+        slot parity and the ordering events survive size changes."""
         arrs, offs, off = [], [], 0
         for name, a, dt in items:
             a = np.ascontiguousarray(a, dtype=np.float32 if dt == torch.float32 else np.int32)
@@ -375,13 +459,24 @@ class CaptionEngine(object):
             offs.append(off)
             off += (a.nbytes + 255) // 256 * 256
         total = max(off, 256)
-        st = self.pinned.get("__pack__")
-        if st is None or st["bytes"] != total:
-            st = self.pinned["__pack__"] = dict(bytes=total, k=0, j=0, e_prev=None,
-                                                devs=[torch.empty(total, dtype=torch.uint8, device=self.dev) for _ in range(2)],
-                                                ring=[[torch.empty(total, dtype=torch.uint8, pin_memory=True), None] for _ in range(3)])
+        main = torch.cuda.current_stream()
+        self._main_stream = main
         if self.copy_stream is None:
             self.copy_stream = torch.cuda.Stream()
+        st = self.pinned.get("__pack__")
+        if st is None:
+            st = self.pinned["__pack__"] = dict(cap=0, k=0, j=0, e_prev=None, devs=[None, None], ring=[[None, None] for _ in range(3)])
+        if total > st["cap"]:
+            cap = (int(total * 1.25) + 4095) // 4096 * 4096
+            # the old landing buffers may still be read by queued compute work and written by a queued copy: let both streams meet
+            # before the new ones exist, and keep the old ones alive (self.retired) instead of returning them to the allocator
+            self.copy_stream.wait_stream(main)
+            main.wait_stream(self.copy_stream)
+            self.retired += [d for d in st["devs"] if d is not None]
+            st["devs"] = [torch.empty(cap, dtype=torch.uint8, device=self.dev) for _ in range(2)]
+            for slot in st["ring"]:   # pinned buffers: torch's host allocator keeps a block until the copies that read it have finished
+                slot[0] = torch.empty(cap, dtype=torch.uint8, pin_memory=True)
+            st["cap"] = cap
         k = st["k"]
         st["k"] = (k + 1) % 3
         pin, ev = st["ring"][k]
@@ -393,22 +488,23 @@ class CaptionEngine(object):
         # The copy runs on its own stream, UNDER the step that is still executing: it lands in the device buffer of the step before
         # that one (two landing buffers alternate), so it only has to wait for the work that was enqueued before the PREVIOUS
         # set_batch call; the compute stream then waits for the copy.
-        main = torch.cuda.current_stream()
         e_now = torch.cuda.Event()
         e_now.record(main)
-        dev = st["devs"][st["j"]]
+        slot = st["j"]
+        dev = st["devs"][slot]
         st["j"] ^= 1
         if st["e_prev"] is not None:
             self.copy_stream.wait_event(st["e_prev"])
         with torch.cuda.stream(self.copy_stream):
-            dev.copy_(pin, non_blocking=True)
+            dev[:total].copy_(pin[:total], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self.copy_stream)
         st["e_prev"] = e_now
         st["ring"][k][1] = ev
+        views = {}
         for (name, _, dt), a, o in zip(items, arrs, offs):
-            self.buf[name] = dev[o:o + a.nbytes].view(dt).view(a.shape)
-        return st["j"] ^ 1  # the landing slot of this batch; the caller makes the compute stream wait for the copy stream
+            views[name] = dev[o:o + a.nbytes].view(dt).view(a.shape)
+        return views, slot, ev
 
     def _noise(self):
         """Device-generated noise when none was injected (Philox, advanced by the step counter)."""
@@ -756,6 +852,7 @@ class CaptionEngine(object):
     def losses(self):
         """(kld, rec_loss, lower_bound, annealing) as Python floats -- the fetches of main.py:241-244."""
         o = self.out.detach().cpu().numpy()
+        self._release_retired()
         return float(o[1]), float(o[0]), float(o[2]), float(o[3])
 
 

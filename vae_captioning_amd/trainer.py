@@ -568,6 +568,9 @@ class Trainer(object):
         """Capture the whole step into one hipGraph (removes ~300 launch latencies per step).
         Requires fixed shapes and device-generated noise; collectives stay outside graphs."""
         assert not self.collectives and not self.cap.inject
+        self.cap.fix_inputs()   # the graph bakes input addresses: later set_batch calls copy INTO these persistent tensors
+        if self.fine:
+            self.images = self.cap.buf["images"]
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):

@@ -52,7 +52,19 @@ def shard_ranges(n, batch_size, shard=None):
         return [(s, min(s + batch_size, n)) for s in range(0, n, batch_size)]
     rank, world = shard
     g = batch_size * world
+    if n % g and rank == 0 and n >= g:
+        print("data-parallel epoch: the ragged last global batch (%d of %d examples) is dropped on every rank" % (n % g, n))
     return [(s + rank * batch_size, s + (rank + 1) * batch_size) for s in range(0, n - g + 1, g)]
+
+
+def global_range(lo, batch_size, shard):
+    """[glo, ghi) of the GLOBAL batch that rank-local range [lo, lo + batch_size) belongs to.  Data-parallel ranks form the captions
+    of the whole global batch (host-side list work) and keep their rows: every rank then pads to the SAME length T (the longest
+    caption of the global batch -- per-rank padding would give the ranks different kernel shapes and step times, and they meet
+    at the gradient all-reduce) and consumes the shared random stream identically (random_select draws)."""
+    rank, world = shard
+    glo = lo - rank * batch_size
+    return glo, glo + batch_size * world
 
 
 class BatchGenerator(object):
@@ -70,7 +82,11 @@ class BatchGenerator(object):
         order = self.rng.permutation(len(self.names)) if shuffle else np.arange(len(self.names))
         for lo, hi in shard_ranges(len(order), self.bs, self.shard):
             names = [self.names[i] for i in order[lo:hi]]
-            ins, lab, lens = form_captions_batch(self.caps, names, num_captions, self.rng)
+            if self.shard is not None:   # captions of the GLOBAL batch, this rank's rows (same T and random draws on every rank)
+                glo, ghi = global_range(lo, self.bs, self.shard)
+                ins, lab, lens = (a[lo - glo:hi - glo] for a in form_captions_batch(self.caps, [self.names[i] for i in order[glo:ghi]], num_captions, self.rng))
+            else:
+                ins, lab, lens = form_captions_batch(self.caps, names, num_captions, self.rng)
             if ins.ndim == 2:
                 ins, lab, lens = ins[:, None, :], lab[:, None, :], lens.reshape(-1, 1)
             cv = None
@@ -212,6 +228,15 @@ class Batch_Generator(object):
         for lo, hi in shard_ranges(len(names), self._batch_size, shard):
             yield self._sorted_for_array(names[lo:hi])
 
+    def _chunks_global(self, names, shard):
+        """data-parallel: (this rank's names, the names of the whole global batch in rank order, this rank's row range in it)"""
+        rank, world = shard
+        bs = self._batch_size
+        for lo, hi in shard_ranges(len(names), bs, shard):
+            glo, _ = global_range(lo, bs, shard)
+            per_rank = [self._sorted_for_array(names[glo + r * bs:glo + (r + 1) * bs]) for r in range(world)]
+            yield per_rank[rank], [n for pr in per_rank for n in pr], (rank * bs, (rank + 1) * bs)
+
     def _imid(self, names, test=False):
         if test:
             return [self._fn_to_id[n.split("/")[-1]] for n in names]
@@ -222,6 +247,12 @@ class Batch_Generator(object):
     def next_batch(self, use_obj_vectors=False, num_captions=1):
         c_v = self._cv_dict() if use_obj_vectors else None
         self.rng.shuffle(self._iterable)  # same seed on every rank: identical order, disjoint slices
+        if self.shard is not None:
+            for names, gnames, (r0, r1) in self._chunks_global(self._iterable, self.shard):
+                images, cl_v = self._images_c_v(names, c_v)
+                ins, lab, lens = (a[r0:r1] for a in self._captions_for(gnames, num_captions == 1, num_captions))   # T of the GLOBAL batch
+                yield images, (ins, lab), lens, cl_v
+            return
         for names in self._chunks(self._iterable, self.shard):
             images, cl_v = self._images_c_v(names, c_v)
             ins, lab, lens = self._captions_for(names, num_captions == 1, num_captions)
