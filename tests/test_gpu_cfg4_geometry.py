@@ -1,0 +1,232 @@
+"""-m gpu: the convolution kernels of the cfg4 bench AT THE GEOMETRY THAT IS TIMED (utils/image_embeddings.py:36-212 at 64 images per
+GPU: half-batch chains of 32 images for forward / data gradient, the full 64 for the weight gradient, ~25 000 workgroups through
+xcd_remap, four tile blocks per workgroup straddling image boundaries).
+
+ * every VGG16 layer shape at B = 32 and 64: Winograd forward (+ bias, ReLU, fused pool, mask bits), data gradient (float mask and
+   mask bits) and weight gradient, per element against the INDEPENDENT implicit-GEMM kernels of csrc/conv.hip on the device
+   (max-abs, 3e-6 sqrt(K) of the tensor maximum -- the tolerance the small-shape oracle tests use); conv1_1's own kernels likewise;
+ * the two widest shapes at B = 2 against the fp64 numpy oracle;
+ * a REAL call over the 2 GiB offset range ((168, 224, 224, 64, 64): 2.16 GB per tensor) against the cut-free results of its halves;
+ * one cfg4 Trainer step at 64 images on three streams against one stream (VC_VGG_STREAMS=1), bit for bit.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from .gpu_util import P, assert_close, dev, empty_bytes, host, stream, zeros
+
+pytestmark = pytest.mark.gpu
+
+from oracle import vgg as OV  # noqa: E402  (checker only)
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from vae_captioning_amd import abi
+    return abi.load()
+
+
+def _pack(lib, w, transpose):
+    wp = torch.empty(16 * w.shape[2] * w.shape[3], dtype=torch.float32, device="cuda")
+    lib.vc_conv3x3_wino_pack_f32(stream(), int(w.shape[2]), int(w.shape[3]), P(w), transpose, P(wp))
+    return wp
+
+
+def _maxerr(got, ref, tol, msg):
+    """max|got - ref| <= tol * max|ref| on the device (the tensors are up to 0.8 GB)."""
+    scale = float(ref.abs().max())
+    err = float((got - ref).abs().max())
+    assert np.isfinite(err) and scale > 0, msg
+    assert err <= tol * scale, "%s: max err %.3e > %.3e (tensor max %.3e)" % (msg, err, tol * scale, scale)
+
+
+# (layer, H = W, Cin, Cout, pooled): the eight distinct 3x3 shapes of VGG16 behind conv1_1
+LAYERS = [("conv1_2", 224, 64, 64, True), ("conv2_1", 112, 64, 128, False), ("conv2_2", 112, 128, 128, True), ("conv3_1", 56, 128, 256, False),
+          ("conv3_2", 56, 256, 256, False), ("conv4_1", 28, 256, 512, False), ("conv4_2", 28, 512, 512, True), ("conv5_2", 14, 512, 512, True)]
+
+
+@pytest.mark.parametrize("B", [32, 64])
+@pytest.mark.parametrize("layer", LAYERS, ids=lambda l: l[0])
+def test_winograd_layer_at_bench_batch_matches_implicit_gemm(lib, layer, B):
+    name, H, Ci, Co, pooled = layer
+    W = H
+    g = torch.Generator(device="cuda").manual_seed(B + H + Ci)
+    x = torch.rand(B, H, W, Ci, device="cuda", generator=g).sub_(0.4).clamp_(min=0)         # a post-ReLU activation: ~40 % zeros
+    w = (torch.rand(3, 3, Ci, Co, device="cuda", generator=g) - 0.5) * float(2.0 / np.sqrt(9 * Ci))
+    b = torch.rand(Co, device="cuda", generator=g) - 0.5
+    dy = torch.rand(B, H, W, Co, device="cuda", generator=g) - 0.5
+    ws = empty_bytes(max(lib.vc_conv3x3_fwd_workspace_bytes(B, H, W, Ci, Co), lib.vc_conv3x3_dgrad_workspace_bytes(B, H, W, Ci, Co),
+                         lib.vc_conv3x3_wgrad_workspace_bytes(B, H, W, Ci, Co), lib.vc_conv3x3_wino_wgrad_workspace_bytes(B, H, W, Ci, Co)))
+    wsb = ws.numel() * 4
+    st = stream()
+    assert lib.vc_conv3x3_wino_supported(B, H, W, Ci, Co, 0) == 1 and lib.vc_conv3x3_wino_supported(B, H, W, Ci, Co, 1) == 1
+    assert lib.vc_conv3x3_wino_single_launch_supported(B, H, W, Ci, Co) == 1
+    # ---- forward (+ bias, ReLU), fused pool, mask bits
+    wp, wpt = _pack(lib, w, 0), _pack(lib, w, 1)
+    y_ref, y = zeros(B, H, W, Co), zeros(B, H, W, Co)
+    lib.vc_conv3x3_fwd_f32(st, B, H, W, Ci, Co, P(x), P(w), P(b), P(y_ref), 1, P(ws), wsb)
+    yp = zeros(B, H // 2, W // 2, Co) if pooled else None
+    lib.vc_conv3x3_wino_fwd_f32(st, B, H, W, Ci, Co, P(x), P(wp), P(b), P(y), P(yp) if pooled else None, 1)
+    tol_f = 3e-6 * np.sqrt(9 * Ci)
+    _maxerr(y, y_ref, tol_f, "%s forward B=%d" % (name, B))
+    if pooled:
+        yp_ref = zeros(B, H // 2, W // 2, Co)
+        lib.vc_maxpool2x2_fwd_f32(st, B, H, W, Co, P(y), P(yp_ref))
+        assert torch.equal(yp, yp_ref), "%s: fused pool != max_pool2x2 of the kernel's own output" % name
+    bits = torch.zeros(lib.vc_conv3x3_wino_mask_words(B, H, W, Co), dtype=torch.int32, device="cuda")
+    y2 = zeros(B, H, W, Co)
+    lib.vc_conv3x3_wino_fwd_mask_f32(st, B, H, W, Ci, Co, P(x), P(wp), P(b), P(y2), 1, P(bits))
+    assert torch.equal(y, y2), "%s: the mask-bit forward writes another y" % name
+    del y2
+    # ---- data gradient of THIS layer (ReluGrad of its input x): float mask against the implicit-GEMM kernel
+    dx_ref, dx = zeros(B, H, W, Ci), zeros(B, H, W, Ci)
+    lib.vc_conv3x3_dgrad_f32(st, B, H, W, Ci, Co, P(dy), P(w), P(x), P(dx_ref), P(ws), wsb)
+    lib.vc_conv3x3_wino_dgrad_f32(st, B, H, W, Ci, Co, P(dy), P(wpt), P(x), P(dx))
+    tol_d = 3e-6 * np.sqrt(9 * Co)
+    _maxerr(dx, dx_ref, tol_d, "%s data gradient B=%d" % (name, B))
+    assert float((dx == 0).float().mean()) > 0.3   # the ReLU mask does mask
+    # ---- data gradient of the NEXT layer with THIS layer's mask bits (the pairing the trainer uses: a [Co -> Co] layer on y)
+    if Ci == Co:
+        dn_ref, dn = zeros(B, H, W, Co), zeros(B, H, W, Co)
+        lib.vc_conv3x3_wino_dgrad_f32(st, B, H, W, Co, Co, P(dy), P(wpt), P(y), P(dn_ref))
+        lib.vc_conv3x3_wino_dgrad_bits_f32(st, B, H, W, Co, Co, P(dy), P(wpt), P(bits), P(dn))
+        assert torch.equal(dn, dn_ref), "%s: mask bits != float mask" % name
+        del dn, dn_ref
+    del dx, dx_ref, y_ref
+    # ---- weight + bias gradient
+    dw_ref, dw, db_ref, db = zeros(3, 3, Ci, Co), zeros(3, 3, Ci, Co), zeros(Co), zeros(Co)
+    lib.vc_conv3x3_wgrad_f32(st, B, H, W, Ci, Co, P(x), P(dy), P(dw_ref), P(db_ref), 0, P(ws), wsb)
+    lib.vc_conv3x3_wino_wgrad_f32(st, B, H, W, Ci, Co, P(x), P(dy), P(dw), P(db), 0, P(ws), wsb)
+    tol_w = 3e-6 * np.sqrt(B * H * W)
+    _maxerr(dw, dw_ref, tol_w, "%s weight gradient B=%d" % (name, B))
+    _maxerr(db, db_ref, tol_w, "%s bias gradient B=%d" % (name, B))
+
+
+@pytest.mark.parametrize("B", [32, 64])
+def test_conv1_1_at_bench_batch_matches_implicit_gemm(lib, B):
+    H = W = 224
+    g = torch.Generator(device="cuda").manual_seed(B)
+    x4 = torch.rand(B, H, W, 4, device="cuda", generator=g) * 255 - 120
+    x4[..., 3] = 0
+    w = (torch.rand(3, 3, 3, 64, device="cuda", generator=g) - 0.5) * 0.02
+    b = torch.rand(64, device="cuda", generator=g) - 0.5
+    dy = torch.rand(B, H, W, 64, device="cuda", generator=g) - 0.5
+    w4 = zeros(3, 3, 4, 64)
+    w4[:, :, :3] = w
+    ws = empty_bytes(max(lib.vc_conv3x3_fwd_workspace_bytes(B, H, W, 4, 64), lib.vc_conv3x3_wgrad_workspace_bytes(B, H, W, 4, 64),
+                         lib.vc_conv1_wgrad_workspace_bytes()))
+    wsb, st = ws.numel() * 4, stream()
+    assert lib.vc_conv1_supported(B, H, W) == 1
+    y_ref, y = zeros(B, H, W, 64), zeros(B, H, W, 64)
+    lib.vc_conv3x3_fwd_f32(st, B, H, W, 4, 64, P(x4), P(w4), P(b), P(y_ref), 1, P(ws), wsb)
+    lib.vc_conv1_fwd_f32(st, B, H, W, P(x4), P(w), P(b), P(y), 1)
+    _maxerr(y, y_ref, 3e-6 * np.sqrt(27), "conv1_1 forward B=%d" % B)
+    del y, y_ref
+    dw4, db_ref, dw, db = zeros(3, 3, 4, 64), zeros(64), zeros(3, 3, 3, 64), zeros(64)
+    lib.vc_conv3x3_wgrad_f32(st, B, H, W, 4, 64, P(x4), P(dy), P(dw4), P(db_ref), 0, P(ws), wsb)
+    lib.vc_conv1_wgrad_f32(st, B, H, W, P(x4), P(dy), P(dw), P(db), 0, P(ws), wsb)
+    _maxerr(dw, dw4[:, :, :3].contiguous(), 3e-6 * np.sqrt(B * H * W), "conv1_1 weight gradient B=%d" % B)
+    _maxerr(db, db_ref, 3e-6 * np.sqrt(B * H * W), "conv1_1 bias gradient B=%d" % B)
+
+
+@pytest.mark.parametrize("case", [(2, 224, 224, 64, 64), (2, 112, 112, 128, 128)], ids=lambda c: "x".join(map(str, c)))
+def test_wide_layers_match_the_fp64_oracle(lib, case):
+    """The 224- and 112-wide layers per element against oracle/vgg.py (the small-shape cases of test_gpu_conv_wino.py stop at 56)."""
+    B, H, W, Ci, Co = case
+    rng = np.random.default_rng(sum(case))
+    x = np.maximum(rng.standard_normal((B, H, W, Ci), dtype=np.float32), 0)
+    w = rng.standard_normal((3, 3, Ci, Co), dtype=np.float32) * np.float32(1 / np.sqrt(9 * Ci))
+    b = rng.standard_normal(Co, dtype=np.float32)
+    dy = rng.standard_normal((B, H, W, Co), dtype=np.float32)
+    x64, w64 = x.astype(np.float64), w.astype(np.float64)
+    pre = OV.conv3x3_fwd(x64, w64, b.astype(np.float64))
+    dxref, _, _ = OV.conv3x3_bwd(x64, w64, dy.astype(np.float64))
+    tx, tw, tdy = dev(x), dev(w), dev(dy)
+    wp, wpt = _pack(lib, tw, 0), _pack(lib, tw, 1)
+    y, yp, dx = zeros(B, H, W, Co), zeros(B, H // 2, W // 2, Co), zeros(B, H, W, Ci)
+    lib.vc_conv3x3_wino_fwd_f32(stream(), B, H, W, Ci, Co, P(tx), P(wp), P(dev(b)), P(y), P(yp), 1)
+    hy = host(y)
+    assert_close(hy, np.maximum(pre, 0), 3e-6 * np.sqrt(9 * Ci) + 1e-6, msg="wino fwd (+bias, relu)")
+    assert np.array_equal(host(yp), hy.reshape(B, H // 2, 2, W // 2, 2, Co).max(axis=(2, 4)))
+    lib.vc_conv3x3_wino_dgrad_f32(stream(), B, H, W, Ci, Co, P(tdy), P(wpt), P(tx), P(dx))
+    assert_close(host(dx), dxref * (x > 0), 3e-6 * np.sqrt(9 * Co) + 1e-6, msg="wino dgrad (+relu mask)")
+
+
+def test_a_real_call_over_two_gib_equals_its_halves(lib):
+    """(168, 224, 224, 64, 64): 2.16 GB per tensor, beyond the 2 GiB the kernels' 32-bit buffer offsets reach -- the library cuts the
+    call into launches over image ranges (167 + 1 images).  Forward (+ fused pool) and data gradient must equal the cut-free results
+    of the two 84-image halves bit for bit (an image's tiles do not depend on the launch it is in); the weight gradient sums the
+    ranges in another order than the halves do: 1e-5 of its maximum."""
+    B, H, W, C = 168, 224, 224, 64
+    assert B * H * W * C * 4 > 2 ** 31
+    assert lib.vc_conv3x3_wino_single_launch_supported(B, H, W, C, C) == 0 and lib.vc_conv3x3_wino_single_launch_supported(B // 2, H, W, C, C) == 1
+    assert lib.vc_conv3x3_wino_supported(B, H, W, C, C, 0) == 1
+    g = torch.Generator(device="cuda").manual_seed(168)
+    x = torch.rand(B, H, W, C, device="cuda", generator=g).sub_(0.4).clamp_(min=0)
+    w = (torch.rand(3, 3, C, C, device="cuda", generator=g) - 0.5) * float(2.0 / np.sqrt(9 * C))
+    b = torch.rand(C, device="cuda", generator=g) - 0.5
+    wp, wpt = _pack(lib, w, 0), _pack(lib, w, 1)
+    st, h = stream(), B // 2
+    y, yp = zeros(B, H, W, C), zeros(B, H // 2, W // 2, C)
+    lib.vc_conv3x3_wino_fwd_f32(st, B, H, W, C, C, P(x), P(wp), P(b), P(y), P(yp), 1)
+    y2, yp2 = zeros(B, H, W, C), zeros(B, H // 2, W // 2, C)
+    for b0 in (0, h):
+        lib.vc_conv3x3_wino_fwd_f32(st, h, H, W, C, C, P(x[b0:]), P(wp), P(b), P(y2[b0:]), P(yp2[b0:]), 1)
+    assert torch.equal(y, y2) and torch.equal(yp, yp2)
+    assert float(y[-1].abs().max()) > 0 and float(y[h].abs().max()) > 0      # the last range (one image) and the seam were written
+    del y2, yp2, yp
+    dy = y   # any tensor of the right shape serves as the incoming gradient
+    dx, dx2 = zeros(B, H, W, C), zeros(B, H, W, C)
+    lib.vc_conv3x3_wino_dgrad_f32(st, B, H, W, C, C, P(dy), P(wpt), P(x), P(dx))
+    for b0 in (0, h):
+        lib.vc_conv3x3_wino_dgrad_f32(st, h, H, W, C, C, P(dy[b0:]), P(wpt), P(x[b0:]), P(dx2[b0:]))
+    assert torch.equal(dx, dx2)
+    del dx, dx2
+    ws = empty_bytes(lib.vc_conv3x3_wino_wgrad_workspace_bytes(B, H, W, C, C))
+    dw, db, dw2, db2 = zeros(3, 3, C, C), zeros(C), zeros(3, 3, C, C), zeros(C)
+    lib.vc_conv3x3_wino_wgrad_f32(st, B, H, W, C, C, P(x), P(dy), P(dw), P(db), 0, P(ws), ws.numel() * 4)
+    for i, b0 in enumerate((0, h)):
+        lib.vc_conv3x3_wino_wgrad_f32(st, h, H, W, C, C, P(x[b0:]), P(dy[b0:]), P(dw2), P(db2), i, P(ws), ws.numel() * 4)
+    _maxerr(dw, dw2, 1e-5, "weight gradient over the cut")
+    _maxerr(db, db2, 1e-5, "bias gradient over the cut")
+
+
+def test_cfg4_step_on_three_streams_equals_one_stream_bit_for_bit(lib):
+    """The bench's step: Normal CVAE + --fine_tune at 64 images (320 caption rows), VGG16 pushed through as two 32-image chains + the
+    weight gradients on a third stream (default) against VC_VGG_STREAMS=1 (one 64-image chain).  Per-image tiles, full-batch weight
+    gradients in both schedules: losses, every gradient and every updated parameter must be IDENTICAL."""
+    from vae_captioning_amd import spec, synth
+    from vae_captioning_amd.trainer import Trainer
+    from vae_captioning_amd.utils.parameters import Parameters
+    p = Parameters()
+    p.fine_tune, p.batch_size = True, 64
+    V, T, B = 10000, 20, 64
+    rng = np.random.default_rng(64)
+    batch = synth.make_batch(rng, B, p.num_captions, T, V, images=True)
+    P0 = {**spec.init_caption_params(p, V, seed=1), **spec.init_vgg_params(seed=2)}
+    res = []
+    old = os.environ.get("VC_VGG_STREAMS")
+    try:
+        for streams in ("3", "1"):
+            os.environ["VC_VGG_STREAMS"] = streams
+            tr = Trainer(p, V, lib=lib, seed=17)
+            assert (tr.vgg.side2 is not None) == (streams == "3")
+            tr.load_state_dict(P0)
+            tr.set_batch(batch)
+            for _ in range(2):
+                tr.train_step()
+            res.append((tr.losses(), tr.gall.clone(), tr.cap.store.p.clone(), tr.vgg.store.p.clone()))
+            del tr
+            torch.cuda.empty_cache()
+    finally:
+        if old is None:
+            os.environ.pop("VC_VGG_STREAMS", None)
+        else:
+            os.environ["VC_VGG_STREAMS"] = old
+    assert res[0][0] == res[1][0], (res[0][0], res[1][0])
+    assert all(np.isfinite(res[0][0]))
+    for i, what in ((1, "gradients"), (2, "caption parameters"), (3, "VGG16 parameters")):
+        assert torch.equal(res[0][i], res[1][i]), "%s differ: max |d| %.3e" % (what, float((res[0][i] - res[1][i]).abs().max()))
+    assert float(res[0][1].abs().max()) > 0
