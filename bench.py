@@ -62,6 +62,40 @@ def conv_flops_per_image():
     return macs
 
 
+def conv_algorithmic_bytes(images):
+    """Algorithmic HBM bytes of one cfg4 step's 3x3 convolution calls (fp32), the denominator of roofline.traffic_over_algorithmic:
+      forward        x [B,H,W,Ci] read + y [B,H,W,Co] written (+ the pooled copy [B,H/2,W/2,Co] behind conv1_2 / 2_2 / 3_3 / 4_3 / 5_3:
+                     the fused max-pool writes it from the same kernel) + the layer's 9 Ci Co weights + Co biases
+      data gradient  dy [B,H,W,Co] read + dx [B,H,W,Ci] written + the ReLU source: 1 bit per element of dx where the producer's forward
+                     left mask bits, else the float tensor [B,H,W,Ci]; none behind a pool (MaxPoolGrad applies it); no data gradient
+                     for conv1_1
+      weight grad    x and dy read, 9 Ci Co + Co written
+    Saved activations are the forward's y (counted once, as its write); Winograd-transformed tensors never touch HBM and do not count;
+    transformed WEIGHTS (16 Ci Co, re-packed once per step) count as the 9 Ci Co they stand for."""
+    from vae_captioning_amd import spec
+    H = 224
+    tot = 0.0
+    prev_pool = True   # conv1_1's input is the image: no data gradient
+    first = True
+    for name, ci, co in spec.VGG_CONV:
+        px = float(images) * H * H
+        wts = 9.0 * ci * co + co
+        cie = 4 if ci == 3 else ci   # conv1_1 reads the NHWC4 image
+        pooled = name in spec.VGG_POOL_AFTER
+        tot += 4 * (px * cie + px * co + (px / 4 * co if pooled else 0) + wts)          # forward
+        if not first:
+            mask = 0.0 if prev_pool else px * ci / 8.0 / 4.0                             # bits (in units of 4 bytes); the conv1_2 float mask below
+            if name == "conv1_2":
+                mask = px * ci
+            tot += 4 * (px * co + px * ci + mask + wts)                                  # data gradient
+        tot += 4 * (px * cie + px * co + wts)                                           # weight gradient
+        first = False
+        prev_pool = pooled
+        if pooled:
+            H //= 2
+    return tot
+
+
 def cpu_baseline(workload, w, seed):
     """Own CPU restatement (numpy oracle, NOT TF1 -- the reference cannot run here), timed on
     the host cores on a bounded sample of the same workload.  Uses oracle/ as the thing timed
@@ -115,13 +149,16 @@ def cpu_baseline(workload, w, seed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="cfg4", choices=sorted(WORKLOADS))
     ap.add_argument("--graph", type=int, default=0,
                     help="1: replay the step from a captured hipGraph (single GPU).  Default 0: eager launches, so the "
                          "dominant kernels can be bracketed by HIP events inside the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--strong-n1", type=int, default=1,
+                    help="cfg4 at N = 1 (weak): after the timed region also run the 512-image GLOBAL batch on this one GPU (1 warm-up + 3 timed "
+                         "steps, ~1 s) and report it as `strong_n1` -- SURVEY.md section 8d's single-GPU point of the strong-scaling curve")
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--images-per-gpu", type=int, default=0, help="override the workload's images per GPU (sweeps; the default is BASELINE's)")
     ap.add_argument("--fresh-batch", type=int, default=0, metavar="K",
@@ -168,6 +205,11 @@ def main():
     p = make_params(w)
     if args.num_captions:
         p.num_captions = args.num_captions
+    # The CPU baseline leg (rank 0, N = 1) runs FIRST: the GPU's timed region is then the last thing the process does (a driver
+    # that samples GPU activity over the whole run otherwise sees mostly the numpy baseline).
+    cpu_base = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not w.get("generate"):
+        cpu_base = cpu_baseline(args.workload, w, args.seed)
     vocab = args.vocab
     p.vocab_size = vocab
     if w.get("generate"):
@@ -251,6 +293,13 @@ def main():
         # PMC bytes are per STEP (the launch count per step depends on VC_VGG_STREAMS: half-batch launches)
         roof["traffic"] = round(t["bytes_per_step"] * (max(2, args.steps // 4) if instrumented_pass else args.steps) / roof["launches"]) if "bytes_per_step" in t else t.get("bytes_per_launch")
         roof["traffic_source"] = t.get("source")
+        if roof.get("traffic") and tr.vgg is not None:
+            # algorithmic bytes of one step's convolution calls (every call reads its input tensor and writes its
+            # output tensor once, + the ReLU source of a data gradient, the pooled copy of a pooled forward, the 3x3 weights)
+            alg = conv_algorithmic_bytes(B)
+            nsteps_t = max(2, args.steps // 4) if instrumented_pass else args.steps
+            roof["algorithmic_bytes_per_launch"] = round(alg * nsteps_t / roof["launches"])
+            roof["traffic_over_algorithmic"] = round(roof["traffic"] / roof["algorithmic_bytes_per_launch"], 3)
     out = {
         "metric": "captions/sec training (224x224, seq20, vocab~10k)",
         "value": round(N * world * args.steps / dt, 2),
@@ -270,13 +319,46 @@ def main():
     }
     if dp_info:
         out["data_parallel"] = dp_info
+    if cpu_base is not None:
+        out["cpu_baseline"] = cpu_base
+    if world == 1 and args.workload == "cfg4" and args.scaling == "weak" and args.strong_n1 and not args.images_per_gpu and not use_graph:
+        del tr
+        torch.cuda.empty_cache()
+        out["strong_n1"] = strong_n1_point(args, lib, w, vocab)
     if rank == 0:
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.workload, w, args.seed)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def strong_n1_point(args, lib, w, vocab, steps=3, warmup=1):
+    """The 512-image global batch of cfg4 on ONE GPU (the N = 1 point of the strong-scaling curve): a fresh
+    Trainer at 8 x the per-GPU batch, `warmup` untimed + `steps` timed steps in the same process as the headline line."""
+    import torch
+    from vae_captioning_amd import spec, synth
+    from vae_captioning_amd.trainer import Trainer
+    w8 = dict(w)
+    w8["B"] = 8 * w["B"]
+    p = make_params(w8)
+    rng = np.random.default_rng(args.seed + 512)
+    tr = Trainer(p, vocab, device="cuda", lib=lib, seed=args.seed)
+    tr.load_state_dict({**spec.init_caption_params(p, vocab, seed=1), **spec.init_vgg_params(seed=2)})
+    tr.set_batch(synth.make_batch(rng, w8["B"], p.num_captions, T_LEN, vocab, use_ci=spec.uses_ci(p), images=True))
+    for _ in range(warmup):
+        tr.train_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.train_step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kld, rec, lb, ann = tr.losses()
+    assert np.isfinite(rec) and np.isfinite(lb), "non-finite loss"
+    N = w8["B"] * p.num_captions
+    return {"images": w8["B"], "caption_rows": N, "steps": steps, "warmup": warmup, "ms_per_step": round(1000 * dt / steps, 3),
+            "value": round(N * steps / dt, 2), "unit": "captions/s",
+            "note": "cfg4's 512-image GLOBAL batch on one GPU (strong scaling, N = 1); calls over the 2 GiB buffer range run as launches over image ranges"}
 
 
 def bench_generation(args, torch, dist, lib, w, p, world, rank):
@@ -327,11 +409,13 @@ def bench_generation(args, torch, dist, lib, w, p, world, rank):
 
 
 def hbm_from_timer(timer):
-    """The HBM-bound kernels of the path (embedding gather, softmax cross-entropy, optimiser update): algorithmic bytes
-     / HIP-event duration, against the 8 TB/s HBM3E peak of MI355X_MICROARCH.md."""
+    """The HBM-bound kernels of the path (embedding gather, softmax cross-entropy, optimiser update, and cfg4's three fc1 products:
+    a [64, 25088] x [25088, 4096] GEMM moves its 411 MB weight matrix -- or writes its gradient -- once per call): algorithmic bytes
+    (fc1: weight matrix + both activations) / HIP-event duration, against the 8 TB/s HBM3E peak of
+    MI355X_MICROARCH.md."""
     sm = timer.summary()
     out = {}
-    for tag in ("hbm_embedding_gather", "hbm_softmax_xent", "hbm_adam"):
+    for tag in ("hbm_embedding_gather", "hbm_softmax_xent", "hbm_adam", "hbm_fc1_gemm"):
         if tag in sm and sm[tag]["seconds"] > 0:
             gbs = sm[tag]["flops"] / sm[tag]["seconds"] / 1e9
             out[tag[4:]] = {"launches": sm[tag]["launches"], "avg_us": round(1e6 * sm[tag]["seconds"] / sm[tag]["launches"], 2),
@@ -375,14 +459,14 @@ def wino_executed_ratio(images):
 def roofline_from_timer(timer, fine_tune, images=0):
     """Dominant kernel family: cfg4 = the 3x3 convolution calls (forward, data gradient, weight gradient; a call = its main
     launch + split reduce); caption-only workloads = the [T*N, H] x [H, V] logits GEMM.
-      achieved / frac        = ALGORITHMIC (direct-convolution) FLOPs / UNION of the calls' HIP-event intervals (= frac_union)
-      frac_serial            = algorithmic FLOPs / SUM of the calls' durations
-      executed / mfma_util   = the FLOPs the MFMAs actually execute (Winograd: 16 multiplications where the direct form has 36, plus
-                               block padding) / the same time, and that rate over the fp32 MFMA peak
-    With the Winograd kernels `frac` exceeds 1: they do the algorithm's work with 2.25x fewer multiplications (fp32 throughout);
-    `mfma_util` is the matrix-pipe utilisation.  With the default single VGG stream nothing overlaps and union = serial; both are
-    recomputable from the tracked rocprofv3 summary of the same command (profiles/*_kernel_stats.md ends with the family's summed
-    and union dispatch time, tools/rocpd_stats.py)."""
+      achieved / frac                     = the FLOPs the MFMAs EXECUTE (Winograd: 16 multiplications where the direct form has 36, plus
+                                            tile-block padding) / UNION of the calls' HIP-event intervals, over the dense fp32 MFMA peak:
+                                            the matrix-pipe utilisation, a fraction of the roofline
+      frac_serial                         = the same FLOPs / SUM of the calls' durations (equal to frac on one stream)
+      effective_tflops / frac_algorithmic = ALGORITHMIC (direct-convolution) FLOPs / the same union time: may exceed
+                                            the peak -- the Winograd kernels do the algorithm's work with 2.25x fewer multiplications (fp32)
+    Both are recomputable from the tracked rocprofv3 summary of the same command (profiles/*_kernel_stats.md ends with the family's
+    summed and union dispatch time, tools/rocpd_stats.py)."""
     tags = ["conv_fwd", "conv_dgrad", "conv_wgrad"] if fine_tune else ["logits_gemm"]
     sm = timer.summary(family=tags)
     fl = sum(sm[t]["flops"] for t in tags)
@@ -401,17 +485,22 @@ def roofline_from_timer(timer, fine_tune, images=0):
                 "(+ vc::conv1_fwd_kernel / vc::conv1_wgrad_kernel for conv1_1)")
     else:
         kern = "vc::conv_patch_kernel / vc::wgrad_patch_kernel (+ vc::conv1_fwd_kernel / vc::conv1_wgrad_kernel for conv1_1)"
+    ex = ach * ratio
     return {"bound": "mfma", "kernel": kern,
-            "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-            "frac_union": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "frac_serial": round(fl / ser / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-            "executed": round(ach * ratio, 2), "mfma_util": round(ach * ratio / PEAK_F32_MFMA_TFLOPS, 4), "executed_over_algorithmic": round(ratio, 4),
+            # achieved / frac: the FLOPs the MFMAs EXECUTE per second against the dense fp32 MFMA peak (a fraction of the roofline, < 1)
+            "achieved": round(ex, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ex / PEAK_F32_MFMA_TFLOPS, 4),
+            "frac_serial": round(fl * ratio / ser / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+            # the same time against the ALGORITHMIC (direct-convolution) FLOPs of SURVEY.md section 8d: what a direct kernel would have to sustain
+            "effective_tflops": round(ach, 2), "frac_algorithmic": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+            "executed_over_algorithmic": round(ratio, 4),
             "family_flops": fl, "family_seconds_union": round(sec, 6), "family_seconds_serial": round(ser, 6),
             "traffic": None, "launches": n, "avg_launch_us": round(1e6 * sec / n, 2), "per_kernel": per,
             "streams": int(os.environ.get("VC_VGG_STREAMS", "3")) if fine_tune else 1,
-            "note": "achieved = ALGORITHMIC (direct-convolution) FLOPs of the family's calls in the timed region / union of their HIP-event "
-                    "intervals (events recorded on the stream each call is launched on); executed = the FLOPs the MFMAs perform "
-                    "(Winograd F(2x2,3x3) / F(3x3,2x2), fp32: 16 multiplications per tile where the direct form has 36, + block padding): "
-                    "frac > 1 means fewer multiplications than the direct algorithm, mfma_util is the matrix-pipe utilisation"}
+            "note": "achieved = EXECUTED MFMA FLOPs of the family's calls in the timed region (Winograd F(2x2,3x3) / F(3x3,2x2), fp32: 16 "
+                    "multiplications per 2x2 tile and channel pair where the direct form has 36, + tile-block padding; = algorithmic FLOPs x "
+                    "executed_over_algorithmic) / union of the calls' HIP-event intervals (events recorded on the stream each call is "
+                    "launched on); frac = achieved / peak = matrix-pipe utilisation.  effective_tflops / frac_algorithmic price the same "
+                    "time against the direct-convolution FLOPs (> peak is possible: fewer multiplications, not a faster pipe)"}
 
 
 if __name__ == "__main__":

@@ -305,7 +305,9 @@ class VggEngine(object):
         self.flat = flat
         F1 = H * W * 512
         fc1 = self._b("fc1", (B, 4096))
-        self.gemm(0, 0, B, 4096, F1, flat, F1, S.param("cnn/fc1/weights"), 4096, fc1, 4096, S.param("cnn/fc1/biases"), 1)
+        fc1_bytes = 4.0 * (F1 * 4096 + B * F1 + B * 4096)   # the weight matrix (411 MB) + both activations: the product is HBM-bound at B <= 64
+        self._timed("hbm_fc1_gemm", fc1_bytes,
+                    lambda: self.gemm(0, 0, B, 4096, F1, flat, F1, S.param("cnn/fc1/weights"), 4096, fc1, 4096, S.param("cnn/fc1/biases"), 1))
         fc2 = self._b("fc2", (B, 4096))
         if self.keep < 1:
             if not self.inject:
@@ -350,10 +352,11 @@ class VggEngine(object):
         self.gemm(0, 1, B, 4096, 4096, d2, 4096, S.param("cnn/fc2/weights"), 4096, d1, 4096)
         lib.vc_relu_bwd_f32(st, P(d1), P(self.buf["fc1"]), m1, self.keep, B * 4096, P(d1))
         F1 = self.flat.numel() // B
-        self.gemm(1, 0, F1, 4096, B, self.flat, F1, d1, 4096, S.grad("cnn/fc1/weights"), 4096)
+        fc1_bytes = 4.0 * (F1 * 4096 + B * F1 + B * 4096)
+        self._timed("hbm_fc1_gemm", fc1_bytes, lambda: self.gemm(1, 0, F1, 4096, B, self.flat, F1, d1, 4096, S.grad("cnn/fc1/weights"), 4096))
         self.colsum(d1, B, 4096, S.grad("cnn/fc1/biases"))
         d = self._b("d_pool5", tuple(self.flat.shape))
-        self.gemm(0, 1, B, F1, 4096, d1, 4096, S.param("cnn/fc1/weights"), 4096, d, F1)
+        self._timed("hbm_fc1_gemm", fc1_bytes, lambda: self.gemm(0, 1, B, F1, 4096, d1, 4096, S.param("cnn/fc1/weights"), 4096, d, F1))
         if after_fc is not None:
             after_fc()
         dw4 = self._b("dw1_4", (3, 3, 4, 64))
