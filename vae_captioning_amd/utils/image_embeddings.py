@@ -10,10 +10,21 @@ from .parameters import Parameters
 
 class vgg16(object):
     def __init__(self, imgs, weight_file=None, sess=None, trainable_fe=False, trainable_top=False, dropout_keep=1.0,
-                 engine=None):
+                 engine=None, params=None):
         """imgs: [B, 224, 224, 3] float RGB 0..255 (numpy or device tensor).  `sess` is accepted for
-        signature compatibility and ignored (there is no session: execution is eager)."""
+        signature compatibility and ignored (there is no session: execution is eager).  params: build on the VGG16 of that
+        Parameters object's session (main.py:74-78 inside the training graph): `.fc2` then runs the session's engine with its step
+        counter (dropout stream) and the images become part of the step's batch."""
         self.imgs = imgs
+        self._session = None
+        if params is not None:
+            from .. import session
+            tr = session.get(params)
+            if tr.vgg is None:
+                raise ValueError("vgg16(params=...): the session has no VGG16 (params.fine_tune is off)")
+            engine = tr.vgg
+            self._session = tr
+            session.stage(params, images=imgs)
         self.dropout_keep = dropout_keep
         self.trainable_fe = trainable_fe
         self.trainable_top = trainable_top
@@ -34,6 +45,8 @@ class vgg16(object):
         return torch.from_numpy(np.ascontiguousarray(imgs, dtype=np.float32)).cuda()
 
     def forward(self, imgs=None, step=None):
+        if step is None and self._session is not None:
+            step = self._session.cap.step
         return self.engine.forward(self._images(self.imgs if imgs is None else imgs), step)
 
     @property

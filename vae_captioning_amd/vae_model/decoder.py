@@ -9,6 +9,11 @@ from ..generate import CaptionGenerator
 
 class Decoder(object):
     def __init__(self, images_fv, captions, lengths, params, data_dict):
+        """images_fv: layers.dense(..., name='imf_emb'); captions: cap_dec [N, T] int (`<BOS>...`, 0-padded); lengths [N]
+        (vae_model/decoder.py:13-20).  Arrays given here are what the step runs on (session.bind)."""
+        from .encoder import check_images_fv
+        check_images_fv(images_fv)
+        session.stage(params, cap_dec=captions, lengths=lengths)
         self.images_fv = images_fv
         self.captions = captions
         self.lengths = lengths
@@ -24,7 +29,15 @@ class Decoder(object):
         encoder's sample held by the shared engine (zs.BayesianNet(observed) semantics)."""
         if gen_mode:
             raise ValueError("generation runs through online_inference / beam_search")
-        eng = session.get(self.params).cap
+        tr = session.get(self.params)
+        eng = tr.cap
+        if session.staged(self.params) and not eng.enc:   # --no_encoder: no q_net ran, this is the first stage of the step
+            if self.c_i_ph is not None:
+                session.stage(self.params, c_v=self.c_i_ph)
+            feats = session.bind(self.params)
+            if tr.vgg is not None and tr.vgg.wd:
+                tr.vgg.reg_sumsq(eng.red.data_ptr() + 12)
+            eng.fw_prepare(feats)
         logits = eng.fw_decode()
         nid = eng.n_init_d
         hs, cs = eng.buf["hs_d"], eng.buf["cs_d"]
