@@ -264,6 +264,8 @@ def main():
         from vae_captioning_amd import dp as dpm
         bk = dpm.gradient_buckets(tr.n_cap, tr.gall.numel(), tr.off_fc, tr.off_c3)
         dp_info = {"backend": backend, "rccl_world_size": dist.get_world_size(), "all_reduce_bytes_per_step": int(tr.gall.numel() * 4),
+                   "collectives": ("libvaecap C ABI (vc_allreduce_sum_f32 / vc_allgather_f32 / vc_reducescatter_sum_f32), RCCL %d" % tr.comm.rccl_version)
+                                  if tr.comm is not None else "torch.distributed (%s)" % backend,
                    "buckets_bytes": [int((b - a) * 4) for a, b in bk] if (tr.buckets and tr.vgg is not None) else [int(tr.gall.numel() * 4)]}
         if tr.dp_stats:
             torch.cuda.synchronize()
@@ -271,6 +273,23 @@ def main():
             for i, nbytes, e0, e1 in tr.dp_stats:
                 waits.setdefault(i, []).append(e0.elapsed_time(e1))
             dp_info["bucket_wait_ms"] = [round(float(np.mean(waits[i])), 4) for i in sorted(waits)]
+        # exposed communication = step - compute-only step (the same step with every collective muted), max over ranks like the step time
+        tr.dp_stats = None
+        restore = tr.mute_collectives()
+        nco = max(5, args.steps // 5)
+        for _ in range(2):
+            tr.train_step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t1 = time.perf_counter()
+        for _ in range(nco):
+            tr.train_step()
+        torch.cuda.synchronize()
+        tco = torch.tensor([time.perf_counter() - t1], device="cuda", dtype=torch.float64)
+        restore()
+        dist.all_reduce(tco, op=dist.ReduceOp.MAX)
+        dp_info["compute_only_ms_per_step"] = round(1000 * float(tco.item()) / nco, 3)
+        dp_info["exposed_comm_ms"] = round(1000 * dt / args.steps - dp_info["compute_only_ms_per_step"], 3)
 
     # ---- roofline of the dominant kernel family from the HIP events of the timed region
     instrumented_pass = False

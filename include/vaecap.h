@@ -356,6 +356,30 @@ int vc_beam_update(void* stream, int B, int beam, int Lmax, int eos, double len_
  * ---------------------------------------------------------------------------------- */
 int vc_host_crc32c(const void* data, size_t nbytes, uint32_t* crc_inout);
 
+/* ------------------------------------------------------------------------------------
+ * Collectives of the data-parallel step (RCCL over xGMI; csrc/comm.hip).  The reference is single-GPU
+ * (utils/parameters.py:163-164 picks one device): these have no counterpart there.  One process per GPU; rank 0 calls
+ * vc_comm_unique_id and hands the 128 bytes to every rank out of band (a file, the launcher's store, MPI ...); every rank then calls
+ * vc_comm_init_rank (collective: returns when all `world` ranks have joined).  RCCL is bound at run time (the process's
+ * already-loaded librccl.so.1 if there is one -- PyTorch bundles its own --, else the ROCm install; VC_RCCL_LIB overrides), so a
+ * single-GPU user needs none.  All calls are stream-ordered on `stream` and in place / out of place as declared; any RCCL failure
+ * (incl. an asynchronous error an earlier collective left on the communicator) is a non-zero return with the RCCL message in
+ * vc_last_error(), and a destroyed / aborted communicator is refused instead of dereferenced.
+ *   vc_allreduce_sum_f32      buf[n] <- sum over ranks, in place: the gradient buffer (or one bucket of it), the CE denominator,
+ *                             the loss scalars (trainer.py, engine.py: fw_loss)
+ *   vc_allgather_f32          out[world * n_per_rank] <- rank-ordered concatenation of in[n_per_rank]: mean / std of the global batch
+ *                             before the Q1-mixed latent sample (vae_model/decoder.py:109-110 reshapes across rows)
+ *   vc_reducescatter_sum_f32  out[n_per_rank] <- this rank's slice of the sum of in[world * n_per_rank]: the gradients of that mix */
+int vc_comm_available(void);                                   /* 1: an RCCL library can be loaded */
+int vc_comm_unique_id(void* id128);                            /* rank 0: 128 bytes to distribute */
+int vc_comm_init_rank(int world, int rank, const void* id128, int device, void** comm_out);
+int vc_comm_info(void* comm, int* world, int* rank, int* rccl_version);
+int vc_comm_destroy(void* comm);
+int vc_comm_abort(void* comm);
+int vc_allreduce_sum_f32(void* comm, void* stream, float* buf, size_t n);
+int vc_allgather_f32(void* comm, void* stream, const float* in, float* out, size_t n_per_rank);
+int vc_reducescatter_sum_f32(void* comm, void* stream, const float* in, float* out, size_t n_per_rank);
+
 #ifdef __cplusplus
 }
 #endif

@@ -242,6 +242,16 @@ def test_bench_two_ranks_through_torchrun_on_one_gpu(tmp_path):
     # the workload description survives the data-parallel statistics (a local of the bucket-wait summary once shadowed it)
     assert d["config"]["workload"].startswith("cfg4: {") and '"fine_tune": true' in d["config"]["workload"]
     assert len(d["data_parallel"]["bucket_wait_ms"]) == 4 and d["data_parallel"]["rccl_world_size"] == 2
+    assert d["data_parallel"]["collectives"].startswith("torch.distributed") and d["data_parallel"]["compute_only_ms_per_step"] > 0
+    assert "exposed_comm_ms" in d["data_parallel"]
+    # VC_DP_COMM=abi asks for libvaecap's own RCCL communicator: RCCL refuses two ranks on ONE GPU (vc_comm_init_rank -> non-zero code with
+    # RCCL's message on both ranks), the ranks agree on that and fall back to torch.distributed together -- same JSON line, a notice on rank 0
+    cmd[cmd.index("cfg4")] = "cfg2"
+    r = subprocess.run(cmd, cwd=tmp_path, env=dict(env, VC_DP_COMM="abi"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "libvaecap communicator not available on every rank" in r.stdout and "ncclCommInitRank failed" in r.stdout
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and np.isfinite(d["final_losses"]["rec_loss"]) and d["data_parallel"]["collectives"].startswith("torch.distributed")
 
 
 def test_gen_caption_cli_single_image(tmp_path, lib):

@@ -177,7 +177,7 @@ def test_bucketed_async_allreduce_equals_single_allreduce_on_rccl(lib):
         P0 = {**spec.init_caption_params(p, V, seed=1), **spec.init_vgg_params(seed=3)}
         res = []
         for force, buckets in ((False, False), (True, False), (True, True)):
-            tr = Trainer(p, V, lib=lib, force_collectives=force, seed=5)
+            tr = Trainer(p, V, lib=lib, force_collectives=force, seed=5, comm="torch")   # (the libvaecap communicator: tests/test_gpu_comm.py)
             tr.buckets = buckets
             tr.load_state_dict(P0)
             tr.set_batch(batch)
@@ -206,7 +206,7 @@ def test_collective_code_path_on_a_one_rank_rccl_group(lib):
         P0, batch, noise = make_case(p, V, B, T, seed=13)
         res = []
         for force in (False, True):
-            tr = Trainer(p, V, lib=lib, force_collectives=force)
+            tr = Trainer(p, V, lib=lib, force_collectives=force, comm="torch")
             tr.load_state_dict(P0)
             for _ in range(2):
                 tr.set_batch(batch, noise)

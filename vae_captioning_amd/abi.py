@@ -21,6 +21,7 @@ _CTYPES = {
     "int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float,
     "size_t": ctypes.c_size_t, "uint64_t": ctypes.c_uint64,
     "const char*": ctypes.c_char_p,
+    "void**": ctypes.c_void_p, "int*": ctypes.c_void_p,
 }
 
 
@@ -68,7 +69,7 @@ class Lib(object):
             raw = getattr(self._cdll, name)
             raw.argtypes = [_CTYPES[t] for t, _ in args]
             raw.restype = _CTYPES[ret]
-            if ret == "int" and name not in ("vc_abi_version", "vc_sumsq_blocks", "vc_embedding_index_max_vocab") and not name.endswith("_supported"):  # value-returning ints
+            if ret == "int" and name not in ("vc_abi_version", "vc_sumsq_blocks", "vc_embedding_index_max_vocab", "vc_comm_available") and not name.endswith("_supported"):  # value-returning ints
                 def fn(*a, _raw=raw, _name=name):
                     rc = _raw(*a)
                     if rc != 0:

@@ -78,3 +78,96 @@ def gradient_buckets(n_cap, n_total, off_fc=None, off_c3=None):
     if off_fc is None or n_total == n_cap:
         return [(0, n_total)]
     return [(0, n_cap), (off_fc, n_total), (off_c3, off_fc), (n_cap, off_c3)]
+
+
+class _Pending(object):
+    """Handle of an asynchronous collective: wait() makes the CURRENT stream wait for it (no host block)."""
+
+    def __init__(self, event):
+        self.event = event
+
+    def wait(self):
+        import torch
+        torch.cuda.current_stream().wait_event(self.event)
+
+
+class AbiComm(object):
+    """The step's collectives through libvaecap's own RCCL entries (include/vaecap.h: vc_comm_*, vc_allreduce_sum_f32,
+    vc_allgather_f32, vc_reducescatter_sum_f32) -- what a maintainer binding the C ABI gets; torch.distributed is not involved in
+    the data path (it may carry the 128-byte unique id to the other ranks, `from_store`).  Every collective of the communicator runs
+    on ONE dedicated HIP stream in issue order; it waits for the issuing stream's work, and the issuing stream waits for it (blocking
+    form) or for its event (`*_async(...).wait()`).  A failing call raises abi.VaecapError with RCCL's message: the step aborts."""
+    _serial = 0
+
+    def __init__(self, lib, world, rank, device, id_bytes):
+        import ctypes
+        import torch
+        self.lib, self.world, self.rank = lib, int(world), int(rank)
+        h = ctypes.c_void_p()
+        buf = ctypes.create_string_buffer(bytes(id_bytes), 128)
+        lib.vc_comm_init_rank(self.world, self.rank, buf, int(device), ctypes.byref(h))
+        self.h = h
+        self.stream = torch.cuda.Stream(device=device)
+        ver = ctypes.c_int(0)
+        lib.vc_comm_info(self.h, None, None, ctypes.byref(ver))
+        self.rccl_version = int(ver.value)
+
+    @staticmethod
+    def unique_id(lib):
+        import ctypes
+        buf = ctypes.create_string_buffer(128)
+        lib.vc_comm_unique_id(buf)
+        return buf.raw
+
+    @classmethod
+    def from_store(cls, lib, world, rank, device):
+        """Rank 0 creates the unique id; it travels through torch.distributed's rendezvous store (host side, any backend)."""
+        import torch.distributed as dist
+        store = dist.distributed_c10d._get_default_store()
+        key = "vc_rccl_unique_id_%d" % cls._serial
+        cls._serial += 1
+        if rank == 0:
+            uid = cls.unique_id(lib)
+            store.set(key, uid)
+        else:
+            uid = store.get(key)
+        return cls(lib, world, rank, device, uid)
+
+    @classmethod
+    def single(cls, lib, device=0):
+        """A one-rank communicator (tests; the collective branches then run through RCCL with nobody to talk to)."""
+        return cls(lib, 1, 0, device, cls.unique_id(lib))
+
+    def _issue(self, fn):
+        import torch
+        main = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(main)
+        self.stream.wait_event(ev)
+        fn(self.stream.cuda_stream)
+        done = torch.cuda.Event()
+        done.record(self.stream)
+        return _Pending(done)
+
+    def all_reduce_async(self, t):
+        assert t.is_contiguous() and t.dtype.is_floating_point and t.element_size() == 4
+        return self._issue(lambda st: self.lib.vc_allreduce_sum_f32(self.h, st, t.data_ptr(), t.numel()))
+
+    def all_reduce(self, t):
+        self.all_reduce_async(t).wait()
+
+    def all_gather(self, out, inp):
+        assert out.numel() == inp.numel() * self.world and out.is_contiguous() and inp.is_contiguous()
+        self._issue(lambda st: self.lib.vc_allgather_f32(self.h, st, inp.data_ptr(), out.data_ptr(), inp.numel())).wait()
+
+    def reduce_scatter(self, out, inp):
+        assert inp.numel() == out.numel() * self.world and out.is_contiguous() and inp.is_contiguous()
+        self._issue(lambda st: self.lib.vc_reducescatter_sum_f32(self.h, st, inp.data_ptr(), out.data_ptr(), out.numel())).wait()
+
+    def destroy(self):
+        if self.h is not None:
+            self.stream.synchronize()
+            self.lib.vc_comm_destroy(self.h)
+
+    def abort(self):
+        self.lib.vc_comm_abort(self.h)

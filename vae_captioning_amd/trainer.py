@@ -478,7 +478,11 @@ class Trainer(object):
     """One training step = main.py:241-244's sess.run([kld, rec_loss, lower_bound, optimize,
     optimize_cnn, annealing])."""
 
-    def __init__(self, p, vocab, device="cuda", lib=None, world=1, rank=0, group=None, seed=0, force_collectives=False):
+    def __init__(self, p, vocab, device="cuda", lib=None, world=1, rank=0, group=None, seed=0, force_collectives=False, comm="auto"):
+        """comm: how the data-parallel collectives run.  "abi" = libvaecap's own RCCL entries (dp.AbiComm: vc_allreduce_sum_f32 ...);
+        "torch" = torch.distributed on `group`; "auto" = "abi" when the collectives are on and the process group is RCCL-backed
+        (backend "nccl") or there is no process group at all (one forced rank), "torch" otherwise (the gloo test path).
+        An existing dp.AbiComm may be passed instead."""
         self.p, self.lib = p, (lib or abi.load())
         self.collectives = world > 1 or force_collectives
         self.world, self.rank, self.group = world, rank, group
@@ -508,6 +512,46 @@ class Trainer(object):
         self.buckets = os.environ.get("VC_DP_BUCKETS", "1") != "0"
         self.off_fc = n_cap + self.vgg.store.offset("cnn/fc1/weights") if self.vgg is not None else None
         self.off_c3 = n_cap + self.vgg.store.offset("cnn/conv3_1/weights") if self.vgg is not None else None
+        self.comm = None
+        if self.collectives:
+            self._setup_comm(comm)
+
+    def _setup_comm(self, comm):
+        import torch.distributed as dist
+        from . import dp
+        if isinstance(comm, dp.AbiComm):
+            self.comm = comm
+        else:
+            if comm == "auto":
+                env = os.environ.get("VC_DP_COMM", "")
+                if env in ("abi", "torch"):
+                    comm = env
+                elif dist.is_available() and dist.is_initialized():
+                    comm = "abi" if dist.get_backend(self.group) == "nccl" else "torch"
+                else:
+                    comm = "abi" if self.world == 1 else "torch"
+            if comm == "abi":
+                dev = torch.cuda.current_device()
+                if self.world == 1:
+                    self.comm = dp.AbiComm.single(self.lib, dev)
+                else:
+                    # every rank must end up on the same path: the ranks agree (through the process group) whether the communicator came
+                    # up everywhere; if not (e.g. RCCL refuses two ranks on one GPU), all of them use torch.distributed instead
+                    err = None
+                    try:
+                        self.comm = dp.AbiComm.from_store(self.lib, self.world, self.rank, dev)
+                    except abi.VaecapError as e:
+                        err = e
+                    flag = torch.tensor([0.0 if err else 1.0], device="cuda" if dist.get_backend(self.group) == "nccl" else "cpu")
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+                    if float(flag.item()) == 0.0:
+                        if self.comm is not None:
+                            self.comm.destroy()
+                            self.comm = None
+                        if self.rank == 0:
+                            print("libvaecap communicator not available on every rank (%s): collectives through torch.distributed" % (err or "another rank failed"), flush=True)
+        if self.comm is not None:   # the engine's collective hooks go through the C ABI
+            self.cap.reduce_fn, self.cap.gather_fn, self.cap.rscatter_fn = self.comm.all_reduce, self.comm.all_gather, self.comm.reduce_scatter
 
     def set_batch(self, batch, noise=None):
         extra = [("images", np.asarray(batch["images"], np.float32), torch.float32)] if self.fine else []
@@ -555,7 +599,23 @@ class Trainer(object):
     def reduce_async_fn(self):
         if getattr(self.cap, "_fake_collectives", False):
             return None
+        if self.comm is not None:
+            return self.comm.all_reduce_async
         return lambda t: torch.distributed.all_reduce(t, group=self.group, async_op=True)
+
+    def mute_collectives(self):
+        """Replace every collective of the step by a no-op (timing only: bench.py measures the compute-only step to report the
+        exposed communication time = step - compute-only step).  Returns the function that restores them."""
+        cap = self.cap
+        saved = (cap.reduce_fn, cap.gather_fn, cap.rscatter_fn, cap.__dict__.get("_fake_collectives", False))
+        cap.reduce_fn = lambda t: None
+        cap.gather_fn = lambda out, inp: None
+        cap.rscatter_fn = lambda out, inp: out.copy_(inp.view(-1)[:out.numel()].view_as(out))
+        cap._fake_collectives = True   # (no asynchronous bucket pieces either)
+
+        def restore():
+            cap.reduce_fn, cap.gather_fn, cap.rscatter_fn, cap._fake_collectives = saved
+        return restore
 
     def all_reduce_grads(self):
         if self.collectives:
