@@ -449,9 +449,12 @@ def _cdiv(a, b):
 def wino_executed_ratio(images):
     """Executed MFMA FLOPs / algorithmic FLOPs of one cfg4 step's 3x3 convolution calls when the Winograd kernels run (default):
     F(2x2,3x3) / F(3x3,2x2) multiply 16 times per 2x2 tile and channel pair where the direct form multiplies 36 times; tile blocks
-    that stick out of the image (csrc/conv_wino.hip plan_wino / plan_wino_wgrad: 32 tile slots per block) add padding work.
-    conv1_1 (3 input channels) stays on its direct HBM-bound kernels."""
+    that stick out of the image add padding work.  Forward / data gradient (csrc/conv_wino2.hip plan_wino2): blocks of 16 tile slots
+    whose halo patch fits 100 pixels (VC_WINO_KERNEL=1, the round-2 kernel: 32 slots, 180 pixels); weight gradient
+    (conv_wino_wgrad.hip plan_wino_wgrad): 4x8 / 4x7 / 2x14 tiles.  conv1_1 (3 input channels) stays on its direct HBM-bound kernels."""
     from vae_captioning_amd import spec
+    v1 = os.environ.get("VC_WINO_KERNEL") == "1"
+    slots, maxpix = (32, 180) if v1 else (16, 100)
     H = 224
     alg = ex = 0.0
     for name, ci, co in spec.VGG_CONV:
@@ -461,12 +464,12 @@ def wino_executed_ratio(images):
             alg += 2 * fl
             ex += 2 * fl
         else:
-            best = 0.0   # forward / data gradient: the block shape with the fewest empty slots (TBH = min(32 // TBW, 8))
+            best = 0.0   # forward / data gradient: the block shape with the fewest empty slots
             for tbw in range(1, min(16, tw) + 1):
-                tbh = min(32 // tbw, 8, th)
-                if (2 * tbh + 2) * (2 * tbw + 2) > 180:
+                tbh = min(slots // tbw, 8, th) if v1 else min(slots // tbw, th)
+                if tbh < 1 or (2 * tbh + 2) * (2 * tbw + 2) > maxpix:
                     continue
-                best = max(best, tw * th / (_cdiv(tw, tbw) * _cdiv(th, tbh) * 32.0))
+                best = max(best, tw * th / (_cdiv(tw, tbw) * _cdiv(th, tbh) * float(slots)))
             effw = max(tw * th / (_cdiv(tw, bw) * _cdiv(th, bh) * float(bh * bw)) for bh, bw in ((4, 8), (4, 7), (2, 14)))
             alg += 3 * fl
             ex += 2 * fl * (16.0 / 36.0) / best + fl * (16.0 / 36.0) / effw
@@ -500,7 +503,7 @@ def roofline_from_timer(timer, fine_tune, images=0):
     if not fine_tune:
         kern = "vc::gemm_kernel<128x128,MK,KM> (logits)"
     elif wino:
-        kern = ("vc::conv_wino_kernel (Winograd F(2x2,3x3) forward / data gradient) / vc::wino_wgrad_kernel (F(3x3,2x2) weight gradient) "
+        kern = ("vc::conv_wino2_kernel (Winograd F(2x2,3x3) forward / data gradient) / vc::wino_wgrad_kernel (F(3x3,2x2) weight gradient) "
                 "(+ vc::conv1_fwd_kernel / vc::conv1_wgrad_kernel for conv1_1)")
     else:
         kern = "vc::conv_patch_kernel / vc::wgrad_patch_kernel (+ vc::conv1_fwd_kernel / vc::conv1_wgrad_kernel for conv1_1)"

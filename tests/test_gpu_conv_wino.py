@@ -2,6 +2,8 @@
 input / output transforms fused around sixteen MFMA position products, weights transformed once per step) against the fp64 numpy
 oracle, through the C ABI.  Tolerance: 3e-6 * sqrt(K) of the tensor max, K = 9*C (the direct kernels are held to 2e-6 * sqrt(K);
 the Winograd transforms add a few more fp32 roundings per term)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -30,13 +32,17 @@ def test_wino_pack_is_G_g_Gt(lib):
     Ci, Co = 32, 64
     w = rng.standard_normal((3, 3, Ci, Co), dtype=np.float32)
     G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]])
+    v1 = os.environ.get("VC_WINO_KERNEL") == "1"
     for transpose in (0, 1):
         g = w.astype(np.float64) if not transpose else w[::-1, ::-1].transpose(0, 1, 3, 2).astype(np.float64)
         C, N = g.shape[2], g.shape[3]
         V = np.einsum("ak,klcn,bl->abcn", G, g, G).reshape(16, C, N)                        # [p][c][n]
-        # packed [nt][chunk][half][p][lane half][nl][e], channel = 16 chunk + 8 half + 4 lane half + e
-        got = host(_pack(lib, dev(w), transpose)).reshape(N // 32, C // 16, 2, 16, 2, 32, 4)
-        ref = V.reshape(16, C // 16, 2, 2, 4, N // 32, 32).transpose(5, 1, 2, 0, 3, 6, 4)
+        if v1:   # round-2 kernel: packed [nt][chunk][half][p][lane half][nl][e], channel = 16 chunk + 8 half + 4 lane half + e
+            got = host(_pack(lib, dev(w), transpose)).reshape(N // 32, C // 16, 2, 16, 2, 32, 4)
+            ref = V.reshape(16, C // 16, 2, 2, 4, N // 32, 32).transpose(5, 1, 2, 0, 3, 6, 4)
+        else:    # round-3 kernel (conv_wino2.hip): packed [nt][chunk][half][p][g][n][ct][e], channel = 16 chunk + 8 half + 2 g + e, column = 32 nt + 16 ct + n
+            got = host(_pack(lib, dev(w), transpose)).reshape(N // 32, C // 16, 2, 16, 4, 16, 2, 2)
+            ref = V.reshape(16, C // 16, 2, 4, 2, N // 32, 2, 16).transpose(5, 1, 2, 0, 3, 7, 6, 4)
         np.testing.assert_allclose(got, ref, rtol=0, atol=1e-6)
 
 

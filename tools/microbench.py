@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vae_captioning_amd import abi  # noqa: E402
 from vae_captioning_amd.abi import ptr as P  # noqa: E402
 
-lib = abi.load()
+lib = abi.load(os.environ.get("VC_LIB"))   # VC_LIB: an ablation build (make -C vae_captioning_amd/csrc ablate)
 
 
 def st():
@@ -194,6 +194,44 @@ def wino():
             res[nm] = med
             print("conv%s %-13s B=%d H=%3d %3d->%3d: %8.3f ms  %6.1f TFLOP/s" % (name, nm, B, H, ci, co, med, fl / med), flush=True)
         print("conv%s speed-up fwd %.3f dgrad %.3f" % (name, res["fwd-patch"] / res["fwd-wino"], res["dgrad-patch"] / res["dgrad-wino"]), flush=True)
+
+
+def winoab():
+    """Winograd forward / data gradient only, VGG16 layer shapes at 64 and 32 images (A/B runs: VC_WINO_KERNEL=1 = the round-2 32x32x2
+    kernel, default = conv_wino2.hip); algorithmic TFLOP/s"""
+    tot = {}
+    for B in (64, 32):
+        for (name, H, ci, co) in [("1_2", 224, 64, 64), ("2_1", 112, 64, 128), ("2_2", 112, 128, 128), ("3_1", 56, 128, 256), ("3_2", 56, 256, 256),
+                                  ("4_1", 28, 256, 512), ("4_2", 28, 512, 512), ("5_2", 14, 512, 512)]:
+            x, w, bias = rnd(B, H, H, ci), rnd(3, 3, ci, co), rnd(co)
+            y, dx = torch.empty(B, H, H, co, device="cuda"), torch.empty(B, H, H, ci, device="cuda")
+            dy = rnd(B, H, H, co)
+            vp, vpt = torch.empty(16 * ci * co, device="cuda"), torch.empty(16 * ci * co, device="cuda")
+            lib.vc_conv3x3_wino_pack_f32(st(), ci, co, P(w), 0, P(vp))
+            lib.vc_conv3x3_wino_pack_f32(st(), ci, co, P(w), 1, P(vpt))
+            bits = torch.zeros(lib.vc_conv3x3_wino_mask_words(B, H, H, ci), dtype=torch.int32, device="cuda")
+            fl = 2e-9 * B * H * H * 9 * ci * co
+            for nm, fn in (("fwd", lambda: lib.vc_conv3x3_wino_fwd_f32(st(), B, H, H, ci, co, P(x), P(vp), P(bias), P(y), None, 1)),
+                           ("dgrad", lambda: lib.vc_conv3x3_wino_dgrad_f32(st(), B, H, H, ci, co, P(dy), P(vpt), P(x), P(dx))),
+                           ("dgrad-bits", lambda: lib.vc_conv3x3_wino_dgrad_bits_f32(st(), B, H, H, ci, co, P(dy), P(vpt), P(bits), P(dx)))):
+                med, mn = timeit(fn, reps=5)
+                tot[(B, nm)] = tot.get((B, nm), 0.0) + med * {"1_2": 1, "2_1": 1, "2_2": 1, "3_1": 1, "3_2": 2, "4_1": 1, "4_2": 2, "5_2": 3}[name]
+                print("conv%s %-10s B=%d H=%3d %3d->%3d: %8.3f ms  %6.1f TFLOP/s" % (name, nm, B, H, ci, co, med, fl / med), flush=True)
+    for k in sorted(tot):
+        print("sum over the twelve layers B=%d %-10s %8.3f ms" % (k[0], k[1], tot[k]))
+
+
+def winoq():
+    """quick form of winoab: conv3_2 / conv1_2 / conv4_2 / conv5_2 forward at 64 images (ablation builds: VC_LIB=.../libvaecap_ablN.so)"""
+    B = 64
+    for (name, H, ci, co) in [("3_2", 56, 256, 256), ("1_2", 224, 64, 64), ("4_2", 28, 512, 512), ("5_2", 14, 512, 512)]:
+        x, w, bias = rnd(B, H, H, ci), rnd(3, 3, ci, co), rnd(co)
+        y = torch.empty(B, H, H, co, device="cuda")
+        vp = torch.empty(16 * ci * co, device="cuda")
+        lib.vc_conv3x3_wino_pack_f32(st(), ci, co, P(w), 0, P(vp))
+        fl = 2e-9 * B * H * H * 9 * ci * co
+        med, mn = timeit(lambda: lib.vc_conv3x3_wino_fwd_f32(st(), B, H, H, ci, co, P(x), P(vp), P(bias), P(y), None, 1), reps=5)
+        print("%s conv%s fwd: %8.3f ms  %6.1f TFLOP/s" % (os.environ.get("VC_LIB", "default")[-12:], name, med, fl / med), flush=True)
 
 
 def winow():

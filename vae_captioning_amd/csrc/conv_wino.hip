@@ -445,6 +445,7 @@ static int launch_wino(hipStream_t st, WinoArgs& a) {
 extern "C" int vc_conv3x3_wino_supported(int B, int H, int W, int Cin, int Cout, int dgrad) {
     vc::WinoGeom g;
     const int nb = vc::wino_images_per_launch(B, H, W, Cin, Cout);
+    if (nb > 0 && vc::wino_version() == 2) return (dgrad ? vc::wino2_plan_ok(nb, H, W, Cout, Cin) : vc::wino2_plan_ok(nb, H, W, Cin, Cout)) ? 1 : 0;
     return nb > 0 && (dgrad ? vc::plan_wino(nb, H, W, Cout, Cin, g) : vc::plan_wino(nb, H, W, Cin, Cout, g)) ? 1 : 0;
 }
 
@@ -457,6 +458,7 @@ extern "C" int vc_conv3x3_wino_pack_f32(void* stream, int Cin, int Cout, const f
     const int C = transpose ? Cout : Cin, N = transpose ? Cin : Cout;
     VC_CHECK_ARG(C > 0 && N > 0 && C % WCH == 0 && N % 32 == 0, "gathered channels % 16 == 0 and output channels % 32 == 0 required");
     VC_CHECK_ARG(w && wp && waligned16(wp), "null or misaligned pointer");
+    if (wino_version() == 2) return wino2_pack((hipStream_t)stream, Cin, Cout, w, transpose, wp);
     const long total = (long)C * N;
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(wino_pack_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, Cin, Cout, transpose, wp);
@@ -472,6 +474,12 @@ extern "C" int vc_conv3x3_wino_fwd_f32(void* stream, int B, int H, int W, int Ci
     VC_CHECK_ARG(per > 0, "unsupported shape (vc_conv3x3_wino_supported)");
     for (int b0 = 0; b0 < B; b0 += per) {   // image ranges of < 2 GiB (one launch for every VGG16 layer up to 160 images)
         const int nb = B - b0 < per ? B - b0 : per;
+        if (wino_version() == 2) {
+            const int rc = wino2_launch((hipStream_t)stream, 0, nb, H, W, Cin, Cout, x + (size_t)b0 * H * W * Cin, wp, y + (size_t)b0 * H * W * Cout, bias,
+                                        ypool ? ypool + (size_t)b0 * (H / 2) * (W / 2) * Cout : nullptr, nullptr, relu);
+            if (rc) return rc;
+            continue;
+        }
         WinoArgs a;
         VC_CHECK_ARG(plan_wino(nb, H, W, Cin, Cout, a.g), "unsupported shape (vc_conv3x3_wino_supported)");
         a.x = x + (size_t)b0 * H * W * Cin; a.wp = wp; a.out = y + (size_t)b0 * H * W * Cout; a.aux = bias; a.relu = relu; a.mask = nullptr;
@@ -483,6 +491,7 @@ extern "C" int vc_conv3x3_wino_fwd_f32(void* stream, int B, int H, int W, int Ci
 }
 
 extern "C" size_t vc_conv3x3_wino_mask_words(int B, int H, int W, int C) {
+    if (vc::wino_version() == 2) return vc::wino2_mask_words(B, H, W, C);
     vc::WinoGeom g;
     if (!vc::plan_wino(B, H, W, 16, C, g)) return 0;
     return (size_t)vc::cdiv(g.nblocks, 4) * (C / 32) * 256 * 2;
@@ -492,10 +501,15 @@ extern "C" int vc_conv3x3_wino_fwd_mask_f32(void* stream, int B, int H, int W, i
                                             const float* bias, float* y, int relu, uint32_t* mask_out) {
     using namespace vc;
     WinoArgs a;
-    VC_CHECK_ARG(wino_images_per_launch(B, H, W, Cin, Cout) >= B && plan_wino(B, H, W, Cin, Cout, a.g),
-                 "unsupported shape, or more images than one launch takes (vc_conv3x3_wino_single_launch_supported): the mask bits are per tile of ONE launch");
     VC_CHECK_ARG(x && wp && y && mask_out, "null pointer");
     VC_CHECK_ARG(waligned16(x) && waligned16(wp) && waligned16(y) && waligned16(bias) && waligned16(mask_out), "pointers must be 16-byte aligned");
+    if (wino_version() == 2) {
+        VC_CHECK_ARG(wino_images_per_launch(B, H, W, Cin, Cout) >= B && wino2_plan_ok(B, H, W, Cin, Cout),
+                     "unsupported shape, or more images than one launch takes (vc_conv3x3_wino_single_launch_supported): the mask bits are per tile of ONE launch");
+        return wino2_launch((hipStream_t)stream, 0, B, H, W, Cin, Cout, x, wp, y, bias, nullptr, mask_out, relu);
+    }
+    VC_CHECK_ARG(wino_images_per_launch(B, H, W, Cin, Cout) >= B && plan_wino(B, H, W, Cin, Cout, a.g),
+                 "unsupported shape, or more images than one launch takes (vc_conv3x3_wino_single_launch_supported): the mask bits are per tile of ONE launch");
     a.x = x; a.wp = wp; a.out = y; a.aux = bias; a.relu = relu; a.pool = nullptr; a.mask = mask_out;
     return launch_wino<WK_FWD, false>((hipStream_t)stream, a);
 }
@@ -509,6 +523,12 @@ extern "C" int vc_conv3x3_wino_dgrad_f32(void* stream, int B, int H, int W, int 
     VC_CHECK_ARG(per > 0, "unsupported shape (vc_conv3x3_wino_supported)");
     for (int b0 = 0; b0 < B; b0 += per) {
         const int nb = B - b0 < per ? B - b0 : per;
+        if (wino_version() == 2) {
+            const int rc = wino2_launch((hipStream_t)stream, 1, nb, H, W, Cout, Cin, dy + (size_t)b0 * H * W * Cout, wpt, dx + (size_t)b0 * H * W * Cin,
+                                        relu_src ? relu_src + (size_t)b0 * H * W * Cin : nullptr, nullptr, nullptr, 0);
+            if (rc) return rc;
+            continue;
+        }
         WinoArgs a;
         VC_CHECK_ARG(plan_wino(nb, H, W, Cout, Cin, a.g), "unsupported shape (vc_conv3x3_wino_supported)");
         a.x = dy + (size_t)b0 * H * W * Cout; a.wp = wpt; a.out = dx + (size_t)b0 * H * W * Cin;
@@ -523,10 +543,15 @@ extern "C" int vc_conv3x3_wino_dgrad_bits_f32(void* stream, int B, int H, int W,
                                               const uint32_t* mask_bits, float* dx) {
     using namespace vc;
     WinoArgs a;
-    VC_CHECK_ARG(wino_images_per_launch(B, H, W, Cin, Cout) >= B && plan_wino(B, H, W, Cout, Cin, a.g),
-                 "unsupported shape, or more images than one launch takes (vc_conv3x3_wino_single_launch_supported)");
     VC_CHECK_ARG(dy && wpt && dx && mask_bits, "null pointer");
     VC_CHECK_ARG(waligned16(dy) && waligned16(wpt) && waligned16(dx) && waligned16(mask_bits), "pointers must be 16-byte aligned");
+    if (wino_version() == 2) {
+        VC_CHECK_ARG(wino_images_per_launch(B, H, W, Cin, Cout) >= B && wino2_plan_ok(B, H, W, Cout, Cin),
+                     "unsupported shape, or more images than one launch takes (vc_conv3x3_wino_single_launch_supported)");
+        return wino2_launch((hipStream_t)stream, 1, B, H, W, Cout, Cin, dy, wpt, dx, nullptr, nullptr, const_cast<uint32_t*>(mask_bits), 0);
+    }
+    VC_CHECK_ARG(wino_images_per_launch(B, H, W, Cin, Cout) >= B && plan_wino(B, H, W, Cout, Cin, a.g),
+                 "unsupported shape, or more images than one launch takes (vc_conv3x3_wino_single_launch_supported)");
     a.x = dy; a.wp = wpt; a.out = dx; a.aux = nullptr; a.relu = 0; a.pool = nullptr; a.mask = const_cast<uint32_t*>(mask_bits);
     return launch_wino<WK_DGRAD, false>((hipStream_t)stream, a);
 }
