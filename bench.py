@@ -449,12 +449,11 @@ def _cdiv(a, b):
 def wino_executed_ratio(images):
     """Executed MFMA FLOPs / algorithmic FLOPs of one cfg4 step's 3x3 convolution calls when the Winograd kernels run (default):
     F(2x2,3x3) / F(3x3,2x2) multiply 16 times per 2x2 tile and channel pair where the direct form multiplies 36 times; tile blocks
-    that stick out of the image add padding work.  Forward / data gradient (csrc/conv_wino2.hip plan_wino2): blocks of 16 tile slots
-    whose halo patch fits 100 pixels (VC_WINO_KERNEL=1, the round-2 kernel: 32 slots, 180 pixels); weight gradient
-    (conv_wino_wgrad.hip plan_wino_wgrad): 4x8 / 4x7 / 2x14 tiles.  conv1_1 (3 input channels) stays on its direct HBM-bound kernels."""
+    that stick out of the image add padding work.  Forward / data gradient (csrc/conv_wino.hip plan_wino2): blocks of 16 tile slots
+    whose halo patch fits 100 pixels; weight gradient (conv_wino_wgrad.hip plan_wino_wgrad): 4x8 / 4x7 / 2x14 tiles.  conv1_1 (3 input
+    channels) stays on its direct HBM-bound kernels."""
     from vae_captioning_amd import spec
-    v1 = os.environ.get("VC_WINO_KERNEL") == "1"
-    slots, maxpix = (32, 180) if v1 else (16, 100)
+    slots, maxpix = 16, 100
     H = 224
     alg = ex = 0.0
     for name, ci, co in spec.VGG_CONV:
@@ -466,7 +465,7 @@ def wino_executed_ratio(images):
         else:
             best = 0.0   # forward / data gradient: the block shape with the fewest empty slots
             for tbw in range(1, min(16, tw) + 1):
-                tbh = min(slots // tbw, 8, th) if v1 else min(slots // tbw, th)
+                tbh = min(slots // tbw, th)
                 if tbh < 1 or (2 * tbh + 2) * (2 * tbw + 2) > maxpix:
                     continue
                 best = max(best, tw * th / (_cdiv(tw, tbw) * _cdiv(th, tbh) * float(slots)))
@@ -498,7 +497,7 @@ def roofline_from_timer(timer, fine_tune, images=0):
     ach = fl / sec / 1e12
     per = {t: dict(launches=sm[t]["launches"], avg_us=round(1e6 * sm[t]["seconds"] / sm[t]["launches"], 2),
                    tflops=round(sm[t]["flops"] / sm[t]["seconds"] / 1e12, 2)) for t in tags}
-    wino = fine_tune and os.environ.get("VC_CONV_PATCH", "1") != "0" and os.environ.get("VC_CONV_WINO", "1") != "0"
+    wino = fine_tune and os.environ.get("VC_CONV_WINO", "1") != "0"
     ratio = wino_executed_ratio(images) if (wino and images) else 1.0
     if not fine_tune:
         kern = "vc::gemm_kernel<128x128,MK,KM> (logits)"

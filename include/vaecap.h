@@ -274,8 +274,8 @@ int vc_conv3x3_wgrad_patch_f32(void* stream, int B, int H, int W, int Cin, int C
                                float* db, int accumulate, float* ws, size_t ws_bytes);
 
 /* Winograd F(2x2, 3x3) forward / data gradient (csrc/conv_wino.hip): the same convolution in fp32 with 2.25x fewer multiplications.
- * Input transform, sixteen position products on MFMA and output transform in one kernel; a wave owns up to 32 tiles (2x2 output
- * pixels each) x 32 output columns x all sixteen positions.  The weights are transformed and packed once per optimiser step
+ * Input transform, sixteen position products on MFMA (16x16x4 tiles) and output transform in one kernel; a wave owns up to 16 tiles
+ * (2x2 output pixels each) x 32 output columns x all sixteen positions, two workgroups share a CU.  The weights are transformed and packed once per optimiser step
  * (wp: 16 * Cin * Cout floats; transpose 0 = forward, 1 = flipped taps + transposed channels for the data gradient).  Results agree
  * with conv3x3_fwd / conv3x3_dgrad to fp32 rounding of a different summation (tests/test_gpu_conv_wino.py: same fp64 oracle, same
  * tolerance class).  ypool != NULL also writes max_pool2x2(y) (a pooling window is one Winograd tile).  Shapes: H, W even, gathered
@@ -290,26 +290,16 @@ int vc_conv3x3_wino_fwd_f32(void* stream, int B, int H, int W, int Cin, int Cout
 int vc_conv3x3_wino_dgrad_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* dy, const float* wpt,
                               const float* relu_src, float* dx);
 
-/* ReLU mask as bits: the forward of a layer can leave (y > 0) of every lane's 2x2 pixels x 16 columns as 64 bits (vc_conv3x3_wino_mask_words
+/* ReLU mask as bits: the forward of a layer can leave (y > 0) of every lane's 2x2 pixels x 8 columns as 32 bits (vc_conv3x3_wino_mask_words
  * (B, H, W, Cout) 32-bit words), and the data gradient of the NEXT 3x3 layer -- whose output has the same [B,H,W,Cout] shape, hence the
- * same tiles and lanes -- reads those bits (one 8-byte load per lane) instead of relu_src (sixteen 16-byte loads + packing per lane:
+ * same tiles and lanes -- reads those bits (one 4-byte load per lane) instead of relu_src (eight 16-byte loads + packing per lane:
  * 6-17 % of a data-gradient call).  Results are bit-identical to vc_conv3x3_wino_dgrad_f32 with relu_src = that y. */
 size_t vc_conv3x3_wino_mask_words(int B, int H, int W, int C);
 int vc_conv3x3_wino_fwd_mask_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const float* wp,
                                  const float* bias, float* y, int relu, uint32_t* mask_out);
 int vc_conv3x3_wino_dgrad_bits_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* dy, const float* wpt,
                                    const uint32_t* mask_bits, float* dx);
-/* The same Winograd forward / data gradient on 16x16x4 MFMA tiles (csrc/conv_wino16.hip): a wave owns up to sixteen 2x2 tiles x 64 output
- * channels, so that one transformed input value feeds four MFMAs (half the transform instructions per MFMA) and 4x4-tile blocks fit the
- * 56-wide layers exactly.  Own packed layout (same size: 16 * Cin * Cout floats).  Shapes: H, W even, gathered channels % 16 == 0,
- * output channels % 64 == 0; ask vc_conv3x3_wino16_supported. */
-int vc_conv3x3_wino16_supported(int B, int H, int W, int Cin, int Cout, int dgrad);
-int vc_conv3x3_wino16_pack_f32(void* stream, int Cin, int Cout, const float* w, int transpose, float* wp);
-int vc_conv3x3_wino16_fwd_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const float* wp,
-                              const float* bias, float* y, float* ypool, int relu);
-int vc_conv3x3_wino16_dgrad_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* dy, const float* wpt,
-                                const float* relu_src, float* dx);
-/* Winograd F(3x3, 2x2) weight gradient (csrc/conv_wino.hip): both operands transformed in registers, the contraction runs over the
+/* Winograd F(3x3, 2x2) weight gradient (csrc/conv_wino_wgrad.hip): both operands transformed in registers, the contraction runs over the
  * 2x2-pixel tiles; raw position sums per K split in the workspace, a reduce kernel sums the splits in fixed order and applies the
  * output transform.  Same contract as conv3x3_wgrad (db != NULL also returns the bias gradient, accumulate adds to dw / db); the
  * workspace is REQUIRED.  Shapes: H, W even, H >= 4, Cin % 64 == 0, Cout % 64 == 0; ask vc_conv3x3_wino_wgrad_supported. */

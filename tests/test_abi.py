@@ -90,7 +90,7 @@ def test_product_code_never_touches_the_oracle_or_the_reference():
 
 def test_bench_executed_ratio_of_the_winograd_kernels():
     """bench.py prices the Winograd kernels' executed MFMA work as a fraction of the algorithmic (direct-convolution) FLOPs: 16 / 36 per
-    layer and pass, divided by the share of a block's tile slots that hold real tiles (forward / data gradient: csrc/conv_wino2.hip
+    layer and pass, divided by the share of a block's tile slots that hold real tiles (forward / data gradient: csrc/conv_wino.hip
     plan_wino2, 16 slots -- 4 x 4 tiles fit the 224 / 112 / 56-wide layers exactly, 2 x 7 the 28-wide ones, 49 of 64 slots at 14; weight
     gradient: plan_wino_wgrad); conv1_1 stays direct.  Hand-worked for the VGG16 shapes at 224 x 224."""
     import bench

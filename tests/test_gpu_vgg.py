@@ -130,7 +130,7 @@ def test_fine_tune_step_matches_oracle(lib):
 
 
 def test_fallback_kernels_without_the_patch_path(lib, monkeypatch):
-    """VC_CONV_PATCH=0: every layer through the general implicit-GEMM kernels of csrc/conv.hip (conv1_1 on zero-padded 4-channel
+    """use_patch = use_wino = False: every layer through the general implicit-GEMM kernels of csrc/conv.hip (conv1_1 on zero-padded 4-channel
     weights, separate max-pool launches) -- the path taken for geometries the patch / conv1 kernels do not support: forward vs
     the fp64 oracle, backward vs the oracle on the device's forward decisions, and close to the default path."""
     p = Parameters()
@@ -144,9 +144,9 @@ def test_fallback_kernels_without_the_patch_path(lib, monkeypatch):
     fc2_ref, cache = ov.forward(P64, img.astype(np.float64), ones.astype(np.float64), ones.astype(np.float64), keep=0.5)
     res = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("VC_CONV_PATCH", mode)
         eng = VggEngine(p, lib=lib)
-        assert eng.use_patch == (mode == "1")
+        if mode == "0":   # (an attribute, not an environment switch: the product never takes this path on a VGG16 shape)
+            eng.use_patch = eng.use_wino = False
         eng.load_params(PV)
         eng.set_masks(ones, ones)
         fc2 = eng.forward(torch.from_numpy(img).cuda())
@@ -165,10 +165,10 @@ def test_fallback_kernels_without_the_patch_path(lib, monkeypatch):
     assert (res["0"][1] - res["1"][1]).norm() <= 2e-3 * res["1"][1].norm()
 
 
-@pytest.mark.parametrize("env", [("VC_CONV_WINO", "0"), ("VC_CONV_WINO16", "1"), ("VC_VGG_STREAMS", "1")], ids=lambda e: "%s=%s" % e)
+@pytest.mark.parametrize("env", [("VC_CONV_WINO", "0"), ("VC_VGG_STREAMS", "1")], ids=lambda e: "%s=%s" % e)
 def test_alternative_convolution_paths_match_the_oracle(lib, monkeypatch, env):
     """The non-default convolution paths stay correct: VC_CONV_WINO=0 (direct patch kernels of the first half of round 2 on every layer),
-    VC_CONV_WINO16=1 (16x16x4-tile Winograd variant on the 56-wide layers), VC_VGG_STREAMS=1 (serial schedule; B = 2 so that the default
+    VC_VGG_STREAMS=1 (serial schedule; B = 2 so that the default
     would have used half-batch chains and the ReLU-mask bits of both geometries are exercised): forward vs the fp64 oracle, backward vs
     the oracle on the device's forward decisions."""
     monkeypatch.setenv(*env)
@@ -183,7 +183,7 @@ def test_alternative_convolution_paths_match_the_oracle(lib, monkeypatch, env):
     P64 = {k: v.astype(np.float64) for k, v in PV.items()}
     fc2_ref, cache = ov.forward(P64, img.astype(np.float64), ones.astype(np.float64), ones.astype(np.float64), keep=0.5)
     eng = VggEngine(p, lib=lib)
-    assert eng.use_wino == (env != ("VC_CONV_WINO", "0")) and eng.use_wino16 == (env == ("VC_CONV_WINO16", "1"))
+    assert eng.use_wino == (env != ("VC_CONV_WINO", "0"))
     eng.load_params(PV)
     eng.set_masks(ones, ones)
     for _ in range(2):   # the first step allocates

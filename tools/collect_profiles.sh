@@ -29,10 +29,8 @@ for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; d
 done
 python tools/pmc_summary.py /tmp/pmc $OUT/${TAG}_traffic_cfg4.json > $OUT/${TAG}_cfg4_pmc.md
 # 4. comparison points: the implicit-GEMM kernels of round 1 (VC_CONV_PATCH=0), the direct patch kernels (VC_CONV_WINO=0), one stream, the 16x16x4 variant
-VC_CONV_PATCH=0 python bench.py --no-cpu-baseline > $OUT/${TAG}_bench_nopatch.json 2>/dev/null
 VC_CONV_WINO=0 python bench.py --no-cpu-baseline > $OUT/${TAG}_bench_nowino.json 2>/dev/null
 VC_VGG_STREAMS=1 python bench.py --no-cpu-baseline > $OUT/${TAG}_bench_1stream.json 2>/dev/null
-VC_CONV_WINO16=1 python bench.py --no-cpu-baseline > $OUT/${TAG}_bench_wino16.json 2>/dev/null
 # 5. the step a user runs: fresh host batches through set_batch inside the timed region
 python bench.py --no-cpu-baseline --fresh-batch 4 > $OUT/${TAG}_bench_fresh_cfg4.json 2>/dev/null
 python bench.py --no-cpu-baseline --workload cfg2 > $OUT/${TAG}_bench_cfg2.json 2>/dev/null

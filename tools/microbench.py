@@ -175,9 +175,6 @@ def wino():
         lib.vc_conv3x3_pack_f32(st(), ci, co, P(w), 1, P(wpt))
         lib.vc_conv3x3_wino_pack_f32(st(), ci, co, P(w), 0, P(vp))
         lib.vc_conv3x3_wino_pack_f32(st(), ci, co, P(w), 1, P(vpt))
-        up, upt = torch.empty(16 * ci * co, device="cuda"), torch.empty(16 * ci * co, device="cuda")
-        lib.vc_conv3x3_wino16_pack_f32(st(), ci, co, P(w), 0, P(up))
-        lib.vc_conv3x3_wino16_pack_f32(st(), ci, co, P(w), 1, P(upt))
         tw = torch.empty(max(lib.vc_conv3x3_packed_workspace_bytes(B, H, H, ci, co, 0), lib.vc_conv3x3_packed_workspace_bytes(B, H, H, ci, co, 1), 16) // 4 + 4, device="cuda")
         tb = tw.numel() * 4
         fl = 2e-9 * B * H * H * 9 * ci * co
@@ -185,8 +182,6 @@ def wino():
         for nm, fn in (("fwd-patch", lambda: lib.vc_conv3x3_fwd_packed_f32(st(), B, H, H, ci, co, P(x), P(wp), P(bias), P(y), 1, P(tw), tb)),
                        ("fwd-wino", lambda: lib.vc_conv3x3_wino_fwd_f32(st(), B, H, H, ci, co, P(x), P(vp), P(bias), P(y), None, 1)),
                        ("fwd-wino-pool", lambda: lib.vc_conv3x3_wino_fwd_f32(st(), B, H, H, ci, co, P(x), P(vp), P(bias), P(y), P(yp), 1)),
-                       ("fwd-wino16", lambda: lib.vc_conv3x3_wino16_fwd_f32(st(), B, H, H, ci, co, P(x), P(up), P(bias), P(y), None, 1)),
-                       ("dgrad-wino16", lambda: lib.vc_conv3x3_wino16_dgrad_f32(st(), B, H, H, ci, co, P(dy), P(upt), P(x), P(dx))),
                        ("dgrad-patch", lambda: lib.vc_conv3x3_dgrad_packed_f32(st(), B, H, H, ci, co, P(dy), P(wpt), P(x), P(dx), P(tw), tb)),
                        ("dgrad-wino", lambda: lib.vc_conv3x3_wino_dgrad_f32(st(), B, H, H, ci, co, P(dy), P(vpt), P(x), P(dx))),
                        ("wino-pack", lambda: lib.vc_conv3x3_wino_pack_f32(st(), ci, co, P(w), 1, P(vpt)))):
@@ -197,8 +192,8 @@ def wino():
 
 
 def winoab():
-    """Winograd forward / data gradient only, VGG16 layer shapes at 64 and 32 images (A/B runs: VC_WINO_KERNEL=1 = the round-2 32x32x2
-    kernel, default = conv_wino2.hip); algorithmic TFLOP/s"""
+    """Winograd forward / data gradient only, VGG16 layer shapes at 64 and 32 images (round 3 A/B: profiles/r03_wino_fwd_dgrad_round2_kernel.txt keeps the round-2 32x32x2 kernel's
+    numbers from the same program); algorithmic TFLOP/s"""
     tot = {}
     for B in (64, 32):
         for (name, H, ci, co) in [("1_2", 224, 64, 64), ("2_1", 112, 64, 128), ("2_2", 112, 128, 128), ("3_1", 56, 128, 256), ("3_2", 56, 256, 256),

@@ -17,7 +17,7 @@ struct WinoGeom {
     int blocks_img;
     int nblocks;           // B * blocks_img
     unsigned m_blocks_img, m_bx_n, m_pw, m_tbw;   // ceil(2^32 / d) of the kernel's divisors (wino_magic): n / d == __umulhi(n, m) while n * d < 2^32
-    int P;                 // conv_wino2.hip only: pitch of a patch row in the LDS, in pixel PAIRS (>= PW / 2; chosen bank-conflict-free)
+    int P;                 // forward / data gradient only: pitch of a patch row in the LDS, in pixel PAIRS (>= PW / 2; chosen bank-conflict-free)
 };
 
 static inline unsigned wino_magic(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ULL + (unsigned)d - 1) / (unsigned)d); }   // 0: divisor 1
@@ -39,18 +39,5 @@ static inline int wino_images_per_launch(int B, int H, int W, int C, int N) {
     if (n > B) n = B;
     return (int)n;   // 0: one image alone is too large
 }
-
-// Forward / data-gradient kernel generation: 2 = conv_wino2.hip (16x16x4 tiles, two workgroups per CU; default), 1 = the round-2
-// kernel of conv_wino.hip (32x32x2 tiles, one wave per SIMD; VC_WINO_KERNEL=1, A/B runs).  Read once: the packed weight layout and the
-// mask-bit layout belong to the generation, so one process uses one of them.
-static inline int wino_version() {
-    static const int v = (getenv("VC_WINO_KERNEL") && atoi(getenv("VC_WINO_KERNEL")) == 1) ? 1 : 2;
-    return v;
-}
-bool wino2_plan_ok(int B, int H, int W, int C, int N);
-size_t wino2_mask_words(int B, int H, int W, int C);
-int wino2_pack(hipStream_t st, int Cin, int Cout, const float* w, int transpose, float* wp);
-int wino2_launch(hipStream_t st, int kind, int nb, int H, int W, int C, int N, const float* x, const float* wp, float* out, const float* aux,
-                 float* pool, unsigned* mask, int relu);
 
 }  // namespace vc

@@ -52,23 +52,15 @@ class VggEngine(object):
         # the weight gradient of layer l and the data-gradient chain (layer l, then l-1 ...) are independent:
         # wgrads run on a side stream so that the tail of one kernel (the last partial round of workgroups)
         # is filled by the other instead of idling the chip
-        import os
-        # patch-staged forward / data-gradient kernels (csrc/conv_patch.hip) wherever the layer shape allows; VC_CONV_PATCH=0
-        # keeps every layer on the implicit-GEMM kernels of csrc/conv.hip (A/B runs)
-        self.use_patch = os.environ.get("VC_CONV_PATCH", "1") != "0"
-        # Winograd F(2x2,3x3) forward / data gradient (csrc/conv_wino.hip: 2.25x fewer multiplications, fp32) wherever the shape allows
-        # (every 3x3 layer but conv1_1); VC_CONV_WINO=0 keeps the direct kernels (A/B runs, tests of the direct path)
-        self.use_wino = self.use_patch and os.environ.get("VC_CONV_WINO", "1") != "0"
-        # experimental (off): the 16x16x4-tile Winograd forward / data gradient (csrc/conv_wino16.hip) on the layers whose tile grid its
-        # 4 x 4 blocks fit exactly while the 32-tile blocks do not (the 56-wide layers): -0.3 ms per step; its MFMAs are inline asm
-        self.use_wino16 = self.use_wino and os.environ.get("VC_CONV_WINO16", "0") == "1"
-        # MaxPoolGrad + ReluGrad inside the next data gradient's epilogue (vc_conv3x3_dgrad_unpool_packed_f32): measured 49.22 / 49.32
-        # vs 49.40 / 49.38 ms per step -- the four pool-gradient launches (0.55 ms at 5.9 TB/s) disappear but their 3.5 GB of traffic
-        # leaves the four data gradients as 32-byte pieces from the accumulator epilogue (+0.4 ms): off by default
-        self.fuse_unpool = os.environ.get("VC_FUSE_UNPOOL", "0") == "1"
-        # three streams (two half-batch convolution chains + the weight gradients on a third): the Winograd kernels run ONE workgroup per
-        # CU, so the tail of a launch leaves CUs idle that another stream's launch fills (36.0 -> 35.0 ms per step; with the direct
-        # kernels of the first half of round 2 -- three workgroups per CU -- one stream was as fast); VC_VGG_STREAMS=1 serialises
+        # Convolution dispatch ("which kernel runs which layer"):
+        #   conv1_1 (3 -> 64 channels, HBM-bound)      csrc/conv_first.hip
+        #   every other 3x3 layer, all three passes    Winograd F(2x2,3x3) / F(3x3,2x2) in fp32 (csrc/conv_wino.hip, conv_wino_wgrad.hip)
+        #   VC_CONV_WINO=0 (A/B runs, tests)           the direct patch-staged kernels (csrc/conv_patch.hip), same layers
+        #   shapes neither takes                       the implicit-GEMM kernels of csrc/conv.hip (also the independent checker of tests/)
+        self.use_patch = True
+        self.use_wino = os.environ.get("VC_CONV_WINO", "1") != "0"
+        # Streams: 3 = two half-batch convolution chains + the weight gradients on a third stream (the tail of one launch is filled by
+        # another stream's launch; the data-parallel gradient buckets are issued from the weight-gradient stream), 1 = serial
         nstreams = int(os.environ.get("VC_VGG_STREAMS", "3"))
         self.side = torch.cuda.Stream() if nstreams >= 2 else None
         self.side2 = torch.cuda.Stream() if nstreams >= 3 else None
@@ -137,21 +129,11 @@ class VggEngine(object):
                     w = S.param(spec.vgg_var_names(name)[0])
                     wf = self.use_wino and bool(lib.vc_conv3x3_wino_supported(1, H, W, ci, co, 0))
                     wb = self.use_wino and bool(lib.vc_conv3x3_wino_supported(1, H, W, ci, co, 1))
-                    if self._wino16_layer(H, W, ci, co, 0):
-                        lib.vc_conv3x3_wino16_pack_f32(sh, ci, co, P(w), 0, P(self._b("up_" + name, (16 * ci * co,))))
-                        wf = None
-                    if backward and self._wino16_layer(H, W, ci, co, 1):
-                        lib.vc_conv3x3_wino16_pack_f32(sh, ci, co, P(w), 1, P(self._b("upt_" + name, (16 * ci * co,))))
-                        wb = None
-                    if wf is None:
-                        pass
-                    elif wf:   # G g G^T of every filter, in the Winograd kernel's operand order
+                    if wf:   # G g G^T of every filter, in the Winograd kernel's operand order
                         lib.vc_conv3x3_wino_pack_f32(sh, ci, co, P(w), 0, P(self._b("vp_" + name, (16 * ci * co,))))
                     else:    # direct patch kernels: [tap][C/4][N][4]
                         lib.vc_conv3x3_pack_f32(sh, ci, co, P(w), 0, P(self._b("wp_" + name, (9 * ci * co,))))
-                    if wb is None:
-                        pass
-                    elif backward and wb:
+                    if backward and wb:
                         lib.vc_conv3x3_wino_pack_f32(sh, ci, co, P(w), 1, P(self._b("vpt_" + name, (16 * ci * co,))))
                     elif backward:
                         lib.vc_conv3x3_pack_f32(sh, ci, co, P(w), 1, P(self._b("wpt_" + name, (9 * ci * co,))))
@@ -167,14 +149,6 @@ class VggEngine(object):
     def _wino_ok(self, name, nb, H, W, ci, co, dgrad):
         return (self.use_wino and (("vpt_" if dgrad else "vp_") + name) in self.buf
                 and bool(self.lib.vc_conv3x3_wino_supported(nb, H, W, ci, co, dgrad)))
-
-    def _wino16_layer(self, H, W, ci, co, dgrad):
-        """the 16-tile variant only where its 4 x 4 blocks tile the image exactly and the 32-tile blocks (4x8 / 8x4 / 2x14 / 4x7) do not"""
-        if not self.use_wino16 or not self.lib.vc_conv3x3_wino16_supported(1, H, W, ci, co, dgrad):
-            return False
-        th, tw = H // 2, W // 2
-        fits32 = any(th % a == 0 and tw % b == 0 for a, b in ((4, 8), (8, 4), (2, 16), (1, 16)))
-        return th % 4 == 0 and tw % 4 == 0 and not fits32
 
     def _wino_wgrad_ok(self, B, H, W, ci, co):
         return self.use_wino and ci % 64 == 0 and co % 64 == 0 and bool(self.lib.vc_conv3x3_wino_wgrad_supported(B, H, W, ci, co))
@@ -252,12 +226,7 @@ class VggEngine(object):
                         if packed is not None and ch not in waited:
                             torch.cuda.current_stream().wait_event(packed)
                             waited.add(ch)
-                        if ("up_" + name) in self.buf and self._wino16_layer(H, W, cie, co, 0):
-                            self._timed("conv_fwd", 2.0 * nb * H * W * 9 * ci * co,
-                                        lambda: lib.vc_conv3x3_wino16_fwd_f32(sh, nb, H, W, cie, co, P(x[b0:]), P(self.buf["up_" + name]), P(S.param(bn)),
-                                                                              P(y[b0:]), P(yp[b0:]) if pooled else None, 1))
-                            continue
-                        if (self._wino_ok(name, nb, H, W, cie, co, 0) and self.train and not pooled and not self.use_wino16
+                        if (self._wino_ok(name, nb, H, W, cie, co, 0) and self.train and not pooled
                                 and lib.vc_conv3x3_wino_single_launch_supported(nb, H, W, cie, co)):
                             # the next layer is a convolution on this output: leave (y > 0) as bits in the lane order of ITS data gradient
                             mk = self._b("mk_%s_%d" % (name, ch), (lib.vc_conv3x3_wino_mask_words(nb, H, W, co),), dtype=torch.int32)
@@ -373,13 +342,9 @@ class VggEngine(object):
         halves = [(0, B // 2, main), (B // 2, B // 2, side)] if split else [(0, B, main)]
         if split:
             side.wait_stream(main)
-        fused_pool = False  # the previous data gradient already wrote this pool's input gradient (MaxPoolGrad fused into its epilogue)
         for li in range(len(self.acts) - 1, -1, -1):
             name, x, H, W, ci, co, w = self.acts[li]
             if name == "P":
-                if fused_pool:
-                    fused_pool = False
-                    continue
                 dx = self._b("dx_%d" % li, (B, H, W, co))
                 for b0, nb, strm in halves:
                     with torch.cuda.stream(strm):  # + ReluGrad of the conv that made x
@@ -417,29 +382,12 @@ class VggEngine(object):
                     after_layer[1]()
             if li > 0:
                 prev_is_pool = self.acts[li - 1][0] == "P"
-                fuse = (prev_is_pool and self.fuse_unpool and self._patch_ok(B // max(len(halves), 1), H, W, ci, co, 1)
-                        and ("wpt_" + name) in self.buf)
-                if fuse:  # MaxPoolGrad + ReluGrad of the pool in front of this layer ride in the data gradient's epilogue
-                    ypre = self.acts[li - 1][1]                                   # the pool's input [B, 2H, 2W, ci]
-                    dx = self._b("dx_%d" % (li - 1), (B, 2 * H, 2 * W, ci))
-                    for ch, (b0, nb, strm) in enumerate(halves):
-                        tws = self._chain_ws(ch, nb)
-                        with torch.cuda.stream(strm):
-                            sh = _stream()
-                            self._timed("conv_dgrad", fl * nb / B, lambda: lib.vc_conv3x3_dgrad_unpool_packed_f32(
-                                sh, nb, H, W, ci, co, P(d[b0:]), P(self.buf["wpt_" + name]), P(ypre[b0:]), P(dx[b0:]), P(tws), tws.numel() * 4))
-                    d = dx
-                    fused_pool = True
-                    continue
                 dx = self._b("dx_%d" % li, (B, H, W, ci))
                 for ch, (b0, nb, strm) in enumerate(halves):
                     tws = self._chain_ws(ch, nb)
                     with torch.cuda.stream(strm):
                         sh = _stream()
-                        if ("upt_" + name) in self.buf and self._wino16_layer(H, W, ci, co, 1):
-                            self._timed("conv_dgrad", fl * nb / B, lambda: lib.vc_conv3x3_wino16_dgrad_f32(
-                                sh, nb, H, W, ci, co, P(d[b0:]), P(self.buf["upt_" + name]), None if prev_is_pool else P(x[b0:]), P(dx[b0:])))
-                        elif (self._wino_ok(name, nb, H, W, ci, co, 1) and not prev_is_pool
+                        if (self._wino_ok(name, nb, H, W, ci, co, 1) and not prev_is_pool
                               and self.mask_geom.get(self.acts[li - 1][0]) == (nb, len(halves))
                               and lib.vc_conv3x3_wino_single_launch_supported(nb, H, W, ci, co)):
                             # ReluGrad from the bits the previous layer's forward left (one 8-byte load per lane instead of sixteen 16-byte ones)
