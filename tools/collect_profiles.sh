@@ -14,25 +14,25 @@ python bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/${TAG}_bench_default.er
 #    with ONE VGG stream (VC_VGG_STREAMS=1: nothing overlaps, the per-kernel durations are the kernels' own)
 for WL in cfg4 cfg2; do
   rm -rf /tmp/kt_$WL
-  (cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/kt_$WL -- python $ROOT/bench.py --workload $WL --no-cpu-baseline > $OUT/${TAG}_${WL}_kt.log 2>&1)
+  (cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/kt_$WL -- python $ROOT/bench.py --workload $WL --no-cpu-baseline --strong-n1 0 > $OUT/${TAG}_${WL}_kt.log 2>&1)
   DB=$(find /tmp/kt_$WL -name "*_results.db" | head -1)
   python tools/rocpd_stats.py "$DB" 60 > $OUT/${TAG}_${WL}_kernel_stats.md
 done
 rm -rf /tmp/kt_1s
-(cd /tmp && VC_VGG_STREAMS=1 rocprofv3 --kernel-trace --stats -d /tmp/kt_1s -- python $ROOT/bench.py --no-cpu-baseline > $OUT/${TAG}_cfg4_1stream_kt.log 2>&1)
+(cd /tmp && VC_VGG_STREAMS=1 rocprofv3 --kernel-trace --stats -d /tmp/kt_1s -- python $ROOT/bench.py --no-cpu-baseline --strong-n1 0 > $OUT/${TAG}_cfg4_1stream_kt.log 2>&1)
 python tools/rocpd_stats.py "$(find /tmp/kt_1s -name "*_results.db" | head -1)" 60 > $OUT/${TAG}_cfg4_kernel_stats_1stream.md
 # 3. PMC passes (each counter set in its own run, with --kernel-trace only; ONE VGG stream so that a kernel's counters are its own)
 rm -rf /tmp/pmc
 for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   D=/tmp/pmc/$(echo $C | tr ' ' '_')
-  (cd /tmp && VC_VGG_STREAMS=1 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $D -- python $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_pmc_$(echo $C | cut -d' ' -f1).log 2>&1)
+  (cd /tmp && VC_VGG_STREAMS=1 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $D -- python $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --strong-n1 0 > $OUT/${TAG}_pmc_$(echo $C | cut -d' ' -f1).log 2>&1)
 done
 python tools/pmc_summary.py /tmp/pmc $OUT/${TAG}_traffic_cfg4.json > $OUT/${TAG}_cfg4_pmc.md
 # 4. comparison points: the implicit-GEMM kernels of round 1 (VC_CONV_PATCH=0), the direct patch kernels (VC_CONV_WINO=0), one stream, the 16x16x4 variant
-VC_CONV_WINO=0 python bench.py --no-cpu-baseline > $OUT/${TAG}_bench_nowino.json 2>/dev/null
-VC_VGG_STREAMS=1 python bench.py --no-cpu-baseline > $OUT/${TAG}_bench_1stream.json 2>/dev/null
+VC_CONV_WINO=0 python bench.py --no-cpu-baseline --strong-n1 0 > $OUT/${TAG}_bench_nowino.json 2>/dev/null
+VC_VGG_STREAMS=1 python bench.py --no-cpu-baseline --strong-n1 0 > $OUT/${TAG}_bench_1stream.json 2>/dev/null
 # 5. the step a user runs: fresh host batches through set_batch inside the timed region
-python bench.py --no-cpu-baseline --fresh-batch 4 > $OUT/${TAG}_bench_fresh_cfg4.json 2>/dev/null
+python bench.py --no-cpu-baseline --strong-n1 0 --fresh-batch 4 > $OUT/${TAG}_bench_fresh_cfg4.json 2>/dev/null
 python bench.py --no-cpu-baseline --workload cfg2 > $OUT/${TAG}_bench_cfg2.json 2>/dev/null
 python bench.py --no-cpu-baseline --workload cfg2 --fresh-batch 4 > $OUT/${TAG}_bench_fresh_cfg2.json 2>/dev/null
 # 6. secondary lines: V = 11313, variable lengths, one caption per image; the other workloads
@@ -43,4 +43,6 @@ python bench.py --no-cpu-baseline --workload cfg1 > $OUT/${TAG}_bench_cfg1.json 
 python bench.py --no-cpu-baseline --workload cfg3 > $OUT/${TAG}_bench_cfg3.json 2>/dev/null
 python bench.py --no-cpu-baseline --workload cfg5 --steps 5 --warmup 1 > $OUT/${TAG}_bench_cfg5.json 2>/dev/null
 # 7. per-layer tables: Winograd kernels against the direct patch kernels (forward / data gradient, weight gradient)
-python tools/microbench.py wino winow > $OUT/${TAG}_wino_layers.txt 2>/dev/null
+python tools/microbench.py winoab winow > $OUT/${TAG}_wino_layers.txt 2>/dev/null
+# 8. SQ counters of the Winograd forward / data-gradient kernel per layer shape
+bash tools/sq_probe_wino.sh ${TAG} > /dev/null 2>&1

@@ -202,11 +202,17 @@ __global__ __launch_bounds__(256) void conv1_wgrad_reduce_kernel(const float* __
 
 constexpr int C1_WGRAD_WGS = 1024;
 
-static bool conv1_ok(int B, int H, int W) { return B > 0 && H > 0 && W > 0 && W % 32 == 0 && (long)B * H * W * 256 < 0x7fffffffL; }
+// a LAUNCH addresses [B,H,W,64] floats with 32-bit offsets (< 2 GiB); a call on more images is cut into launches over image ranges
+static int conv1_images_per_launch(int B, int H, int W) {
+    const long per = (long)H * W * 256;
+    long n = per > 0 ? 0x7fffffffL / per : 0;
+    return (int)(n > B ? B : n);
+}
+static bool conv1_ok(int B, int H, int W) { return B > 0 && H > 0 && W > 0 && W % 32 == 0 && conv1_images_per_launch(B, H, W) > 0; }
 
 }  // namespace vc
 
-// 1 when the specialised conv1_1 kernels handle this geometry (W % 32 == 0, activation < 2 GiB), else callers use vc_conv3x3_*_f32
+// 1 when the specialised conv1_1 kernels handle this geometry (W % 32 == 0, one image's activation < 2 GiB), else callers use vc_conv3x3_*_f32
 extern "C" int vc_conv1_supported(int B, int H, int W) { return vc::conv1_ok(B, H, W) ? 1 : 0; }
 
 extern "C" size_t vc_conv1_wgrad_workspace_bytes(void) { return (size_t)vc::C1_WGRAD_WGS * 28 * 64 * sizeof(float); }
@@ -217,13 +223,19 @@ extern "C" int vc_conv1_fwd_f32(void* stream, int B, int H, int W, const float* 
     VC_CHECK_ARG(conv1_ok(B, H, W), "unsupported geometry (W % 32 == 0 and activation < 2 GiB required; see vc_conv1_supported)");
     VC_CHECK_ARG(x4 && w && bias && y, "null pointer");
     VC_CHECK_ARG((((uintptr_t)x4 | (uintptr_t)y | (uintptr_t)bias) & 15) == 0, "x4 / y / bias must be 16-byte aligned");
-    Conv1Args a{};
-    a.x4 = x4; a.w = w; a.bias = bias; a.y = y; a.B = B; a.H = H; a.W = W; a.relu = relu;
-    a.segs = W / 32; a.groups = B * H * a.segs;
-    int wgs = cdiv(a.groups, 4);
-    if (wgs > 2048) wgs = 2048;
-    hipLaunchKernelGGL(conv1_fwd_kernel, dim3(wgs), dim3(256), 0, (hipStream_t)stream, a);
-    return launch_status(__func__);
+    const int per = conv1_images_per_launch(B, H, W);
+    for (int b0 = 0; b0 < B; b0 += per) {
+        const int nb = B - b0 < per ? B - b0 : per;
+        Conv1Args a{};
+        a.x4 = x4 + (size_t)b0 * H * W * 4; a.w = w; a.bias = bias; a.y = y + (size_t)b0 * H * W * 64; a.B = nb; a.H = H; a.W = W; a.relu = relu;
+        a.segs = W / 32; a.groups = nb * H * a.segs;
+        int wgs = cdiv(a.groups, 4);
+        if (wgs > 2048) wgs = 2048;
+        hipLaunchKernelGGL(conv1_fwd_kernel, dim3(wgs), dim3(256), 0, (hipStream_t)stream, a);
+        const int rc = launch_status(__func__);
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 // dw [3,3,3,64] (+)= sum over pixels of patch x dy; db [64] (+)= sum of dy (may be null); dy is the gradient w.r.t. the layer's
@@ -234,14 +246,20 @@ extern "C" int vc_conv1_wgrad_f32(void* stream, int B, int H, int W, const float
     VC_CHECK_ARG(conv1_ok(B, H, W), "unsupported geometry (W % 32 == 0 and activation < 2 GiB required; see vc_conv1_supported)");
     VC_CHECK_ARG(x4 && dy && dw, "null pointer");
     if (!ws || ws_bytes < vc_conv1_wgrad_workspace_bytes()) return fail(VC_EWORKSPACE, "%s: workspace too small (vc_conv1_wgrad_workspace_bytes)", __func__);
-    Conv1Args a{};
-    a.x4 = x4; a.dy = dy; a.ws = ws; a.B = B; a.H = H; a.W = W;
-    a.segs = W / 32; a.groups = B * H * a.segs;
-    int wgs = cdiv(a.groups, 4);
-    if (wgs > C1_WGRAD_WGS) wgs = C1_WGRAD_WGS;
-    hipLaunchKernelGGL(conv1_wgrad_kernel, dim3(wgs), dim3(256), 0, (hipStream_t)stream, a);
-    int rc = launch_status(__func__);
-    if (rc) return rc;
-    hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3(56), dim3(256), 0, (hipStream_t)stream, ws, wgs, dw, db, accumulate);
-    return launch_status(__func__);
+    const int per = conv1_images_per_launch(B, H, W);
+    for (int b0 = 0; b0 < B; b0 += per) {   // the later image ranges accumulate into dw / db
+        const int nb = B - b0 < per ? B - b0 : per;
+        Conv1Args a{};
+        a.x4 = x4 + (size_t)b0 * H * W * 4; a.dy = dy + (size_t)b0 * H * W * 64; a.ws = ws; a.B = nb; a.H = H; a.W = W;
+        a.segs = W / 32; a.groups = nb * H * a.segs;
+        int wgs = cdiv(a.groups, 4);
+        if (wgs > C1_WGRAD_WGS) wgs = C1_WGRAD_WGS;
+        hipLaunchKernelGGL(conv1_wgrad_kernel, dim3(wgs), dim3(256), 0, (hipStream_t)stream, a);
+        int rc = launch_status(__func__);
+        if (rc) return rc;
+        hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3(56), dim3(256), 0, (hipStream_t)stream, ws, wgs, dw, db, accumulate || b0 > 0);
+        rc = launch_status(__func__);
+        if (rc) return rc;
+    }
+    return 0;
 }

@@ -222,44 +222,33 @@ class VggEngine(object):
                     if ci == 3 and c1:  # conv1_1: its own HBM-bound kernel, unpadded weights
                         self._timed("conv_fwd", 2.0 * nb * H * W * 9 * ci * co,
                                     lambda: lib.vc_conv1_fwd_f32(sh, nb, H, W, P(x[b0:]), P(S.param(wn)), P(S.param(bn)), P(y[b0:]), 1))
-                    elif self._patch_ok(nb, H, W, cie, co, 0):
-                        if packed is not None and ch not in waited:
-                            torch.cuda.current_stream().wait_event(packed)
-                            waited.add(ch)
-                        if (self._wino_ok(name, nb, H, W, cie, co, 0) and self.train and not pooled
-                                and lib.vc_conv3x3_wino_single_launch_supported(nb, H, W, cie, co)):
+                        continue
+                    fl = 2.0 * nb * H * W * 9 * ci * co
+                    if packed is not None and ch not in waited:   # the packed / transformed weights of this step are ready
+                        torch.cuda.current_stream().wait_event(packed)
+                        waited.add(ch)
+                    if self._wino_ok(name, nb, H, W, cie, co, 0):   # Winograd (calls over 2 GiB are cut into image ranges inside the library)
+                        if self.train and not pooled and lib.vc_conv3x3_wino_single_launch_supported(nb, H, W, cie, co):
                             # the next layer is a convolution on this output: leave (y > 0) as bits in the lane order of ITS data gradient
                             mk = self._b("mk_%s_%d" % (name, ch), (lib.vc_conv3x3_wino_mask_words(nb, H, W, co),), dtype=torch.int32)
                             self.mask_geom[name] = (nb, len(halves))   # the bits are per tile of THIS launch geometry
-                            self._timed("conv_fwd", 2.0 * nb * H * W * 9 * ci * co,
-                                        lambda: lib.vc_conv3x3_wino_fwd_mask_f32(sh, nb, H, W, cie, co, P(x[b0:]), P(self.buf["vp_" + name]), P(S.param(bn)),
-                                                                                 P(y[b0:]), 1, P(mk)))
-                            continue
-                        if self._wino_ok(name, nb, H, W, cie, co, 0):   # Winograd; the 2x2 max-pool is register math in its epilogue
-                            self._timed("conv_fwd", 2.0 * nb * H * W * 9 * ci * co,
-                                        lambda: lib.vc_conv3x3_wino_fwd_f32(sh, nb, H, W, cie, co, P(x[b0:]), P(self.buf["vp_" + name]), P(S.param(bn)),
-                                                                            P(y[b0:]), P(yp[b0:]) if pooled else None, 1))
-                            continue
-                        wp = self.buf.get("wp_" + name)
-                        if wp is None:   # (not packed: the layer was expected on the Winograd path) general kernel
-                            self._timed("conv_fwd", 2.0 * nb * H * W * 9 * ci * co,
-                                        lambda: lib.vc_conv3x3_fwd_f32(sh, nb, H, W, cie, co, P(x[b0:]), P(w), P(S.param(bn)), P(y[b0:]), 1,
-                                                                       P(tws), tws.numel() * 4))
-                            if pooled:
-                                lib.vc_maxpool2x2_fwd_f32(sh, nb, H, W, co, P(y[b0:]), P(yp[b0:]))
-                            continue
+                            self._timed("conv_fwd", fl, lambda: lib.vc_conv3x3_wino_fwd_mask_f32(
+                                sh, nb, H, W, cie, co, P(x[b0:]), P(self.buf["vp_" + name]), P(S.param(bn)), P(y[b0:]), 1, P(mk)))
+                        else:   # the 2x2 max-pool is register math in the epilogue
+                            self._timed("conv_fwd", fl, lambda: lib.vc_conv3x3_wino_fwd_f32(
+                                sh, nb, H, W, cie, co, P(x[b0:]), P(self.buf["vp_" + name]), P(S.param(bn)), P(y[b0:]), P(yp[b0:]) if pooled else None, 1))
+                        continue
+                    wp = self.buf.get("wp_" + name)
+                    if wp is not None and self._patch_ok(nb, H, W, cie, co, 0):   # direct patch-staged kernels (VC_CONV_WINO=0)
                         if pooled and W % 8 == 0 and H % 4 == 0:  # 2x2 max-pool fused into the epilogue (4 x 8 sub-tile tiling)
-                            self._timed("conv_fwd", 2.0 * nb * H * W * 9 * ci * co,
-                                        lambda: lib.vc_conv3x3_fwd_pool_packed_f32(sh, nb, H, W, cie, co, P(x[b0:]), P(wp), P(S.param(bn)), P(y[b0:]),
-                                                                                   P(yp[b0:]), 1, P(tws), tws.numel() * 4))
+                            self._timed("conv_fwd", fl, lambda: lib.vc_conv3x3_fwd_pool_packed_f32(
+                                sh, nb, H, W, cie, co, P(x[b0:]), P(wp), P(S.param(bn)), P(y[b0:]), P(yp[b0:]), 1, P(tws), tws.numel() * 4))
                             continue
-                        self._timed("conv_fwd", 2.0 * nb * H * W * 9 * ci * co,
-                                    lambda: lib.vc_conv3x3_fwd_packed_f32(sh, nb, H, W, cie, co, P(x[b0:]), P(wp), P(S.param(bn)), P(y[b0:]), 1,
-                                                                          P(tws), tws.numel() * 4))
-                    else:
-                        self._timed("conv_fwd", 2.0 * nb * H * W * 9 * ci * co,
-                                    lambda: lib.vc_conv3x3_fwd_f32(sh, nb, H, W, cie, co, P(x[b0:]), P(w), P(S.param(bn)), P(y[b0:]), 1,
-                                                                   P(tws), tws.numel() * 4))
+                        self._timed("conv_fwd", fl, lambda: lib.vc_conv3x3_fwd_packed_f32(
+                            sh, nb, H, W, cie, co, P(x[b0:]), P(wp), P(S.param(bn)), P(y[b0:]), 1, P(tws), tws.numel() * 4))
+                    else:   # implicit-GEMM kernels of csrc/conv.hip: any shape
+                        self._timed("conv_fwd", fl, lambda: lib.vc_conv3x3_fwd_f32(
+                            sh, nb, H, W, cie, co, P(x[b0:]), P(w), P(S.param(bn)), P(y[b0:]), 1, P(tws), tws.numel() * 4))
                     if pooled:
                         lib.vc_maxpool2x2_fwd_f32(sh, nb, H, W, co, P(y[b0:]), P(yp[b0:]))
             self.acts.append((name, x, H, W, cie, co, w))
