@@ -35,9 +35,9 @@ def test_wino_pack_is_G_g_Gt(lib):
         g = w.astype(np.float64) if not transpose else w[::-1, ::-1].transpose(0, 1, 3, 2).astype(np.float64)
         C, N = g.shape[2], g.shape[3]
         V = np.einsum("ak,klcn,bl->abcn", G, g, G).reshape(16, C, N)                        # [p][c][n]
-        # packed [nt][chunk][half][p][g][n][ct][e], channel = 16 chunk + 8 half + 2 g + e, column = 32 nt + 16 ct + n
-        got = host(_pack(lib, dev(w), transpose)).reshape(N // 32, C // 16, 2, 16, 4, 16, 2, 2)
-        ref = V.reshape(16, C // 16, 2, 4, 2, N // 32, 2, 16).transpose(5, 1, 2, 0, 3, 7, 6, 4)
+        # packed [nt][chunk][half][p][g][n][ct][e], channel = 16 chunk + 8 half + 2 g + e, column = 32 nt + 8 (n >> 2) + 4 ct + (n & 3)
+        got = host(_pack(lib, dev(w), transpose)).reshape(N // 32, C // 16, 2, 16, 4, 4, 4, 2, 2)       # n split as (n >> 2, n & 3)
+        ref = V.reshape(16, C // 16, 2, 4, 2, N // 32, 4, 2, 4).transpose(5, 1, 2, 0, 3, 6, 8, 7, 4)      # column as (nt, n >> 2, ct, n & 3)
         np.testing.assert_allclose(got, ref, rtol=0, atol=1e-6)
 
 

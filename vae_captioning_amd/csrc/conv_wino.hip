@@ -128,7 +128,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(Wino2Args a) {
     const long rowN = (long)g.W * N;
     unsigned mbits = 0xffffffffu;
 
-    f32x4 acc[16][2];   // [position][column tile]: M_p[n0 + 16 ct + 4 lg + r][tile lj]
+    // [position][column tile]: M_p[n0 + 8 lg + 4 ct + r][tile lj] -- row m = 4 lg + r of column tile ct stands for output channel
+    // 8 (m >> 2) + 4 ct + (m & 3) of the workgroup's 32 (wino2_pack_kernel), so a lane's two float4 are 32 consecutive bytes of a pixel and
+    // four lanes write a full 128-byte line (column = 16 ct + m: two 64-byte pieces per pixel)
+    f32x4 acc[16][2];
 #pragma unroll
     for (int p = 0; p < 16; ++p)
 #pragma unroll
@@ -138,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(Wino2Args a) {
     if (KIND == W2_FWD && a.aux) {
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
-            const float4 bv = *reinterpret_cast<const float4*>(a.aux + n0 + 16 * ct + 4 * lg);
+            const float4 bv = *reinterpret_cast<const float4*>(a.aux + n0 + 8 * lg + 4 * ct);
             acc[5][ct] = f32x4{bv.x, bv.y, bv.z, bv.w};
         }
     }
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(Wino2Args a) {
 #pragma unroll
                 for (int bb = 0; bb < 2; ++bb) {
                     const bool ok = aa == 0 ? (bb == 0 ? ok00 : ok01) : (bb == 0 ? ok10 : ok11);
-                    const float4 m = ok ? *reinterpret_cast<const float4*>(a.aux + p00 + aa * rowN + bb * N + n0 + 16 * ct + 4 * lg) : f4zero();
+                    const float4 m = ok ? *reinterpret_cast<const float4*>(a.aux + p00 + aa * rowN + bb * N + n0 + 8 * lg + 4 * ct) : f4zero();
                     const unsigned bits = (m.x > 0.f ? 1u : 0u) | (m.y > 0.f ? 2u : 0u) | (m.z > 0.f ? 4u : 0u) | (m.w > 0.f ? 8u : 0u);
                     mbits |= bits << (16 * ct + 8 * aa + 4 * bb);
                 }
@@ -267,11 +270,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(Wino2Args a) {
     half(1, false, false, 0);
 #undef WSB
 
-    // ---- output transform + epilogue: acc[p][ct][r] = M_p[column n0 + 16 ct + 4 lg + r][tile lj]
+    // ---- output transform + epilogue: acc[p][ct][r] = M_p[column n0 + 8 lg + 4 ct + r][tile lj]
     unsigned obits = 0u;
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
-        const int col = n0 + 16 * ct + 4 * lg;
+        const int col = n0 + 8 * lg + 4 * ct;
         float4 Y[2][2];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -341,7 +344,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(Wino2Args a) {
 }
 
 // w [3][3][Ci][Co] (HWIO) -> V = G g G^T, G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1], packed
-// [N/32][C/16][half 2][p 16][g 4][n 16][ct 2][e 2] (channel = 16 chunk + 8 half + 2 g + e, column = 32 nt + 16 ct + n):
+// [N/32][C/16][half 2][p 16][g 4][n 16][ct 2][e 2] (channel = 16 chunk + 8 half + 2 g + e, column = 32 nt + 8 (n >> 2) + 4 ct + (n & 3)):
 //   transpose 0 (forward):        C = Ci, N = Co, g[ky][kx] = w[ky][kx][c][n]
 //   transpose 1 (data gradient):  C = Co, N = Ci, g[ky][kx] = w[2 - ky][2 - kx][n][c]
 __global__ __launch_bounds__(256) void wino2_pack_kernel(const float* __restrict__ w, int Ci, int Co, int transpose, float* __restrict__ out) {
@@ -364,7 +367,7 @@ __global__ __launch_bounds__(256) void wino2_pack_kernel(const float* __restrict
             t[2][kx] = 0.5f * (gk[0][kx] - gk[1][kx] + gk[2][kx]);
             t[3][kx] = gk[2][kx];
         }
-        const int nt = n >> 5, ct = (n >> 4) & 1, nn = n & 15, ch = c >> 4, cc = c & 15, q = cc >> 3, gg = (cc & 7) >> 1, e = cc & 1;
+        const int nt = n >> 5, ct = (n >> 2) & 1, nn = ((n & 31) >> 3) * 4 + (n & 3), ch = c >> 4, cc = c & 15, q = cc >> 3, gg = (cc & 7) >> 1, e = cc & 1;
         float* o = out + (((long)nt * nchunks + ch) * 2 + q) * W2_VHALF + (gg * 16 + nn) * 4 + ct * 2 + e;
 #pragma unroll
         for (int xi = 0; xi < 4; ++xi) {
