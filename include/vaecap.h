@@ -28,6 +28,12 @@ int vc_abi_version(void);
 const char* vc_last_error(void);
 /* 0 if a gfx950 device is usable from this process, else an error code. */
 int vc_device_check(int device);
+/* Tracing: named roctx ranges (`rocprofv3 --marker-trace --kernel-trace`); libroctx64 is bound at run time, without it push / pop are
+ * no-ops.  trainer.Trainer brackets the phases of a step (VGG16 forward, caption forward / backward, VGG16 backward with its gradient
+ * buckets, optimisers) when VC_TRACE=1. */
+int vc_trace_available(void);
+int vc_trace_push(const char* name);
+int vc_trace_pop(void);
 
 /* ------------------------------------------------------------------------------------
  * GEMM  C[M,N] = op(A)[M,K] . op(B)[K,N] (+ bias[N]) ; flags below.   fp32 MFMA.

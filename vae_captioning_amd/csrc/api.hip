@@ -27,6 +27,45 @@ extern "C" int vc_device_check(int device) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// roctx ranges (tracing): named ranges around the phases of a step, visible to `rocprofv3 --marker-trace`.
+// the roctx library is bound at run time (no link-time dependency; without it the calls are no-ops that still return 0).
+#include <dlfcn.h>
+namespace vc {
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+};
+static Roctx* roctx() {
+    static Roctx r;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        // rocprofv3 (rocprofiler-sdk) sees the ranges of ITS roctx library; the roctracer-era libroctx64 is the fallback
+        const char* names[] = {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "/opt/rocm/lib/librocprofiler-sdk-roctx.so.1",
+                               "libroctx64.so.4", "libroctx64.so", "/opt/rocm/lib/libroctx64.so.4"};
+        void* h = nullptr;
+        for (int i = 0; !h && i < 6; ++i) h = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+        if (h) {
+            *(void**)(&r.push) = dlsym(h, "roctxRangePushA");
+            *(void**)(&r.pop) = dlsym(h, "roctxRangePop");
+        }
+    }
+    return (r.push && r.pop) ? &r : nullptr;
+}
+}  // namespace vc
+
+extern "C" int vc_trace_available(void) { return vc::roctx() ? 1 : 0; }
+extern "C" int vc_trace_push(const char* name) {
+    VC_CHECK_ARG(name, "null name");
+    if (vc::Roctx* r = vc::roctx()) r->push(name);
+    return 0;
+}
+extern "C" int vc_trace_pop(void) {
+    if (vc::Roctx* r = vc::roctx()) r->pop();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // CRC-32C (polynomial 0x1EDC6F41, reflected 0x82F63B78), slicing-by-8, host only.
 namespace vc {
 struct Crc32cTables {

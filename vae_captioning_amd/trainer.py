@@ -450,6 +450,8 @@ class Trainer(object):
         self.off_fc = n_cap + self.vgg.store.offset("cnn/fc1/weights") if self.vgg is not None else None
         self.off_c3 = n_cap + self.vgg.store.offset("cnn/conv3_1/weights") if self.vgg is not None else None
         self.comm = None
+        self.trace = os.environ.get("VC_TRACE", "0") == "1" and bool(self.lib.vc_trace_available())
+        self._open_range = False
         if self.collectives:
             self._setup_comm(comm)
 
@@ -498,16 +500,29 @@ class Trainer(object):
             if noise is not None and "cnn_drop1" in noise:
                 self.vgg.set_masks(noise["cnn_drop1"], noise["cnn_drop2"])
 
+    def _range(self, name):
+        """roctx range around a phase of the step (VC_TRACE=1; `rocprofv3 --marker-trace`); name None closes the open range."""
+        if self.trace:
+            if self._open_range:
+                self.lib.vc_trace_pop()
+            if name is not None:
+                self.lib.vc_trace_push(name.encode())
+            self._open_range = name is not None
+
     def _step(self):
         cap, vgg = self.cap, self.vgg
         feats = None
         if vgg is not None:
+            self._range("vgg16_forward")
             feats = vgg.forward(self.images, cap.step)
             if vgg.wd:
                 vgg.reg_sumsq(cap.red.data_ptr() + 12)
+        self._range("caption_forward")
         cap.forward(feats)
+        self._range("caption_backward")
         dfe = cap.backward(want_dfeatures=vgg is not None)
         cap.pack_tail()
+        self._range("vgg16_backward+allreduce" if vgg is not None and vgg.train else "allreduce")
         if self.collectives and self.buckets and vgg is not None and vgg.train and self.reduce_async_fn is not None:
             from . import dp
             bk = dp.gradient_buckets(self.n_cap, self.gall.numel(), self.off_fc, self.off_c3)
@@ -528,9 +543,11 @@ class Trainer(object):
             if vgg is not None and vgg.train:
                 vgg.backward(dfe)
             self.all_reduce_grads()
+        self._range("optimizers")
         cap.apply_gradients()
         if vgg is not None and vgg.train:
             vgg.apply_gradients(cap.scal)
+        self._range(None)
 
     @property
     def reduce_async_fn(self):
