@@ -229,6 +229,18 @@ def winoq():
         print("%s conv%s fwd: %8.3f ms  %6.1f TFLOP/s" % (os.environ.get("VC_LIB", "default")[-12:], name, med, fl / med), flush=True)
 
 
+def winowq():
+    """quick form of winow: Winograd weight gradient only (ablation builds: VC_LIB=.../libvaecap_wgablN.so)"""
+    B = 64
+    for (name, H, ci, co) in [("1_2", 224, 64, 64), ("2_2", 112, 128, 128), ("3_2", 56, 256, 256), ("4_2", 28, 512, 512), ("5_2", 14, 512, 512)]:
+        x, dy, bias = rnd(B, H, H, ci), rnd(B, H, H, co), rnd(co)
+        dw = torch.empty(3, 3, ci, co, device="cuda")
+        ws = torch.empty(lib.vc_conv3x3_wino_wgrad_workspace_bytes(B, H, H, ci, co) // 4 + 4, device="cuda")
+        fl = 2e-9 * B * H * H * 9 * ci * co
+        med, mn = timeit(lambda: lib.vc_conv3x3_wino_wgrad_f32(st(), B, H, H, ci, co, P(x), P(dy), P(dw), P(bias), 0, P(ws), ws.numel() * 4), reps=5)
+        print("%s conv%s wgrad: %8.3f ms  %6.1f TFLOP/s" % (os.environ.get("VC_LIB", "default")[-14:], name, med, fl / med), flush=True)
+
+
 def winow():
     """Winograd F(3x3,2x2) weight gradient against the patch-staged direct kernel, VGG16 layer shapes at 64 images (algorithmic TFLOP/s)"""
     B = 64

@@ -4,6 +4,12 @@
 #pragma once
 #include "conv_wino.h"
 
+// `make ablate-wgrad` builds the kernels with WG_ABL = a bit mask that REMOVES parts of the main loop (results wrong; timing only):
+// 1 transform arithmetic, 2 LDS operand reads, 4 staging (global loads + LDS writes)
+#ifndef WG_ABL
+#define WG_ABL 0
+#endif
+
 namespace vc {
 
 struct WinoWgArgs {
@@ -85,16 +91,19 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(WinoWgArgs a) {
         const int nread = fresh ? 16 : 8;
         if (k < nread) {
             const int idx = fresh ? k : 8 + k, j = idx >> 2, i = idx & 3;
+            if (WG_ABL & 2) return;
             dv[i][j] = smem[buf * BUF + xbase + ((4 * r + i) * PW + 2 * tx + j) * 64];
             return;
         }
         k -= nread;
         if (k < 4) {
             const int aa = k >> 1, bb = k & 1;
+            if (WG_ABL & 2) return;
             ev[aa][bb] = smem[buf * BUF + ybase + ((4 * r + aa) * DW + 2 * tx + bb) * 64];
             return;
         }
         k -= 4;
+        if (WG_ABL & 1) return;
         if (k < nread) {   // vertical transforms of the new patch columns (the two older ones carry over from the previous step)
             const int idx = fresh ? k : 8 + k, j = idx >> 2, xi = idx & 3;
             if (!fresh && k == 0) {
@@ -163,7 +172,7 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(WinoWgArgs a) {
                     for (int k2 = 0; k2 < 5; ++k2)
                         if (k2 < per && m * per + k2 < total) prep(nbuf, sn, nob, m * per + k2);
                 }
-                if (more && m < 10) {   // the next block's data: two batches of ten slots, loaded early, written a few steps later
+                if (more && m < 10 && !(WG_ABL & 4)) {   // the next block's data: two batches of ten slots, loaded early, written a few steps later
                     if (s == 0) gload1(m, m);
                     if (s == NS / 2 - 2) lstore1(buf ^ 1, m, m);
                     if (s == NS / 2 - 1) gload1(10 + m, m);
