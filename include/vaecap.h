@@ -205,6 +205,11 @@ int vc_step_update(void* stream, int32_t* step, float* scalars, float lr, float 
                    float ann_param, int ann_on, int decay_steps);
 int vc_adam_f32(void* stream, float* p, const float* g, float* m, float* v, long n, const float* lr_t, const float* scale,
                 float beta1, float beta2, float eps, float l2);
+/* The same update that also leaves sum(p_new^2) per workgroup in sumsq_partial[0 .. vc_adam_blocks(n)) (summed by vc_reduce_sum_f32):
+ * the L2 regulariser's loss term of the NEXT step (main.py:69-74) without another pass over the 134 M VGG16 parameters. */
+int vc_adam_blocks(long n);
+int vc_adam_sumsq_f32(void* stream, float* p, const float* g, float* m, float* v, long n, const float* lr_t, const float* scale,
+                      float beta1, float beta2, float eps, float l2, float* sumsq_partial);
 int vc_sgd_f32(void* stream, float* p, const float* g, long n, const float* lr, const float* scale, float l2);
 int vc_momentum_f32(void* stream, float* p, const float* g, float* accum, long n, const float* lr, const float* scale,
                     float momentum, float l2, const float* row_mask, int E);

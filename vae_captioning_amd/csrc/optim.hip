@@ -72,10 +72,15 @@ __global__ void step_update_kernel(int32_t* step, float* s, float lr, float cnn_
 
 // tf.train.AdamOptimizer.apply_gradients (ops/optimizers.py:37-40,72-75; TF-sem.):
 //   g' = g*scale (+ l2*p);  m = b1*m + (1-b1)*g';  v = b2*v + (1-b2)*g'^2;  p -= lr_t*m/(sqrt(v)+eps)
+// SUMSQ: also leaves sum(p_new^2) of the block in sumsq_partial[blockIdx.x] -- the regulariser's loss term of the NEXT step
+// (main.py:69-74 sums w^2 over the cnn/* variables) without another 0.5 GB pass over the parameters.
+template <bool SUMSQ>
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long n, const float* __restrict__ lr_t,
                                                    const float* __restrict__ scale, float beta1, float beta2, float eps,
-                                                   float l2) {
+                                                   float l2, float* __restrict__ sumsq_partial) {
+    __shared__ float sh[4];
+    float s2 = 0.f;
     const float lr = lr_t[0];
     const float sc = scale ? scale[0] : 1.f;
     const long n4 = n >> 2;
@@ -88,6 +93,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         mm = beta1 * mm + (1.f - beta1) * gg;
         vv = beta2 * vv + (1.f - beta2) * gg * gg;
         pp -= lr * mm / (sqrtf(vv) + eps);
+        if (SUMSQ) s2 += pp * pp;
     };
     // two independent 16-byte groups per thread and iteration: eight loads in flight before the first use (HBM-bound: 28 B / parameter)
     const long stride = (long)gridDim.x * 256;
@@ -113,6 +119,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         p4[i] = pp; m4[i] = mm; v4[i] = vv;
     }
     for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) upd(p[i], g[i], m[i], v[i]);
+    if (SUMSQ) {
+        s2 = block_sum<256>(s2, sh);
+        if (threadIdx.x == 0) sumsq_partial[blockIdx.x] = s2;
+    }
 }
 
 // GradientDescentOptimizer: p -= lr * (g*scale + l2*p)
@@ -230,7 +240,18 @@ extern "C" int vc_adam_f32(void* stream, float* p, const float* g, float* m, flo
     VC_CHECK_ARG(p && g && m && v && lr_t && n >= 0, "bad argument");
     VC_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "buffers must be 16-byte aligned");
     if (n == 0) return 0;
-    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr_t, scale, beta1, beta2, eps, l2);
+    hipLaunchKernelGGL(adam_kernel<false>, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr_t, scale, beta1, beta2, eps, l2, nullptr);
+    VC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vc_adam_blocks(long n) { return grid_for(n / 4 + 1); }
+
+extern "C" int vc_adam_sumsq_f32(void* stream, float* p, const float* g, float* m, float* v, long n, const float* lr_t,
+                                 const float* scale, float beta1, float beta2, float eps, float l2, float* sumsq_partial) {
+    VC_CHECK_ARG(p && g && m && v && lr_t && sumsq_partial && n > 0, "bad argument");
+    VC_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "buffers must be 16-byte aligned");
+    hipLaunchKernelGGL(adam_kernel<true>, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr_t, scale, beta1, beta2, eps, l2, sumsq_partial);
     VC_LAUNCH_CHECK();
     return 0;
 }
