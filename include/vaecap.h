@@ -301,6 +301,16 @@ int vc_conv3x3_wino_fwd_f32(void* stream, int B, int H, int W, int Cin, int Cout
 int vc_conv3x3_wino_dgrad_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* dy, const float* wpt,
                               const float* relu_src, float* dx);
 
+/* MaxPoolGrad routing codes: a pooled forward (bias + ReLU applied) can also leave, per pooled element, four bits = the position of the
+ * first maximum of its 2x2 window (row-major) | 4 if that maximum is > 0 -- vc_conv3x3_wino_pool_words(B, H, W, Cout) 32-bit words, a word =
+ * 8 consecutive channels of a pooled pixel, layout [B,H/2,W/2,Cout/8] --, and vc_maxpool2x2_bwd_bits_f32 routes the pooled gradient with
+ * them: bit-identical to vc_maxpool2x2_bwd_f32(x = y, dy, dx, relu_grad = 1) without re-reading the pre-pool activation (H, W = the
+ * PRE-pool size in both calls). */
+size_t vc_conv3x3_wino_pool_words(int B, int H, int W, int C);
+int vc_conv3x3_wino_fwd_pool_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const float* wp,
+                                 const float* bias, float* y, float* ypool, uint32_t* pool_bits);
+int vc_maxpool2x2_bwd_bits_f32(void* stream, int B, int H, int W, int C, const uint32_t* pool_bits, const float* dy, float* dx);
+
 /* ReLU mask as bits: the forward of a layer can leave (y > 0) of every lane's 2x2 pixels x 8 columns as 32 bits (vc_conv3x3_wino_mask_words
  * (B, H, W, Cout) 32-bit words), and the data gradient of the NEXT 3x3 layer -- whose output has the same [B,H,W,Cout] shape, hence the
  * same tiles and lanes -- reads those bits (one 4-byte load per lane) instead of relu_src (eight 16-byte loads + packing per lane:

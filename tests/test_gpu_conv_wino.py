@@ -202,3 +202,35 @@ def test_wino_calls_over_the_launch_limit_are_cut_into_image_ranges(tmp_path):
         assert np.array_equal(out["one"][k], out["cut"][k]), k
     for k in ("dw", "db"):
         assert np.abs(out["one"][k] - out["cut"][k]).max() <= 1e-5 * np.abs(out["one"][k]).max(), k
+
+
+@pytest.mark.parametrize("case", [(2, 8, 8, 32, 64), (1, 56, 56, 64, 64), (3, 28, 28, 32, 96), (5, 14, 14, 64, 32), (2, 12, 20, 16, 64)], ids=lambda c: "x".join(map(str, c)))
+def test_pool_routing_codes_equal_maxpool_bwd_on_the_activation(lib, case):
+    """The pooled forward also leaves MaxPoolGrad's routing codes (first maximum of the 2x2 window | valid if > 0); routing the pooled
+    gradient with them is bit-identical to vc_maxpool2x2_bwd_f32 on the pre-pool activation (ties -- whole windows of zeros behind the
+    ReLU, equal positives -- included), and y / ypool equal the plain pooled forward."""
+    B, H, W, Ci, Co = case
+    rng = np.random.default_rng(sum(case) + 11)
+    x = np.maximum(rng.standard_normal((B, H, W, Ci), dtype=np.float32), 0)
+    x[:, : H // 2] = np.round(x[:, : H // 2])                      # small integers: exact ties between window positions
+    w = np.round(rng.standard_normal((3, 3, Ci, Co), dtype=np.float32))
+    w[:, :, :, : Co // 4] = 0                                       # whole channels at the bias value: four-way ties
+    b = np.concatenate([np.full(Co // 8, -1.0), np.full(Co // 8, 2.0), rng.standard_normal(Co - Co // 4)]).astype(np.float32)
+    tx, tw, tb = dev(x), dev(w), dev(b)
+    wp = _pack(lib, tw, 0)
+    y0, p0 = zeros(B, H, W, Co), zeros(B, H // 2, W // 2, Co)
+    lib.vc_conv3x3_wino_fwd_f32(stream(), B, H, W, Ci, Co, P(tx), P(wp), P(tb), P(y0), P(p0), 1)
+    y1, p1 = zeros(B, H, W, Co), zeros(B, H // 2, W // 2, Co)
+    nw = lib.vc_conv3x3_wino_pool_words(B, H, W, Co)
+    assert nw == B * (H // 2) * (W // 2) * (Co // 8)
+    bits = torch.zeros(nw, dtype=torch.int32, device="cuda")
+    lib.vc_conv3x3_wino_fwd_pool_f32(stream(), B, H, W, Ci, Co, P(tx), P(wp), P(tb), P(y1), P(p1), P(bits))
+    assert torch.equal(y0, y1) and torch.equal(p0, p1)
+    dy = dev(rng.standard_normal((B, H // 2, W // 2, Co), dtype=np.float32))
+    d_ref, d_bits = zeros(B, H, W, Co), torch.full((B, H, W, Co), 7.0, device="cuda")
+    lib.vc_maxpool2x2_bwd_f32(stream(), B, H, W, Co, P(y1), P(dy), P(d_ref), 1)
+    lib.vc_maxpool2x2_bwd_bits_f32(stream(), B, H, W, Co, P(bits), P(dy), P(d_bits))
+    assert torch.equal(d_ref, d_bits)
+    hy = host(y1)
+    win = hy.reshape(B, H // 2, 2, W // 2, 2, Co)
+    assert (win.max(axis=(2, 4)) == 0).mean() > 0.05 and ((win == win.max(axis=(2, 4), keepdims=True)).sum(axis=(2, 4)) > 1).mean() > 0.1   # ties do occur

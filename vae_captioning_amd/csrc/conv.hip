@@ -505,6 +505,40 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float4* __restri
     }
 }
 
+// MaxPoolGrad + ReluGrad from the routing codes the pooled Winograd forward left (vc_conv3x3_wino_fwd_pool_f32): per pooled element four
+// bits = position of the window's first maximum | 4 if that maximum is > 0; a word = 8 consecutive channels.  Reads dy [B,H/2,W/2,C]
+// and C/2 bytes of codes per pooled pixel instead of the whole pre-pool activation: 1.3 instead of 2.25 tensor passes.
+__global__ __launch_bounds__(256) void maxpool_bwd_bits_kernel(const unsigned* __restrict__ bits, const float4* __restrict__ dy, int B, int H,
+                                                               int W, int C8, float4* __restrict__ dx) {
+    const int Ho = H >> 1, Wo = W >> 1;
+    const long total = (long)B * Ho * Wo * C8;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C8);
+        long p = i / C8;
+        const int xo = (int)(p % Wo);
+        p /= Wo;
+        const int yo = (int)(p % Ho);
+        const long b = p / Ho;
+        const long base = ((b * H + 2 * yo) * W + 2 * xo) * (2 * C8) + 2 * c;   // float4 index of the window's first pixel
+        const long rowo = (long)W * 2 * C8;
+        const unsigned code = bits[i];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float4 g = dy[2 * i + h];
+            const unsigned cd = code >> (16 * h);
+            float4 o[4];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                o[w].x = ((cd & 7u) == (4u | w)) ? g.x : 0.f;
+                o[w].y = (((cd >> 4) & 7u) == (4u | w)) ? g.y : 0.f;
+                o[w].z = (((cd >> 8) & 7u) == (4u | w)) ? g.z : 0.f;
+                o[w].w = (((cd >> 12) & 7u) == (4u | w)) ? g.w : 0.f;
+            }
+            dx[base + h] = o[0]; dx[base + 2 * C8 + h] = o[1]; dx[base + rowo + h] = o[2]; dx[base + rowo + 2 * C8 + h] = o[3];
+        }
+    }
+}
+
 // images - mean_rgb (utils/image_embeddings.py:31-34), RGB -> NHWC4 (4th channel zero)
 __global__ __launch_bounds__(256) void preprocess_kernel(const float* __restrict__ img, long P, float4* __restrict__ out) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < P; i += (long)gridDim.x * 256)
@@ -600,6 +634,14 @@ extern "C" int vc_maxpool2x2_bwd_f32(void* stream, int B, int H, int W, int C, c
     VC_CHECK_ARG(x && dy && dx && B > 0 && H > 0 && W > 0 && C > 0 && H % 2 == 0 && W % 2 == 0 && C % 4 == 0, "even H/W, C % 4 == 0 required");
     const long total = (long)B * (H / 2) * (W / 2) * (C / 4);
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float4*)x, (const float4*)dy, B, H, W, C / 4, relu_grad, (float4*)dx);
+    VC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vc_maxpool2x2_bwd_bits_f32(void* stream, int B, int H, int W, int C, const uint32_t* pool_bits, const float* dy, float* dx) {
+    VC_CHECK_ARG(pool_bits && dy && dx && B > 0 && H > 0 && W > 0 && C > 0 && H % 2 == 0 && W % 2 == 0 && C % 8 == 0, "even H/W, C % 8 == 0 required");
+    const long total = (long)B * (H / 2) * (W / 2) * (C / 8);
+    hipLaunchKernelGGL(maxpool_bwd_bits_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, pool_bits, (const float4*)dy, B, H, W, C / 8, (float4*)dx);
     VC_LAUNCH_CHECK();
     return 0;
 }

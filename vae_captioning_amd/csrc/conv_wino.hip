@@ -67,6 +67,8 @@ struct Wino2Args {
     float* out;         // [P, N]
     const float* aux;   // fwd: bias [N] or null; dgrad: ReLU source [P, N] or null
     float* pool;        // fwd: also max_pool2x2(out) (null: none)
+    unsigned* pbits;    // fwd + pool: MaxPoolGrad routing codes [B,H/2,W/2,N/8] (null: not wanted): per pooled element 4 bits = position of the
+                        // first maximum of its 2 x 2 window (row-major) | 4 if that maximum is > 0; a word = 8 consecutive channels
     unsigned* mask;     // [workgroups][256 threads]: (out > 0) of each lane's 2 x 2 pixels x 8 columns as 32 bits -- written by the forward
                         // (null: not wanted), read by the data gradient of the NEXT layer instead of relu_src (same shape => same lanes)
     int relu;
@@ -271,7 +273,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(Wino2Args a) {
 #undef WSB
 
     // ---- output transform + epilogue: acc[p][ct][r] = M_p[column n0 + 8 lg + 4 ct + r][tile lj]
-    unsigned obits = 0u;
+    unsigned obits = 0u, pcode = 0u;
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
         const int col = n0 + 8 * lg + 4 * ct;
@@ -338,9 +340,17 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(Wino2Args a) {
             m.z = fmaxf(fmaxf(Y[0][0].z, Y[0][1].z), fmaxf(Y[1][0].z, Y[1][1].z));
             m.w = fmaxf(fmaxf(Y[0][0].w, Y[0][1].w), fmaxf(Y[1][0].w, Y[1][1].w));
             *reinterpret_cast<float4*>(a.pool + ((long)(b * (g.H >> 1) + (y0 >> 1)) * (g.W >> 1) + (x0 >> 1)) * N + col) = m;
+            if (a.pbits) {   // where MaxPoolGrad will send the gradient (vc_maxpool2x2_bwd_bits_f32): first maximum in row-major order, valid if > 0
+                auto code = [](float v00, float v01, float v10, float v11, float mx) -> unsigned {
+                    return (v00 == mx ? 0u : v01 == mx ? 1u : v10 == mx ? 2u : 3u) | (mx > 0.f ? 4u : 0u);
+                };
+                pcode |= (code(Y[0][0].x, Y[0][1].x, Y[1][0].x, Y[1][1].x, m.x) | code(Y[0][0].y, Y[0][1].y, Y[1][0].y, Y[1][1].y, m.y) << 4 |
+                          code(Y[0][0].z, Y[0][1].z, Y[1][0].z, Y[1][1].z, m.z) << 8 | code(Y[0][0].w, Y[0][1].w, Y[1][0].w, Y[1][1].w, m.w) << 12) << (16 * ct);
+            }
         }
     }
     if (KIND == W2_FWD && a.mask) a.mask[(size_t)id * 256 + tid] = obits;
+    if (POOL && a.pbits && ok11) a.pbits[(((size_t)(b * (g.H >> 1) + (y0 >> 1)) * (g.W >> 1) + (x0 >> 1)) * N + n0 + 8 * lg) >> 3] = pcode;
 }
 
 // w [3][3][Ci][Co] (HWIO) -> V = G g G^T, G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1], packed
@@ -495,10 +505,10 @@ extern "C" int vc_conv3x3_wino_pack_f32(void* stream, int Cin, int Cout, const f
 namespace vc {
 // one launch over nb images; C = gathered channels, N = produced channels
 static int wino2_launch(hipStream_t st, int kind, int nb, int H, int W, int C, int N, const float* x, const float* wp, float* out, const float* aux,
-                        float* pool, unsigned* mask, int relu) {
+                        float* pool, unsigned* mask, int relu, unsigned* pbits = nullptr) {
     Wino2Args a;
     if (!plan_wino2(nb, H, W, C, N, a.g)) return fail(VC_EINVAL, "%s: unsupported shape (vc_conv3x3_wino_supported)", "conv wino");
-    a.x = x; a.wp = wp; a.out = out; a.aux = aux; a.pool = pool; a.mask = mask; a.relu = relu;
+    a.x = x; a.wp = wp; a.out = out; a.aux = aux; a.pool = pool; a.mask = mask; a.relu = relu; a.pbits = pbits;
     if (kind == W2_DGRAD) return launch_wino2<W2_DGRAD, false>(st, a);
     return pool ? launch_wino2<W2_FWD, true>(st, a) : launch_wino2<W2_FWD, false>(st, a);
 }
@@ -515,6 +525,25 @@ extern "C" int vc_conv3x3_wino_fwd_f32(void* stream, int B, int H, int W, int Ci
         const int nb = B - b0 < per ? B - b0 : per;
         const int rc = wino2_launch((hipStream_t)stream, W2_FWD, nb, H, W, Cin, Cout, x + (size_t)b0 * H * W * Cin, wp, y + (size_t)b0 * H * W * Cout, bias,
                                     ypool ? ypool + (size_t)b0 * (H / 2) * (W / 2) * Cout : nullptr, nullptr, relu);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+extern "C" size_t vc_conv3x3_wino_pool_words(int B, int H, int W, int C) { return (size_t)B * (H / 2) * (W / 2) * (C / 8); }
+
+extern "C" int vc_conv3x3_wino_fwd_pool_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const float* wp,
+                                            const float* bias, float* y, float* ypool, uint32_t* pool_bits) {
+    using namespace vc;
+    VC_CHECK_ARG(x && wp && y && ypool && pool_bits, "null pointer");
+    VC_CHECK_ARG(waligned16(x) && waligned16(wp) && waligned16(y) && waligned16(bias) && waligned16(ypool), "pointers must be 16-byte aligned");
+    const int per = wino_images_per_launch(B, H, W, Cin, Cout);
+    VC_CHECK_ARG(per > 0 && vc_conv3x3_wino_supported(B, H, W, Cin, Cout, 0), "unsupported shape (vc_conv3x3_wino_supported)");
+    for (int b0 = 0; b0 < B; b0 += per) {
+        const int nb = B - b0 < per ? B - b0 : per;
+        const size_t po = (size_t)b0 * (H / 2) * (W / 2) * Cout;
+        const int rc = wino2_launch((hipStream_t)stream, W2_FWD, nb, H, W, Cin, Cout, x + (size_t)b0 * H * W * Cin, wp, y + (size_t)b0 * H * W * Cout, bias,
+                                    ypool + po, nullptr, 1, pool_bits + po / 8);
         if (rc) return rc;
     }
     return 0;

@@ -221,6 +221,7 @@ class VggEngine(object):
             y = self._b("y_" + name, (B, H, W, co))
             pooled = name in spec.VGG_POOL_AFTER
             yp = self._b("p_" + name, (B, H // 2, W // 2, co)) if pooled else None
+            pool_bits = None   # set when every chain's forward of this pooled layer left routing codes
             for ch, (b0, nb, strm) in enumerate(halves):
                 tws = self._chain_ws(ch, nb)
                 with torch.cuda.stream(strm):
@@ -240,7 +241,15 @@ class VggEngine(object):
                             self.mask_geom[name] = (nb, len(halves))   # the bits are per tile of THIS launch geometry
                             self._timed("conv_fwd", fl, lambda: lib.vc_conv3x3_wino_fwd_mask_f32(
                                 sh, nb, H, W, cie, co, P(x[b0:]), P(self.buf["vp_" + name]), P(S.param(bn)), P(y[b0:]), 1, P(mk)))
-                        else:   # the 2x2 max-pool is register math in the epilogue
+                        elif pooled and self.train:
+                            # the 2x2 max-pool is register math in the epilogue; it also leaves MaxPoolGrad's routing codes (4 bits per pooled
+                            # element), so the backward pass does not re-read the pre-pool activation
+                            pb = self._b("pb_" + name, (lib.vc_conv3x3_wino_pool_words(B, H, W, co),), dtype=torch.int32)
+                            pool_bits = pb
+                            w0 = b0 * (H // 2) * (W // 2) * (co // 8)
+                            self._timed("conv_fwd", fl, lambda: lib.vc_conv3x3_wino_fwd_pool_f32(
+                                sh, nb, H, W, cie, co, P(x[b0:]), P(self.buf["vp_" + name]), P(S.param(bn)), P(y[b0:]), P(yp[b0:]), P(pb[w0:])))
+                        else:
                             self._timed("conv_fwd", fl, lambda: lib.vc_conv3x3_wino_fwd_f32(
                                 sh, nb, H, W, cie, co, P(x[b0:]), P(self.buf["vp_" + name]), P(S.param(bn)), P(y[b0:]), P(yp[b0:]) if pooled else None, 1))
                         continue
@@ -260,7 +269,7 @@ class VggEngine(object):
             self.acts.append((name, x, H, W, cie, co, w))
             x = y
             if pooled:
-                self.acts.append(("P", x, H, W, co, co, None))
+                self.acts.append(("P", x, H, W, co, co, pool_bits))
                 x = yp
                 H, W = H // 2, W // 2
         if side is not None:
@@ -346,7 +355,10 @@ class VggEngine(object):
                 dx = self._b("dx_%d" % li, (B, H, W, co))
                 for b0, nb, strm in halves:
                     with torch.cuda.stream(strm):  # + ReluGrad of the conv that made x
-                        lib.vc_maxpool2x2_bwd_f32(_stream(), nb, H, W, co, P(x[b0:]), P(d[b0:]), P(dx[b0:]), 1)
+                        if w is not None:   # routing codes from the pooled Winograd forward: no read of x
+                            lib.vc_maxpool2x2_bwd_bits_f32(_stream(), nb, H, W, co, P(w[b0 * (H // 2) * (W // 2) * (co // 8):]), P(d[b0:]), P(dx[b0:]))
+                        else:
+                            lib.vc_maxpool2x2_bwd_f32(_stream(), nb, H, W, co, P(x[b0:]), P(d[b0:]), P(dx[b0:]), 1)
                 d = dx
                 continue
             wn, bn = spec.vgg_var_names(name)
