@@ -37,3 +37,20 @@ def test_load_image_and_keras_load_img(tmp_path):
     assert set(np.unique(x)).issubset(set(np.unique(a).astype(np.float32)))
     same, _ = keras_load_img(str(tmp_path / "a.png"), target_size=(60, 90))
     assert np.array_equal(same[0], a.astype(np.float32))
+
+
+def test_bilinear_resize_geometry_matches_torch_interpolate():
+    """cv2.resize(INTER_LINEAR) cannot run here; its sampling GEOMETRY (half-pixel centres, edge clamping, no anti-aliasing) is what
+    torch.nn.functional.interpolate(mode='bilinear', align_corners=False, antialias=False) implements in floating point.  The 8-bit
+    restatement (11-bit fixed-point coefficients, two-pass rounding) must agree with it to within ONE grey level for up- and
+    down-scaling, odd sizes and non-square targets -- a wrong centre convention or tap index shows up as errors of tens of levels."""
+    import torch
+    from vae_captioning_amd.utils.image_utils import resize_bilinear_u8
+    rng = np.random.default_rng(3)
+    for (sh, sw), (dw, dh) in (((37, 53), (224, 224)), ((480, 640), (224, 224)), ((300, 200), (224, 224)), ((224, 224), (97, 131)), ((5, 7), (16, 9))):
+        img = rng.integers(0, 256, size=(sh, sw, 3), dtype=np.uint8)
+        got = resize_bilinear_u8(img, (dw, dh)).astype(np.int64)
+        t = torch.from_numpy(img.astype(np.float64)).permute(2, 0, 1)[None]
+        ref = torch.nn.functional.interpolate(t, size=(dh, dw), mode="bilinear", align_corners=False, antialias=False)[0].permute(1, 2, 0).numpy()
+        assert got.shape == (dh, dw, 3)
+        assert np.abs(got - ref).max() <= 1.0, ((sh, sw), (dw, dh), np.abs(got - ref).max())

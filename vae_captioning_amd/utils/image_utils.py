@@ -8,8 +8,11 @@ OpenCV and Keras are not in this image):
 
 `resize_bilinear_u8` restates OpenCV's 8-bit INTER_LINEAR resize (half-pixel centres, 11-bit fixed-point
 coefficients, its two-pass rounding) from the published algorithm; it cannot be checked against cv2 here
-and is marked UNVERIFIED -- the tests pin the properties that do not need cv2 (identity at equal size,
-exact 2x2 box means at integer 1/2 scale, constant images, range)."""
+-- the tests pin the properties that do not need cv2 (identity at equal size, exact 2x2 box means at integer
+1/2 scale, constant images, range) and, since round 3, the sampling geometry against a third-party
+implementation of the same convention (torch.nn.functional.interpolate, bilinear, half-pixel centres, no
+anti-aliasing: within one grey level for up- and down-scaling).  The exact fixed-point rounding stays
+UNVERIFIED against cv2."""
 import numpy as np
 
 
