@@ -394,7 +394,15 @@ __global__ __launch_bounds__(256) void wino2_pack_kernel(const float* __restrict
 // ds_read_b128 is served in four groups of sixteen lanes (MI355X_MICROARCH.md, LDS), a group is conflict-free when its sixteen 16-byte
 // units fall into sixteen different bank quads (unit index mod 16).  Lane = (tile lj = lane % 16, k group lg = lane / 16) reads unit
 // lg * W2_PLANE + (2 ty + r) * P + tx + c.  0: the patch does not fit a plane.
-static int wino2_row_pitch(int TBH, int TBW) {
+static int wino2_row_pitch_search(int TBH, int TBW);
+static int wino2_row_pitch(int TBH, int TBW) {   // memoised: the search costs ~0.1 ms and every launch plans its geometry
+    static int cache[17][17];   // 0 = not searched yet, -1 = does not fit; block shapes have TBH * TBW <= 16
+    if (TBH < 1 || TBW < 1 || TBH > 16 || TBW > 16) return 0;
+    int& c = cache[TBH][TBW];
+    if (c == 0) { const int p = wino2_row_pitch_search(TBH, TBW); c = p > 0 ? p : -1; }
+    return c > 0 ? c : 0;
+}
+static int wino2_row_pitch_search(int TBH, int TBW) {
     static const int groups[4][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27}, {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
                                       {32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59}, {36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63}};
     const int PW = 2 * TBW + 2, PH = 2 * TBH + 2, ntl = TBH * TBW;
