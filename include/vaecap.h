@@ -114,6 +114,15 @@ int vc_lstm_seq_fwd_f32(void* stream, int T, int N, int E, int H, const float* X
 int vc_lstm_seq_bwd_f32(void* stream, int T, int N, int E, int H, const float* X, const float* W, const int32_t* lens_eff,
                         const float* act, const float* cs, const float* hs, const float* dhs_ext, float* dH_run,
                         float* dC_run, float* dG, float* dX, float* dW, float* db, float* ws, size_t ws_bytes);
+/* The backward pass in two calls (vc_lstm_seq_bwd_f32 = the first followed by the second on one stream): the recurrence with
+ * dX = dG.Wx^T, which is all the gradient chain below the LSTM waits for, and the weight gradients dWx = X^T.dG, dWh = hs[0:T]^T.dG,
+ * db = colsum(dG) from the dG the first call left -- tf.gradients has no consumer for them before the optimiser
+ * (ops/optimizers.py:13-16), so a caller may enqueue the second call on another stream with its own workspace. */
+int vc_lstm_seq_bwd_data_f32(void* stream, int T, int N, int E, int H, const float* W, const int32_t* lens_eff, const float* act,
+                             const float* cs, const float* dhs_ext, float* dH_run, float* dC_run, float* dG, float* dX, float* ws,
+                             size_t ws_bytes);
+int vc_lstm_seq_bwd_weights_f32(void* stream, int T, int N, int E, int H, const float* X, const float* hs, const float* dG, float* dW,
+                                float* db, float* ws, size_t ws_bytes);
 
 /* ------------------------------------------------------------------------------------
  * Masked sparse softmax cross-entropy, main.py:152-158.  In place: `logits` [rows, V] (ld)

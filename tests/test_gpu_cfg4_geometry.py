@@ -195,8 +195,10 @@ def test_a_real_call_over_two_gib_equals_its_halves(lib):
 
 def test_cfg4_step_on_three_streams_equals_one_stream_bit_for_bit(lib):
     """The bench's step: Normal CVAE + --fine_tune at 64 images (320 caption rows), VGG16 pushed through as two 32-image chains + the
-    weight gradients on a third stream (default) against VC_VGG_STREAMS=1 (one 64-image chain).  Per-image tiles, full-batch weight
-    gradients in both schedules: losses, every gradient and every updated parameter must be IDENTICAL."""
+    weight gradients on a third stream, the caption side's weight gradients / clip / Adam and fc1 + fc2's Adam on the
+    weight-gradient stream (default) against VC_VGG_STREAMS=1 + wgrad_stream=False (one 64-image chain, everything in program
+    order on ONE stream).  Per-image tiles, full-batch weight gradients in both schedules: losses, every gradient and every
+    updated parameter must be IDENTICAL."""
     from vae_captioning_amd import spec, synth
     from vae_captioning_amd.trainer import Trainer
     from vae_captioning_amd.utils.parameters import Parameters
@@ -211,11 +213,11 @@ def test_cfg4_step_on_three_streams_equals_one_stream_bit_for_bit(lib):
     try:
         for streams in ("3", "1"):
             os.environ["VC_VGG_STREAMS"] = streams
-            tr = Trainer(p, V, lib=lib, seed=17)
-            assert (tr.vgg.side2 is not None) == (streams == "3")
+            tr = Trainer(p, V, lib=lib, seed=17, wgrad_stream=streams == "3")
+            assert (tr.vgg.side2 is not None) == (streams == "3") and (tr.cap.wgrad_stream is not None) == (streams == "3")
             tr.load_state_dict(P0)
             tr.set_batch(batch)
-            for _ in range(2):
+            for _ in range(3):   # (the third step reads the sums of w^2 that the second one's two Adam launches left)
                 tr.train_step()
             res.append((tr.losses(), tr.gall.clone(), tr.cap.store.p.clone(), tr.vgg.store.p.clone()))
             del tr

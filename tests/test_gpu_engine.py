@@ -338,3 +338,45 @@ def test_set_batch_under_a_captured_graph_feeds_the_replayed_step(lib):
         np.testing.assert_array_equal(res[0][1][k], res[1][1][k], err_msg=k)
     with pytest.raises(ValueError):
         tr.set_batch(synth.make_batch(rng, B, p.num_captions, T + 2, V, feature_size=p.cnn_feature_size))
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(prior="GMM"), dict(prior="AG", use_c_v=True), dict(no_encoder=True), dict(fine_tune=True),
+                                dict(fine_tune=True, collectives=True), dict(collectives=True), dict(graph=True)],
+                         ids=["normal", "gmm", "ag_cv", "no_encoder", "fine_tune", "fine_tune_rccl_buckets", "rccl", "hipgraph"])
+def test_weight_gradient_stream_equals_program_order_bit_for_bit(lib, kw):
+    """Trainer's second stream (weight gradients of the caption side, clip + optimiser, fc1 / fc2's optimiser; engine.off_chain)
+    against the same step in program order on one stream: the same kernels on the same data, so losses, gradients and updated
+    parameters of three steps are identical -- a missing stream dependency would show as a difference (or as garbage)."""
+    from vae_captioning_amd.trainer import Trainer
+    kw = dict(kw)
+    coll, graph = kw.pop("collectives", False), kw.pop("graph", False)
+    p = Parameters()
+    for k, v in kw.items():
+        setattr(p, k, v)
+    V, T, B = 600, 11, 6
+    p.batch_size = B
+    rng = np.random.default_rng(8)
+    batch = synth.make_batch(rng, B, p.num_captions, T, V, use_ci=spec.uses_ci(p), variable_len=True, images=bool(p.fine_tune))
+    P0 = spec.init_caption_params(p, V, seed=1)
+    if p.fine_tune:
+        P0.update(spec.init_vgg_params(seed=2))
+    res = []
+    for side in (True, False):
+        tr = Trainer(p, V, lib=lib, seed=5, force_collectives=coll, wgrad_stream=side)
+        assert (tr.cap.wgrad_stream is not None) == side
+        tr.load_state_dict(P0)
+        tr.set_batch(batch)
+        if graph:
+            tr.capture()
+        for _ in range(3):
+            tr.train_step()
+        torch.cuda.synchronize()
+        res.append((tr.losses(), tr.gall.clone(), tr.cap.store.p.clone(), tr.vgg.store.p.clone() if tr.vgg is not None else None))
+        if tr.comm is not None:
+            tr.comm.destroy()
+        del tr
+    assert res[0][0] == res[1][0] and all(np.isfinite(res[0][0])), (res[0][0], res[1][0])
+    assert torch.equal(res[0][1], res[1][1]) and float(res[0][1].abs().max()) > 0
+    assert torch.equal(res[0][2], res[1][2])
+    if res[0][3] is not None:
+        assert torch.equal(res[0][3], res[1][3])

@@ -62,5 +62,58 @@ def families(db):
         print("| %s | %d | %.3f | %.3f | %.3f / %.3f |" % (title, len(iv), tot / 1e6, uni / 1e6, tot / 1e6 / max(steps, 1), uni / 1e6 / max(steps, 1)))
 
 
+def gaps(db, last=30, top=25):
+    """Where the step's time OUTSIDE the convolution family goes: over the last `last` steps (window = start of one
+    preprocess_kernel to the start of the one `last` steps later, so exactly `last` steps), every elementary interval in which
+    no convolution dispatch is running is charged to the kernels that ARE running (split evenly) or to `idle` (nothing on the
+    device: launch latency, host enqueue, event waits)."""
+    rows = db.execute("select s.kernel_name, d.start, d.end from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s "
+                      "on d.kernel_id = s.id order by d.start").fetchall()
+    marks = [a for n, a, b in rows if "preprocess_kernel" in n]
+    if len(marks) < last + 1:
+        return
+    lo, hi = marks[-last - 1], marks[-1]
+    conv = FAMILIES[0][1]
+    ev = []
+    for n, a, b in rows:
+        a, b = max(a, lo), min(b, hi)
+        if b > a:
+            ev.append((a, 1, n))
+            ev.append((b, -1, n))
+    ev.sort(key=lambda e: (e[0], e[1]))
+    active, charge, prev, nconv, covered = {}, {}, lo, 0, 0
+    for t, sgn, n in ev:
+        dt = t - prev
+        if dt > 0:
+            if nconv:
+                covered += dt
+            elif active:
+                for k in active:
+                    charge[k] = charge.get(k, 0) + dt / len(active)
+            else:
+                charge["idle (no kernel on the device)"] = charge.get("idle (no kernel on the device)", 0) + dt
+        prev = t
+        isconv = any(p in n for p in conv)
+        if sgn > 0:
+            active[n] = active.get(n, 0) + 1 if not isconv else active.get(n, 0)
+            nconv += isconv
+        else:
+            if isconv:
+                nconv -= 1
+            else:
+                active[n] -= 1
+        active = {k: v for k, v in active.items() if v > 0}
+    if hi > prev:
+        charge["idle (no kernel on the device)"] = charge.get("idle (no kernel on the device)", 0) + hi - prev
+    span = hi - lo
+    print("\nlast %d steps: %.3f ms per step, %.3f ms with a convolution dispatch running, %.3f ms without; the time without, by "
+          "what was running instead (ms per step):\n" % (last, span / 1e6 / last, covered / 1e6 / last, (span - covered) / 1e6 / last))
+    print("| running while no convolution is | ms per step |")
+    print("|---|---|")
+    for k, v in sorted(charge.items(), key=lambda kv: -kv[1])[:top]:
+        print("| `%s` | %.3f |" % (k if len(k) <= 110 else k[:107] + "...", v / 1e6 / last))
+
+
 if __name__ == "__main__":
     main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 40)
+    gaps(sqlite3.connect(sys.argv[1]))

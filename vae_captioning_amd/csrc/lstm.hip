@@ -959,13 +959,38 @@ extern "C" int vc_lstm_seq_fwd_f32(void* stream, int T, int N, int E, int H, con
 // (may be null); dH_run / dC_run: [N,H] scratch that must hold the gradient w.r.t. the
 // final state on entry (zeros, or the encoder's d h_T) and holds d(hs[1]), d(cs[0]) on exit.
 // Outputs: dG [T,N,4H], dX [T,N,E], dW [E+H,4H], db [4H].
+// The same pass in two calls, for callers that keep the weight gradients off the chain that the data gradient feeds (they have
+// no consumer before the optimiser, so they may run on another stream under whatever follows dX):
+//   vc_lstm_seq_bwd_data_f32     the recurrence (dG for every step) and dX = dG.Wx^T
+//   vc_lstm_seq_bwd_weights_f32  dWx = X^T.dG, dWh = hs[0:T]^T.dG, db = colsum(dG), from the dG the first call left
+// vc_lstm_seq_bwd_f32 is the first followed by the second on one stream.
+extern "C" int vc_lstm_seq_bwd_weights_f32(void* stream, int T, int N, int E, int H, const float* X, const float* hs, const float* dG,
+                                           float* dW, float* db, float* ws, size_t ws_bytes) {
+    VC_CHECK_ARG(T > 0 && N > 0 && E > 0 && H > 0 && H % 32 == 0, "bad dimensions (H % 32 == 0 required)");
+    VC_CHECK_ARG(X && hs && dG && dW && db, "null pointer");
+    int rc = vc_gemm_f32(stream, 1, 0, E, 4 * H, T * N, X, E, dG, 4 * H, dW, 4 * H, nullptr, 0, ws, ws_bytes);
+    if (rc) return rc;
+    rc = vc_gemm_f32(stream, 1, 0, H, 4 * H, T * N, hs, H, dG, 4 * H, dW + (long)E * 4 * H, 4 * H, nullptr, 0, ws, ws_bytes);
+    if (rc) return rc;
+    return vc_colsum_f32(stream, dG, T * N, 4 * H, 4 * H, db, 0, ws, ws_bytes);
+}
+
 extern "C" int vc_lstm_seq_bwd_f32(void* stream, int T, int N, int E, int H, const float* X, const float* W,
                                    const int32_t* lens_eff, const float* act, const float* cs, const float* hs,
                                    const float* dhs_ext, float* dH_run, float* dC_run, float* dG, float* dX, float* dW,
                                    float* db, float* ws, size_t ws_bytes) {
+    VC_CHECK_ARG(dW && db, "null pointer");
+    int rc = vc_lstm_seq_bwd_data_f32(stream, T, N, E, H, W, lens_eff, act, cs, dhs_ext, dH_run, dC_run, dG, dX, ws, ws_bytes);
+    if (rc) return rc;
+    return vc_lstm_seq_bwd_weights_f32(stream, T, N, E, H, X, hs, dG, dW, db, ws, ws_bytes);
+}
+
+extern "C" int vc_lstm_seq_bwd_data_f32(void* stream, int T, int N, int E, int H, const float* W, const int32_t* lens_eff,
+                                        const float* act, const float* cs, const float* dhs_ext, float* dH_run, float* dC_run,
+                                        float* dG, float* dX, float* ws, size_t ws_bytes) {
     using namespace vc;
     VC_CHECK_ARG(T > 0 && N > 0 && E > 0 && H > 0 && H % 32 == 0, "bad dimensions (H % 32 == 0 required)");
-    VC_CHECK_ARG(X && W && lens_eff && act && cs && hs && dH_run && dC_run && dG && dX && dW && db, "null pointer");
+    VC_CHECK_ARG(W && lens_eff && act && cs && dH_run && dC_run && dG && dX, "null pointer");
     const float* Wx = W;
     const float* Wh = W + (long)E * 4 * H;
     const long NH = (long)N * H, NG = (long)N * 4 * H;
@@ -1001,12 +1026,5 @@ extern "C" int vc_lstm_seq_bwd_f32(void* stream, int T, int N, int E, int H, con
         }
         if (rc) return rc;
     }
-    // dWx = X^T.dG, dWh = hs[0:T]^T.dG, db = colsum(dG), dX = dG.Wx^T
-    rc = vc_gemm_f32(stream, 1, 0, E, 4 * H, T * N, X, E, dG, 4 * H, dW, 4 * H, nullptr, 0, ws, ws_bytes);
-    if (rc) return rc;
-    rc = vc_gemm_f32(stream, 1, 0, H, 4 * H, T * N, hs, H, dG, 4 * H, dW + (long)E * 4 * H, 4 * H, nullptr, 0, ws, ws_bytes);
-    if (rc) return rc;
-    rc = vc_colsum_f32(stream, dG, T * N, 4 * H, 4 * H, db, 0, ws, ws_bytes);
-    if (rc) return rc;
     return vc_gemm_f32(stream, 0, 1, T * N, E, 4 * H, dG, 4 * H, Wx, 4 * H, dX, E, nullptr, 0, ws, ws_bytes);
 }

@@ -13,6 +13,8 @@ Layout decisions (MI355X-first):
   * the 180 GMM/AG head layers are stored as one [H, 2*90*L] matrix (split only when
     a reference-named checkpoint is exported).
 """
+import contextlib
+
 import numpy as np
 import torch
 
@@ -191,6 +193,12 @@ class CaptionEngine(object):
         self.gmm_draw = False
         self.ws = None
         self.ws_bytes = 0
+        # weight gradients, the global-norm clip and the optimiser have no consumer on the gradient chain (tf.gradients hands them
+        # to apply_gradients only, ops/optimizers.py:13-16,37-47): with a second stream they run under the LSTM recurrences and,
+        # when fine-tuning, under the VGG16 backward pass.  None = everything on the caller's stream.
+        self.wgrad_stream = None
+        self._off = False
+        self.ws_off, self.ws_off_bytes = None, 0
         i32 = dict(dtype=torch.int32, device=device)
         f32 = dict(dtype=torch.float32, device=device)
         self.step = torch.zeros(1, **i32)
@@ -288,14 +296,45 @@ class CaptionEngine(object):
         return t
 
     def _need_ws(self, nbytes):
+        """Scratch for the launches of the CURRENT stream: (pointer, bytes).  Launches on the weight-gradient stream get their
+        own buffer, since they run next to the ones of the caller's stream."""
+        nb = max(int(nbytes), 1 << 20)
+        if self._off:
+            if nbytes > self.ws_off_bytes:
+                self.ws_off = torch.empty(nb // 4 + 16, dtype=torch.float32, device=self.dev)
+                self.ws_off_bytes = self.ws_off.numel() * 4
+            return P(self.ws_off), self.ws_off_bytes
         if nbytes > self.ws_bytes:
-            nb = max(int(nbytes), 1 << 20)
             self.ws = torch.empty(nb // 4 + 16, dtype=torch.float32, device=self.dev)
             self.ws_bytes = self.ws.numel() * 4
+        return P(self.ws), self.ws_bytes
+
+    def enable_wgrad_stream(self, on=True):
+        self.wgrad_stream = torch.cuda.Stream(self.dev) if on else None
+
+    @contextlib.contextmanager
+    def off_chain(self):
+        """Launches inside run on the weight-gradient stream, ordered after everything the caller's stream holds so far; what
+        they write is final for the caller only after join_off_chain().  Without a second stream: the caller's stream."""
+        side = self.wgrad_stream
+        if side is None or self._off:
+            yield
+            return
+        side.wait_stream(torch.cuda.current_stream())
+        self._off = True
+        try:
+            with torch.cuda.stream(side):
+                yield
+        finally:
+            self._off = False
+
+    def join_off_chain(self):
+        if self.wgrad_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.wgrad_stream)
 
     def gemm(self, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias=None, flags=0):
-        self._need_ws(self.lib.vc_gemm_workspace_bytes(M, N, K))
-        self.lib.vc_gemm_f32(_stream(), ta, tb, M, N, K, P(A), lda, P(B), ldb, P(C), ldc, P(bias), flags, P(self.ws), self.ws_bytes)
+        ws, nb = self._need_ws(self.lib.vc_gemm_workspace_bytes(M, N, K))
+        self.lib.vc_gemm_f32(_stream(), ta, tb, M, N, K, P(A), lda, P(B), ldb, P(C), ldc, P(bias), flags, ws, nb)
 
     def _timed(self, tag, flops, fn):
         if self.timer is not None:
@@ -304,8 +343,8 @@ class CaptionEngine(object):
             fn()
 
     def colsum(self, x, rows, cols, out, accumulate=0, ld=None):
-        self._need_ws(self.lib.vc_colsum_workspace_bytes(rows, cols))
-        self.lib.vc_colsum_f32(_stream(), P(x), rows, cols, ld or cols, P(out), accumulate, P(self.ws), self.ws_bytes)
+        ws, nb = self._need_ws(self.lib.vc_colsum_workspace_bytes(rows, cols))
+        self.lib.vc_colsum_f32(_stream(), P(x), rows, cols, ld or cols, P(out), accumulate, ws, nb)
 
     def dense_bwd_w(self, x, rows, fin, fout, dy, wname, bname, ld_dy=None):
         """dW = x^T.dy, db = colsum(dy) written straight into the flat gradient buffer (ld_dy: row pitch of dy, default fout)."""
@@ -585,10 +624,10 @@ class CaptionEngine(object):
         self._timed("hbm_embedding_gather", T * N * (4.0 + 8.0 * E),
                     lambda: lib.vc_embedding_gather_f32(st, P(S.param("encoder/enc_embeddings")), P(self.buf["cap_enc_t"]), T * N, E, V, P(Xe[self.n_init_e])))
         act_e, cs_e, hs_e = self._b("act_e", (Te, N, 4 * He)), self._b("cs_e", (Te + 1, N, He)), self._b("hs_e", (Te + 1, N, He))
-        self._need_ws(lib.vc_lstm_seq_workspace_bytes(Te, N, E, He))
+        ws, wsb = self._need_ws(lib.vc_lstm_seq_workspace_bytes(Te, N, E, He))
         # (cs_e[0] / hs_e[0] = the zero initial state: `_b` allocates zeros and nothing ever writes row 0)
         lib.vc_lstm_seq_fwd_f32(st, Te, N, E, He, P(Xe), P(S.param(spec.ENC_CELL + "kernel")), P(S.param(spec.ENC_CELL + "bias")),
-                                P(self.buf["lens_e"]), P(act_e), P(cs_e), P(hs_e), P(self.ws), self.ws_bytes)
+                                P(self.buf["lens_e"]), P(act_e), P(cs_e), P(hs_e), ws, wsb)
         hT = hs_e[Te]
         mean, std = self._b("mean", (N, L)), self._b("std", (N, L))
         if p.prior == "Normal":
@@ -650,10 +689,10 @@ class CaptionEngine(object):
         if p.dec_keep_rate < 1:  # no train/eval switch in the reference (Q21)
             lib.vc_dropout_f32(st, P(xw), P(self.buf["drop_in"]), p.dec_keep_rate, T * N * E, P(xw))
         act_d, cs_d, hs_d = self._b("act_d", (Td, N, 4 * Hd)), self._b("cs_d", (Td + 1, N, Hd)), self._b("hs_d", (Td + 1, N, Hd))
-        self._need_ws(lib.vc_lstm_seq_workspace_bytes(Td, N, E, Hd))
+        ws, wsb = self._need_ws(lib.vc_lstm_seq_workspace_bytes(Td, N, E, Hd))
         # (cs_d[0] / hs_d[0]: zero initial state, as above)
         lib.vc_lstm_seq_fwd_f32(st, Td, N, E, Hd, P(Xd), P(S.param(spec.DEC_CELL + "kernel")), P(S.param(spec.DEC_CELL + "bias")),
-                                P(self.buf["lens_d"]), P(act_d), P(cs_d), P(hs_d), P(self.ws), self.ws_bytes)
+                                P(self.buf["lens_d"]), P(act_d), P(cs_d), P(hs_d), ws, wsb)
         # outputs of the word steps.  (The reference zeroes outputs past the caption length; those rows
         # have PAD labels, so neither the loss nor any gradient can see the difference.)
         outs = hs_d[self.n_init_d + 1:]
@@ -716,32 +755,40 @@ class CaptionEngine(object):
         dlogits = self.buf["logits"]
         outs = self.outs
         Vp = _round(V, 4)
-        self.dense_bwd_w(outs, T * N, Hd, Vp, dlogits, "decoder/rnn_logits/kernel", "decoder/rnn_logits/bias")  # padding columns of dlogits are 0
+        # (off_chain: weight gradients go to the weight-gradient stream when there is one -- nothing below reads them, and nothing
+        # below overwrites what they read: dlogits, the saved activations, dG and the dX rows of the init steps)
         dhs = self._b("dhs_d", (Td + 1, N, Hd))  # external gradient w.r.t. every decoder state; init steps stay 0
         douts = dhs[nid + 1:]
         self.gemm(0, 1, T * N, Hd, Vp, dlogits, Vp, S.param("decoder/rnn_logits/kernel"), Vp, douts, Hd)
+        with self.off_chain():
+            self.dense_bwd_w(outs, T * N, Hd, Vp, dlogits, "decoder/rnn_logits/kernel", "decoder/rnn_logits/bias")  # padding columns of dlogits are 0
         if p.dec_lstm_drop < 1:
             lib.vc_dropout_f32(st, P(douts), P(self.buf["drop_out"]), p.dec_lstm_drop, T * N * Hd, P(douts))
         # running state gradients of both LSTMs: one buffer, one fill ([dH_d | dC_d | dC_e])
         dstate = self._b("dstate0", (N * (2 * Hd + He),), zero=True)
         dH, dC = dstate[:N * Hd].view(N, Hd), dstate[N * Hd:2 * N * Hd].view(N, Hd)
         dG, dXd = self._b("dG_d", (Td, N, 4 * Hd)), self._b("dXd", (Td, N, E))
-        lib.vc_lstm_seq_bwd_f32(st, Td, N, E, Hd, P(self.buf["Xd"]), P(S.param(spec.DEC_CELL + "kernel")), P(self.buf["lens_d"]),
-                                P(self.buf["act_d"]), P(self.buf["cs_d"]), P(self.buf["hs_d"]), P(dhs), P(dH), P(dC), P(dG), P(dXd),
-                                P(S.grad(spec.DEC_CELL + "kernel")), P(S.grad(spec.DEC_CELL + "bias")), P(self.ws), self.ws_bytes)
+        ws, wsb = self._need_ws(lib.vc_lstm_seq_workspace_bytes(Td, N, E, Hd))
+        lib.vc_lstm_seq_bwd_data_f32(st, Td, N, E, Hd, P(S.param(spec.DEC_CELL + "kernel")), P(self.buf["lens_d"]), P(self.buf["act_d"]),
+                                     P(self.buf["cs_d"]), P(dhs), P(dH), P(dC), P(dG), P(dXd), ws, wsb)
         dxw = dXd[nid]
         if p.dec_keep_rate < 1:
             lib.vc_dropout_f32(st, P(dxw), P(self.buf["drop_in"]), p.dec_keep_rate, T * N * E, P(dxw))
-        self._embedding_grad("decoder/net/dec_embeddings", "dec", dxw)
         nb = self.nb
-        lib.vc_sumsq_partial_f32(st, P(dxw), T * N * E, self.part.data_ptr() + nb * 4)  # IndexedSlices.values (Q5)
+        with self.off_chain():
+            ws, wsb = self._need_ws(lib.vc_lstm_seq_workspace_bytes(Td, N, E, Hd))
+            lib.vc_lstm_seq_bwd_weights_f32(_stream(), Td, N, E, Hd, P(self.buf["Xd"]), P(self.buf["hs_d"]), P(dG),
+                                            P(S.grad(spec.DEC_CELL + "kernel")), P(S.grad(spec.DEC_CELL + "bias")), ws, wsb)
+            self._embedding_grad("decoder/net/dec_embeddings", "dec", dxw)
+            lib.vc_sumsq_partial_f32(_stream(), P(dxw), T * N * E, self.part.data_ptr() + nb * 4)  # IndexedSlices.values (Q5)
         d_imfv = dXd[0]       # [N, E] gradient w.r.t. images_fv (decoder part)
         d_ci = dXd[1] if self.feed_cv else None
         if self.enc:
             zi = nid - 1
             dz_dec = dXd[zi]
             z = self.buf["z"]
-            self.dense_bwd_w(z, N, Sm * L, E, dz_dec, "decoder/net/z_rnn/kernel", "decoder/net/z_rnn/bias")
+            with self.off_chain():
+                self.dense_bwd_w(z, N, Sm * L, E, dz_dec, "decoder/net/z_rnn/kernel", "decoder/net/z_rnn/bias")
             dz = self._b("dz", (Sm, N, L))
             self.gemm(0, 1, N, Sm * L, E, dz_dec, E, S.param("decoder/net/z_rnn/kernel"), E, dz, Sm * L)
             mean, std = self.buf["mean"], self.buf["std"]
@@ -759,8 +806,9 @@ class CaptionEngine(object):
             dhT = self._b("dH_e", (N, He))
             if p.prior == "Normal":
                 lib.vc_latent_bwd_f32(st, Sb, N, L, 0, 1, P(dz), P(self.buf["eps"]), P(mean), P(std), None, P(ann), kl_n, P(dmean), P(dstd))
-                self.dense_bwd_w(hT, N, He, L, dmean, "encoder/dense/kernel", "encoder/dense/bias")
-                self.dense_bwd_w(hT, N, He, L, dstd, "encoder/dense_1/kernel", "encoder/dense_1/bias")
+                with self.off_chain():
+                    self.dense_bwd_w(hT, N, He, L, dmean, "encoder/dense/kernel", "encoder/dense/bias")
+                    self.dense_bwd_w(hT, N, He, L, dstd, "encoder/dense_1/kernel", "encoder/dense_1/bias")
                 self.gemm(0, 1, N, He, L, dmean, L, S.param("encoder/dense/kernel"), L, dhT, He)
                 self.gemm(0, 1, N, He, L, dstd, L, S.param("encoder/dense_1/kernel"), L, dhT, He, None, 2)
             else:
@@ -773,38 +821,45 @@ class CaptionEngine(object):
                 dheads = self._b("dheads", (N, 2 * K_CL * L))
                 lib.vc_heads_mix_bwd_f32(st, N, K_CL, L, P(heads), None if gmm else P(self.buf["c_v"]), P(self.buf["gmm_idx"]) if gmm else None,
                                          P(dmean), P(dstd), P(dheads))
-                self.dense_bwd_w(hT, N, He, 2 * K_CL * L, dheads, "encoder/heads/kernel", "encoder/heads/bias")
+                with self.off_chain():
+                    self.dense_bwd_w(hT, N, He, 2 * K_CL * L, dheads, "encoder/heads/kernel", "encoder/heads/bias")
                 self.gemm(0, 1, N, He, 2 * K_CL * L, dheads, 2 * K_CL * L, S.param("encoder/heads/kernel"), 2 * K_CL * L, dhT, He)
             dC = self.buf["dstate0"][2 * N * Hd:].view(N, He)
             dG, dXe = self._b("dG_e", (Te, N, 4 * He)), self._b("dXe", (Te, N, E))
-            lib.vc_lstm_seq_bwd_f32(st, Te, N, E, He, P(self.buf["Xe"]), P(S.param(spec.ENC_CELL + "kernel")), P(self.buf["lens_e"]),
-                                    P(self.buf["act_e"]), P(self.buf["cs_e"]), P(self.buf["hs_e"]), None, P(dhT), P(dC), P(dG), P(dXe),
-                                    P(S.grad(spec.ENC_CELL + "kernel")), P(S.grad(spec.ENC_CELL + "bias")), P(self.ws), self.ws_bytes)
+            ws, wsb = self._need_ws(lib.vc_lstm_seq_workspace_bytes(Te, N, E, He))
+            lib.vc_lstm_seq_bwd_data_f32(st, Te, N, E, He, P(S.param(spec.ENC_CELL + "kernel")), P(self.buf["lens_e"]), P(self.buf["act_e"]),
+                                         P(self.buf["cs_e"]), None, P(dhT), P(dC), P(dG), P(dXe), ws, wsb)
             lib.vc_axpy_f32(st, 1.0, P(dXe[0]), N * E, P(d_imfv))
             if self.feed_cv:
                 lib.vc_axpy_f32(st, 1.0, P(dXe[1]), N * E, P(d_ci))
             dxe = dXe[self.n_init_e]
-            self._embedding_grad("encoder/enc_embeddings", "enc", dxe)
-            lib.vc_sumsq_partial_f32(st, P(dxe), T * N * E, self.part.data_ptr() + 2 * nb * 4)
+            with self.off_chain():
+                ws, wsb = self._need_ws(lib.vc_lstm_seq_workspace_bytes(Te, N, E, He))
+                lib.vc_lstm_seq_bwd_weights_f32(_stream(), Te, N, E, He, P(self.buf["Xe"]), P(self.buf["hs_e"]), P(dG),
+                                                P(S.grad(spec.ENC_CELL + "kernel")), P(S.grad(spec.ENC_CELL + "bias")), ws, wsb)
+                self._embedding_grad("encoder/enc_embeddings", "enc", dxe)
+                lib.vc_sumsq_partial_f32(_stream(), P(dxe), T * N * E, self.part.data_ptr() + 2 * nb * 4)
         else:
-            self.part[2 * nb:3 * nb].zero_()
+            with self.off_chain():
+                self.part[2 * nb:3 * nb].zero_()
         dimf = self._b("dimf", (B, E))
         if nc > 1:
             lib.vc_segment_sum_rows_f32(st, P(d_imfv), B, nc, E, P(dimf), 0)
         else:
             dimf.copy_(d_imfv)
-        self.dense_bwd_w(self.feats, B, F, E, dimf, "imf_emb/kernel", "imf_emb/bias")
-        if self.use_ci:
-            if self.feed_cv:
-                self.dense_bwd_w(self.buf["c_v"], N, K_CL, E, d_ci, "cv_emb/kernel", "cv_emb/bias")
-            else:  # variable exists but is off the loss path (tf.gradients -> None)
-                S.grad("cv_emb/kernel").zero_()
-                S.grad("cv_emb/bias").zero_()
+        dfe = None
         if want_dfeatures:
             dfe = self._b("dfeatures", (B, F))
             self.gemm(0, 1, B, F, E, dimf, E, S.param("imf_emb/kernel"), E, dfe, F)
-            return dfe
-        return None
+        with self.off_chain():
+            self.dense_bwd_w(self.feats, B, F, E, dimf, "imf_emb/kernel", "imf_emb/bias")
+            if self.use_ci:
+                if self.feed_cv:
+                    self.dense_bwd_w(self.buf["c_v"], N, K_CL, E, d_ci, "cv_emb/kernel", "cv_emb/bias")
+                else:  # variable exists but is off the loss path (tf.gradients -> None)
+                    S.grad("cv_emb/kernel").zero_()
+                    S.grad("cv_emb/bias").zero_()
+        return dfe
 
     def _embedding_grad(self, name, key, dX):
         """Dense [V, E] gradient of an embedding table from the per-position rows dX, deterministic,

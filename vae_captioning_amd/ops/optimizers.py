@@ -13,6 +13,7 @@ def non_cnn_optimizer(loss, params):
 
     def optimize():
         dfe = cap.backward(want_dfeatures=tr.vgg is not None)
+        cap.join_off_chain()   # (Trainer.train_step keeps the weight gradients on their own stream up to the optimiser; here: program order)
         tr._pending_dfeatures = dfe
         cap.pack_tail()
         if tr.vgg is None or not tr.vgg.train:

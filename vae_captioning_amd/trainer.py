@@ -67,7 +67,11 @@ class VggEngine(object):
         self.part = torch.zeros(self.lib.vc_sumsq_blocks(), dtype=torch.float32, device=device)
         # sum(w^2) of the regulariser: the Adam update of step t leaves the per-workgroup sums of the NEW parameters, which are step t + 1's
         # w (0.16 ms per step saved: no second pass over 0.54 GB); invalid after any other write to the parameters
-        self.w2_part = torch.zeros(self.lib.vc_adam_blocks(self.store.n), dtype=torch.float32, device=device)
+        # fc1 / fc2 (the tail of the flat buffer, 89 % of it) may be updated before the convolution layers: two launches, each
+        # leaving its own per-block sums of w^2
+        self.o_fc = self.store.offset("cnn/fc1/weights")
+        self.w2_blocks = (self.lib.vc_adam_blocks(self.o_fc), self.lib.vc_adam_blocks(self.store.n - self.o_fc))
+        self.w2_part = torch.zeros(sum(self.w2_blocks), dtype=torch.float32, device=device)
         self.w2_valid = False
 
     def _b(self, name, shape, dtype=torch.float32):
@@ -118,7 +122,10 @@ class VggEngine(object):
     def _pack_weights(self, backward, H=224, W=224):
         """[tap][C/4][N][4] copies of the 3x3 kernels for the patch-staged convolutions (forward layout, and the flipped
         + transposed one of the data gradient when a backward pass follows).  Runs on the weight-gradient stream, which is
-        idle during the forward pass; returns the event the convolution chains wait for (conv1_1 does not need it)."""
+        idle during the forward pass: the forward copies first, in layer order, each followed by the event its layer's
+        launches wait for (returned as {layer: event}; conv1_1 needs none), then the data-gradient copies, which only the
+        backward pass waits for (self.packed_bwd)."""
+        self.packed_bwd = None
         if not self.use_patch:
             return None
         lib, S = self.lib, self.store
@@ -126,26 +133,28 @@ class VggEngine(object):
         st = self.side2 if self.side2 is not None else (self.side if self.side is not None else main)
         if st != main:
             st.wait_stream(main)
+        evs = {}
         with torch.cuda.stream(st):
             sh = _stream()
-            for name, ci, co in spec.VGG_CONV:
-                if ci % 32 == 0:
-                    w = S.param(spec.vgg_var_names(name)[0])
-                    wf = self.use_wino and bool(lib.vc_conv3x3_wino_supported(1, H, W, ci, co, 0))
-                    wb = self.use_wino and bool(lib.vc_conv3x3_wino_supported(1, H, W, ci, co, 1))
-                    if wf:   # G g G^T of every filter, in the Winograd kernel's operand order
-                        lib.vc_conv3x3_wino_pack_f32(sh, ci, co, P(w), 0, P(self._b("vp_" + name, (16 * ci * co,))))
-                    else:    # direct patch kernels: [tap][C/4][N][4]
-                        lib.vc_conv3x3_pack_f32(sh, ci, co, P(w), 0, P(self._b("wp_" + name, (9 * ci * co,))))
-                    if backward and wb:
-                        lib.vc_conv3x3_wino_pack_f32(sh, ci, co, P(w), 1, P(self._b("vpt_" + name, (16 * ci * co,))))
-                    elif backward:
-                        lib.vc_conv3x3_pack_f32(sh, ci, co, P(w), 1, P(self._b("wpt_" + name, (9 * ci * co,))))
-                if name in spec.VGG_POOL_AFTER:
-                    H, W = H // 2, W // 2
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream())
-        return ev
+            for dgrad in ((0, 1) if backward else (0,)):
+                h, w_ = H, W
+                for name, ci, co in spec.VGG_CONV:
+                    if ci % 32 == 0:
+                        w = S.param(spec.vgg_var_names(name)[0])
+                        if self.use_wino and bool(lib.vc_conv3x3_wino_supported(1, h, w_, ci, co, dgrad)):
+                            # G g G^T of every filter, in the Winograd kernel's operand order
+                            lib.vc_conv3x3_wino_pack_f32(sh, ci, co, P(w), dgrad, P(self._b(("vpt_" if dgrad else "vp_") + name, (16 * ci * co,))))
+                        else:    # direct patch kernels: [tap][C/4][N][4]
+                            lib.vc_conv3x3_pack_f32(sh, ci, co, P(w), dgrad, P(self._b(("wpt_" if dgrad else "wp_") + name, (9 * ci * co,))))
+                        if not dgrad:
+                            evs[name] = torch.cuda.Event()
+                            evs[name].record(torch.cuda.current_stream())
+                    if name in spec.VGG_POOL_AFTER:
+                        h, w_ = h // 2, w_ // 2
+            if backward:
+                self.packed_bwd = torch.cuda.Event()
+                self.packed_bwd.record(torch.cuda.current_stream())
+        return evs
 
     def _patch_ok(self, nb, H, W, ci, co, dgrad):
         return self.use_patch and ci % 32 == 0 and bool(self.lib.vc_conv3x3_patch_supported(nb, H, W, ci, co, dgrad))
@@ -203,7 +212,7 @@ class VggEngine(object):
         w4 = self._b("w1_4", (3, 3, 4, 64))
         if not c1:
             lib.vc_pad_dim_f32(st, P(S.param("cnn/conv1_1/weights")), 9, 3, 4, 64, P(w4))
-        packed, waited = self._pack_weights(self.train, H, W), set()
+        packed = self._pack_weights(self.train, H, W)
         self.acts = []  # (layer name, input tensor, H, W, Cin_eff, Cout, weights used)
         self.mask_geom = {}  # layer name -> (images per launch, launches): forward launches that left their ReLU mask as bits
         # The conv / pool chain of one image is independent of every other image: with two streams the
@@ -231,9 +240,8 @@ class VggEngine(object):
                                     lambda: lib.vc_conv1_fwd_f32(sh, nb, H, W, P(x[b0:]), P(S.param(wn)), P(S.param(bn)), P(y[b0:]), 1))
                         continue
                     fl = 2.0 * nb * H * W * 9 * ci * co
-                    if packed is not None and ch not in waited:   # the packed / transformed weights of this step are ready
-                        torch.cuda.current_stream().wait_event(packed)
-                        waited.add(ch)
+                    if packed is not None and name in packed:   # this layer's packed / transformed weights of this step are ready
+                        torch.cuda.current_stream().wait_event(packed[name])
                     if self._wino_ok(name, nb, H, W, cie, co, 0):   # Winograd (calls over 2 GiB are cut into image ranges inside the library)
                         if self.train and not pooled and lib.vc_conv3x3_wino_single_launch_supported(nb, H, W, cie, co):
                             # the next layer is a convolution on this output: leave (y > 0) as bits in the lane order of ITS data gradient
@@ -347,6 +355,8 @@ class VggEngine(object):
         split = side2 is not None and B % 2 == 0
         wst = side2 if split else side
         halves = [(0, B // 2, main), (B // 2, B // 2, side)] if split else [(0, B, main)]
+        if self.packed_bwd is not None:   # the data-gradient weight copies made during the forward pass
+            main.wait_event(self.packed_bwd)
         if split:
             side.wait_stream(main)
         for li in range(len(self.acts) - 1, -1, -1):
@@ -419,30 +429,41 @@ class VggEngine(object):
         if wst is not None:
             main.wait_stream(wst)
 
-    def apply_gradients(self, scal):
+    def apply_gradients(self, scal, part=None):
         """cnn_optimizer: no clipping; Adam(cnn_lr, beta1=0.8) by default; the L2 regulariser's
-        gradient wd*w is folded into the update."""
+        gradient wd*w is folded into the update.  part: None = every cnn/* variable; "fc" = fc1 + fc2 only (their gradients are
+        final as soon as the fc backward has run: the caller may update them on another stream under the convolution backward);
+        "conv" = the convolution layers only.  The update is elementwise, so the two halves equal the whole."""
         p, lib, st, S = self.p, self.lib, _stream(), self.store
-        self.w2_valid = False
-        if p.cnn_optimizer == "Adam" and self.wd:
-            self._timed("hbm_adam", 28.0 * S.n, lambda: lib.vc_adam_sumsq_f32(
-                st, P(S.p), P(S.g), P(S.slot("m")), P(S.slot("v")), S.n, scal.data_ptr() + 12, None, 0.8, 0.999, 1e-8, self.wd, P(self.w2_part)))
-            self.w2_valid = True
-        elif p.cnn_optimizer == "Adam":
-            self._timed("hbm_adam", 28.0 * S.n, lambda: lib.vc_adam_f32(
-                st, P(S.p), P(S.g), P(S.slot("m")), P(S.slot("v")), S.n, scal.data_ptr() + 12, None, 0.8, 0.999, 1e-8, self.wd))
-        elif p.cnn_optimizer == "SGD":
-            lib.vc_sgd_f32(st, P(S.p), P(S.g), S.n, scal.data_ptr() + 16, None, self.wd)
-        else:
-            lib.vc_momentum_f32(st, P(S.p), P(S.g), P(S.slot("a")), S.n, scal.data_ptr() + 16, None, 0.9, self.wd, None, 0)
+        for which, lo, n, w2o in (("conv", 0, self.o_fc, 0), ("fc", self.o_fc, S.n - self.o_fc, self.w2_blocks[0])):
+            if part is not None and part != which:
+                continue
+            sl = lambda t: t.data_ptr() + lo * 4
+            if p.cnn_optimizer == "Adam" and self.wd:
+                self._timed("hbm_adam", 28.0 * n, lambda: lib.vc_adam_sumsq_f32(
+                    st, sl(S.p), sl(S.g), sl(S.slot("m")), sl(S.slot("v")), n, scal.data_ptr() + 12, None, 0.8, 0.999, 1e-8, self.wd,
+                    self.w2_part.data_ptr() + w2o * 4))
+            elif p.cnn_optimizer == "Adam":
+                self._timed("hbm_adam", 28.0 * n, lambda: lib.vc_adam_f32(
+                    st, sl(S.p), sl(S.g), sl(S.slot("m")), sl(S.slot("v")), n, scal.data_ptr() + 12, None, 0.8, 0.999, 1e-8, self.wd))
+            elif p.cnn_optimizer == "SGD":
+                lib.vc_sgd_f32(st, sl(S.p), sl(S.g), n, scal.data_ptr() + 16, None, self.wd)
+            else:
+                lib.vc_momentum_f32(st, sl(S.p), sl(S.g), sl(S.slot("a")), n, scal.data_ptr() + 16, None, 0.9, self.wd, None, 0)
+        # (every block of both halves has written its sum by the time the next forward pass reads them, whatever the order)
+        self.w2_valid = p.cnn_optimizer == "Adam" and bool(self.wd)
 
 
 class Trainer(object):
     """One training step = main.py:241-244's sess.run([kld, rec_loss, lower_bound, optimize,
     optimize_cnn, annealing])."""
 
-    def __init__(self, p, vocab, device="cuda", lib=None, world=1, rank=0, group=None, seed=0, force_collectives=False, comm="auto"):
-        """comm: how the data-parallel collectives run.  "abi" = libvaecap's own RCCL entries (dp.AbiComm: vc_allreduce_sum_f32 ...);
+    def __init__(self, p, vocab, device="cuda", lib=None, world=1, rank=0, group=None, seed=0, force_collectives=False, comm="auto",
+                 wgrad_stream=True):
+        """wgrad_stream: weight gradients of the caption side, its clip + optimiser and fc1 / fc2's optimiser run on a second
+        stream (under the LSTM recurrences and the VGG16 backward pass); False = everything in program order on one stream --
+        the same kernels on the same data either way, so the results are bit-identical.
+        comm: how the data-parallel collectives run.  "abi" = libvaecap's own RCCL entries (dp.AbiComm: vc_allreduce_sum_f32 ...);
         "torch" = torch.distributed on `group`; "auto" = "abi" when the collectives are on and the process group is RCCL-backed
         (backend "nccl") or there is no process group at all (one forced rank), "torch" otherwise (the gloo test path).
         An existing dp.AbiComm may be passed instead."""
@@ -456,6 +477,7 @@ class Trainer(object):
         self.gall = torch.zeros(n_cap + n_vgg, dtype=torch.float32, device=device)  # THE all-reduce buffer
         self.cap = CaptionEngine(p, vocab, device, self.lib, grad_backing=self.gall[:n_cap], world=world, rank=rank, group=group, seed=seed,
                                  force_collectives=force_collectives)
+        self.cap.enable_wgrad_stream(bool(wgrad_stream))
         self.vgg = None
         if self.fine:
             self.vgg = VggEngine(p, device, self.lib, grad_backing=self.gall[n_cap:], seed=seed, rank=rank)
@@ -547,17 +569,20 @@ class Trainer(object):
         cap.forward(feats)
         self._range("caption_backward")
         dfe = cap.backward(want_dfeatures=vgg is not None)
-        cap.pack_tail()
-        self._range("vgg16_backward+allreduce" if vgg is not None and vgg.train else "allreduce")
-        if self.collectives and self.buckets and vgg is not None and vgg.train and self.reduce_async_fn is not None:
+        # Weight gradients, the clip and the optimisers are off the gradient chain (cap.off_chain: the weight-gradient stream when
+        # Trainer has enabled it, else this stream): the caption side's run under the VGG16 backward pass, fc1 / fc2's Adam under
+        # the convolution layers' backward.  Collectives keep their order: caption bucket, fc, conv3_1.., conv1_1..
+        with cap.off_chain():
+            cap.pack_tail()
+        fine = vgg is not None and vgg.train
+        self._range("vgg16_backward+allreduce" if fine else "allreduce")
+        if self.collectives and self.buckets and fine and self.reduce_async_fn is not None:
             from . import dp
             bk = dp.gradient_buckets(self.n_cap, self.gall.numel(), self.off_fc, self.off_c3)
             issue = lambda i: self.reduce_async_fn(self.gall[bk[i][0]:bk[i][1]])
-            pending = [issue(0)]
-            vgg.backward(dfe, after_fc=lambda: pending.append(issue(1)), after_layer=("conv3_1", lambda: pending.append(issue(2))))
-            pending.append(issue(3))
-            for i, h in enumerate(pending):
-                if self.dp_stats is not None:  # how long the compute stream stalls on each bucket (bench.py reports it)
+
+            def wait(i, h):
+                if self.dp_stats is not None:  # how long the waiting stream stalls on each bucket (bench.py reports it)
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
                     h.wait()
@@ -565,14 +590,44 @@ class Trainer(object):
                     self.dp_stats.append((i, (bk[i][1] - bk[i][0]) * 4, e0, e1))
                 else:
                     h.wait()
+
+            def fc_final():
+                with cap.off_chain():
+                    wait(1, issue(1))
+                    vgg.apply_gradients(cap.scal, "fc")
+
+            pending = []
+            with cap.off_chain():
+                wait(0, issue(0))
+                cap.apply_gradients()
+            vgg.backward(dfe, after_fc=fc_final, after_layer=("conv3_1", lambda: pending.append((2, issue(2)))))
+            pending.append((3, issue(3)))
+            for i, h in pending:
+                wait(i, h)
+            self._range("optimizers")
+            vgg.apply_gradients(cap.scal, "conv")
         else:
-            if vgg is not None and vgg.train:
-                vgg.backward(dfe)
-            self.all_reduce_grads()
-        self._range("optimizers")
-        cap.apply_gradients()
-        if vgg is not None and vgg.train:
-            vgg.apply_gradients(cap.scal)
+            if self.collectives:
+                if fine:
+                    vgg.backward(dfe)
+                cap.join_off_chain()
+                self.all_reduce_grads()  # the single gradient all-reduce (RCCL over xGMI)
+                self._range("optimizers")
+                with cap.off_chain():
+                    cap.apply_gradients()
+                if fine:
+                    vgg.apply_gradients(cap.scal)
+            else:
+                with cap.off_chain():
+                    cap.apply_gradients()
+                if fine:
+                    def fc_final():
+                        with cap.off_chain():
+                            vgg.apply_gradients(cap.scal, "fc")
+                    vgg.backward(dfe, after_fc=fc_final)
+                    self._range("optimizers")
+                    vgg.apply_gradients(cap.scal, "conv")
+        cap.join_off_chain()
         self._range(None)
 
     @property
