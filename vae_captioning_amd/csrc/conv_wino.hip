@@ -33,7 +33,8 @@
 #include "conv_wino.h"
 
 // `make -C vae_captioning_amd/csrc ablate` builds this file with W2_ABL = a bit mask that REMOVES parts of the main loop (results are then wrong;
-// timing only): 1 transform additions, 2 patch reads, 4 weight-fragment reads, 8 staging (global loads + LDS writes), 16 barriers
+// timing only): 1 transform additions, 2 patch reads, 4 weight-fragment reads, 8 staging (global loads + LDS writes), 16 barriers,
+// 32 patch loads contiguous over the lanes
 #ifndef W2_ABL
 #define W2_ABL 0
 #endif
@@ -103,6 +104,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(Wino2Args a) {
         const bool ok = blk < 4 && gb < (unsigned)g.nblocks && pix < (unsigned)(g.PH * g.PW) && (unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W;
         const unsigned off = (((b * (unsigned)g.H + (unsigned)y) * (unsigned)g.W + (unsigned)x) * (unsigned)C + ((unsigned)tid & 1u) * 4u) * 4u;
         voff[i] = ok ? off : WOOB;
+        // (timing only) the patch loads made contiguous over the lanes: what a channel-blocked activation layout would present to the L1
+        if (W2_ABL & 32) voff[i] = (unsigned)(((unsigned)tm * 1024u + (unsigned)tid + 256u * i) * 16u) % (unsigned)(g.B * g.H * g.W * C * 4 - 4096);
         // the slot's float4 = channels 4 (tid & 1) .. + 3 of the half = k groups 2 (tid & 1) (.xy) and 2 (tid & 1) + 1 (.zw)
         // (slots past the workgroup's patches -- a fifth block, pixels past PH x PW -- land on unit 79 of block 0, which no plane uses: PH * P <= 79)
         pst[i] = (blk < 4 && pix < (unsigned)(g.PH * g.PW))

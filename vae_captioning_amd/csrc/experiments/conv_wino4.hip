@@ -1,0 +1,480 @@
+// 3x3 / stride 1 / SAME convolution by Winograd's F(4x4, 3x3) for gfx950: forward and data gradient of
+// utils/image_embeddings.py:36-212 in fp32 with FOUR times fewer multiplications than the direct form (F(2x2,3x3), conv_wino.hip: 2.25).
+//
+//   Y = A^T [ sum_c (G g_c G^T) (.) (B^T d_c B) ] A     per 4 x 4 output tile: d = its 6 x 6 input patch, g = the 3 x 3 filter
+//
+// Why a second Winograd kernel (tools/probes/mfma16_f43.hip, mfma_specialised.hip): on one SIMD a VALU
+// instruction and the matrix pipe do NOT overlap -- beside back-to-back v_mfma_f32_16x16x4_f32 a partner wave gets ~0.5 VALU issues
+// per MFMA, inside one stream every VALU operation costs 4-8 cycles of matrix time -- so the F(2x2,3x3) kernel's 71 % MFMA-busy is its
+// instruction mix, not its LDS traffic, and the way down is fewer MFMAs per output: the 36 positions of F(4x4,3x3) cost 36 / 16 = 2.25
+// MFMAs per output where F(2x2,3x3) spends 16 / 4 = 4.  The input transform is heavier (144 operations per tile and channel against
+// 32), which is why the kernel is built around the instruction count: 12-operation 1-D transforms (FMA with the constants 4, 5, 2),
+// a lane owns ONE tile and ONE input channel of a four-channel phase.
+//
+// Structure: workgroup = four waves = TWO blocks of 4 x 4 tiles (16 x 16 output pixels each) x TWO groups of sixteen output channels
+// (wave = 2 block + group); 36 accumulators of four registers per wave (16 tiles x 16 channels x 36 positions), two workgroups per CU.
+// A phase = four input channels = ONE k-step: 36 MFMAs per wave.  LDS per phase: the blocks' 18 x 18 halo patches as four channel
+// planes [g 4][row 18][pixel, pitch 20] (a lane's patch row = ds_read_b128 + ds_read_b64, conflict-free: the plane stride is a
+// multiple of 64 floats) and the phase's transformed weights [group 2][position / 4][g 4][n 16][position % 4] (a lane's fragment of
+// four positions = one ds_read_b128, 1 KB contiguous per wave); both double-buffered, 60 KB per workgroup.
+// Rounding: the transforms' constants (4, 5, 8; 1/4, 1/6, 1/24 in the weights) cost about a decimal digit against F(2x2,3x3):
+// ~1e-5 of the tensor maximum (tests/test_gpu_conv_wino4.py against the fp64 oracle).
+#include <stdlib.h>
+#include <type_traits>
+#include "../conv_wino.h"
+
+// `make wino4 W4FLAGS=-DW4_ABL=n` builds this file with W4_ABL = a bit mask that REMOVES parts of the main loop (results are then wrong; timing only):
+// 1 transform arithmetic, 2 patch-row reads, 4 weight-fragment reads, 8 staging (global loads + LDS writes), 16 barriers,
+// 256 the patch loads made contiguous over the lanes (what a channel-blocked activation layout would give the L1), 32 the global loads only (the LDS writes store stale registers), 64 staging group A (patches + weight piece 0), 128 staging group B
+#ifndef W4_ABL
+#define W4_ABL 0
+#endif
+// gaps (0 .. 35, behind MFMA m of a phase) at which the two staging groups load from global memory and write to the LDS
+#ifndef W4_A_LD
+#define W4_A_LD 0
+#define W4_A_ST 12
+#define W4_B_LD 16
+#define W4_B_ST 24
+#endif
+#ifndef W4_B_REG
+#define W4_B_REG 0   // 4: group B has its own staging registers (the groups may then be in flight together)
+#endif
+
+namespace vc {
+
+enum { W4_FWD = 0, W4_DGRAD = 1 };
+constexpr int W4_PITCH = 20;                 // floats per patch row (18 pixels + 2)
+constexpr int W4_PLANE = 384;                // floats per channel plane: 18 x 20 = 360, padded to 6 x 64 (bank-quad aligned planes)
+constexpr int W4_BLKF = 4 * W4_PLANE;        // one block's patch of a phase: four channel planes
+constexpr int W4_NBLK = 2;                   // blocks per workgroup
+constexpr int W4_PBUF = W4_NBLK * W4_BLKF;   // 12 KB
+constexpr int W4_WGRP = 9 * 256;             // floats of one channel group's weights of a phase: [pq 9][g 4][n 16][pp 4]
+constexpr int W4_WBUF = 2 * W4_WGRP;         // 18 KB
+constexpr int W4_POFF = 2 * W4_WBUF;         // LDS: two weight buffers, then two patch buffers
+constexpr int W4_DUMP = W4_POFF + 360;       // plane padding of block 0: where the staging slots past the data write
+constexpr int WINO4_LDS_BYTES = (2 * W4_WBUF + 2 * W4_PBUF) * 4;   // 61 440: two workgroups per CU
+constexpr int W4_WPH = W4_WBUF * 4;          // bytes of a phase's packed weights per 32-channel tile
+constexpr int W4_NPIX = W4_NBLK * 324;       // patch pixels of a workgroup
+
+struct Wino4Geom {
+    int B, H, W, C, N;
+    int bx_n, by_n, blocks_img, nblocks;     // blocks of 16 x 16 output pixels
+    unsigned m_blocks_img, m_bx_n;
+};
+
+struct Wino4Args {
+    Wino4Geom g;
+    const float* x;      // [P, C]
+    const float* wp;     // packed [N/32][C/4][group 2][pq 9][g 4][n 16][pp 4]
+    float* out;          // [P, N]
+    const float* aux;    // fwd: bias [N] or null; dgrad: ReLU source [P, N] or null
+    int relu;
+    int tiles_n, ntiles, nphases;
+};
+
+// one 1-D input transform B^T (6 -> 6) in twelve operations, step by step (so that the caller can spread them over MFMA gaps):
+//   o0 = 4 d0 - 5 d2 + d4      o1 = (d4 - 4 d2) + (d3 - 4 d1)     o2 = (d4 - 4 d2) - (d3 - 4 d1)
+//   o5 = 4 d1 - 5 d3 + d5      o3 = (d4 - d2) + 2 (d3 - d1)       o4 = (d4 - d2) - 2 (d3 - d1)
+// Two orders of the same twelve operations:
+//   w4_bstep_h (rows, from the raw pixels): the raw inputs are dead after step 7, so the next row may be read over them;
+//   w4_bstep_v (columns, into the MFMA operands): output o_j is not written before step 2 j -- a column transform running two steps
+//   per gap beside the six MFMAs of the previous column writes o_j over the operand that MFMA j has just consumed (single-buffered U).
+__device__ __forceinline__ void w4_bstep_h(int k, const float& d0, const float& d1, const float& d2, const float& d3, const float& d4, const float& d5,
+                                           float* o, float* t) {
+    if (k == 0) t[0] = __builtin_fmaf(-4.f, d2, d4);
+    if (k == 1) t[1] = __builtin_fmaf(-4.f, d1, d3);
+    if (k == 2) t[2] = d4 - d2;
+    if (k == 3) t[3] = d3 - d1;
+    if (k == 4) t[4] = __builtin_fmaf(-5.f, d2, d4);
+    if (k == 5) o[0] = __builtin_fmaf(4.f, d0, t[4]);
+    if (k == 6) t[4] = __builtin_fmaf(-5.f, d3, d5);
+    if (k == 7) o[5] = __builtin_fmaf(4.f, d1, t[4]);
+    if (k == 8) o[1] = t[0] + t[1];
+    if (k == 9) o[2] = t[0] - t[1];
+    if (k == 10) o[3] = __builtin_fmaf(2.f, t[3], t[2]);
+    if (k == 11) o[4] = __builtin_fmaf(-2.f, t[3], t[2]);
+}
+__device__ __forceinline__ void w4_bstep_v(int k, const float& d0, const float& d1, const float& d2, const float& d3, const float& d4, const float& d5,
+                                           float* o, float* t) {
+    if (k == 0) t[0] = __builtin_fmaf(-4.f, d2, d4);
+    if (k == 1) t[1] = __builtin_fmaf(-4.f, d1, d3);
+    if (k == 2) t[4] = __builtin_fmaf(-5.f, d2, d4);
+    if (k == 3) o[0] = __builtin_fmaf(4.f, d0, t[4]);
+    if (k == 4) t[2] = d4 - d2;
+    if (k == 5) o[1] = t[0] + t[1];
+    if (k == 6) t[3] = d3 - d1;
+    if (k == 7) t[4] = __builtin_fmaf(-5.f, d3, d5);
+    if (k == 8) o[2] = t[0] - t[1];
+    if (k == 9) o[3] = __builtin_fmaf(2.f, t[3], t[2]);
+    if (k == 10) o[4] = __builtin_fmaf(-2.f, t[3], t[2]);
+    if (k == 11) o[5] = __builtin_fmaf(4.f, d1, t[4]);
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const Wino4Geom& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lj = lane & 15, lg = lane >> 4;
+    const int wb = wave >> 1, cg = wave & 1;
+    const int id = xcd_remap(blockIdx.x, a.ntiles);
+    const int tm = id / a.tiles_n, nt = id - tm * a.tiles_n;
+    const int C = g.C, N = g.N;
+    const int nc0 = nt * 32 + cg * 16 + 4 * lg;   // this lane's four output channels
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)((long)g.B * g.H * g.W * C * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, (int)(36L * C * N * 4), 0x00020000);
+
+    // patch slots: slot s = tid + 256 j < 648 = (block s / 324, patch pixel s % 324); one float4 = the phase's four channels of the pixel
+    unsigned voff[3];
+    int pst[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const unsigned s = (unsigned)tid + 256u * j;
+        const unsigned blk = s >= 324u ? 1u : 0u, pix = s - blk * 324u;
+        const unsigned py = pix / 18u, px = pix - py * 18u;
+        const unsigned gb = (unsigned)tm * W4_NBLK + blk;
+        const bool live = s < (unsigned)W4_NPIX && gb < (unsigned)g.nblocks;
+        const unsigned gbc = live ? gb : 0u;
+        const unsigned b = wino_div(gbc, g.m_blocks_img), rem = gbc - b * (unsigned)g.blocks_img;
+        const unsigned by = wino_div(rem, g.m_bx_n), bx = rem - by * (unsigned)g.bx_n;
+        const int y = (int)(by * 16u + py) - 1, x = (int)(bx * 16u + px) - 1;
+        const bool ok = live && (unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W;
+        voff[j] = ok ? (((b * (unsigned)g.H + (unsigned)y) * (unsigned)g.W + (unsigned)x) * (unsigned)C) * 4u : WOOB;
+        if (W4_ABL & 256) voff[j] = (unsigned)((tm * 648 + (int)s) * 16) % (unsigned)(g.B * g.H * g.W * C * 4 - 4096);   // timing only: consecutive lanes, consecutive 16-byte pieces
+        pst[j] = s < (unsigned)W4_NPIX ? W4_POFF + (int)blk * W4_BLKF + (int)py * W4_PITCH + (int)px : W4_DUMP + (tid & 15);
+    }
+    // weight slots: piece i of the phase's 18 KB = float4 tid + 256 i < 1152
+    const unsigned vsrc = (unsigned)nt * (unsigned)a.nphases * (unsigned)W4_WPH + (unsigned)tid * 16u;
+    const bool w4ok = tid < 128;   // piece 4: only the first half of the workgroup has one
+
+    const int ty = lj >> 2, tx = lj & 3;
+    const int rbase = W4_POFF + wb * W4_BLKF + lg * W4_PLANE + (4 * ty) * W4_PITCH + 4 * tx;   // + buffer + 4 * PLANE (odd phase) + r * PITCH
+    const int vbase = cg * W4_WGRP + (lg * 16 + lj) * 4;                                       // + wq * WBUF + k * 256
+
+    // M_p[channel nc0 + r][tile lj], p = 6 v + u (u: vertical index, v: horizontal index)
+    f32x4 acc[36];
+#pragma unroll
+    for (int p = 0; p < 36; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // forward: the bias rides in the accumulator of position (1, 1): column 1 of A^T is (1, 1, 1, 1), so A^T M A adds M_(1,1) to all
+    // sixteen outputs of the tile
+    if (KIND == W4_FWD && a.aux) {
+        const float4 bv = *reinterpret_cast<const float4*>(a.aux + nc0);
+        acc[7] = f32x4{bv.x, bv.y, bv.z, bv.w};
+    }
+
+    float4 st[4 + W4_B_REG];    // staging registers
+    float HA[6][6], HB[6][6];   // [patch row r][horizontal index v]: rows transformed horizontally (B^T over the pixels of a row)
+    float U[6];                 // one column v of B^T d B = the B operands of the unit's six MFMAs
+    float4 vf[2];               // weight fragments: fragment k = positions 4 k .. 4 k + 3
+    float rr[6];                // the raw patch row in flight
+    float tv[5], th[5];
+    if (W4_ABL) {   // ablated builds read registers nobody wrote: give them values
+#pragma unroll
+        for (int i = 0; i < 4 + W4_B_REG; ++i) st[i] = make_float4(1.f, 2.f, 3.f, 4.f);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) vf[i] = make_float4(1.f + lane, 2.f, 3.f, 4.f);
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) { HA[r][c] = 1.f + lane + r; HB[r][c] = 2.f + lane + c; rr[c] = 0.5f * lane; U[c] = 1.f * lane; }
+    }
+
+    auto pload = [&](int i, int hp) { if (!(W4_ABL & (8 | 32))) st[i] = wbufload(rx, voff[i], (unsigned)hp * 16u); };
+    auto pstore = [&](int i, int pq) {
+        if (W4_ABL & 8) return;
+        float* d = &smem[pst[i] + pq * W4_PBUF];
+        d[0] = st[i].x; d[W4_PLANE] = st[i].y; d[2 * W4_PLANE] = st[i].z; d[3 * W4_PLANE] = st[i].w;
+    };
+    auto wload = [&](int si, int i, int hp) { if (!(W4_ABL & (8 | 32))) st[si] = wbufload(rw, (i == 4 && !w4ok) ? WOOB : vsrc + (unsigned)i * 4096u, (unsigned)hp * (unsigned)W4_WPH); };
+    auto wstore = [&](int si, int i, int wq) {
+        if (W4_ABL & 8) return;
+        const int dst = (i == 4 && !w4ok) ? W4_DUMP + 4 * (tid & 3) : wq * W4_WBUF + (tid + 256 * i) * 4;
+        *reinterpret_cast<float4*>(&smem[dst]) = st[si];
+    };
+    auto rdrow = [&](int off, int r) {   // off: float offset of the patch buffer whose rows are read
+        if (W4_ABL & 2) return;
+        const float4 v = *reinterpret_cast<const float4*>(&smem[rbase + off + r * W4_PITCH]);
+        const float2 w = *reinterpret_cast<const float2*>(&smem[rbase + off + r * W4_PITCH + 4]);
+        rr[0] = v.x; rr[1] = v.y; rr[2] = v.z; rr[3] = v.w; rr[4] = w.x; rr[5] = w.y;
+    };
+#define WSB() __builtin_amdgcn_sched_barrier(0)
+
+    // One phase (index h, parity q) = 36 MFMAs on the columns of Hc.  Beside them the next phase's rows are read (patch buffer q ^ 1)
+    // and transformed into Hn, the next phase's weights are staged into weight buffer q ^ 1 and the patches of the phase after it into
+    // patch buffer q (free: this phase's rows were read during the previous one); the barrier at gap 28 publishes the writes and
+    // closes this phase's reads.
+    auto phase = [&](auto qc, float (&Hc)[6][6], float (&Hn)[6][6], bool stP, bool stW, int h) {
+        constexpr int q = decltype(qc)::value;
+        const bool nxt = stW;   // a next phase exists exactly when its weights are still to be staged
+        const bool rd0ok = stP;
+        constexpr int rdo = (q ^ 1) * W4_PBUF, rd0 = q * W4_PBUF;
+#pragma unroll
+        for (int m = 0; m < 36; ++m) {
+            const int v = m / 6, u = m % 6;
+            {   // fragment k = m / 4 lives in vf[(k + q) & 1]: nine fragments per phase, so the parity flips with the phase
+                const float4& f = vf[((m >> 2) + q) & 1];
+                const float av = (m & 3) == 0 ? f.x : (m & 3) == 1 ? f.y : (m & 3) == 2 ? f.z : f.w;
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, U[u], acc[m], 0, 0, 0);
+            }
+            WSB();
+            // (A) vertical transform of the next unit's column, two steps per gap, written over the operands just consumed
+            if (W4_ABL & 1) {
+            } else if (v < 5) {
+#pragma unroll
+                for (int k = 2 * u; k < 2 * u + 2; ++k) w4_bstep_v(k, Hc[0][v + 1], Hc[1][v + 1], Hc[2][v + 1], Hc[3][v + 1], Hc[4][v + 1], Hc[5][v + 1], U, tv);
+            } else if (nxt) {
+#pragma unroll
+                for (int k = 2 * u; k < 2 * u + 2; ++k) w4_bstep_v(k, Hn[0][0], Hn[1][0], Hn[2][0], Hn[3][0], Hn[4][0], Hn[5][0], U, tv);
+            }
+            // (B) horizontal transform of the next phase's rows: 72 steps over gaps 1 .. 30 (row r: gaps 5 r + 1 .. 5 r + 5)
+            if (nxt && m >= 1 && m <= 30 && !(W4_ABL & 1)) {
+#pragma unroll
+                for (int S = (m - 1) * 72 / 30; S < m * 72 / 30; ++S) w4_bstep_h(S % 12, rr[0], rr[1], rr[2], rr[3], rr[4], rr[5], Hn[S / 12], th);
+            }
+            // (C) row reads: the raw row is dead after step 7 of its transform (gap 5 r + 3); row r + 1 is read at gap 5 r + 4, row 0 of
+            // the phase after the next at gap 34 (behind the barrier)
+            if (nxt && m >= 4 && m <= 24 && (m - 4) % 5 == 0) rdrow(rdo, (m - 4) / 5 + 1);
+            if (rd0ok && m == 34) rdrow(rd0, 0);
+            // (D) weight fragments: fragment k >= 1 of this phase at gap 4 k - 3; fragment 0 of the next phase at gap 33
+            if (m >= 1 && m <= 29 && (m - 1) % 4 == 0 && !(W4_ABL & 4)) {
+                const int k = (m - 1) / 4 + 1;
+                vf[(k + q) & 1] = *reinterpret_cast<const float4*>(&smem[vbase + q * W4_WBUF + k * 256]);
+            }
+            if (nxt && m == 33 && !(W4_ABL & 4)) vf[(q ^ 1) & 1] = *reinterpret_cast<const float4*>(&smem[vbase + (q ^ 1) * W4_WBUF]);
+            // (E) staging: group A = the three patch slots + weight piece 0, group B = weight pieces 1 .. 4
+            if (!(W4_ABL & 64)) {
+                if (m >= W4_A_LD && m < W4_A_LD + 3 && stP) pload(m - W4_A_LD, h + 2);
+                if (m == W4_A_LD + 3 && stW) wload(3, 0, h + 1);
+                if (m >= W4_A_ST && m < W4_A_ST + 3 && stP) pstore(m - W4_A_ST, q);
+                if (m == W4_A_ST + 3 && stW) wstore(3, 0, q ^ 1);
+            }
+            if (!(W4_ABL & 128)) {
+                if (m >= W4_B_LD && m < W4_B_LD + 4 && stW) wload(m - W4_B_LD + W4_B_REG, m - W4_B_LD + 1, h + 1);
+                if (m >= W4_B_ST && m < W4_B_ST + 4 && stW) wstore(m - W4_B_ST + W4_B_REG, m - W4_B_ST + 1, q ^ 1);
+            }
+            // (F)
+            if (m == 28 && nxt && !(W4_ABL & 16)) __syncthreads();
+            WSB();
+        }
+    };
+
+    // ---- prologue: phases 0 (patches + weights) and 1 (patches) into the LDS, rows of phase 0 transformed
+#pragma unroll
+    for (int i = 0; i < 3; ++i) pload(i, 0);
+    wload(3, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) pstore(i, 0);
+    wstore(3, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wload(i, i + 1, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wstore(i, i + 1, 0);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) pload(i, 1);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) pstore(i, 1);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        rdrow(0, r);
+#pragma unroll
+        for (int k = 0; k < 12; ++k) w4_bstep_h(k, rr[0], rr[1], rr[2], rr[3], rr[4], rr[5], HA[r], th);
+    }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) w4_bstep_v(k, HA[0][0], HA[1][0], HA[2][0], HA[3][0], HA[4][0], HA[5][0], U, tv);
+    if (!(W4_ABL & 4)) vf[0] = *reinterpret_cast<const float4*>(&smem[vbase]);
+    rdrow(W4_PBUF, 0);   // row 0 of phase 1
+    __syncthreads();     // (nobody stages over rows that somebody still reads)
+    WSB();
+
+    using Q0 = std::integral_constant<int, 0>;
+    using Q1 = std::integral_constant<int, 1>;
+    int h = 0;
+    for (; h + 2 < a.nphases; h += 2) {
+        phase(Q0{}, HA, HB, true, true, h);
+        phase(Q1{}, HB, HA, true, true, h + 1);
+    }
+    phase(Q0{}, HA, HB, false, true, h);
+    phase(Q1{}, HB, HA, false, false, h + 1);
+#undef WSB
+
+    // ---- output transform A^T M A (6 x 6 -> 4 x 4) and epilogue
+    //   y0 = m0 + m1 + m2 + m3 + m4   y1 = (m1 - m2) + 2 (m3 - m4)   y2 = (m1 + m2) + 4 (m3 + m4)   y3 = (m1 - m2) + 8 (m3 - m4) + m5
+    const int gb = tm * W4_NBLK + wb;
+    const bool blk_ok = gb < g.nblocks;
+    const int gbc = blk_ok ? gb : 0;
+    const int b = (int)wino_div((unsigned)gbc, g.m_blocks_img), rem = gbc - b * g.blocks_img;
+    const int by = (int)wino_div((unsigned)rem, g.m_bx_n), bx = rem - by * g.bx_n;
+    const int y0 = by * 16 + 4 * ty, x0 = bx * 16 + 4 * tx;
+    float4 Y[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float T[4][6];
+#pragma unroll
+        for (int v = 0; v < 6; ++v) {
+            const float m0 = acc[6 * v + 0][r], m1 = acc[6 * v + 1][r], m2 = acc[6 * v + 2][r], m3 = acc[6 * v + 3][r], m4 = acc[6 * v + 4][r], m5 = acc[6 * v + 5][r];
+            const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+            T[0][v] = m0 + s1 + s2;
+            T[1][v] = __builtin_fmaf(2.f, d2, d1);
+            T[2][v] = __builtin_fmaf(4.f, s2, s1);
+            T[3][v] = __builtin_fmaf(8.f, d2, d1) + m5;
+        }
+#pragma unroll
+        for (int aa = 0; aa < 4; ++aa) {
+            const float s1 = T[aa][1] + T[aa][2], d1 = T[aa][1] - T[aa][2], s2 = T[aa][3] + T[aa][4], d2 = T[aa][3] - T[aa][4];
+            const float o0 = T[aa][0] + s1 + s2, o1 = __builtin_fmaf(2.f, d2, d1), o2 = __builtin_fmaf(4.f, s2, s1), o3 = __builtin_fmaf(8.f, d2, d1) + T[aa][5];
+            if (r == 0) { Y[aa][0].x = o0; Y[aa][1].x = o1; Y[aa][2].x = o2; Y[aa][3].x = o3; }
+            if (r == 1) { Y[aa][0].y = o0; Y[aa][1].y = o1; Y[aa][2].y = o2; Y[aa][3].y = o3; }
+            if (r == 2) { Y[aa][0].z = o0; Y[aa][1].z = o1; Y[aa][2].z = o2; Y[aa][3].z = o3; }
+            if (r == 3) { Y[aa][0].w = o0; Y[aa][1].w = o1; Y[aa][2].w = o2; Y[aa][3].w = o3; }
+        }
+    }
+    const long rowN = (long)g.W * N;
+    const long p00 = ((long)(b * g.H + y0) * g.W + x0) * N + nc0;
+#pragma unroll
+    for (int aa = 0; aa < 4; ++aa)
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+            const bool ok = blk_ok && y0 + aa < g.H && x0 + bb < g.W;
+            float4 v = Y[aa][bb];
+            if (KIND == W4_FWD) {
+                if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            } else if (a.aux) {
+                const float4 mk = ok ? *reinterpret_cast<const float4*>(a.aux + p00 + aa * rowN + bb * N) : f4zero();
+                if (!(mk.x > 0.f)) v.x = 0.f;
+                if (!(mk.y > 0.f)) v.y = 0.f;
+                if (!(mk.z > 0.f)) v.z = 0.f;
+                if (!(mk.w > 0.f)) v.w = 0.f;
+            }
+            if (ok) *reinterpret_cast<float4*>(a.out + p00 + aa * rowN + bb * N) = v;
+        }
+}
+
+// w [3][3][Ci][Co] (HWIO) -> V = G g G^T (6 x 6), G = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1],
+// packed [N/32][C/4][group 2][pq 9][g 4][n 16][pp 4]: channel c = 4 phase + g, column = 32 nt + 16 group + n, position p = 6 v + u = 4 pq + pp
+//   transpose 0 (forward):        C = Ci, N = Co, g[ky][kx] = w[ky][kx][c][n]
+//   transpose 1 (data gradient):  C = Co, N = Ci, g[ky][kx] = w[2 - ky][2 - kx][n][c]
+__global__ __launch_bounds__(256) void wino4_pack_kernel(const float* __restrict__ w, int Ci, int Co, int transpose, float* __restrict__ out) {
+    const int C = transpose ? Co : Ci, N = transpose ? Ci : Co;
+    const long total = (long)C * N;
+    const int nph = C / 4;
+    const float G[6][3] = {{0.25f, 0.f, 0.f}, {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
+                           {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0.f, 0.f, 1.f}};
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = transpose ? (int)(i % C) : (int)(i / N), n = transpose ? (int)(i / C) : (int)(i % N);
+        float gk[3][3];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+                gk[ky][kx] = transpose ? w[((long)((2 - ky) * 3 + (2 - kx)) * Ci + n) * Co + c] : w[((long)(ky * 3 + kx) * Ci + c) * Co + n];
+        float t[6][3];   // G g
+#pragma unroll
+        for (int u = 0; u < 6; ++u)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) t[u][kx] = G[u][0] * gk[0][kx] + G[u][1] * gk[1][kx] + G[u][2] * gk[2][kx];
+        const int nt = n >> 5, grp = (n >> 4) & 1, nn = n & 15, ph = c >> 2, gg = c & 3;
+        float* o = out + (((long)nt * nph + ph) * 2 + grp) * W4_WGRP + (gg * 16 + nn) * 4;
+#pragma unroll
+        for (int u = 0; u < 6; ++u)
+#pragma unroll
+            for (int v = 0; v < 6; ++v) {
+                const int p = 6 * v + u;
+                o[(p >> 2) * 256 + (p & 3)] = t[u][0] * G[v][0] + t[u][1] * G[v][1] + t[u][2] * G[v][2];
+            }
+    }
+}
+
+static bool plan_wino4(int B, int H, int W, int C, int N, Wino4Geom& g) {
+    g.B = B; g.H = H; g.W = W; g.C = C; g.N = N;
+    if (B <= 0 || H < 4 || W < 4 || C <= 0 || N <= 0 || C % 8 || N % 32) return false;
+    if ((long)B * H * W * (long)(C > N ? C : N) * 4 > 0x7fffffffL || 36L * C * N * 4 > 0x7fffffffL) return false;
+    g.bx_n = cdiv(W, 16); g.by_n = cdiv(H, 16);
+    g.blocks_img = g.bx_n * g.by_n;
+    if ((long)B * g.blocks_img > 0x3fffffffL) return false;
+    g.nblocks = B * g.blocks_img;
+    if ((long)g.nblocks * g.blocks_img >= 0x100000000L) return false;
+    g.m_blocks_img = wino_magic(g.blocks_img); g.m_bx_n = wino_magic(g.bx_n);
+    return true;
+}
+
+static int wino4_attr() {
+    static int once = [] {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4_kernel<W4_FWD>), hipFuncAttributeMaxDynamicSharedMemorySize, WINO4_LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4_kernel<W4_DGRAD>), hipFuncAttributeMaxDynamicSharedMemorySize, WINO4_LDS_BYTES);
+        return e == hipSuccess ? 0 : fail((int)e, "%s: hipFuncSetAttribute failed", "conv wino4 kernel");
+    }();
+    return once;
+}
+
+static int wino4_launch(hipStream_t st, int kind, int nb, int H, int W, int C, int N, const float* x, const float* wp, float* out, const float* aux, int relu) {
+    Wino4Args a;
+    if (!plan_wino4(nb, H, W, C, N, a.g)) return fail(VC_EINVAL, "%s: unsupported shape (vc_conv3x3_wino4_supported)", "conv wino4");
+    int rc = wino4_attr();
+    if (rc) return rc;
+    a.x = x; a.wp = wp; a.out = out; a.aux = aux; a.relu = relu;
+    a.tiles_n = N / 32;
+    a.nphases = C / 4;
+    a.ntiles = cdiv(a.g.nblocks, W4_NBLK) * a.tiles_n;
+    if (kind == W4_DGRAD) hipLaunchKernelGGL((conv_wino4_kernel<W4_DGRAD>), dim3(a.ntiles), dim3(256), WINO4_LDS_BYTES, st, a);
+    else hipLaunchKernelGGL((conv_wino4_kernel<W4_FWD>), dim3(a.ntiles), dim3(256), WINO4_LDS_BYTES, st, a);
+    return launch_status("conv wino4");
+}
+
+}  // namespace vc
+
+// (experiment: these entries are not declared in include/vaecap.h and not linked into libvaecap.so)
+extern "C" int vc_conv3x3_wino4_supported(int B, int H, int W, int Cin, int Cout, int dgrad);
+extern "C" int vc_conv3x3_wino4_pack_f32(void* stream, int Cin, int Cout, const float* w, int transpose, float* wp);
+extern "C" int vc_conv3x3_wino4_fwd_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const float* wp, const float* bias,
+                                        float* y, int relu);
+extern "C" int vc_conv3x3_wino4_dgrad_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* dy, const float* wpt,
+                                          const float* relu_src, float* dx);
+
+extern "C" int vc_conv3x3_wino4_supported(int B, int H, int W, int Cin, int Cout, int dgrad) {
+    vc::Wino4Geom g;
+    const int nb = vc::wino_images_per_launch(B, H, W, Cin, Cout);
+    return nb > 0 && (dgrad ? vc::plan_wino4(nb, H, W, Cout, Cin, g) : vc::plan_wino4(nb, H, W, Cin, Cout, g)) ? 1 : 0;
+}
+
+extern "C" int vc_conv3x3_wino4_pack_f32(void* stream, int Cin, int Cout, const float* w, int transpose, float* wp) {
+    using namespace vc;
+    const int C = transpose ? Cout : Cin, N = transpose ? Cin : Cout;
+    VC_CHECK_ARG(C > 0 && N > 0 && C % 8 == 0 && N % 32 == 0, "gathered channels % 8 == 0 and output channels % 32 == 0 required");
+    VC_CHECK_ARG(w && wp && waligned16(wp), "null or misaligned pointer");
+    const long total = (long)Cin * Cout;
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(wino4_pack_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, Cin, Cout, transpose, wp);
+    return launch_status(__func__);
+}
+
+extern "C" int vc_conv3x3_wino4_fwd_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const float* wp,
+                                        const float* bias, float* y, int relu) {
+    using namespace vc;
+    VC_CHECK_ARG(x && wp && y, "null pointer");
+    VC_CHECK_ARG(waligned16(x) && waligned16(wp) && waligned16(y) && waligned16(bias), "pointers must be 16-byte aligned");
+    const int per = wino_images_per_launch(B, H, W, Cin, Cout);
+    VC_CHECK_ARG(per > 0 && vc_conv3x3_wino4_supported(B, H, W, Cin, Cout, 0), "unsupported shape (vc_conv3x3_wino4_supported)");
+    for (int b0 = 0; b0 < B; b0 += per) {
+        const int nb = B - b0 < per ? B - b0 : per;
+        const int rc = wino4_launch((hipStream_t)stream, W4_FWD, nb, H, W, Cin, Cout, x + (size_t)b0 * H * W * Cin, wp, y + (size_t)b0 * H * W * Cout, bias, relu);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+extern "C" int vc_conv3x3_wino4_dgrad_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* dy, const float* wpt,
+                                          const float* relu_src, float* dx) {
+    using namespace vc;
+    VC_CHECK_ARG(dy && wpt && dx, "null pointer");
+    VC_CHECK_ARG(waligned16(dy) && waligned16(wpt) && waligned16(dx) && waligned16(relu_src), "pointers must be 16-byte aligned");
+    const int per = wino_images_per_launch(B, H, W, Cin, Cout);
+    VC_CHECK_ARG(per > 0 && vc_conv3x3_wino4_supported(B, H, W, Cin, Cout, 1), "unsupported shape (vc_conv3x3_wino4_supported)");
+    for (int b0 = 0; b0 < B; b0 += per) {
+        const int nb = B - b0 < per ? B - b0 : per;
+        const int rc = wino4_launch((hipStream_t)stream, W4_DGRAD, nb, H, W, Cout, Cin, dy + (size_t)b0 * H * W * Cout, wpt, dx + (size_t)b0 * H * W * Cin,
+                                    relu_src ? relu_src + (size_t)b0 * H * W * Cin : nullptr, 0);
+        if (rc) return rc;
+    }
+    return 0;
+}
