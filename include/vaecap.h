@@ -329,6 +329,29 @@ int vc_conv3x3_wino_fwd_mask_f32(void* stream, int B, int H, int W, int Cin, int
                                  const float* bias, float* y, int relu, uint32_t* mask_out);
 int vc_conv3x3_wino_dgrad_bits_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* dy, const float* wpt,
                                    const uint32_t* mask_bits, float* dx);
+
+/* Winograd F(4x4,3x3) (csrc/conv_wino4.hip): the same convolution with 36 positions per 4 x 4 output tile -- 2.25 multiplications per
+ * output where F(2x2,3x3) spends 4 -- for layers whose gathered channels are a multiple of 8 and produced channels a multiple of 32.
+ * Every entry mirrors its vc_conv3x3_wino_* namesake argument for argument (same tensors, same routing-code format of the pooled
+ * forward); what differs: the packed weights (36 * Cin * Cout floats, vc_conv3x3_wino4_pack_f32), the ReLU mask bits (64 per lane,
+ * vc_conv3x3_wino4_mask_words words; bits written by this family's forward are read by this family's data gradient only), the
+ * rounding (~1e-5 of the tensor maximum against ~1e-6).  vc_conv3x3_wino4_preferred: 1 where this kernel is the faster of the two
+ * Winograd forms (the 224-, 112-, 28- and 14-wide layers of VGG16; the callers keep one family per block of layers between two
+ * pools, since the mask bits pass from a layer's forward to the next layer's data gradient). */
+int vc_conv3x3_wino4_supported(int B, int H, int W, int Cin, int Cout, int dgrad);
+int vc_conv3x3_wino4_preferred(int B, int H, int W, int Cin, int Cout);
+int vc_conv3x3_wino4_pack_f32(void* stream, int Cin, int Cout, const float* w, int transpose, float* wp);
+int vc_conv3x3_wino4_fwd_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const float* wp, const float* bias,
+                             float* y, float* ypool, int relu);
+int vc_conv3x3_wino4_fwd_pool_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const float* wp,
+                                  const float* bias, float* y, float* ypool, uint32_t* pool_bits);
+size_t vc_conv3x3_wino4_mask_words(int B, int H, int W, int C);
+int vc_conv3x3_wino4_fwd_mask_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const float* wp,
+                                  const float* bias, float* y, int relu, uint32_t* mask_out);
+int vc_conv3x3_wino4_dgrad_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* dy, const float* wpt,
+                               const float* relu_src, float* dx);
+int vc_conv3x3_wino4_dgrad_bits_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* dy, const float* wpt,
+                                    const uint32_t* mask_bits, float* dx);
 /* Winograd F(3x3, 2x2) weight gradient (csrc/conv_wino_wgrad.hip): both operands transformed in registers, the contraction runs over the
  * 2x2-pixel tiles; raw position sums per K split in the workspace, a reduce kernel sums the splits in fixed order and applies the
  * output transform.  Same contract as conv3x3_wgrad (db != NULL also returns the bias gradient, accumulate adds to dw / db); the

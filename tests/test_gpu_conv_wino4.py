@@ -1,0 +1,180 @@
+"""Winograd F(4x4, 3x3) convolution (csrc/conv_wino4.hip: forward and data gradient of utils/image_embeddings.py:36-212 with 36
+positions per 4 x 4 output tile, blocks of 4 x 4 tiles) against the fp64 numpy oracle, through the C ABI.
+Tolerance: 2e-5 * sqrt(K) of the tensor max, K = 9 * C -- the transforms multiply by 4, 5, 8 and 1/24, which costs about a decimal
+digit against F(2x2,3x3) (held to 3e-6 * sqrt(K)); measured on the VGG16 shapes: 1e-5 of the tensor maximum without the sqrt(K)."""
+import numpy as np
+import pytest
+import torch
+
+from .gpu_util import P, assert_close, dev, host, stream, zeros
+
+pytestmark = pytest.mark.gpu
+
+from oracle import vgg as OV  # noqa: E402  (checker only)
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from vae_captioning_amd import abi
+    return abi.load()
+
+
+def _pack(lib, w, transpose):
+    wp = torch.empty(36 * w.shape[2] * w.shape[3], dtype=torch.float32, device="cuda")
+    lib.vc_conv3x3_wino4_pack_f32(stream(), int(w.shape[2]), int(w.shape[3]), P(w), transpose, P(wp))
+    return wp
+
+
+def test_wino4_pack_is_G_g_Gt(lib):
+    rng = np.random.default_rng(0)
+    Ci, Co = 32, 64
+    w = rng.standard_normal((3, 3, Ci, Co), dtype=np.float32)
+    G = np.array([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]])
+    for transpose in (0, 1):
+        g = w.astype(np.float64) if not transpose else w[::-1, ::-1].transpose(0, 1, 3, 2).astype(np.float64)
+        C, N = g.shape[2], g.shape[3]
+        V = np.einsum("uk,klcn,vl->vucn", G, g, G).reshape(36, C, N)              # position p = 6 v + u (u: vertical index)
+        # packed [nt][phase][group][pq][g][n][pp]: channel = 4 phase + g, column = 32 nt + 16 group + n, position = 4 pq + pp
+        got = host(_pack(lib, dev(w), transpose)).reshape(N // 32, C // 4, 2, 9, 4, 16, 4)
+        ref = V.reshape(9, 4, C // 4, 4, N // 32, 2, 16).transpose(4, 2, 5, 0, 3, 6, 1)
+        np.testing.assert_allclose(got, ref, rtol=0, atol=1e-6)
+
+
+# (B, H, W, Cin, Cout): whole blocks (16, 32, 48 wide), ragged blocks (28, 14, 20, 12: tiles and pixels past the image), tiny images,
+# W != H, a ragged last workgroup (odd block count), several column tiles, the shortest reduction (two phases)
+CASES = [(2, 16, 16, 32, 64), (3, 4, 8, 8, 32), (1, 56, 56, 64, 64), (2, 28, 28, 64, 128), (3, 14, 14, 32, 64), (5, 14, 14, 96, 128),
+         (2, 12, 20, 32, 64), (1, 20, 12, 64, 96), (1, 32, 48, 16, 32), (1, 6, 10, 48, 32), (1, 112, 112, 16, 32)]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "x".join(map(str, c)))
+def test_wino4_fwd_dgrad_match_oracle(lib, case):
+    B, H, W, Ci, Co = case
+    assert lib.vc_conv3x3_wino4_supported(B, H, W, Ci, Co, 0) == 1
+    rng = np.random.default_rng(sum(case))
+    x = np.maximum(rng.standard_normal((B, H, W, Ci), dtype=np.float32), 0)
+    w = rng.standard_normal((3, 3, Ci, Co), dtype=np.float32) * np.float32(1 / np.sqrt(9 * Ci))
+    b = rng.standard_normal(Co, dtype=np.float32)
+    dy = rng.standard_normal((B, H, W, Co), dtype=np.float32)
+    x64, w64 = x.astype(np.float64), w.astype(np.float64)
+    if B * H * W <= 20000:
+        pre = OV.conv3x3_fwd(x64, w64, b.astype(np.float64))
+        dxref = OV.conv3x3_bwd(x64, w64, dy.astype(np.float64))[0] if Ci % 32 == 0 else None
+    else:   # the 112 x 112 case: torch fp64 on the device as the reference of the reference (same contraction)
+        t = lambda a: torch.from_numpy(a).cuda().double()
+        wt = t(w).permute(3, 2, 0, 1)
+        pre = torch.nn.functional.conv2d(t(x).permute(0, 3, 1, 2), wt, t(b), padding=1).permute(0, 2, 3, 1).cpu().numpy()
+        dxref = None
+    tx, tw, tdy = dev(x), dev(w), dev(dy)
+    wp = _pack(lib, tw, 0)
+    y = zeros(B, H, W, Co)
+    tol = 2e-5 * np.sqrt(9 * Ci) + 1e-6
+    lib.vc_conv3x3_wino4_fwd_f32(stream(), B, H, W, Ci, Co, P(tx), P(wp), P(dev(b)), P(y), None, 1)
+    assert_close(host(y), np.maximum(pre, 0), tol, msg="wino4 fwd (+bias, relu)")
+    lib.vc_conv3x3_wino4_fwd_f32(stream(), B, H, W, Ci, Co, P(tx), P(wp), None, P(y), None, 0)
+    assert_close(host(y), pre - b, tol, msg="wino4 fwd (no bias, no relu)")
+    yp = zeros(B, H // 2, W // 2, Co)
+    y.zero_()
+    lib.vc_conv3x3_wino4_fwd_f32(stream(), B, H, W, Ci, Co, P(tx), P(wp), P(dev(b)), P(y), P(yp), 1)
+    hy = host(y)
+    assert_close(hy, np.maximum(pre, 0), tol, msg="wino4 fwd + pool: y")
+    assert np.array_equal(host(yp), hy.reshape(B, H // 2, 2, W // 2, 2, Co).max(axis=(2, 4))), "fused pool != max_pool2x2(y)"
+    if dxref is not None:
+        assert lib.vc_conv3x3_wino4_supported(B, H, W, Ci, Co, 1) == 1
+        wpt = _pack(lib, tw, 1)
+        dx = zeros(B, H, W, Ci)
+        told = 2e-5 * np.sqrt(9 * Co) + 1e-6
+        lib.vc_conv3x3_wino4_dgrad_f32(stream(), B, H, W, Ci, Co, P(tdy), P(wpt), P(tx), P(dx))
+        assert_close(host(dx), dxref * (x > 0), told, msg="wino4 dgrad (+relu mask)")
+        lib.vc_conv3x3_wino4_dgrad_f32(stream(), B, H, W, Ci, Co, P(tdy), P(wpt), None, P(dx))
+        assert_close(host(dx), dxref, told, msg="wino4 dgrad")
+
+
+def test_wino4_error_is_a_digit_above_f23_and_far_inside_the_tolerance(lib):
+    """What the constants of F(4x4,3x3) cost, measured where it is used: conv4_2's reduction (K = 9 * 512), post-ReLU inputs, He-scaled
+    weights -- the error against fp64 is ~1e-5 of the tensor maximum (F(2x2,3x3): ~1e-6), the test tolerance 1.4e-3."""
+    B, H, Ci, Co = 2, 28, 512, 64
+    rng = np.random.default_rng(5)
+    x = np.maximum(rng.standard_normal((B, H, H, Ci), dtype=np.float32), 0)
+    w = rng.standard_normal((3, 3, Ci, Co), dtype=np.float32) * np.float32(np.sqrt(2.0 / (9 * Ci)))
+    pre = OV.conv3x3_fwd(x.astype(np.float64), w.astype(np.float64), np.zeros(Co))
+    tx, tw = dev(x), dev(w)
+    y4, y2 = zeros(B, H, H, Co), zeros(B, H, H, Co)
+    lib.vc_conv3x3_wino4_fwd_f32(stream(), B, H, H, Ci, Co, P(tx), P(_pack(lib, tw, 0)), None, P(y4), None, 0)
+    wp2 = torch.empty(16 * Ci * Co, dtype=torch.float32, device="cuda")
+    lib.vc_conv3x3_wino_pack_f32(stream(), Ci, Co, P(tw), 0, P(wp2))
+    lib.vc_conv3x3_wino_fwd_f32(stream(), B, H, H, Ci, Co, P(tx), P(wp2), None, P(y2), None, 0)
+    scale = np.abs(pre).max()
+    e4, e2 = np.abs(host(y4) - pre).max() / scale, np.abs(host(y2) - pre).max() / scale
+    assert e2 < 2e-6 and e4 < 4e-5 and e4 < 40 * max(e2, 1e-7), (e2, e4)
+
+
+def test_wino4_unsupported_shapes_are_refused_and_preference_follows_the_block_coverage(lib):
+    from vae_captioning_amd.abi import VaecapError
+    assert lib.vc_conv3x3_wino4_supported(2, 224, 224, 4, 64, 0) == 0     # conv1_1: 4 gathered channels
+    assert lib.vc_conv3x3_wino4_supported(2, 8, 8, 32, 48, 0) == 0         # output channels % 32
+    assert lib.vc_conv3x3_wino4_supported(2, 8, 8, 32, 64, 1) == 1 and lib.vc_conv3x3_wino4_supported(2, 8, 8, 24, 64, 1) == 0
+    x, wp, y = zeros(2, 8, 8, 32), zeros(36 * 32 * 48), zeros(2, 8, 8, 48)
+    with pytest.raises(VaecapError):
+        lib.vc_conv3x3_wino4_fwd_f32(stream(), 2, 8, 8, 32, 48, P(x), P(wp), None, P(y), None, 0)
+    # VGG16 at 224 x 224: every 3x3 layer but the 56-wide block (4 x 4-tile blocks cover 56 x 56 to 77 %, the 2 x 2-tile blocks to 100 %)
+    pref = {H: lib.vc_conv3x3_wino4_preferred(32, H, H, 64, 64) for H in (224, 112, 56, 28, 14)}
+    assert pref == {224: 1, 112: 1, 56: 0, 28: 1, 14: 1}, pref
+    assert lib.vc_conv3x3_wino4_preferred(32, 224, 224, 4, 64) == 0
+
+
+@pytest.mark.parametrize("case", [(2, 16, 16, 32, 64), (1, 56, 56, 64, 64), (2, 28, 28, 64, 128), (3, 14, 14, 32, 64), (2, 12, 20, 32, 64)], ids=lambda c: "x".join(map(str, c)))
+def test_wino4_relu_mask_as_bits(lib, case):
+    """forward of layer L leaves (y > 0) as bits; the data gradient of layer L + 1 (Cin = L's Cout, same H x W) reads them: bit-identical
+    to the data gradient that loads relu_src = y, and y itself is what the plain forward writes"""
+    B, H, W, Ci, Cm = case
+    Co = 64
+    rng = np.random.default_rng(sum(case) + 3)
+    x = dev(rng.standard_normal((B, H, W, Ci), dtype=np.float32))
+    w1 = dev(rng.standard_normal((3, 3, Ci, Cm), dtype=np.float32) * np.float32(0.1))
+    b1 = dev(rng.standard_normal(Cm, dtype=np.float32))
+    w2 = dev(rng.standard_normal((3, 3, Cm, Co), dtype=np.float32) * np.float32(0.1))
+    dy = dev(rng.standard_normal((B, H, W, Co), dtype=np.float32))
+    y, y0 = zeros(B, H, W, Cm), zeros(B, H, W, Cm)
+    nw = lib.vc_conv3x3_wino4_mask_words(B, H, W, Cm)
+    assert nw > 0
+    bits = torch.zeros(nw, dtype=torch.int32, device="cuda")
+    wp1 = _pack(lib, w1, 0)
+    lib.vc_conv3x3_wino4_fwd_f32(stream(), B, H, W, Ci, Cm, P(x), P(wp1), P(b1), P(y0), None, 1)
+    lib.vc_conv3x3_wino4_fwd_mask_f32(stream(), B, H, W, Ci, Cm, P(x), P(wp1), P(b1), P(y), 1, P(bits))
+    assert np.array_equal(host(y), host(y0))
+    wpt2 = _pack(lib, w2, 1)
+    dx_ref, dx = zeros(B, H, W, Cm), zeros(B, H, W, Cm)
+    lib.vc_conv3x3_wino4_dgrad_f32(stream(), B, H, W, Cm, Co, P(dy), P(wpt2), P(y), P(dx_ref))
+    lib.vc_conv3x3_wino4_dgrad_bits_f32(stream(), B, H, W, Cm, Co, P(dy), P(wpt2), P(bits), P(dx))
+    assert np.array_equal(host(dx), host(dx_ref))
+    assert float(np.abs(host(dx_ref)).max()) > 0 and (host(dx_ref) == 0).mean() > 0.2   # the mask does mask
+
+
+@pytest.mark.parametrize("case", [(2, 16, 16, 32, 64), (1, 56, 56, 64, 64), (3, 28, 28, 32, 96), (5, 14, 14, 64, 32), (2, 12, 20, 16, 64)], ids=lambda c: "x".join(map(str, c)))
+def test_wino4_pool_routing_codes_equal_maxpool_bwd_on_the_activation(lib, case):
+    """The pooled forward also leaves MaxPoolGrad's routing codes in conv_wino.hip's format (a lane owns four channels = half a word);
+    routing the pooled gradient with them is bit-identical to vc_maxpool2x2_bwd_f32 on the pre-pool activation, ties included."""
+    B, H, W, Ci, Co = case
+    rng = np.random.default_rng(sum(case) + 11)
+    x = np.maximum(rng.standard_normal((B, H, W, Ci), dtype=np.float32), 0)
+    x[:, : H // 2] = np.round(x[:, : H // 2])                      # small integers: exact ties between window positions
+    w = np.round(rng.standard_normal((3, 3, Ci, Co), dtype=np.float32))
+    w[:, :, :, : Co // 4] = 0                                       # whole channels at the bias value: four-way ties
+    b = np.concatenate([np.full(Co // 8, -1.0), np.full(Co // 8, 2.0), rng.standard_normal(Co - Co // 4)]).astype(np.float32)
+    tx, tw, tb = dev(x), dev(w), dev(b)
+    wp = _pack(lib, tw, 0)
+    y0, p0 = zeros(B, H, W, Co), zeros(B, H // 2, W // 2, Co)
+    lib.vc_conv3x3_wino4_fwd_f32(stream(), B, H, W, Ci, Co, P(tx), P(wp), P(tb), P(y0), P(p0), 1)
+    y1, p1 = zeros(B, H, W, Co), zeros(B, H // 2, W // 2, Co)
+    nw = lib.vc_conv3x3_wino_pool_words(B, H, W, Co)
+    bits = torch.zeros(nw, dtype=torch.int32, device="cuda")
+    lib.vc_conv3x3_wino4_fwd_pool_f32(stream(), B, H, W, Ci, Co, P(tx), P(wp), P(tb), P(y1), P(p1), P(bits))
+    assert torch.equal(y0, y1) and torch.equal(p0, p1)
+    dy = dev(rng.standard_normal((B, H // 2, W // 2, Co), dtype=np.float32))
+    d_ref, d_bits = zeros(B, H, W, Co), torch.full((B, H, W, Co), 7.0, device="cuda")
+    lib.vc_maxpool2x2_bwd_f32(stream(), B, H, W, Co, P(y1), P(dy), P(d_ref), 1)
+    lib.vc_maxpool2x2_bwd_bits_f32(stream(), B, H, W, Co, P(bits), P(dy), P(d_bits))
+    assert torch.equal(d_ref, d_bits)
+    hy = host(y1)
+    win = hy.reshape(B, H // 2, 2, W // 2, 2, Co)
+    assert (win.max(axis=(2, 4)) == 0).mean() > 0.05 and ((win == win.max(axis=(2, 4), keepdims=True)).sum(axis=(2, 4)) > 1).mean() > 0.1   # ties do occur

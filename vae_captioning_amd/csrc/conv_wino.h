@@ -28,6 +28,21 @@ __device__ __forceinline__ float4 wbufload(__amdgpu_buffer_rsrc_t r, unsigned vo
     return *reinterpret_cast<float4*>(&v);
 }
 
+// fraction of the F(2x2,3x3) kernel's tile slots that hold real tiles on an H x W image (its blocks: at most sixteen 2 x 2 tiles whose
+// halo patch fits 100 pixels -- the search of plan_wino2 in conv_wino.hip)
+static inline double wino2_coverage(int H, int W) {
+    const int TW = W / 2, TH = H / 2;
+    double best = 0.0;
+    for (int tbw = 1; tbw <= 16 && tbw <= TW; ++tbw) {
+        int tbh = 16 / tbw;
+        if (tbh > TH) tbh = TH;
+        if (tbh < 1 || (2 * tbh + 2) * (2 * tbw + 2) > 100) continue;
+        const double eff = (double)TW * TH / ((double)((TW + tbw - 1) / tbw) * ((TH + tbh - 1) / tbh) * 16.0);
+        if (eff > best) best = eff;
+    }
+    return best;
+}
+
 static inline bool waligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 // The kernels address their tensors with 32-bit buffer offsets (< 2 GiB per launch): a call on more images is cut into launches

@@ -3,6 +3,8 @@
 //
 //   Y = A^T [ sum_c (G g_c G^T) (.) (B^T d_c B) ] A     per 4 x 4 output tile: d = its 6 x 6 input patch, g = the 3 x 3 filter
 //
+// Used where its blocks of 4 x 4 tiles cover the image about as well as the F(2x2,3x3) kernel's (vc_conv3x3_wino4_preferred: the 224-,
+// 112-, 28- and 14-wide layers of VGG16: 7-27 % faster there, profiles/r03_wino4_experiment.txt; the 56-wide layers stay on conv_wino.hip).
 // Why a second Winograd kernel (tools/probes/mfma16_f43.hip, mfma_specialised.hip): on one SIMD a VALU
 // instruction and the matrix pipe do NOT overlap -- beside back-to-back v_mfma_f32_16x16x4_f32 a partner wave gets ~0.5 VALU issues
 // per MFMA, inside one stream every VALU operation costs 4-8 cycles of matrix time -- so the F(2x2,3x3) kernel's 71 % MFMA-busy is its
@@ -21,9 +23,9 @@
 // ~1e-5 of the tensor maximum (tests/test_gpu_conv_wino4.py against the fp64 oracle).
 #include <stdlib.h>
 #include <type_traits>
-#include "../conv_wino.h"
+#include "conv_wino.h"
 
-// `make wino4 W4FLAGS=-DW4_ABL=n` builds this file with W4_ABL = a bit mask that REMOVES parts of the main loop (results are then wrong; timing only):
+// `make wino4abl W4FLAGS=-DW4_ABL=n` builds this file with W4_ABL = a bit mask that REMOVES parts of the main loop (results are then wrong; timing only):
 // 1 transform arithmetic, 2 patch-row reads, 4 weight-fragment reads, 8 staging (global loads + LDS writes), 16 barriers,
 // 256 the patch loads made contiguous over the lanes (what a channel-blocked activation layout would give the L1), 32 the global loads only (the LDS writes store stale registers), 64 staging group A (patches + weight piece 0), 128 staging group B
 #ifndef W4_ABL
@@ -68,6 +70,11 @@ struct Wino4Args {
     const float* wp;     // packed [N/32][C/4][group 2][pq 9][g 4][n 16][pp 4]
     float* out;          // [P, N]
     const float* aux;    // fwd: bias [N] or null; dgrad: ReLU source [P, N] or null
+    float* pool;         // fwd: also max_pool2x2(out) [B, H/2, W/2, N] (null: none)
+    unsigned* pbits;     // fwd + pool: MaxPoolGrad routing codes, the format of conv_wino.hip ([B,H/2,W/2,N/8] words, 4 bits per pooled element:
+                         // position of the first maximum of its window | 4 if it is > 0); a lane owns four channels = half a word
+    unsigned* mask;      // [workgroups][256 threads][2]: (out > 0) of each lane's 4 x 4 pixels x 4 channels as 64 bits -- written by the forward
+                         // (null: not wanted), read by the data gradient of the NEXT layer instead of the float source (same shape => same lanes)
     int relu;
     int tiles_n, ntiles, nphases;
 };
@@ -110,7 +117,7 @@ __device__ __forceinline__ void w4_bstep_v(int k, const float& d0, const float& 
     if (k == 11) o[5] = __builtin_fmaf(4.f, d1, t[4]);
 }
 
-template <int KIND>
+template <int KIND, bool POOL>
 __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const Wino4Geom& g = a.g;
@@ -160,6 +167,35 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
     if (KIND == W4_FWD && a.aux) {
         const float4 bv = *reinterpret_cast<const float4*>(a.aux + nc0);
         acc[7] = f32x4{bv.x, bv.y, bv.z, bv.w};
+    }
+
+    // this lane's 4 x 4 output pixels
+    const int gbo = tm * W4_NBLK + wb;
+    const bool blk_ok = gbo < g.nblocks;
+    const int gboc = blk_ok ? gbo : 0;
+    const int ob = (int)wino_div((unsigned)gboc, g.m_blocks_img), orem = gboc - ob * g.blocks_img;
+    const int oby = (int)wino_div((unsigned)orem, g.m_bx_n), obx = orem - oby * g.bx_n;
+    const int y0 = oby * 16 + 4 * ty, x0 = obx * 16 + 4 * tx;
+    const long rowN = (long)g.W * N;
+    const long p00 = ((long)(ob * g.H + y0) * g.W + x0) * N + nc0;
+    // data gradient: the ReLU mask of the lane's outputs as 64 bits (bit 16 aa + 4 bb + c), from the producer's forward (one 8-byte
+    // load) or from the float activation (sixteen loads that overlap the first patch loads)
+    unsigned mb0 = 0xffffffffu, mb1 = 0xffffffffu;
+    if (KIND == W4_DGRAD && a.mask) {
+        const uint2 m = *reinterpret_cast<const uint2*>(a.mask + ((size_t)id * 256 + tid) * 2);
+        mb0 = m.x; mb1 = m.y;
+    } else if (KIND == W4_DGRAD && a.aux) {
+        mb0 = mb1 = 0u;
+#pragma unroll
+        for (int aa = 0; aa < 4; ++aa)
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+                const bool ok = blk_ok && y0 + aa < g.H && x0 + bb < g.W;
+                const float4 m = ok ? *reinterpret_cast<const float4*>(a.aux + p00 + aa * rowN + bb * N) : f4zero();
+                const unsigned bits = (m.x > 0.f ? 1u : 0u) | (m.y > 0.f ? 2u : 0u) | (m.z > 0.f ? 4u : 0u) | (m.w > 0.f ? 8u : 0u);
+                if (aa < 2) mb0 |= bits << (16 * aa + 4 * bb);
+                else mb1 |= bits << (16 * (aa - 2) + 4 * bb);
+            }
     }
 
     float4 st[4 + W4_B_REG];    // staging registers
@@ -300,12 +336,6 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
 
     // ---- output transform A^T M A (6 x 6 -> 4 x 4) and epilogue
     //   y0 = m0 + m1 + m2 + m3 + m4   y1 = (m1 - m2) + 2 (m3 - m4)   y2 = (m1 + m2) + 4 (m3 + m4)   y3 = (m1 - m2) + 8 (m3 - m4) + m5
-    const int gb = tm * W4_NBLK + wb;
-    const bool blk_ok = gb < g.nblocks;
-    const int gbc = blk_ok ? gb : 0;
-    const int b = (int)wino_div((unsigned)gbc, g.m_blocks_img), rem = gbc - b * g.blocks_img;
-    const int by = (int)wino_div((unsigned)rem, g.m_bx_n), bx = rem - by * g.bx_n;
-    const int y0 = by * 16 + 4 * ty, x0 = bx * 16 + 4 * tx;
     float4 Y[4][4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -329,25 +359,55 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
             if (r == 3) { Y[aa][0].w = o0; Y[aa][1].w = o1; Y[aa][2].w = o2; Y[aa][3].w = o3; }
         }
     }
-    const long rowN = (long)g.W * N;
-    const long p00 = ((long)(b * g.H + y0) * g.W + x0) * N + nc0;
+    unsigned ob0 = 0u, ob1 = 0u;
 #pragma unroll
     for (int aa = 0; aa < 4; ++aa)
 #pragma unroll
         for (int bb = 0; bb < 4; ++bb) {
             const bool ok = blk_ok && y0 + aa < g.H && x0 + bb < g.W;
-            float4 v = Y[aa][bb];
-            if (KIND == W4_FWD) {
+            float4& v = Y[aa][bb];
+            if (KIND == W4_FWD) {   // (the bias is already in the accumulators)
                 if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            } else if (a.aux) {
-                const float4 mk = ok ? *reinterpret_cast<const float4*>(a.aux + p00 + aa * rowN + bb * N) : f4zero();
-                if (!(mk.x > 0.f)) v.x = 0.f;
-                if (!(mk.y > 0.f)) v.y = 0.f;
-                if (!(mk.z > 0.f)) v.z = 0.f;
-                if (!(mk.w > 0.f)) v.w = 0.f;
+                if (a.mask) {
+                    const unsigned bits = (v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u);
+                    if (aa < 2) ob0 |= bits << (16 * aa + 4 * bb);
+                    else ob1 |= bits << (16 * (aa - 2) + 4 * bb);
+                }
+            } else if (a.aux || a.mask) {
+                const unsigned mb = (aa < 2 ? mb0 >> (16 * aa + 4 * bb) : mb1 >> (16 * (aa - 2) + 4 * bb));
+                if (!(mb & 1u)) v.x = 0.f;
+                if (!(mb & 2u)) v.y = 0.f;
+                if (!(mb & 4u)) v.z = 0.f;
+                if (!(mb & 8u)) v.w = 0.f;
             }
             if (ok) *reinterpret_cast<float4*>(a.out + p00 + aa * rowN + bb * N) = v;
         }
+    if (KIND == W4_FWD && a.mask) *reinterpret_cast<uint2*>(a.mask + ((size_t)id * 256 + tid) * 2) = make_uint2(ob0, ob1);
+    if (POOL) {   // a 4 x 4 tile is 2 x 2 pooling windows: register math, no LDS, no separate pooling pass
+        const int HP = g.H >> 1, WP = g.W >> 1;
+#pragma unroll
+        for (int pa = 0; pa < 2; ++pa)
+#pragma unroll
+            for (int pc = 0; pc < 2; ++pc) {
+                const float4 &v00 = Y[2 * pa][2 * pc], &v01 = Y[2 * pa][2 * pc + 1], &v10 = Y[2 * pa + 1][2 * pc], &v11 = Y[2 * pa + 1][2 * pc + 1];
+                if (!(blk_ok && y0 + 2 * pa + 1 < g.H && x0 + 2 * pc + 1 < g.W)) continue;
+                float4 m;
+                m.x = fmaxf(fmaxf(v00.x, v01.x), fmaxf(v10.x, v11.x));
+                m.y = fmaxf(fmaxf(v00.y, v01.y), fmaxf(v10.y, v11.y));
+                m.z = fmaxf(fmaxf(v00.z, v01.z), fmaxf(v10.z, v11.z));
+                m.w = fmaxf(fmaxf(v00.w, v01.w), fmaxf(v10.w, v11.w));
+                const size_t pp = ((size_t)(ob * HP + (y0 >> 1) + pa) * WP + (x0 >> 1) + pc) * N + nc0;
+                *reinterpret_cast<float4*>(a.pool + pp) = m;
+                if (a.pbits) {   // where MaxPoolGrad will send the gradient (vc_maxpool2x2_bwd_bits_f32): first maximum in row-major order, valid if > 0
+                    auto code = [](float a00, float a01, float a10, float a11, float mx) -> unsigned {
+                        return (a00 == mx ? 0u : a01 == mx ? 1u : a10 == mx ? 2u : 3u) | (mx > 0.f ? 4u : 0u);
+                    };
+                    const unsigned c16 = code(v00.x, v01.x, v10.x, v11.x, m.x) | code(v00.y, v01.y, v10.y, v11.y, m.y) << 4 |
+                                         code(v00.z, v01.z, v10.z, v11.z, m.z) << 8 | code(v00.w, v01.w, v10.w, v11.w, m.w) << 12;
+                    reinterpret_cast<unsigned short*>(a.pbits)[pp >> 2] = (unsigned short)c16;   // half-word (pp / 8) * 2 + (channel / 4) % 2
+                }
+            }
+    }
 }
 
 // w [3][3][Ci][Co] (HWIO) -> V = G g G^T (6 x 6), G = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1],
@@ -387,7 +447,7 @@ __global__ __launch_bounds__(256) void wino4_pack_kernel(const float* __restrict
 
 static bool plan_wino4(int B, int H, int W, int C, int N, Wino4Geom& g) {
     g.B = B; g.H = H; g.W = W; g.C = C; g.N = N;
-    if (B <= 0 || H < 4 || W < 4 || C <= 0 || N <= 0 || C % 8 || N % 32) return false;
+    if (B <= 0 || H < 4 || W < 4 || C <= 0 || N <= 0 || C % 8 || N % 32) return false;   // (any H, W: stores and pooling windows past the image are masked)
     if ((long)B * H * W * (long)(C > N ? C : N) * 4 > 0x7fffffffL || 36L * C * N * 4 > 0x7fffffffL) return false;
     g.bx_n = cdiv(W, 16); g.by_n = cdiv(H, 16);
     g.blocks_img = g.bx_n * g.by_n;
@@ -400,41 +460,49 @@ static bool plan_wino4(int B, int H, int W, int C, int N, Wino4Geom& g) {
 
 static int wino4_attr() {
     static int once = [] {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4_kernel<W4_FWD>), hipFuncAttributeMaxDynamicSharedMemorySize, WINO4_LDS_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4_kernel<W4_DGRAD>), hipFuncAttributeMaxDynamicSharedMemorySize, WINO4_LDS_BYTES);
+        hipError_t e = hipSuccess;
+        auto set = [&](const void* f) { if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, WINO4_LDS_BYTES); };
+        set(reinterpret_cast<const void*>(conv_wino4_kernel<W4_FWD, false>));
+        set(reinterpret_cast<const void*>(conv_wino4_kernel<W4_FWD, true>));
+        set(reinterpret_cast<const void*>(conv_wino4_kernel<W4_DGRAD, false>));
         return e == hipSuccess ? 0 : fail((int)e, "%s: hipFuncSetAttribute failed", "conv wino4 kernel");
     }();
     return once;
 }
 
-static int wino4_launch(hipStream_t st, int kind, int nb, int H, int W, int C, int N, const float* x, const float* wp, float* out, const float* aux, int relu) {
+// one launch over nb images; C = gathered channels, N = produced channels
+static int wino4_launch(hipStream_t st, int kind, int nb, int H, int W, int C, int N, const float* x, const float* wp, float* out, const float* aux,
+                        float* pool, unsigned* mask, int relu, unsigned* pbits = nullptr) {
     Wino4Args a;
     if (!plan_wino4(nb, H, W, C, N, a.g)) return fail(VC_EINVAL, "%s: unsupported shape (vc_conv3x3_wino4_supported)", "conv wino4");
     int rc = wino4_attr();
     if (rc) return rc;
-    a.x = x; a.wp = wp; a.out = out; a.aux = aux; a.relu = relu;
+    a.x = x; a.wp = wp; a.out = out; a.aux = aux; a.pool = pool; a.mask = mask; a.pbits = pbits; a.relu = relu;
     a.tiles_n = N / 32;
     a.nphases = C / 4;
     a.ntiles = cdiv(a.g.nblocks, W4_NBLK) * a.tiles_n;
-    if (kind == W4_DGRAD) hipLaunchKernelGGL((conv_wino4_kernel<W4_DGRAD>), dim3(a.ntiles), dim3(256), WINO4_LDS_BYTES, st, a);
-    else hipLaunchKernelGGL((conv_wino4_kernel<W4_FWD>), dim3(a.ntiles), dim3(256), WINO4_LDS_BYTES, st, a);
+    if (kind == W4_DGRAD) hipLaunchKernelGGL((conv_wino4_kernel<W4_DGRAD, false>), dim3(a.ntiles), dim3(256), WINO4_LDS_BYTES, st, a);
+    else if (pool) hipLaunchKernelGGL((conv_wino4_kernel<W4_FWD, true>), dim3(a.ntiles), dim3(256), WINO4_LDS_BYTES, st, a);
+    else hipLaunchKernelGGL((conv_wino4_kernel<W4_FWD, false>), dim3(a.ntiles), dim3(256), WINO4_LDS_BYTES, st, a);
     return launch_status("conv wino4");
 }
 
 }  // namespace vc
 
-// (experiment: these entries are not declared in include/vaecap.h and not linked into libvaecap.so)
-extern "C" int vc_conv3x3_wino4_supported(int B, int H, int W, int Cin, int Cout, int dgrad);
-extern "C" int vc_conv3x3_wino4_pack_f32(void* stream, int Cin, int Cout, const float* w, int transpose, float* wp);
-extern "C" int vc_conv3x3_wino4_fwd_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const float* wp, const float* bias,
-                                        float* y, int relu);
-extern "C" int vc_conv3x3_wino4_dgrad_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* dy, const float* wpt,
-                                          const float* relu_src, float* dx);
-
+// ---- C ABI (the entries mirror conv_wino.hip's, argument for argument) ------------------------------
 extern "C" int vc_conv3x3_wino4_supported(int B, int H, int W, int Cin, int Cout, int dgrad) {
     vc::Wino4Geom g;
     const int nb = vc::wino_images_per_launch(B, H, W, Cin, Cout);
     return nb > 0 && (dgrad ? vc::plan_wino4(nb, H, W, Cout, Cin, g) : vc::plan_wino4(nb, H, W, Cin, Cout, g)) ? 1 : 0;
+}
+
+// 1 when this kernel is the faster Winograd form for the layer: its 16 x 16-pixel blocks must cover the image nearly as well as the
+// F(2x2,3x3) kernel's blocks of sixteen 2 x 2 tiles do (measured, profiles/r03_wino4_experiment.txt: 224 / 112 wide x1.1-1.27, 28 wide
+// x1.07-1.10 at 77 % against 88 % coverage, 14 wide x1.22 at 77 % both; 56 wide x0.97 at 77 % against 100 %).
+extern "C" int vc_conv3x3_wino4_preferred(int B, int H, int W, int Cin, int Cout) {
+    if (!vc_conv3x3_wino4_supported(B, H, W, Cin, Cout, 0) || !vc_conv3x3_wino4_supported(B, H, W, Cin, Cout, 1) || (H & 1) || (W & 1)) return 0;
+    const double e4 = (double)H * W / ((double)vc::cdiv(H, 16) * vc::cdiv(W, 16) * 256.0);
+    return e4 >= 0.85 * vc::wino2_coverage(H, W) ? 1 : 0;
 }
 
 extern "C" int vc_conv3x3_wino4_pack_f32(void* stream, int Cin, int Cout, const float* w, int transpose, float* wp) {
@@ -449,18 +517,54 @@ extern "C" int vc_conv3x3_wino4_pack_f32(void* stream, int Cin, int Cout, const 
 }
 
 extern "C" int vc_conv3x3_wino4_fwd_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const float* wp,
-                                        const float* bias, float* y, int relu) {
+                                        const float* bias, float* y, float* ypool, int relu) {
     using namespace vc;
     VC_CHECK_ARG(x && wp && y, "null pointer");
-    VC_CHECK_ARG(waligned16(x) && waligned16(wp) && waligned16(y) && waligned16(bias), "pointers must be 16-byte aligned");
+    VC_CHECK_ARG(waligned16(x) && waligned16(wp) && waligned16(y) && waligned16(bias) && waligned16(ypool), "pointers must be 16-byte aligned");
+    VC_CHECK_ARG(!ypool || !((H | W) & 1), "the fused max-pool needs even H and W");
+    const int per = wino_images_per_launch(B, H, W, Cin, Cout);
+    VC_CHECK_ARG(per > 0 && vc_conv3x3_wino4_supported(B, H, W, Cin, Cout, 0), "unsupported shape (vc_conv3x3_wino4_supported)");
+    for (int b0 = 0; b0 < B; b0 += per) {   // image ranges of < 2 GiB
+        const int nb = B - b0 < per ? B - b0 : per;
+        const int rc = wino4_launch((hipStream_t)stream, W4_FWD, nb, H, W, Cin, Cout, x + (size_t)b0 * H * W * Cin, wp, y + (size_t)b0 * H * W * Cout, bias,
+                                    ypool ? ypool + (size_t)b0 * (H / 2) * (W / 2) * Cout : nullptr, nullptr, relu);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+extern "C" int vc_conv3x3_wino4_fwd_pool_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const float* wp,
+                                             const float* bias, float* y, float* ypool, uint32_t* pool_bits) {
+    using namespace vc;
+    VC_CHECK_ARG(x && wp && y && ypool && pool_bits, "null pointer");
+    VC_CHECK_ARG(waligned16(x) && waligned16(wp) && waligned16(y) && waligned16(bias) && waligned16(ypool), "pointers must be 16-byte aligned");
+    VC_CHECK_ARG(!((H | W) & 1), "the fused max-pool needs even H and W");
     const int per = wino_images_per_launch(B, H, W, Cin, Cout);
     VC_CHECK_ARG(per > 0 && vc_conv3x3_wino4_supported(B, H, W, Cin, Cout, 0), "unsupported shape (vc_conv3x3_wino4_supported)");
     for (int b0 = 0; b0 < B; b0 += per) {
         const int nb = B - b0 < per ? B - b0 : per;
-        const int rc = wino4_launch((hipStream_t)stream, W4_FWD, nb, H, W, Cin, Cout, x + (size_t)b0 * H * W * Cin, wp, y + (size_t)b0 * H * W * Cout, bias, relu);
+        const size_t po = (size_t)b0 * (H / 2) * (W / 2) * Cout;
+        const int rc = wino4_launch((hipStream_t)stream, W4_FWD, nb, H, W, Cin, Cout, x + (size_t)b0 * H * W * Cin, wp, y + (size_t)b0 * H * W * Cout, bias,
+                                    ypool + po, nullptr, 1, pool_bits + po / 8);
         if (rc) return rc;
     }
     return 0;
+}
+
+extern "C" size_t vc_conv3x3_wino4_mask_words(int B, int H, int W, int C) {
+    vc::Wino4Geom g;
+    if (!vc::plan_wino4(B, H, W, 8, C, g)) return 0;
+    return (size_t)vc::cdiv(g.nblocks, vc::W4_NBLK) * (C / 32) * 512;
+}
+
+extern "C" int vc_conv3x3_wino4_fwd_mask_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const float* wp,
+                                             const float* bias, float* y, int relu, uint32_t* mask_out) {
+    using namespace vc;
+    VC_CHECK_ARG(x && wp && y && mask_out, "null pointer");
+    VC_CHECK_ARG(waligned16(x) && waligned16(wp) && waligned16(y) && waligned16(bias) && waligned16(mask_out), "pointers must be 16-byte aligned");
+    VC_CHECK_ARG(wino_images_per_launch(B, H, W, Cin, Cout) >= B && vc_conv3x3_wino4_supported(B, H, W, Cin, Cout, 0),
+                 "unsupported shape, or more images than one launch takes (vc_conv3x3_wino_single_launch_supported): the mask bits are per tile of ONE launch");
+    return wino4_launch((hipStream_t)stream, W4_FWD, B, H, W, Cin, Cout, x, wp, y, bias, nullptr, mask_out, relu);
 }
 
 extern "C" int vc_conv3x3_wino4_dgrad_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* dy, const float* wpt,
@@ -473,8 +577,18 @@ extern "C" int vc_conv3x3_wino4_dgrad_f32(void* stream, int B, int H, int W, int
     for (int b0 = 0; b0 < B; b0 += per) {
         const int nb = B - b0 < per ? B - b0 : per;
         const int rc = wino4_launch((hipStream_t)stream, W4_DGRAD, nb, H, W, Cout, Cin, dy + (size_t)b0 * H * W * Cout, wpt, dx + (size_t)b0 * H * W * Cin,
-                                    relu_src ? relu_src + (size_t)b0 * H * W * Cin : nullptr, 0);
+                                    relu_src ? relu_src + (size_t)b0 * H * W * Cin : nullptr, nullptr, nullptr, 0);
         if (rc) return rc;
     }
     return 0;
+}
+
+extern "C" int vc_conv3x3_wino4_dgrad_bits_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* dy, const float* wpt,
+                                               const uint32_t* mask_bits, float* dx) {
+    using namespace vc;
+    VC_CHECK_ARG(dy && wpt && dx && mask_bits, "null pointer");
+    VC_CHECK_ARG(waligned16(dy) && waligned16(wpt) && waligned16(dx) && waligned16(mask_bits), "pointers must be 16-byte aligned");
+    VC_CHECK_ARG(wino_images_per_launch(B, H, W, Cin, Cout) >= B && vc_conv3x3_wino4_supported(B, H, W, Cin, Cout, 1),
+                 "unsupported shape, or more images than one launch takes (vc_conv3x3_wino_single_launch_supported)");
+    return wino4_launch((hipStream_t)stream, W4_DGRAD, B, H, W, Cout, Cin, dy, wpt, dx, nullptr, nullptr, const_cast<uint32_t*>(mask_bits), 0);
 }
