@@ -446,12 +446,14 @@ def _cdiv(a, b):
     return (a + b - 1) // b
 
 
-def wino_executed_ratio(images):
+def wino_executed_ratio(images, wino4=True):
     """Executed MFMA FLOPs / algorithmic FLOPs of one cfg4 step's 3x3 convolution calls when the Winograd kernels run (default):
-    F(2x2,3x3) / F(3x3,2x2) multiply 16 times per 2x2 tile and channel pair where the direct form multiplies 36 times; tile blocks
-    that stick out of the image add padding work.  Forward / data gradient (csrc/conv_wino.hip plan_wino2): blocks of 16 tile slots
-    whose halo patch fits 100 pixels; weight gradient (conv_wino_wgrad.hip plan_wino_wgrad): 4x8 / 4x7 / 2x14 tiles.  conv1_1 (3 input
-    channels) stays on its direct HBM-bound kernels."""
+    F(2x2,3x3) / F(3x3,2x2) multiply 16 times per 2x2 tile and channel pair where the direct form multiplies 36 times, F(4x4,3x3) 36
+    times per 4x4 tile where the direct form multiplies 144 times; tile blocks that stick out of the image add padding work.  Forward /
+    data gradient: F(4x4,3x3) on blocks of 16 x 16 pixels (csrc/conv_wino4.hip) where vc_conv3x3_wino4_preferred says so -- coverage
+    >= 0.85 x the F(2x2,3x3) blocks' coverage: the 224-, 112-, 28-, 14-wide layers --, else F(2x2,3x3) on blocks of 16 tile slots whose
+    halo patch fits 100 pixels (csrc/conv_wino.hip plan_wino2: the 56-wide layers); weight gradient (conv_wino_wgrad.hip
+    plan_wino_wgrad): F(3x3,2x2) on 4x8 / 4x7 / 2x14 tiles.  conv1_1 (3 input channels) stays on its direct HBM-bound kernels."""
     from vae_captioning_amd import spec
     slots, maxpix = 16, 100
     H = 224
@@ -470,8 +472,10 @@ def wino_executed_ratio(images):
                     continue
                 best = max(best, tw * th / (_cdiv(tw, tbw) * _cdiv(th, tbh) * float(slots)))
             effw = max(tw * th / (_cdiv(tw, bw) * _cdiv(th, bh) * float(bh * bw)) for bh, bw in ((4, 8), (4, 7), (2, 14)))
+            eff4 = H * H / (_cdiv(H, 16) ** 2 * 256.0)
+            fd = (36.0 / 144.0) / eff4 if (wino4 and eff4 >= 0.85 * best) else (16.0 / 36.0) / best
             alg += 3 * fl
-            ex += 2 * fl * (16.0 / 36.0) / best + fl * (16.0 / 36.0) / effw
+            ex += 2 * fl * fd + fl * (16.0 / 36.0) / effw
         if name in spec.VGG_POOL_AFTER:
             H //= 2
     return ex / alg
@@ -502,8 +506,8 @@ def roofline_from_timer(timer, fine_tune, images=0):
     if not fine_tune:
         kern = "vc::gemm_kernel<128x128,MK,KM> (logits)"
     elif wino:
-        kern = ("vc::conv_wino2_kernel (Winograd F(2x2,3x3) forward / data gradient) / vc::wino_wgrad_kernel (F(3x3,2x2) weight gradient) "
-                "(+ vc::conv1_fwd_kernel / vc::conv1_wgrad_kernel for conv1_1)")
+        kern = ("vc::conv_wino4_kernel (Winograd F(4x4,3x3) forward / data gradient; the 56-wide layers: vc::conv_wino2_kernel, F(2x2,3x3)) / "
+                "vc::wino_wgrad_kernel (F(3x3,2x2) weight gradient) (+ vc::conv1_fwd_kernel / vc::conv1_wgrad_kernel for conv1_1)")
     else:
         kern = "vc::conv_patch_kernel / vc::wgrad_patch_kernel (+ vc::conv1_fwd_kernel / vc::conv1_wgrad_kernel for conv1_1)"
     ex = ach * ratio
@@ -517,8 +521,9 @@ def roofline_from_timer(timer, fine_tune, images=0):
             "family_flops": fl, "family_seconds_union": round(sec, 6), "family_seconds_serial": round(ser, 6),
             "traffic": None, "launches": n, "avg_launch_us": round(1e6 * sec / n, 2), "per_kernel": per,
             "streams": int(os.environ.get("VC_VGG_STREAMS", "3")) if fine_tune else 1,
-            "note": "achieved = EXECUTED MFMA FLOPs of the family's calls in the timed region (Winograd F(2x2,3x3) / F(3x3,2x2), fp32: 16 "
-                    "multiplications per 2x2 tile and channel pair where the direct form has 36, + tile-block padding; = algorithmic FLOPs x "
+            "note": "achieved = EXECUTED MFMA FLOPs of the family's calls in the timed region (Winograd, fp32: F(4x4,3x3) 36 multiplications per "
+                    "4x4 tile and channel pair where the direct form has 144, F(2x2,3x3) / F(3x3,2x2) 16 per 2x2 tile where it has 36, + tile-block "
+                    "padding; = algorithmic FLOPs x "
                     "executed_over_algorithmic) / union of the calls' HIP-event intervals (events recorded on the stream each call is "
                     "launched on); frac = achieved / peak = matrix-pipe utilisation.  effective_tflops / frac_algorithmic price the same "
                     "time against the direct-convolution FLOPs (> peak is possible: fewer multiplications, not a faster pipe)"}

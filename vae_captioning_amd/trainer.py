@@ -64,6 +64,7 @@ class VggEngine(object):
         nstreams = int(os.environ.get("VC_VGG_STREAMS", "3"))
         self.side = torch.cuda.Stream() if nstreams >= 2 else None
         self.side2 = torch.cuda.Stream() if nstreams >= 3 else None
+        self.wino4 = set()
         self.part = torch.zeros(self.lib.vc_sumsq_blocks(), dtype=torch.float32, device=device)
         # sum(w^2) of the regulariser: the Adam update of step t leaves the per-workgroup sums of the NEW parameters, which are step t + 1's
         # w (0.16 ms per step saved: no second pass over 0.54 GB); invalid after any other write to the parameters
@@ -126,6 +127,7 @@ class VggEngine(object):
         launches wait for (returned as {layer: event}; conv1_1 needs none), then the data-gradient copies, which only the
         backward pass waits for (self.packed_bwd)."""
         self.packed_bwd = None
+        self.wino4 = set()   # layers on the F(4x4,3x3) kernels this step
         if not self.use_patch:
             return None
         lib, S = self.lib, self.store
@@ -141,7 +143,12 @@ class VggEngine(object):
                 for name, ci, co in spec.VGG_CONV:
                     if ci % 32 == 0:
                         w = S.param(spec.vgg_var_names(name)[0])
-                        if self.use_wino and bool(lib.vc_conv3x3_wino_supported(1, h, w_, ci, co, dgrad)):
+                        if self.use_wino and bool(lib.vc_conv3x3_wino4_preferred(1, h, w_, ci, co)):
+                            # F(4x4,3x3) where its blocks cover the image as well as F(2x2,3x3)'s (every layer of a block between two pools
+                            # has the same H x W, so a block stays in one family: the ReLU bits pass from layer to layer)
+                            self.wino4.add(name)
+                            lib.vc_conv3x3_wino4_pack_f32(sh, ci, co, P(w), dgrad, P(self._b(("vpt_" if dgrad else "vp_") + name, (36 * ci * co,))))
+                        elif self.use_wino and bool(lib.vc_conv3x3_wino_supported(1, h, w_, ci, co, dgrad)):
                             # G g G^T of every filter, in the Winograd kernel's operand order
                             lib.vc_conv3x3_wino_pack_f32(sh, ci, co, P(w), dgrad, P(self._b(("vpt_" if dgrad else "vp_") + name, (16 * ci * co,))))
                         else:    # direct patch kernels: [tap][C/4][N][4]
@@ -160,8 +167,13 @@ class VggEngine(object):
         return self.use_patch and ci % 32 == 0 and bool(self.lib.vc_conv3x3_patch_supported(nb, H, W, ci, co, dgrad))
 
     def _wino_ok(self, name, nb, H, W, ci, co, dgrad):
-        return (self.use_wino and (("vpt_" if dgrad else "vp_") + name) in self.buf
-                and bool(self.lib.vc_conv3x3_wino_supported(nb, H, W, ci, co, dgrad)))
+        ok = self.lib.vc_conv3x3_wino4_supported if name in self.wino4 else self.lib.vc_conv3x3_wino_supported
+        return self.use_wino and (("vpt_" if dgrad else "vp_") + name) in self.buf and bool(ok(nb, H, W, ci, co, dgrad))
+
+    def _wino(self, name, entry):
+        """The Winograd entry `entry` ("fwd_f32", "dgrad_bits_f32", "mask_words" ...) of the family that holds layer `name` this
+        step: vc_conv3x3_wino4_* (F(4x4,3x3)) or vc_conv3x3_wino_* (F(2x2,3x3)) -- same arguments in both."""
+        return getattr(self.lib, ("vc_conv3x3_wino4_" if name in self.wino4 else "vc_conv3x3_wino_") + entry)
 
     def _wino_wgrad_ok(self, B, H, W, ci, co):
         return self.use_wino and ci % 64 == 0 and co % 64 == 0 and bool(self.lib.vc_conv3x3_wino_wgrad_supported(B, H, W, ci, co))
@@ -245,9 +257,9 @@ class VggEngine(object):
                     if self._wino_ok(name, nb, H, W, cie, co, 0):   # Winograd (calls over 2 GiB are cut into image ranges inside the library)
                         if self.train and not pooled and lib.vc_conv3x3_wino_single_launch_supported(nb, H, W, cie, co):
                             # the next layer is a convolution on this output: leave (y > 0) as bits in the lane order of ITS data gradient
-                            mk = self._b("mk_%s_%d" % (name, ch), (lib.vc_conv3x3_wino_mask_words(nb, H, W, co),), dtype=torch.int32)
+                            mk = self._b("mk_%s_%d" % (name, ch), (self._wino(name, "mask_words")(nb, H, W, co),), dtype=torch.int32)
                             self.mask_geom[name] = (nb, len(halves))   # the bits are per tile of THIS launch geometry
-                            self._timed("conv_fwd", fl, lambda: lib.vc_conv3x3_wino_fwd_mask_f32(
+                            self._timed("conv_fwd", fl, lambda: self._wino(name, "fwd_mask_f32")(
                                 sh, nb, H, W, cie, co, P(x[b0:]), P(self.buf["vp_" + name]), P(S.param(bn)), P(y[b0:]), 1, P(mk)))
                         elif pooled and self.train:
                             # the 2x2 max-pool is register math in the epilogue; it also leaves MaxPoolGrad's routing codes (4 bits per pooled
@@ -255,10 +267,10 @@ class VggEngine(object):
                             pb = self._b("pb_" + name, (lib.vc_conv3x3_wino_pool_words(B, H, W, co),), dtype=torch.int32)
                             pool_bits = pb
                             w0 = b0 * (H // 2) * (W // 2) * (co // 8)
-                            self._timed("conv_fwd", fl, lambda: lib.vc_conv3x3_wino_fwd_pool_f32(
+                            self._timed("conv_fwd", fl, lambda: self._wino(name, "fwd_pool_f32")(
                                 sh, nb, H, W, cie, co, P(x[b0:]), P(self.buf["vp_" + name]), P(S.param(bn)), P(y[b0:]), P(yp[b0:]), P(pb[w0:])))
                         else:
-                            self._timed("conv_fwd", fl, lambda: lib.vc_conv3x3_wino_fwd_f32(
+                            self._timed("conv_fwd", fl, lambda: self._wino(name, "fwd_f32")(
                                 sh, nb, H, W, cie, co, P(x[b0:]), P(self.buf["vp_" + name]), P(S.param(bn)), P(y[b0:]), P(yp[b0:]) if pooled else None, 1))
                         continue
                     wp = self.buf.get("wp_" + name)
@@ -409,12 +421,13 @@ class VggEngine(object):
                         sh = _stream()
                         if (self._wino_ok(name, nb, H, W, ci, co, 1) and not prev_is_pool
                               and self.mask_geom.get(self.acts[li - 1][0]) == (nb, len(halves))
+                              and (self.acts[li - 1][0] in self.wino4) == (name in self.wino4)   # (bits are in their family's lane order)
                               and lib.vc_conv3x3_wino_single_launch_supported(nb, H, W, ci, co)):
                             # ReluGrad from the bits the previous layer's forward left (one 8-byte load per lane instead of sixteen 16-byte ones)
-                            self._timed("conv_dgrad", fl * nb / B, lambda: lib.vc_conv3x3_wino_dgrad_bits_f32(
+                            self._timed("conv_dgrad", fl * nb / B, lambda: self._wino(name, "dgrad_bits_f32")(
                                 sh, nb, H, W, ci, co, P(d[b0:]), P(self.buf["vpt_" + name]), P(self.buf["mk_%s_%d" % (self.acts[li - 1][0], ch)]), P(dx[b0:])))
                         elif self._wino_ok(name, nb, H, W, ci, co, 1):
-                            self._timed("conv_dgrad", fl * nb / B, lambda: lib.vc_conv3x3_wino_dgrad_f32(
+                            self._timed("conv_dgrad", fl * nb / B, lambda: self._wino(name, "dgrad_f32")(
                                 sh, nb, H, W, ci, co, P(d[b0:]), P(self.buf["vpt_" + name]), None if prev_is_pool else P(x[b0:]), P(dx[b0:])))
                         elif self._patch_ok(nb, H, W, ci, co, 1) and ("wpt_" + name) in self.buf:
                             wpt = self.buf["wpt_" + name]
