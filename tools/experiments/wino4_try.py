@@ -1,29 +1,21 @@
-"""EXPERIMENT: the Winograd F(4x4,3x3) forward / data gradient of csrc/experiments/conv_wino4.hip against the
-library's F(2x2,3x3) kernel -- values and time on the VGG16 layer shapes.  Build: make -C vae_captioning_amd/csrc wino4 (+ W4FLAGS=-DW4_ABL=n
-for the ablations); run: VC_LIB=vae_captioning_amd/lib/libvaecap_wino4.so python tools/experiments/wino4_try.py [images] [dgrad]
+"""the Winograd F(4x4,3x3) forward / data gradient of csrc/conv_wino4.hip against the
+library's F(2x2,3x3) kernel -- values and time on the VGG16 layer shapes.  Run: python tools/experiments/wino4_try.py [images] [dgrad|bits]; ablations: make -C vae_captioning_amd/csrc wino4abl W4FLAGS=-DW4_ABL=n, then
+VC_LIB=vae_captioning_amd/lib/libvaecap_wino4abl.so
 (W4_ONLY=conv2_2,conv4_2 restricts the layers)."""
 import sys, torch
 sys.path.insert(0, ".")
 from vae_captioning_amd import abi
 from vae_captioning_amd.abi import ptr as P
 import os
-import ctypes
-lib = abi.load(os.environ.get("VC_LIB", "vae_captioning_amd/lib/libvaecap_wino4.so"))
-# the experiment's entries are not in include/vaecap.h: bound by hand
-_vp, _i = ctypes.c_void_p, ctypes.c_int
-for _n, _a in (("vc_conv3x3_wino4_pack_f32", [_vp, _i, _i, _vp, _i, _vp]), ("vc_conv3x3_wino4_fwd_f32", [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i]),
-               ("vc_conv3x3_wino4_dgrad_f32", [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp])):
-    _f = getattr(lib._cdll, _n)
-    _f.argtypes, _f.restype = _a, _i
+lib = abi.load(os.environ.get("VC_LIB"))
 
 
 def w4(name, *a):
-    rc = getattr(lib._cdll, name)(*a)
-    if rc:
-        raise RuntimeError("%s: %s" % (name, lib._cdll.vc_last_error().decode()))
+    return getattr(lib, name)(*a)
 st = lambda: torch.cuda.current_stream().cuda_stream
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-dg = len(sys.argv) > 2 and sys.argv[2] == "dgrad"
+dg = len(sys.argv) > 2 and sys.argv[2] in ("dgrad", "bits")
+bits = len(sys.argv) > 2 and sys.argv[2] == "bits"   # data gradient with the ReLU mask as bits (what the training step runs)
 if os.environ.get("VC_LIB"):
     pass
 shapes = [("conv1_2", 224, 64, 64), ("conv2_1", 112, 64, 128), ("conv2_2", 112, 128, 128), ("conv3_1", 56, 128, 256), ("conv3_2", 56, 256, 256),
@@ -44,12 +36,18 @@ for name, H, ci, co in shapes:
     wp2 = torch.empty(16 * ci * co, device="cuda"); wp4 = torch.empty(36 * ci * co, device="cuda")
     lib.vc_conv3x3_wino_pack_f32(st(), ci, co, P(w), int(dg), P(wp2))
     w4("vc_conv3x3_wino4_pack_f32", st(), ci, co, P(w), int(dg), P(wp4))
-    if dg:
+    if bits:
+        m2 = torch.zeros(lib.vc_conv3x3_wino_mask_words(B, H, H, ci), dtype=torch.int32, device="cuda")
+        m4 = torch.zeros(lib.vc_conv3x3_wino4_mask_words(B, H, H, ci), dtype=torch.int32, device="cuda")
+        m2.random_(0, 2 ** 31 - 1); m4.random_(0, 2 ** 31 - 1)
+        f2 = lambda: lib.vc_conv3x3_wino_dgrad_bits_f32(st(), B, H, H, ci, co, P(x), P(wp2), P(m2), P(y2))
+        f4 = lambda: lib.vc_conv3x3_wino4_dgrad_bits_f32(st(), B, H, H, ci, co, P(x), P(wp4), P(m4), P(y4))
+    elif dg:
         f2 = lambda: lib.vc_conv3x3_wino_dgrad_f32(st(), B, H, H, ci, co, P(x), P(wp2), P(src), P(y2))
         f4 = lambda: w4("vc_conv3x3_wino4_dgrad_f32", st(), B, H, H, ci, co, P(x), P(wp4), P(src), P(y4))
     else:
         f2 = lambda: lib.vc_conv3x3_wino_fwd_f32(st(), B, H, H, ci, co, P(x), P(wp2), P(bias), P(y2), None, 1)
-        f4 = lambda: w4("vc_conv3x3_wino4_fwd_f32", st(), B, H, H, ci, co, P(x), P(wp4), P(bias), P(y4), 1)
+        f4 = lambda: w4("vc_conv3x3_wino4_fwd_f32", st(), B, H, H, ci, co, P(x), P(wp4), P(bias), P(y4), None, 1)
     f2(); f4(); torch.cuda.synchronize()
     err = float((y2 - y4).abs().max()); scale = float(y2.abs().max())
     ts = []

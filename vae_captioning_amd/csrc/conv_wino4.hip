@@ -3,8 +3,8 @@
 //
 //   Y = A^T [ sum_c (G g_c G^T) (.) (B^T d_c B) ] A     per 4 x 4 output tile: d = its 6 x 6 input patch, g = the 3 x 3 filter
 //
-// Used where its blocks of 4 x 4 tiles cover the image about as well as the F(2x2,3x3) kernel's (vc_conv3x3_wino4_preferred: the 224-,
-// 112-, 28- and 14-wide layers of VGG16: 7-27 % faster there, profiles/r03_wino4_experiment.txt; the 56-wide layers stay on conv_wino.hip).
+// Used where vc_conv3x3_wino4_preferred says so (block coverage: the 224-, 112-, 28- and 14-wide layers of VGG16; the 56-wide block
+// stays on conv_wino.hip): kernel by kernel 7-30 % faster there, 0.9 ms of the 31.8 ms cfg4 step (profiles/r03_wino4_layers.txt).
 // Why a second Winograd kernel (tools/probes/mfma16_f43.hip, mfma_specialised.hip): on one SIMD a VALU
 // instruction and the matrix pipe do NOT overlap -- beside back-to-back v_mfma_f32_16x16x4_f32 a partner wave gets ~0.5 VALU issues
 // per MFMA, inside one stream every VALU operation costs 4-8 cycles of matrix time -- so the F(2x2,3x3) kernel's 71 % MFMA-busy is its
@@ -497,8 +497,10 @@ extern "C" int vc_conv3x3_wino4_supported(int B, int H, int W, int Cin, int Cout
 }
 
 // 1 when this kernel is the faster Winograd form for the layer: its 16 x 16-pixel blocks must cover the image nearly as well as the
-// F(2x2,3x3) kernel's blocks of sixteen 2 x 2 tiles do (measured, profiles/r03_wino4_experiment.txt: 224 / 112 wide x1.1-1.27, 28 wide
-// x1.07-1.10 at 77 % against 88 % coverage, 14 wide x1.22 at 77 % both; 56 wide x0.97 at 77 % against 100 %).
+// F(2x2,3x3) kernel's blocks of sixteen 2 x 2 tiles do (>= 0.85 x).  Decided on the training step itself, block of layers by block
+// (cfg4 at 64 images, three streams, ms per step; profiles/r03_wino4_layers.txt): none 31.76; conv1_2 31.43; + conv2_x 31.08; + conv4_x
+// 31.04; + conv5_x 30.89; the 56-wide conv3_x on top 31.03 (77 % coverage against 100 %) -- although, kernel by kernel at 32 images, conv3_x
+// gains 2-11 % and conv5_x loses 10 %: beside the other streams' launches the ranking is not the stand-alone one.
 extern "C" int vc_conv3x3_wino4_preferred(int B, int H, int W, int Cin, int Cout) {
     if (!vc_conv3x3_wino4_supported(B, H, W, Cin, Cout, 0) || !vc_conv3x3_wino4_supported(B, H, W, Cin, Cout, 1) || (H & 1) || (W & 1)) return 0;
     const double e4 = (double)H * W / ((double)vc::cdiv(H, 16) * vc::cdiv(W, 16) * 256.0);

@@ -120,7 +120,7 @@ class VggEngine(object):
         else:
             fn()
 
-    def _pack_weights(self, backward, H=224, W=224):
+    def _pack_weights(self, backward, H=224, W=224, nb=1):
         """[tap][C/4][N][4] copies of the 3x3 kernels for the patch-staged convolutions (forward layout, and the flipped
         + transposed one of the data gradient when a backward pass follows).  Runs on the weight-gradient stream, which is
         idle during the forward pass: the forward copies first, in layer order, each followed by the event its layer's
@@ -143,9 +143,9 @@ class VggEngine(object):
                 for name, ci, co in spec.VGG_CONV:
                     if ci % 32 == 0:
                         w = S.param(spec.vgg_var_names(name)[0])
-                        if self.use_wino and bool(lib.vc_conv3x3_wino4_preferred(1, h, w_, ci, co)):
-                            # F(4x4,3x3) where its blocks cover the image as well as F(2x2,3x3)'s (every layer of a block between two pools
-                            # has the same H x W, so a block stays in one family: the ReLU bits pass from layer to layer)
+                        if self.use_wino and bool(lib.vc_conv3x3_wino4_preferred(nb, h, w_, ci, co)):
+                            # F(4x4,3x3) where it is the faster form for launches over nb images (every layer of a block between two pools has
+                            # the same H x W and at least 64 channels, so a block stays in one family: the ReLU bits pass from layer to layer)
                             self.wino4.add(name)
                             lib.vc_conv3x3_wino4_pack_f32(sh, ci, co, P(w), dgrad, P(self._b(("vpt_" if dgrad else "vp_") + name, (36 * ci * co,))))
                         elif self.use_wino and bool(lib.vc_conv3x3_wino_supported(1, h, w_, ci, co, dgrad)):
@@ -224,7 +224,7 @@ class VggEngine(object):
         w4 = self._b("w1_4", (3, 3, 4, 64))
         if not c1:
             lib.vc_pad_dim_f32(st, P(S.param("cnn/conv1_1/weights")), 9, 3, 4, 64, P(w4))
-        packed = self._pack_weights(self.train, H, W)
+        packed = self._pack_weights(self.train, H, W, B // 2 if (self.side is not None and B % 2 == 0 and B >= 2) else B)
         self.acts = []  # (layer name, input tensor, H, W, Cin_eff, Cout, weights used)
         self.mask_geom = {}  # layer name -> (images per launch, launches): forward launches that left their ReLU mask as bits
         # The conv / pool chain of one image is independent of every other image: with two streams the
