@@ -1,5 +1,6 @@
 """Workload for SQ-counter probes of the Winograd forward / data-gradient kernel only (tools/sq_probe.sh with PROBE=tools/pmc_probe_wino.py):
-conv3_2-, conv1_2-, conv4_2- and conv5_2-shaped forward + the conv3_2 data gradient at 64 images, three launches each."""
+conv3_2-, conv1_2-, conv4_2- and conv5_2-shaped forward + the conv3_2 data gradient at 64 images, three launches each.
+FAMILY=4 in the environment: the F(4x4,3x3) entries (vc_conv3x3_wino4_*) instead of the F(2x2,3x3) ones."""
 import os
 import sys
 
@@ -10,6 +11,9 @@ from vae_captioning_amd import abi  # noqa: E402
 from vae_captioning_amd.abi import ptr as P  # noqa: E402
 
 lib = abi.load()
+F4 = os.environ.get("FAMILY", "2") == "4"
+PRE = "vc_conv3x3_wino4_" if F4 else "vc_conv3x3_wino_"
+fn = lambda e: getattr(lib, PRE + e)
 st = lambda: torch.cuda.current_stream().cuda_stream
 B = 64
 cases = []
@@ -18,13 +22,13 @@ for (H, ci, co) in ((56, 256, 256), (224, 64, 64), (28, 512, 512), (14, 512, 512
     w = torch.rand(3, 3, ci, co, device="cuda") * 2 - 1
     bias = torch.rand(co, device="cuda")
     y = torch.empty(B, H, H, co, device="cuda")
-    vp, vpt = torch.empty(16 * ci * co, device="cuda"), torch.empty(16 * ci * co, device="cuda")
-    lib.vc_conv3x3_wino_pack_f32(st(), ci, co, P(w), 0, P(vp))
-    lib.vc_conv3x3_wino_pack_f32(st(), ci, co, P(w), 1, P(vpt))
+    vp, vpt = torch.empty((36 if F4 else 16) * ci * co, device="cuda"), torch.empty((36 if F4 else 16) * ci * co, device="cuda")
+    fn("pack_f32")(st(), ci, co, P(w), 0, P(vp))
+    fn("pack_f32")(st(), ci, co, P(w), 1, P(vpt))
     cases.append((H, ci, co, x, bias, y, vp, vpt))
 for _ in range(3):
     for i, (H, ci, co, x, bias, y, vp, vpt) in enumerate(cases):
-        lib.vc_conv3x3_wino_fwd_f32(st(), B, H, H, ci, co, P(x), P(vp), P(bias), P(y), None, 1)
+        fn("fwd_f32")(st(), B, H, H, ci, co, P(x), P(vp), P(bias), P(y), None, 1)
         if i == 0:
-            lib.vc_conv3x3_wino_dgrad_f32(st(), B, H, H, ci, co, P(y), P(vpt), P(x), P(x))
+            fn("dgrad_f32")(st(), B, H, H, ci, co, P(y), P(vpt), P(x), P(x))
 torch.cuda.synchronize()

@@ -25,6 +25,9 @@ def family(name):
         return "conv_patch_kernel<%s>" % {"0": "fwd", "1": "dgrad"}.get(k.group(1) if k else "?", "?")
     if "wgrad_patch_kernel" in name:
         return "wgrad_patch_kernel<4x8 | 4x7 | 2x14>"
+    if "conv_wino4_kernel" in name:  # conv_wino4_kernel<KIND, POOL> (round 3: Winograd F(4x4,3x3))
+        k = re.search(r"conv_wino4_kernel<\s*(\d)", name)
+        return "conv_wino4_kernel<%s>" % {"0": "fwd", "1": "dgrad"}.get(k.group(1) if k else "?", "?")
     if "conv_wino2_kernel" in name:  # conv_wino2_kernel<KIND, POOL> (round 3: 16x16x4 tiles, two workgroups per CU)
         k = re.search(r"conv_wino2_kernel<\s*(\d)", name)
         return "conv_wino2_kernel<%s>" % {"0": "fwd", "1": "dgrad"}.get(k.group(1) if k else "?", "?")
@@ -37,7 +40,7 @@ def family(name):
 
 
 CONV_FAMILY = ("conv_kernel", "conv1_", "conv_patch_kernel", "wgrad_patch", "conv_tail_reduce", "patch_tail_reduce", "wgrad_reduce", "wgrad_patch_reduce",
-               "conv_wino_kernel", "conv_wino2_kernel", "wino_wgrad")
+               "conv_wino_kernel", "conv_wino2_kernel", "conv_wino4_kernel", "wino_wgrad")
 
 
 def main(root):
