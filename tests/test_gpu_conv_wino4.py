@@ -178,3 +178,48 @@ def test_wino4_pool_routing_codes_equal_maxpool_bwd_on_the_activation(lib, case)
     hy = host(y1)
     win = hy.reshape(B, H // 2, 2, W // 2, 2, Co)
     assert (win.max(axis=(2, 4)) == 0).mean() > 0.05 and ((win == win.max(axis=(2, 4), keepdims=True)).sum(axis=(2, 4)) > 1).mean() > 0.1   # ties do occur
+
+
+def test_wino4_calls_over_the_launch_limit_are_cut_into_image_ranges(tmp_path):
+    """Like conv_wino.hip, the kernel addresses a launch's tensors with 32-bit offsets; a call on more images runs as launches over image
+    ranges (cfg4's 512-image step on one GPU does).  VC_WINO_MAX_BYTES forces that on a small shape (a fresh process: the limit is read
+    once): forward, pooled forward with routing codes and data gradient must equal the single-launch results bit for bit."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "run.py"
+    script.write_text(
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from vae_captioning_amd import abi\n"
+        "from vae_captioning_amd.abi import ptr as P\n"
+        "lib = abi.load(); st = torch.cuda.current_stream().cuda_stream\n"
+        "B, H, W, Ci, Co = 5, 12, 20, 64, 64\n"
+        "g = torch.Generator(device='cuda').manual_seed(1)\n"
+        "x = torch.rand(B, H, W, Ci, device='cuda', generator=g); w = torch.rand(3, 3, Ci, Co, device='cuda', generator=g) - 0.5\n"
+        "dy = torch.rand(B, H, W, Co, device='cuda', generator=g) - 0.5; b = torch.rand(Co, device='cuda', generator=g) - 0.5\n"
+        "vp = torch.empty(36 * Ci * Co, device='cuda'); vpt = torch.empty(36 * Ci * Co, device='cuda')\n"
+        "lib.vc_conv3x3_wino4_pack_f32(st, Ci, Co, P(w), 0, P(vp)); lib.vc_conv3x3_wino4_pack_f32(st, Ci, Co, P(w), 1, P(vpt))\n"
+        "y = torch.zeros(B, H, W, Co, device='cuda'); yp = torch.zeros(B, H // 2, W // 2, Co, device='cuda'); dx = torch.zeros(B, H, W, Ci, device='cuda')\n"
+        "y2 = torch.zeros_like(y); yp2 = torch.zeros_like(yp); bits = torch.zeros(lib.vc_conv3x3_wino_pool_words(B, H, W, Co), dtype=torch.int32, device='cuda')\n"
+        "lib.vc_conv3x3_wino4_fwd_f32(st, B, H, W, Ci, Co, P(x), P(vp), P(b), P(y), P(yp), 1)\n"
+        "lib.vc_conv3x3_wino4_fwd_pool_f32(st, B, H, W, Ci, Co, P(x), P(vp), P(b), P(y2), P(yp2), P(bits))\n"
+        "lib.vc_conv3x3_wino4_dgrad_f32(st, B, H, W, Ci, Co, P(dy), P(vpt), P(x), P(dx))\n"
+        "torch.cuda.synchronize()\n"
+        "print(int(lib.vc_conv3x3_wino_single_launch_supported(B, H, W, Ci, Co)))\n"
+        "np.savez(sys.argv[1], y=y.cpu().numpy(), yp=yp.cpu().numpy(), y2=y2.cpu().numpy(), yp2=yp2.cpu().numpy(), bits=bits.cpu().numpy(), dx=dx.cpu().numpy())\n" % root)
+    out = {}
+    for tag, cap in (("one", None), ("cut", str(2 * 12 * 20 * 64 * 4))):   # cut: two images per launch -> ranges of 2, 2, 1
+        env = dict(os.environ)
+        env.pop("VC_WINO_MAX_BYTES", None)
+        if cap:
+            env["VC_WINO_MAX_BYTES"] = cap
+        f = str(tmp_path / (tag + ".npz"))
+        r = subprocess.run([sys.executable, str(script), f], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert r.stdout.strip().splitlines()[-1] == ("1" if cap is None else "0")
+        out[tag] = np.load(f)
+    for k in ("y", "yp", "y2", "yp2", "bits", "dx"):
+        assert np.array_equal(out["one"][k], out["cut"][k]), k
+    assert np.array_equal(out["one"]["y"], out["one"]["y2"]) and np.abs(out["one"]["dx"]).max() > 0 and out["one"]["bits"].any()
