@@ -341,12 +341,13 @@ def test_set_batch_under_a_captured_graph_feeds_the_replayed_step(lib):
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(prior="GMM"), dict(prior="AG", use_c_v=True), dict(no_encoder=True), dict(fine_tune=True),
-                                dict(fine_tune=True, collectives=True), dict(collectives=True), dict(graph=True)],
-                         ids=["normal", "gmm", "ag_cv", "no_encoder", "fine_tune", "fine_tune_rccl_buckets", "rccl", "hipgraph"])
+                                dict(fine_tune=True, collectives=True), dict(collectives=True), dict(graph=True), dict(fine_tune=True, graph=True)],
+                         ids=["normal", "gmm", "ag_cv", "no_encoder", "fine_tune", "fine_tune_rccl_buckets", "rccl", "hipgraph", "fine_tune_hipgraph"])
 def test_weight_gradient_stream_equals_program_order_bit_for_bit(lib, kw):
     """Trainer's second stream (weight gradients of the caption side, clip + optimiser, fc1 / fc2's optimiser; engine.off_chain)
     against the same step in program order on one stream: the same kernels on the same data, so losses, gradients and updated
-    parameters of three steps are identical -- a missing stream dependency would show as a difference (or as garbage)."""
+    parameters of three steps are identical -- a missing stream dependency would show as a difference (or as garbage).
+    (fine_tune_hipgraph: a captured fine-tune step; Trainer.capture runs the VGG16 on one stream, see VggEngine.one_stream.)"""
     from vae_captioning_amd.trainer import Trainer
     kw = dict(kw)
     coll, graph = kw.pop("collectives", False), kw.pop("graph", False)

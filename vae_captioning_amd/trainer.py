@@ -62,8 +62,12 @@ class VggEngine(object):
         # Streams: 3 = two half-batch convolution chains + the weight gradients on a third stream (the tail of one launch is filled by
         # another stream's launch; the data-parallel gradient buckets are issued from the weight-gradient stream), 1 = serial
         nstreams = int(os.environ.get("VC_VGG_STREAMS", "3"))
-        self.side = torch.cuda.Stream() if nstreams >= 2 else None
-        self.side2 = torch.cuda.Stream() if nstreams >= 3 else None
+        self._side = torch.cuda.Stream() if nstreams >= 2 else None
+        self._side2 = torch.cuda.Stream() if nstreams >= 3 else None
+        # Trainer.capture() sets this: a hipGraph capture of the backward pass's stream pattern (the weight-gradient stream waiting
+        # for the chain streams layer after layer) crashes in hipStreamEndCapture (ROCm 7.2); forward-only captures are fine.  A
+        # captured step therefore runs the VGG16 on the caller's stream alone.
+        self.one_stream = False
         self.wino4 = set()
         self.part = torch.zeros(self.lib.vc_sumsq_blocks(), dtype=torch.float32, device=device)
         # sum(w^2) of the regulariser: the Adam update of step t leaves the per-workgroup sums of the NEW parameters, which are step t + 1's
@@ -74,6 +78,14 @@ class VggEngine(object):
         self.w2_blocks = (self.lib.vc_adam_blocks(self.o_fc), self.lib.vc_adam_blocks(self.store.n - self.o_fc))
         self.w2_part = torch.zeros(sum(self.w2_blocks), dtype=torch.float32, device=device)
         self.w2_valid = False
+
+    @property
+    def side(self):
+        return None if self.one_stream else self._side
+
+    @property
+    def side2(self):
+        return None if self.one_stream else self._side2
 
     def _b(self, name, shape, dtype=torch.float32):
         t = self.buf.get(name)
@@ -136,6 +148,7 @@ class VggEngine(object):
         if st != main:
             st.wait_stream(main)
         evs = {}
+        self._pack_events = evs   # (kept alive for the step: a hipGraph capture holds their records)
         with torch.cuda.stream(st):
             sh = _stream()
             for dgrad in ((0, 1) if backward else (0,)):
@@ -682,6 +695,9 @@ class Trainer(object):
         self.cap.fix_inputs()   # the graph bakes input addresses: later set_batch calls copy INTO these persistent tensors
         if self.fine:
             self.images = self.cap.buf["images"]
+        if self.vgg is not None:
+            self.vgg.one_stream = True   # (see VggEngine.__init__; the buffers of the one-chain geometry are made by the un-captured steps below)
+            warmup = max(warmup, 1)
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
