@@ -261,44 +261,24 @@ int vc_maxpool2x2_bwd_f32(void* stream, int B, int H, int W, int C, const float*
 int vc_vgg_preprocess_f32(void* stream, const float* images, int B, int H, int W, float* out_nhwc4);
 int vc_pad_dim_f32(void* stream, const float* src, long outer, int c_src, int c_dst, int inner, float* dst);
 
-/* Patch-staged forward / data gradient (csrc/conv_patch.hip): the workgroup stages the halo patch of its 128 output
- * pixels in LDS once per 32-channel chunk and walks the nine taps as constant LDS offsets; the weights come pre-packed
- * [tap][C/4][N][4] (pack once per optimiser step: transpose 0 for forward, 1 = flipped + transposed for the data
- * gradient).  Same results as conv3x3_fwd / conv3x3_dgrad up to fp32 summation order.  Shapes: gathered channels % 32 == 0,
- * output channels % 64 == 0, (W % 8 == 0 and H % 4 == 0) or (H*W >= 128 and W <= ~30); ask vc_conv3x3_patch_supported. */
-int vc_conv3x3_patch_supported(int B, int H, int W, int Cin, int Cout, int dgrad);
-size_t vc_conv3x3_packed_workspace_bytes(int B, int H, int W, int Cin, int Cout, int dgrad);
-int vc_conv3x3_pack_f32(void* stream, int Cin, int Cout, const float* w, int transpose, float* wp);
-int vc_conv3x3_fwd_packed_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const float* wp,
-                              const float* bias, float* y, int relu, float* ws, size_t ws_bytes);
-/* forward with the 2x2 / stride 2 max-pool fused into the epilogue: writes y AND ypool = max_pool2x2(y) [B, H/2, W/2, Cout] (the
- * 4 x 8 sub-tile tiling only: W % 8 == 0, H % 4 == 0; a pooling window never straddles a tile) */
-int vc_conv3x3_fwd_pool_packed_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const float* wp,
-                                   const float* bias, float* y, float* ypool, int relu, float* ws, size_t ws_bytes);
-int vc_conv3x3_dgrad_packed_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* dy, const float* wpt,
-                                const float* relu_src, float* dx, float* ws, size_t ws_bytes);
-/* The same data gradient for a convolution that sits BEHIND a 2x2 max-pool, with MaxPoolGrad + the ReluGrad of the pool's
- * producer fused into the epilogue: the gradient w.r.t. the pooled tensor [B,H,W,Cin] is never written; each value goes to the
- * first maximum (row-major scan) of its 2x2 window of y_prepool [B,2H,2W,Cin] unless that maximum is <= 0, the other three
- * positions get zeros: dx_prepool [B,2H,2W,Cin] == vc_maxpool2x2_bwd_f32(y_prepool, vc_conv3x3_dgrad_packed_f32(...), relu_grad = 1)
- * bit for bit (tests/test_gpu_conv_patch.py). */
-int vc_conv3x3_dgrad_unpool_packed_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* dy, const float* wpt,
-                                       const float* y_prepool, float* dx_prepool, float* ws, size_t ws_bytes);
-/* Patch-staged weight gradient: a workgroup owns 64 input channels x all nine taps x 64 output channels and stages the
- * halo patch of every 4 x 8 pixel sub-tile once (the nine taps share it).  Same contract as conv3x3_wgrad (split-K into the
- * workspace, deterministic reduce, db != NULL also returns the bias gradient).  Shapes: Cin % 64 == 0, Cout % 64 == 0,
- * W % 8 == 0, H % 4 == 0; ask vc_conv3x3_wgrad_patch_supported. */
-int vc_conv3x3_wgrad_patch_supported(int B, int H, int W, int Cin, int Cout);
-size_t vc_conv3x3_wgrad_patch_workspace_bytes(int B, int H, int W, int Cin, int Cout);
-int vc_conv3x3_wgrad_patch_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const float* dy, float* dw,
-                               float* db, int accumulate, float* ws, size_t ws_bytes);
+/* THE C4 ACTIVATION LAYOUT.  Every Winograd entry below (vc_conv3x3_wino_*, vc_conv3x3_wino4_*, vc_conv3x3_wino_wgrad_*) and conv1_1's
+ * output / output gradient take their activation tensors channel-blocked: [B][C/4][H][W][4] -- per image C/4 planes, a plane = H x W
+ * pixels, a pixel = 16 bytes = four consecutive channels (element (b, y, x, c) at float index (((b * C/4 + c/4) * H + y) * W + x) * 4 + c%4).
+ * Why: the kernels gather 16-byte pieces (a pixel's four channels of one Winograd phase) for the pixels of a halo patch; in NHWC the
+ * pixels of a patch row are 4 C bytes apart, one wave load touches 64 cache lines and the L1's tag rate bounds the kernel (measured:
+ * DESIGN.md section 4g); in C4 a patch row is 288 consecutive bytes.  Images stay contiguous (image ranges, data-parallel shards and the
+ * > 2 GiB cuts are slices of the leading dimension as before); C = 4 (conv1_1's zero-padded RGB input) is the same memory in both
+ * layouts.  The reference's NHWC order (utils/image_embeddings.py:222: pool5 flattened as (h, w, c)) is restored at the fc1 boundary.
+ * vc_maxpool2x2_fwd_f32 / vc_maxpool2x2_bwd_f32 work on C4 tensors when called with (B * C/4, H, W, 4). */
+int vc_nhwc_to_c4_f32(void* stream, int B, int H, int W, int C, const float* nhwc, float* c4);
+int vc_c4_to_nhwc_f32(void* stream, int B, int H, int W, int C, const float* c4, float* nhwc);
 
 /* Winograd F(2x2, 3x3) forward / data gradient (csrc/conv_wino.hip): the same convolution in fp32 with 2.25x fewer multiplications.
  * Input transform, sixteen position products on MFMA (16x16x4 tiles) and output transform in one kernel; a wave owns up to 16 tiles
  * (2x2 output pixels each) x 32 output columns x all sixteen positions, two workgroups share a CU.  The weights are transformed and packed once per optimiser step
  * (wp: 16 * Cin * Cout floats; transpose 0 = forward, 1 = flipped taps + transposed channels for the data gradient).  Results agree
  * with conv3x3_fwd / conv3x3_dgrad to fp32 rounding of a different summation (tests/test_gpu_conv_wino.py: same fp64 oracle, same
- * tolerance class).  ypool != NULL also writes max_pool2x2(y) (a pooling window is one Winograd tile).  Shapes: H, W even, gathered
+ * tolerance class).  x, y, ypool, dy, dx, relu_src: C4 layout.  ypool != NULL also writes max_pool2x2(y) (a pooling window is one Winograd tile).  Shapes: H, W even, gathered
  * channels % 16 == 0, output channels % 32 == 0; ask vc_conv3x3_wino_supported. */
 int vc_conv3x3_wino_supported(int B, int H, int W, int Cin, int Cout, int dgrad);
 /* The kernels address a launch's tensors with 32-bit offsets: calls on more than 2 GiB per tensor are cut into launches over image
@@ -311,17 +291,17 @@ int vc_conv3x3_wino_dgrad_f32(void* stream, int B, int H, int W, int Cin, int Co
                               const float* relu_src, float* dx);
 
 /* MaxPoolGrad routing codes: a pooled forward (bias + ReLU applied) can also leave, per pooled element, four bits = the position of the
- * first maximum of its 2x2 window (row-major) | 4 if that maximum is > 0 -- vc_conv3x3_wino_pool_words(B, H, W, Cout) 32-bit words, a word =
- * 8 consecutive channels of a pooled pixel, layout [B,H/2,W/2,Cout/8] --, and vc_maxpool2x2_bwd_bits_f32 routes the pooled gradient with
- * them: bit-identical to vc_maxpool2x2_bwd_f32(x = y, dy, dx, relu_grad = 1) without re-reading the pre-pool activation (H, W = the
- * PRE-pool size in both calls). */
+ * first maximum of its 2x2 window (row-major) | 4 if that maximum is > 0 -- vc_conv3x3_wino_pool_words(B, H, W, Cout) 32-bit words; a
+ * 16-bit half-word = the four channels of one pooled pixel of one channel quad, layout [B][Cout/4][H/2][W/2] half-words --, and
+ * vc_maxpool2x2_bwd_bits_f32 (dy, dx in the C4 layout) routes the pooled gradient with them: bit-identical to vc_maxpool2x2_bwd_f32(x = y,
+ * dy, dx, relu_grad = 1) on the same planes without re-reading the pre-pool activation (H, W = the PRE-pool size in both calls). */
 size_t vc_conv3x3_wino_pool_words(int B, int H, int W, int C);
 int vc_conv3x3_wino_fwd_pool_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const float* wp,
                                  const float* bias, float* y, float* ypool, uint32_t* pool_bits);
 int vc_maxpool2x2_bwd_bits_f32(void* stream, int B, int H, int W, int C, const uint32_t* pool_bits, const float* dy, float* dx);
 
 /* ReLU mask as bits: the forward of a layer can leave (y > 0) of every lane's 2x2 pixels x 8 columns as 32 bits (vc_conv3x3_wino_mask_words
- * (B, H, W, Cout) 32-bit words), and the data gradient of the NEXT 3x3 layer -- whose output has the same [B,H,W,Cout] shape, hence the
+ * (B, H, W, Cout) 32-bit words), and the data gradient of the NEXT 3x3 layer -- whose output has the same shape, hence the
  * same tiles and lanes -- reads those bits (one 4-byte load per lane) instead of relu_src (eight 16-byte loads + packing per lane:
  * 6-17 % of a data-gradient call).  Results are bit-identical to vc_conv3x3_wino_dgrad_f32 with relu_src = that y. */
 size_t vc_conv3x3_wino_mask_words(int B, int H, int W, int C);
@@ -355,17 +335,18 @@ int vc_conv3x3_wino4_dgrad_bits_f32(void* stream, int B, int H, int W, int Cin, 
 /* Winograd F(3x3, 2x2) weight gradient (csrc/conv_wino_wgrad.hip): both operands transformed in registers, the contraction runs over the
  * 2x2-pixel tiles; raw position sums per K split in the workspace, a reduce kernel sums the splits in fixed order and applies the
  * output transform.  Same contract as conv3x3_wgrad (db != NULL also returns the bias gradient, accumulate adds to dw / db); the
- * workspace is REQUIRED.  Shapes: H, W even, H >= 4, Cin % 64 == 0, Cout % 64 == 0; ask vc_conv3x3_wino_wgrad_supported. */
+ * workspace is REQUIRED.  x, dy: C4 layout; dw: HWIO.  Shapes: H, W even, H >= 4, Cin % 64 == 0, Cout % 64 == 0; ask vc_conv3x3_wino_wgrad_supported. */
 int vc_conv3x3_wino_wgrad_supported(int B, int H, int W, int Cin, int Cout);
 size_t vc_conv3x3_wino_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
 int vc_conv3x3_wino_wgrad_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const float* dy, float* dw,
                               float* db, int accumulate, float* ws, size_t ws_bytes);
 
 /* conv1_1 (utils/image_embeddings.py:36-48: 3 -> 64 channels), csrc/conv_first.hip: the layer is HBM-bound (it writes / re-reads
- * the [B,H,W,64] activation, 822 MB at 64 images, for 0.6 % of the multiply-adds), so it has its own kernels: the forward makes
+ * the 64-channel activation, 822 MB at 64 images, for 0.6 % of the multiply-adds), so it has its own kernels: the forward makes
  * the 64 output channels the M dimension of the MFMA so that every lane stores 16-byte vectors of consecutive channels straight
- * from its accumulators; the weight gradient contracts 27 patch rows + one row of ones (= the bias gradient) against dy and
- * reduces per-workgroup partials in a fixed order.  x4: [B,H,W,4] from vc_vgg_preprocess_f32 (fourth channel ignored);
+ * from its accumulators (32 lanes = 32 consecutive pixels of one C4 plane); the weight gradient contracts 27 patch rows + one row of
+ * ones (= the bias gradient) against dy and reduces per-workgroup partials in a fixed order.  y, dy: C4 layout ([B][16][H][W][4]);
+ * x4: [B,H,W,4] from vc_vgg_preprocess_f32 (fourth channel ignored);
  * w / dw: [3,3,3,64] HWIO (no padding to 4 channels); W % 32 == 0 (ask vc_conv1_supported, else use vc_conv3x3_*_f32 on the
  * zero-padded weights).  There is no data gradient: the images are not trained. */
 int vc_conv1_supported(int B, int H, int W);

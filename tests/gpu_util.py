@@ -58,3 +58,30 @@ def assert_close(got, ref, rtol, atol_scale=None, msg=""):
     assert np.isfinite(got).all(), "%s: non-finite output" % msg
     assert err.max() <= tol, "%s: max err %.3e > tol %.3e at %s (got %r ref %r), %d/%d elements off" % (
         msg, err.max(), tol, worst, got[worst], ref[worst], int((err > tol).sum()), err.size)
+
+
+# ---- the C4 activation layout of the Winograd kernels (include/vaecap.h): [B][C/4][H][W][4] ----
+def to_c4(a):
+    """NHWC numpy array [B,H,W,C] -> C4 [B, C/4, H, W, 4]."""
+    a = np.asarray(a)
+    B, H, W, C = a.shape
+    return np.ascontiguousarray(a.reshape(B, H, W, C // 4, 4).transpose(0, 3, 1, 2, 4))
+
+
+def from_c4(a, shape=None):
+    """C4 array (any shape holding B*C/4*H*W*4 elements; `shape` = the NHWC shape [B,H,W,C]) -> NHWC numpy array."""
+    a = np.asarray(a)
+    if shape is None:
+        B, C4, H, W, _ = a.shape
+        shape = (B, H, W, C4 * 4)
+    B, H, W, C = shape
+    return np.ascontiguousarray(a.reshape(B, C // 4, H, W, 4).transpose(0, 2, 3, 1, 4).reshape(B, H, W, C))
+
+
+def dev_c4(x, dtype=None):
+    return dev(to_c4(x), dtype)
+
+
+def host_c4(t, shape):
+    """device tensor holding a C4 activation -> NHWC numpy array of `shape` [B,H,W,C]."""
+    return from_c4(host(t), shape)

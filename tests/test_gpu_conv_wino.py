@@ -2,12 +2,13 @@
 input / output transforms fused around sixteen MFMA position products on 16-tile blocks, weights transformed once per step; weight
 gradient F(3x3, 2x2): csrc/conv_wino_wgrad.hip) against the fp64 numpy
 oracle, through the C ABI.  Tolerance: 3e-6 * sqrt(K) of the tensor max, K = 9*C (the direct kernels are held to 2e-6 * sqrt(K);
-the Winograd transforms add a few more fp32 roundings per term)."""
+the Winograd transforms add a few more fp32 roundings per term).  Activations go in and come out in the C4 layout [B][C/4][H][W][4]
+(include/vaecap.h); the oracle is NHWC, the tests convert on the host (tests/gpu_util.py to_c4 / from_c4)."""
 import numpy as np
 import pytest
 import torch
 
-from .gpu_util import P, assert_close, dev, empty_bytes, host, stream, zeros
+from .gpu_util import P, assert_close, dev, dev_c4, empty_bytes, from_c4, host, host_c4, stream, to_c4, zeros
 
 pytestmark = pytest.mark.gpu
 
@@ -24,6 +25,22 @@ def _pack(lib, w, transpose):
     wp = torch.empty(16 * w.shape[2] * w.shape[3], dtype=torch.float32, device="cuda")
     lib.vc_conv3x3_wino_pack_f32(stream(), int(w.shape[2]), int(w.shape[3]), P(w), transpose, P(wp))
     return wp
+
+
+@pytest.mark.parametrize("shape", [(2, 6, 10, 8), (1, 7, 5, 64), (3, 4, 4, 4), (2, 14, 14, 512)], ids=lambda c: "x".join(map(str, c)))
+def test_layout_conversion_kernels_match_numpy(lib, shape):
+    """vc_nhwc_to_c4_f32 / vc_c4_to_nhwc_f32 (the fc1 boundary of the trainer, and what the -m gpu tests use on device tensors) against
+    the numpy transposition; C = 4 is the identity (conv1_1's zero-padded RGB input is both layouts at once)."""
+    B, H, W, C = shape
+    x = np.random.default_rng(C).standard_normal(shape, dtype=np.float32)
+    out = zeros(B, C // 4, H, W, 4)
+    lib.vc_nhwc_to_c4_f32(stream(), B, H, W, C, P(dev(x)), P(out))
+    assert np.array_equal(host(out), to_c4(x))
+    back = zeros(*shape)
+    lib.vc_c4_to_nhwc_f32(stream(), B, H, W, C, P(out), P(back))
+    assert np.array_equal(host(back), x) and np.array_equal(from_c4(to_c4(x)), x)
+    if C == 4:
+        assert np.array_equal(host(out).reshape(shape), x)
 
 
 def test_wino_pack_is_G_g_Gt(lib):
@@ -58,29 +75,30 @@ def test_wino_fwd_dgrad_match_oracle(lib, case):
     dy = rng.standard_normal((B, H, W, Co), dtype=np.float32)
     x64, w64 = x.astype(np.float64), w.astype(np.float64)
     pre = OV.conv3x3_fwd(x64, w64, b.astype(np.float64))
-    tx, tw, tdy = dev(x), dev(w), dev(dy)
+    tx, tw, tdy = dev_c4(x), dev(w), dev_c4(dy)
     wp = _pack(lib, tw, 0)
     y = zeros(B, H, W, Co)
+    ys, ps, xs = (B, H, W, Co), (B, H // 2, W // 2, Co), (B, H, W, Ci)
     tol = 3e-6 * np.sqrt(9 * Ci) + 1e-6
     lib.vc_conv3x3_wino_fwd_f32(stream(), B, H, W, Ci, Co, P(tx), P(wp), P(dev(b)), P(y), None, 1)
-    assert_close(host(y), np.maximum(pre, 0), tol, msg="wino fwd (+bias, relu)")
+    assert_close(host_c4(y, ys), np.maximum(pre, 0), tol, msg="wino fwd (+bias, relu)")
     lib.vc_conv3x3_wino_fwd_f32(stream(), B, H, W, Ci, Co, P(tx), P(wp), None, P(y), None, 0)
-    assert_close(host(y), pre - b, tol, msg="wino fwd (no bias, no relu)")
+    assert_close(host_c4(y, ys), pre - b, tol, msg="wino fwd (no bias, no relu)")
     yp = zeros(B, H // 2, W // 2, Co)
     y.zero_()
     lib.vc_conv3x3_wino_fwd_f32(stream(), B, H, W, Ci, Co, P(tx), P(wp), P(dev(b)), P(y), P(yp), 1)
-    hy = host(y)
+    hy = host_c4(y, ys)
     assert_close(hy, np.maximum(pre, 0), tol, msg="wino fwd + pool: y")
-    assert np.array_equal(host(yp), hy.reshape(B, H // 2, 2, W // 2, 2, Co).max(axis=(2, 4))), "fused pool != max_pool2x2(y)"
+    assert np.array_equal(host_c4(yp, ps), hy.reshape(B, H // 2, 2, W // 2, 2, Co).max(axis=(2, 4))), "fused pool != max_pool2x2(y)"
     if lib.vc_conv3x3_wino_supported(B, H, W, Ci, Co, 1):
         dxref, _, _ = OV.conv3x3_bwd(x64, w64, dy.astype(np.float64))
         wpt = _pack(lib, tw, 1)
         dx = zeros(B, H, W, Ci)
         told = 3e-6 * np.sqrt(9 * Co) + 1e-6
         lib.vc_conv3x3_wino_dgrad_f32(stream(), B, H, W, Ci, Co, P(tdy), P(wpt), P(tx), P(dx))
-        assert_close(host(dx), dxref * (x > 0), told, msg="wino dgrad (+relu mask)")
+        assert_close(host_c4(dx, xs), dxref * (x > 0), told, msg="wino dgrad (+relu mask)")
         lib.vc_conv3x3_wino_dgrad_f32(stream(), B, H, W, Ci, Co, P(tdy), P(wpt), None, P(dx))
-        assert_close(host(dx), dxref, told, msg="wino dgrad")
+        assert_close(host_c4(dx, xs), dxref, told, msg="wino dgrad")
     else:
         assert Ci % 32 != 0 or Co % 16 != 0
 
@@ -116,16 +134,16 @@ def test_wino_wgrad_matches_oracle(lib, case):
         dbref = dy.astype(np.float64).sum(axis=(0, 1, 2))
     ws = empty_bytes(lib.vc_conv3x3_wino_wgrad_workspace_bytes(B, H, W, Ci, Co))
     dw, db = zeros(3, 3, Ci, Co), zeros(Co)
-    lib.vc_conv3x3_wino_wgrad_f32(stream(), B, H, W, Ci, Co, P(dev(x)), P(dev(dy)), P(dw), P(db), 0, P(ws), ws.numel() * 4)
+    lib.vc_conv3x3_wino_wgrad_f32(stream(), B, H, W, Ci, Co, P(dev_c4(x)), P(dev_c4(dy)), P(dw), P(db), 0, P(ws), ws.numel() * 4)
     tol = 3e-6 * np.sqrt(B * H * W) + 1e-6
     assert_close(host(dw), dwref, tol, msg="wino wgrad")
     assert_close(host(db), dbref, tol, msg="wino wgrad: bias gradient")
     first = host(dw).copy()
-    lib.vc_conv3x3_wino_wgrad_f32(stream(), B, H, W, Ci, Co, P(dev(x)), P(dev(dy)), P(dw), P(db), 1, P(ws), ws.numel() * 4)
+    lib.vc_conv3x3_wino_wgrad_f32(stream(), B, H, W, Ci, Co, P(dev_c4(x)), P(dev_c4(dy)), P(dw), P(db), 1, P(ws), ws.numel() * 4)
     assert_close(host(dw), 2 * dwref, tol, msg="wino wgrad (accumulate)")
     assert_close(host(db), 2 * dbref, tol, msg="wino wgrad (accumulate): bias gradient")
     dw2 = zeros(3, 3, Ci, Co)
-    lib.vc_conv3x3_wino_wgrad_f32(stream(), B, H, W, Ci, Co, P(dev(x)), P(dev(dy)), P(dw2), None, 0, P(ws), ws.numel() * 4)
+    lib.vc_conv3x3_wino_wgrad_f32(stream(), B, H, W, Ci, Co, P(dev_c4(x)), P(dev_c4(dy)), P(dw2), None, 0, P(ws), ws.numel() * 4)
     assert np.array_equal(host(dw2), first), "not bit-reproducible"
 
 
@@ -216,7 +234,7 @@ def test_pool_routing_codes_equal_maxpool_bwd_on_the_activation(lib, case):
     w = np.round(rng.standard_normal((3, 3, Ci, Co), dtype=np.float32))
     w[:, :, :, : Co // 4] = 0                                       # whole channels at the bias value: four-way ties
     b = np.concatenate([np.full(Co // 8, -1.0), np.full(Co // 8, 2.0), rng.standard_normal(Co - Co // 4)]).astype(np.float32)
-    tx, tw, tb = dev(x), dev(w), dev(b)
+    tx, tw, tb = dev_c4(x), dev(w), dev(b)
     wp = _pack(lib, tw, 0)
     y0, p0 = zeros(B, H, W, Co), zeros(B, H // 2, W // 2, Co)
     lib.vc_conv3x3_wino_fwd_f32(stream(), B, H, W, Ci, Co, P(tx), P(wp), P(tb), P(y0), P(p0), 1)
@@ -226,11 +244,11 @@ def test_pool_routing_codes_equal_maxpool_bwd_on_the_activation(lib, case):
     bits = torch.zeros(nw, dtype=torch.int32, device="cuda")
     lib.vc_conv3x3_wino_fwd_pool_f32(stream(), B, H, W, Ci, Co, P(tx), P(wp), P(tb), P(y1), P(p1), P(bits))
     assert torch.equal(y0, y1) and torch.equal(p0, p1)
-    dy = dev(rng.standard_normal((B, H // 2, W // 2, Co), dtype=np.float32))
+    dy = dev_c4(rng.standard_normal((B, H // 2, W // 2, Co), dtype=np.float32))
     d_ref, d_bits = zeros(B, H, W, Co), torch.full((B, H, W, Co), 7.0, device="cuda")
-    lib.vc_maxpool2x2_bwd_f32(stream(), B, H, W, Co, P(y1), P(dy), P(d_ref), 1)
+    lib.vc_maxpool2x2_bwd_f32(stream(), B * (Co // 4), H, W, 4, P(y1), P(dy), P(d_ref), 1)   # (C4 planes of four-channel pixels)
     lib.vc_maxpool2x2_bwd_bits_f32(stream(), B, H, W, Co, P(bits), P(dy), P(d_bits))
     assert torch.equal(d_ref, d_bits)
-    hy = host(y1)
+    hy = host_c4(y1, (B, H, W, Co))
     win = hy.reshape(B, H // 2, 2, W // 2, 2, Co)
     assert (win.max(axis=(2, 4)) == 0).mean() > 0.05 and ((win == win.max(axis=(2, 4), keepdims=True)).sum(axis=(2, 4)) > 1).mean() > 0.1   # ties do occur

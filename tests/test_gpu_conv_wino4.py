@@ -1,12 +1,13 @@
 """Winograd F(4x4, 3x3) convolution (csrc/conv_wino4.hip: forward and data gradient of utils/image_embeddings.py:36-212 with 36
-positions per 4 x 4 output tile, blocks of 4 x 4 tiles) against the fp64 numpy oracle, through the C ABI.
-Tolerance: 2e-5 * sqrt(K) of the tensor max, K = 9 * C -- the transforms multiply by 4, 5, 8 and 1/24, which costs about a decimal
-digit against F(2x2,3x3) (held to 3e-6 * sqrt(K)); measured on the VGG16 shapes: 1e-5 of the tensor maximum without the sqrt(K)."""
+positions per 4 x 4 output tile, blocks of 4 x 4 tiles) against the fp64 numpy oracle, through the C ABI.  Activations go in and come
+out in the C4 layout (include/vaecap.h); the oracle is NHWC, the tests convert on the host (tests/gpu_util.py to_c4 / from_c4).
+Tolerance: 6e-5 of the tensor max, FLAT (no sqrt(K)) -- the transforms multiply by 4, 5, 8 and 1/24, which costs about a decimal
+digit against F(2x2,3x3) (held to 3e-6 * sqrt(K)); measured on the VGG16 shapes: 1e-5 of the tensor maximum."""
 import numpy as np
 import pytest
 import torch
 
-from .gpu_util import P, assert_close, dev, host, stream, zeros
+from .gpu_util import P, assert_close, dev, dev_c4, host, host_c4, stream, zeros
 
 pytestmark = pytest.mark.gpu
 
@@ -58,53 +59,54 @@ def test_wino4_fwd_dgrad_match_oracle(lib, case):
     x64, w64 = x.astype(np.float64), w.astype(np.float64)
     if B * H * W <= 20000:
         pre = OV.conv3x3_fwd(x64, w64, b.astype(np.float64))
-        dxref = OV.conv3x3_bwd(x64, w64, dy.astype(np.float64))[0] if Ci % 32 == 0 else None
+        dxref = OV.conv3x3_bwd(x64, w64, dy.astype(np.float64))[0] if Ci % 32 == 0 and Co % 8 == 0 else None
     else:   # the 112 x 112 case: torch fp64 on the device as the reference of the reference (same contraction)
         t = lambda a: torch.from_numpy(a).cuda().double()
         wt = t(w).permute(3, 2, 0, 1)
         pre = torch.nn.functional.conv2d(t(x).permute(0, 3, 1, 2), wt, t(b), padding=1).permute(0, 2, 3, 1).cpu().numpy()
-        dxref = None
-    tx, tw, tdy = dev(x), dev(w), dev(dy)
+        dxref = torch.nn.grad.conv2d_input((B, Ci, H, W), wt, t(dy).permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1).cpu().numpy() if Ci % 32 == 0 else None
+    tx, tw, tdy = dev_c4(x), dev(w), dev_c4(dy)
     wp = _pack(lib, tw, 0)
     y = zeros(B, H, W, Co)
-    tol = 2e-5 * np.sqrt(9 * Ci) + 1e-6
+    ys, ps = (B, H, W, Co), (B, H // 2, W // 2, Co)
+    tol = 6e-5
     lib.vc_conv3x3_wino4_fwd_f32(stream(), B, H, W, Ci, Co, P(tx), P(wp), P(dev(b)), P(y), None, 1)
-    assert_close(host(y), np.maximum(pre, 0), tol, msg="wino4 fwd (+bias, relu)")
+    assert_close(host_c4(y, ys), np.maximum(pre, 0), tol, msg="wino4 fwd (+bias, relu)")
     lib.vc_conv3x3_wino4_fwd_f32(stream(), B, H, W, Ci, Co, P(tx), P(wp), None, P(y), None, 0)
-    assert_close(host(y), pre - b, tol, msg="wino4 fwd (no bias, no relu)")
+    assert_close(host_c4(y, ys), pre - b, tol, msg="wino4 fwd (no bias, no relu)")
     yp = zeros(B, H // 2, W // 2, Co)
     y.zero_()
     lib.vc_conv3x3_wino4_fwd_f32(stream(), B, H, W, Ci, Co, P(tx), P(wp), P(dev(b)), P(y), P(yp), 1)
-    hy = host(y)
+    hy = host_c4(y, ys)
     assert_close(hy, np.maximum(pre, 0), tol, msg="wino4 fwd + pool: y")
-    assert np.array_equal(host(yp), hy.reshape(B, H // 2, 2, W // 2, 2, Co).max(axis=(2, 4))), "fused pool != max_pool2x2(y)"
+    assert np.array_equal(host_c4(yp, ps), hy.reshape(B, H // 2, 2, W // 2, 2, Co).max(axis=(2, 4))), "fused pool != max_pool2x2(y)"
     if dxref is not None:
         assert lib.vc_conv3x3_wino4_supported(B, H, W, Ci, Co, 1) == 1
         wpt = _pack(lib, tw, 1)
         dx = zeros(B, H, W, Ci)
-        told = 2e-5 * np.sqrt(9 * Co) + 1e-6
+        told, xs = 6e-5, (B, H, W, Ci)
         lib.vc_conv3x3_wino4_dgrad_f32(stream(), B, H, W, Ci, Co, P(tdy), P(wpt), P(tx), P(dx))
-        assert_close(host(dx), dxref * (x > 0), told, msg="wino4 dgrad (+relu mask)")
+        assert_close(host_c4(dx, xs), dxref * (x > 0), told, msg="wino4 dgrad (+relu mask)")
         lib.vc_conv3x3_wino4_dgrad_f32(stream(), B, H, W, Ci, Co, P(tdy), P(wpt), None, P(dx))
-        assert_close(host(dx), dxref, told, msg="wino4 dgrad")
+        assert_close(host_c4(dx, xs), dxref, told, msg="wino4 dgrad")
 
 
 def test_wino4_error_is_a_digit_above_f23_and_far_inside_the_tolerance(lib):
     """What the constants of F(4x4,3x3) cost, measured where it is used: conv4_2's reduction (K = 9 * 512), post-ReLU inputs, He-scaled
-    weights -- the error against fp64 is ~1e-5 of the tensor maximum (F(2x2,3x3): ~1e-6), the test tolerance 1.4e-3."""
+    weights -- the error against fp64 is ~1e-5 of the tensor maximum (F(2x2,3x3): ~1e-6), the test tolerance 6e-5 (flat)."""
     B, H, Ci, Co = 2, 28, 512, 64
     rng = np.random.default_rng(5)
     x = np.maximum(rng.standard_normal((B, H, H, Ci), dtype=np.float32), 0)
     w = rng.standard_normal((3, 3, Ci, Co), dtype=np.float32) * np.float32(np.sqrt(2.0 / (9 * Ci)))
     pre = OV.conv3x3_fwd(x.astype(np.float64), w.astype(np.float64), np.zeros(Co))
-    tx, tw = dev(x), dev(w)
+    tx, tw = dev_c4(x), dev(w)
     y4, y2 = zeros(B, H, H, Co), zeros(B, H, H, Co)
     lib.vc_conv3x3_wino4_fwd_f32(stream(), B, H, H, Ci, Co, P(tx), P(_pack(lib, tw, 0)), None, P(y4), None, 0)
     wp2 = torch.empty(16 * Ci * Co, dtype=torch.float32, device="cuda")
     lib.vc_conv3x3_wino_pack_f32(stream(), Ci, Co, P(tw), 0, P(wp2))
     lib.vc_conv3x3_wino_fwd_f32(stream(), B, H, H, Ci, Co, P(tx), P(wp2), None, P(y2), None, 0)
     scale = np.abs(pre).max()
-    e4, e2 = np.abs(host(y4) - pre).max() / scale, np.abs(host(y2) - pre).max() / scale
+    e4, e2 = np.abs(host_c4(y4, pre.shape) - pre).max() / scale, np.abs(host_c4(y2, pre.shape) - pre).max() / scale
     assert e2 < 2e-6 and e4 < 4e-5 and e4 < 40 * max(e2, 1e-7), (e2, e4)
 
 
@@ -152,7 +154,7 @@ def test_wino4_relu_mask_as_bits(lib, case):
 
 @pytest.mark.parametrize("case", [(2, 16, 16, 32, 64), (1, 56, 56, 64, 64), (3, 28, 28, 32, 96), (5, 14, 14, 64, 32), (2, 12, 20, 16, 64)], ids=lambda c: "x".join(map(str, c)))
 def test_wino4_pool_routing_codes_equal_maxpool_bwd_on_the_activation(lib, case):
-    """The pooled forward also leaves MaxPoolGrad's routing codes in conv_wino.hip's format (a lane owns four channels = half a word);
+    """The pooled forward also leaves MaxPoolGrad's routing codes in conv_wino.hip's format (a lane owns four channels = one half-word);
     routing the pooled gradient with them is bit-identical to vc_maxpool2x2_bwd_f32 on the pre-pool activation, ties included."""
     B, H, W, Ci, Co = case
     rng = np.random.default_rng(sum(case) + 11)
@@ -161,7 +163,7 @@ def test_wino4_pool_routing_codes_equal_maxpool_bwd_on_the_activation(lib, case)
     w = np.round(rng.standard_normal((3, 3, Ci, Co), dtype=np.float32))
     w[:, :, :, : Co // 4] = 0                                       # whole channels at the bias value: four-way ties
     b = np.concatenate([np.full(Co // 8, -1.0), np.full(Co // 8, 2.0), rng.standard_normal(Co - Co // 4)]).astype(np.float32)
-    tx, tw, tb = dev(x), dev(w), dev(b)
+    tx, tw, tb = dev_c4(x), dev(w), dev(b)
     wp = _pack(lib, tw, 0)
     y0, p0 = zeros(B, H, W, Co), zeros(B, H // 2, W // 2, Co)
     lib.vc_conv3x3_wino4_fwd_f32(stream(), B, H, W, Ci, Co, P(tx), P(wp), P(tb), P(y0), P(p0), 1)
@@ -170,12 +172,12 @@ def test_wino4_pool_routing_codes_equal_maxpool_bwd_on_the_activation(lib, case)
     bits = torch.zeros(nw, dtype=torch.int32, device="cuda")
     lib.vc_conv3x3_wino4_fwd_pool_f32(stream(), B, H, W, Ci, Co, P(tx), P(wp), P(tb), P(y1), P(p1), P(bits))
     assert torch.equal(y0, y1) and torch.equal(p0, p1)
-    dy = dev(rng.standard_normal((B, H // 2, W // 2, Co), dtype=np.float32))
+    dy = dev_c4(rng.standard_normal((B, H // 2, W // 2, Co), dtype=np.float32))
     d_ref, d_bits = zeros(B, H, W, Co), torch.full((B, H, W, Co), 7.0, device="cuda")
-    lib.vc_maxpool2x2_bwd_f32(stream(), B, H, W, Co, P(y1), P(dy), P(d_ref), 1)
+    lib.vc_maxpool2x2_bwd_f32(stream(), B * (Co // 4), H, W, 4, P(y1), P(dy), P(d_ref), 1)   # (C4 planes of four-channel pixels)
     lib.vc_maxpool2x2_bwd_bits_f32(stream(), B, H, W, Co, P(bits), P(dy), P(d_bits))
     assert torch.equal(d_ref, d_bits)
-    hy = host(y1)
+    hy = host_c4(y1, (B, H, W, Co))
     win = hy.reshape(B, H // 2, 2, W // 2, 2, Co)
     assert (win.max(axis=(2, 4)) == 0).mean() > 0.05 and ((win == win.max(axis=(2, 4), keepdims=True)).sum(axis=(2, 4)) > 1).mean() > 0.1   # ties do occur
 

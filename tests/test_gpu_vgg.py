@@ -22,9 +22,18 @@ from vae_captioning_amd.utils.parameters import Parameters
 pytestmark = pytest.mark.gpu
 
 
+def nhwc(t):
+    """a VggEngine activation -- C4 layout [B, C/4, H, W, 4] between conv1_1 and pool5 (include/vaecap.h) -- as an NHWC numpy array"""
+    a = t.detach().cpu().numpy()
+    if a.ndim == 5:
+        B, C4, H, W, _ = a.shape
+        a = a.transpose(0, 2, 3, 1, 4).reshape(B, H, W, C4 * 4)
+    return a
+
+
 def device_cache(eng, P64, keep):
     """oracle.vgg cache rebuilt from the device's forward activations (fp32 values, as fp64)."""
-    f = lambda t: t.detach().cpu().numpy().astype(np.float64)
+    f = lambda t: nhwc(t).astype(np.float64)
     conv = []
     for name, x, H, W, ci, co, w in eng.acts:
         x64 = f(x)
@@ -67,7 +76,7 @@ def test_vgg_forward_backward(lib):
     # intermediate activations, layer by layer
     convs = [c for c in cache["conv"] if c[0] != "P"]
     for name, x, y in convs:
-        got = eng.buf["y_" + name].cpu().numpy()
+        got = nhwc(eng.buf["y_" + name])
         assert rel_l2(got, y) < 2e-5, name
     eng.backward(torch.from_numpy(dfc2).cuda())
     G = eng.grads_dict()
@@ -129,10 +138,11 @@ def test_fine_tune_step_matches_oracle(lib):
         assert rel_l2(new[n] - PV[n], PVn[n] - PV[n]) < 2e-2, (n, rel_l2(new[n] - PV[n], PVn[n] - PV[n]), upd)
 
 
-def test_fallback_kernels_without_the_patch_path(lib, monkeypatch):
-    """use_patch = use_wino = False: every layer through the general implicit-GEMM kernels of csrc/conv.hip (conv1_1 on zero-padded 4-channel
-    weights, separate max-pool launches) -- the path taken for geometries the patch / conv1 kernels do not support: forward vs
-    the fp64 oracle, backward vs the oracle on the device's forward decisions, and close to the default path."""
+def test_fallback_kernels_without_the_winograd_path(lib, monkeypatch):
+    """use_wino = False: every layer through the NHWC implicit-GEMM kernels of csrc/conv.hip behind layout conversions (conv1_1 on zero-padded
+    4-channel weights, separate max-pool launches) -- the path taken for geometries the Winograd / conv1 kernels do not support, and an
+    independent implementation of the whole VGG16: forward vs the fp64 oracle, backward vs the oracle on the device's forward decisions,
+    and close to the default path."""
     p = Parameters()
     p.fine_tune = True
     rng = np.random.default_rng(21)
@@ -146,7 +156,7 @@ def test_fallback_kernels_without_the_patch_path(lib, monkeypatch):
     for mode in ("0", "1"):
         eng = VggEngine(p, lib=lib)
         if mode == "0":   # (an attribute, not an environment switch: the product never takes this path on a VGG16 shape)
-            eng.use_patch = eng.use_wino = False
+            eng.use_wino = False
         eng.load_params(PV)
         eng.set_masks(ones, ones)
         fc2 = eng.forward(torch.from_numpy(img).cuda())
@@ -156,7 +166,7 @@ def test_fallback_kernels_without_the_patch_path(lib, monkeypatch):
         if mode == "0":
             assert rel_l2(fc2.cpu().numpy(), fc2_ref) < 2e-5
             for name, x, y in [c for c in cache["conv"] if c[0] != "P"]:
-                assert rel_l2(eng.buf["y_" + name].cpu().numpy(), y) < 2e-5, name
+                assert rel_l2(nhwc(eng.buf["y_" + name]), y) < 2e-5, name
             G = eng.grads_dict()
             Gdev = ov.backward(P64, device_cache(eng, P64, 0.5), dfc2.astype(np.float64))
             for n, ref in Gdev.items():
@@ -167,7 +177,7 @@ def test_fallback_kernels_without_the_patch_path(lib, monkeypatch):
 
 @pytest.mark.parametrize("env", [("VC_CONV_WINO", "0"), ("VC_VGG_STREAMS", "1")], ids=lambda e: "%s=%s" % e)
 def test_alternative_convolution_paths_match_the_oracle(lib, monkeypatch, env):
-    """The non-default convolution paths stay correct: VC_CONV_WINO=0 (direct patch kernels of the first half of round 2 on every layer),
+    """The non-default convolution paths stay correct: VC_CONV_WINO=0 (the NHWC implicit-GEMM kernels behind layout conversions on every layer),
     VC_VGG_STREAMS=1 (serial schedule; B = 2 so that the default
     would have used half-batch chains and the ReLU-mask bits of both geometries are exercised): forward vs the fp64 oracle, backward vs
     the oracle on the device's forward decisions."""
@@ -192,7 +202,7 @@ def test_alternative_convolution_paths_match_the_oracle(lib, monkeypatch, env):
     torch.cuda.synchronize()
     assert rel_l2(fc2.cpu().numpy(), fc2_ref) < 2e-5
     for name, x, y in [c for c in cache["conv"] if c[0] != "P"]:
-        assert rel_l2(eng.buf["y_" + name].cpu().numpy(), y) < 2e-5, name
+        assert rel_l2(nhwc(eng.buf["y_" + name]), y) < 2e-5, name
     G = eng.grads_dict()
     Gdev = ov.backward(P64, device_cache(eng, P64, 0.5), dfc2.astype(np.float64))
     for n, ref in Gdev.items():
@@ -230,7 +240,7 @@ def test_half_batch_chains_on_three_streams(lib, monkeypatch):
         if ns == "3":
             assert rel_l2(fc2.cpu().numpy(), fc2_ref) < 2e-5
             for name, x, y in [c for c in cache["conv"] if c[0] != "P"]:
-                assert rel_l2(eng.buf["y_" + name].cpu().numpy(), y) < 2e-5, name
+                assert rel_l2(nhwc(eng.buf["y_" + name]), y) < 2e-5, name
             G = eng.grads_dict()
             Gdev = ov.backward(P64, device_cache(eng, P64, 0.5), dfc2.astype(np.float64))
             for n, ref in Gdev.items():

@@ -506,36 +506,44 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float4* __restri
 }
 
 // MaxPoolGrad + ReluGrad from the routing codes the pooled Winograd forward left (vc_conv3x3_wino_fwd_pool_f32): per pooled element four
-// bits = position of the window's first maximum | 4 if that maximum is > 0; a word = 8 consecutive channels.  Reads dy [B,H/2,W/2,C]
-// and C/2 bytes of codes per pooled pixel instead of the whole pre-pool activation: 1.3 instead of 2.25 tensor passes.
-__global__ __launch_bounds__(256) void maxpool_bwd_bits_kernel(const unsigned* __restrict__ bits, const float4* __restrict__ dy, int B, int H,
-                                                               int W, int C8, float4* __restrict__ dx) {
+// bits = position of the window's first maximum | 4 if that maximum is > 0.  Reads the pooled gradient and 2 bytes of codes per pooled
+// pixel and channel quad instead of the whole pre-pool activation: 1.3 instead of 2.25 tensor passes.
+// C4 activation layout: codes [planes = B * C/4][H/2][W/2] half-words (one per channel quad and pooled pixel),
+// dy [planes][H/2][W/2][4], dx [planes][H][W][4].  A thread owns one pooled pixel of one plane: it writes 2 x 32 consecutive bytes, consecutive
+// threads consecutive pieces (full lines).
+__global__ __launch_bounds__(256) void maxpool_bwd_bits_c4_kernel(const unsigned short* __restrict__ bits, const float4* __restrict__ dy, long planes, int H,
+                                                                  int W, float4* __restrict__ dx) {
     const int Ho = H >> 1, Wo = W >> 1;
-    const long total = (long)B * Ho * Wo * C8;
+    const long total = planes * Ho * Wo;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c = (int)(i % C8);
-        long p = i / C8;
-        const int xo = (int)(p % Wo);
-        p /= Wo;
-        const int yo = (int)(p % Ho);
-        const long b = p / Ho;
-        const long base = ((b * H + 2 * yo) * W + 2 * xo) * (2 * C8) + 2 * c;   // float4 index of the window's first pixel
-        const long rowo = (long)W * 2 * C8;
-        const unsigned code = bits[i];
+        const int xo = (int)(i % Wo);
+        const long p = i / Wo;   // plane * Ho + yo
+        const long base = (2 * p) * W + 2 * xo;
+        const unsigned cd = bits[i];
+        const float4 g = dy[i];
+        float4 o[4];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const float4 g = dy[2 * i + h];
-            const unsigned cd = code >> (16 * h);
-            float4 o[4];
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                o[w].x = ((cd & 7u) == (4u | w)) ? g.x : 0.f;
-                o[w].y = (((cd >> 4) & 7u) == (4u | w)) ? g.y : 0.f;
-                o[w].z = (((cd >> 8) & 7u) == (4u | w)) ? g.z : 0.f;
-                o[w].w = (((cd >> 12) & 7u) == (4u | w)) ? g.w : 0.f;
-            }
-            dx[base + h] = o[0]; dx[base + 2 * C8 + h] = o[1]; dx[base + rowo + h] = o[2]; dx[base + rowo + 2 * C8 + h] = o[3];
+        for (int w = 0; w < 4; ++w) {
+            o[w].x = ((cd & 7u) == (4u | w)) ? g.x : 0.f;
+            o[w].y = (((cd >> 4) & 7u) == (4u | w)) ? g.y : 0.f;
+            o[w].z = (((cd >> 8) & 7u) == (4u | w)) ? g.z : 0.f;
+            o[w].w = (((cd >> 12) & 7u) == (4u | w)) ? g.w : 0.f;
         }
+        dx[base] = o[0]; dx[base + 1] = o[1]; dx[base + W] = o[2]; dx[base + W + 1] = o[3];
+    }
+}
+
+// NHWC [B,H,W,C] <-> C4 [B][C/4][H][W][4] (vaecap.h: the activation layout of the Winograd kernels); one float4 per thread, the C4 side coalesced
+__global__ __launch_bounds__(256) void nhwc_c4_kernel(const float4* __restrict__ in, long B, long HW, int C4, int to_c4, float4* __restrict__ out) {
+    const long total = B * HW * C4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {   // i = C4-side index (b, q, p)
+        const long p = i % HW;
+        const long t = i / HW;
+        const int q = (int)(t % C4);
+        const long b = t / C4;
+        const long j = (b * HW + p) * C4 + q;   // NHWC-side index
+        if (to_c4) out[i] = in[j];
+        else out[j] = in[i];
     }
 }
 
@@ -639,9 +647,24 @@ extern "C" int vc_maxpool2x2_bwd_f32(void* stream, int B, int H, int W, int C, c
 }
 
 extern "C" int vc_maxpool2x2_bwd_bits_f32(void* stream, int B, int H, int W, int C, const uint32_t* pool_bits, const float* dy, float* dx) {
-    VC_CHECK_ARG(pool_bits && dy && dx && B > 0 && H > 0 && W > 0 && C > 0 && H % 2 == 0 && W % 2 == 0 && C % 8 == 0, "even H/W, C % 8 == 0 required");
-    const long total = (long)B * (H / 2) * (W / 2) * (C / 8);
-    hipLaunchKernelGGL(maxpool_bwd_bits_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, pool_bits, (const float4*)dy, B, H, W, C / 8, (float4*)dx);
+    VC_CHECK_ARG(pool_bits && dy && dx && B > 0 && H > 0 && W > 0 && C > 0 && H % 2 == 0 && W % 2 == 0 && C % 4 == 0, "even H/W, C % 4 == 0 required");
+    const long planes = (long)B * (C / 4), total = planes * (H / 2) * (W / 2);
+    hipLaunchKernelGGL(maxpool_bwd_bits_c4_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)pool_bits, (const float4*)dy,
+                       planes, H, W, (float4*)dx);
+    VC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vc_nhwc_to_c4_f32(void* stream, int B, int H, int W, int C, const float* nhwc, float* c4) {
+    VC_CHECK_ARG(nhwc && c4 && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "C % 4 == 0 required");
+    hipLaunchKernelGGL(nhwc_c4_kernel, dim3(grid_for((long)B * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream, (const float4*)nhwc, (long)B, (long)H * W, C / 4, 1, (float4*)c4);
+    VC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vc_c4_to_nhwc_f32(void* stream, int B, int H, int W, int C, const float* c4, float* nhwc) {
+    VC_CHECK_ARG(nhwc && c4 && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "C % 4 == 0 required");
+    hipLaunchKernelGGL(nhwc_c4_kernel, dim3(grid_for((long)B * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream, (const float4*)c4, (long)B, (long)H * W, C / 4, 0, (float4*)nhwc);
     VC_LAUNCH_CHECK();
     return 0;
 }

@@ -37,8 +37,8 @@ struct Conv1Args {
     const float* x4;    // [B, H, W, 4] mean-subtracted RGB + one zero channel (vc_vgg_preprocess_f32)
     const float* w;     // [3, 3, 3, 64] HWIO
     const float* bias;  // [64]
-    float* y;           // [B, H, W, 64]
-    const float* dy;    // weight gradient: [B, H, W, 64]
+    float* y;           // [B][16][H][W][4] (the C4 activation layout, vaecap.h)
+    const float* dy;    // weight gradient: layout of y
     float* ws;          // weight gradient: [workgroups][28][64] partial sums
     int B, H, W, relu;
     int groups;         // B * H * W / 32
@@ -46,7 +46,6 @@ struct Conv1Args {
 };
 
 __global__ __launch_bounds__(256, 3) void conv1_fwd_kernel(Conv1Args a) {
-    __shared__ __attribute__((aligned(16))) float tile[4][32 * 68];  // per wave: 32 pixels x 64 channels (+4 pad)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
     const int H = a.H, W = a.W;
     // A operand: W^T[channel 32 tm + li][k = 14 lh + s]; the padding row k = 27 carries the BIAS (its B operand is 1.0)
@@ -106,22 +105,20 @@ __global__ __launch_bounds__(256, 3) void conv1_fwd_kernel(Conv1Args a) {
         };
         if (cur == 0) mac(slot[0]); else mac(slot[1]);
         cur ^= 1;
-        // lane (li, lh) holds pixel li, channels 32 tm + 8 q + 4 lh .. + 3: through the wave's LDS tile so that every store
-        // instruction writes 1 KB of CONSECUTIVE memory (four pixels x 256 B) -- measured 0.31 ms with 16-byte stores straight from
-        // the accumulators (32 partial lines per instruction), 0.24 ms with full-line 4-byte stores
-        float* T = tile[wave];
+        // lane (li, lh) holds pixel li, channels 32 tm + 8 q + 4 lh .. + 3 = channel quad 8 tm + 2 q + lh: in the C4 layout
+        // ([B][16][H][W][4]) the 32 lanes of a half write 32 consecutive pixels of ONE plane -- every store instruction is two runs of
+        // 512 consecutive bytes straight from the accumulators (the NHWC form needed a transpose through the LDS for full lines)
+        const int row = g / a.segs, xs = (g - row * a.segs) * 32 + li, bi = row / H;
+        float* yp = a.y + (((long)(row + bi * 15 * H + lh * H)) * W + xs) * 4;
+        const long qstep = (long)H * W * 4;   // floats per channel-quad plane
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float4 v = make_float4(acc[tm][4 * q], acc[tm][4 * q + 1], acc[tm][4 * q + 2], acc[tm][4 * q + 3]);
                 if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                *reinterpret_cast<float4*>(T + li * 68 + tm * 32 + 8 * q + 4 * lh) = v;
+                *reinterpret_cast<float4*>(yp + (8 * tm + 2 * q) * qstep) = v;
             }
-        float* yp = a.y + (long)g * 32 * 64 + lane * 4;
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            *reinterpret_cast<float4*>(yp + j * 256) = *reinterpret_cast<const float4*>(T + (4 * j + (lane >> 4)) * 68 + (lane & 15) * 4);
     }
 }
 
@@ -149,14 +146,17 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(Conv1Args a) {
         // lane-half lh takes pixels x0 + 16 lh + s
         const int xb = x0 + 16 * lh + dxm;
         const unsigned abase = (unsigned)((row + dym) * W + xb) * 16u + (unsigned)ch * 4u;
-        const unsigned bbase = (unsigned)(g * 32 + 16 * lh) * 256u + (unsigned)li * 4u;
+        // dy in the C4 layout: channel 32 tn + li = component li & 3 of channel quad 8 tn + li / 4 (a plane per quad, 16 bytes per pixel)
+        const int bi = row / H;
+        const unsigned bbase = (unsigned)(((row + bi * 15 * H + (li >> 2) * H) * W + x0 + 16 * lh) * 16 + (li & 3) * 4);
+        const unsigned tnstep = (unsigned)(8 * H * W * 16);
         float av[16], bv[2][16];
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const bool ok = oky & ((unsigned)(xb + s) < (unsigned)W);
             av[s] = c1_load1(rx, ok ? abase + (unsigned)s * 16u : C1_OOB);
 #pragma unroll
-            for (int tn = 0; tn < 2; ++tn) bv[tn][s] = c1_load1(rd, bbase + (unsigned)s * 256u + (unsigned)tn * 128u);
+            for (int tn = 0; tn < 2; ++tn) bv[tn][s] = c1_load1(rd, bbase + (unsigned)s * 16u + (unsigned)tn * tnstep);
         }
         __builtin_amdgcn_sched_barrier(0);  // every load of the group is in flight before its first MFMA
 #pragma unroll

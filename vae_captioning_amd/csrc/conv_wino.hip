@@ -63,13 +63,13 @@ constexpr int WINO2_LDS_BYTES = (W2_POFF + 4 * W2_BLK) * 4;   // 64 KB: two work
 
 struct Wino2Args {
     WinoGeom g;         // TBH * TBW <= 16
-    const float* x;     // [P, C]
+    const float* x;     // [B][C/4][H][W][4] (the C4 activation layout, vaecap.h)
     const float* wp;    // packed [N/32][C/16][half 2][p 16][g 4][n 16][ct 2][e 2]
-    float* out;         // [P, N]
-    const float* aux;   // fwd: bias [N] or null; dgrad: ReLU source [P, N] or null
+    float* out;         // [B][N/4][H][W][4]
+    const float* aux;   // fwd: bias [N] or null; dgrad: ReLU source, layout of out, or null
     float* pool;        // fwd: also max_pool2x2(out) (null: none)
-    unsigned* pbits;    // fwd + pool: MaxPoolGrad routing codes [B,H/2,W/2,N/8] (null: not wanted): per pooled element 4 bits = position of the
-                        // first maximum of its 2 x 2 window (row-major) | 4 if that maximum is > 0; a word = 8 consecutive channels
+    unsigned* pbits;    // fwd + pool: MaxPoolGrad routing codes [B][N/4][H/2][W/2] half-words (null: not wanted): per pooled element 4 bits =
+                        // position of the first maximum of its 2 x 2 window (row-major) | 4 if that maximum is > 0; a half-word = a channel quad
     unsigned* mask;     // [workgroups][256 threads]: (out > 0) of each lane's 2 x 2 pixels x 8 columns as 32 bits -- written by the forward
                         // (null: not wanted), read by the data gradient of the NEXT layer instead of relu_src (same shape => same lanes)
     int relu;
@@ -102,7 +102,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(Wino2Args a) {
         const unsigned py = wino_div(pix, g.m_pw), px = pix - py * (unsigned)g.PW;
         const int y = (int)(by * 2u * g.TBH + py) - 1, x = (int)(bx * 2u * g.TBW + px) - 1;
         const bool ok = blk < 4 && gb < (unsigned)g.nblocks && pix < (unsigned)(g.PH * g.PW) && (unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W;
-        const unsigned off = (((b * (unsigned)g.H + (unsigned)y) * (unsigned)g.W + (unsigned)x) * (unsigned)C + ((unsigned)tid & 1u) * 4u) * 4u;
+        // C4 layout [B][C/4][H][W][4]: channel quad 2 h + (tid & 1) of half-phase h is a plane (soffset h * 2 planes)
+        const unsigned off = ((((b * (unsigned)(C >> 2) + ((unsigned)tid & 1u)) * (unsigned)g.H + (unsigned)y) * (unsigned)g.W + (unsigned)x)) * 16u;
         voff[i] = ok ? off : WOOB;
         // (timing only) the patch loads made contiguous over the lanes: what a channel-blocked activation layout would present to the L1
         if (W2_ABL & 32) voff[i] = (unsigned)(((unsigned)tm * 1024u + (unsigned)tid + 256u * i) * 16u) % (unsigned)(g.B * g.H * g.W * C * 4 - 4096);
@@ -129,8 +130,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(Wino2Args a) {
     const int by = (int)wino_div((unsigned)rem, g.m_bx_n), bx = rem - by * g.bx_n;
     const int y0 = (by * g.TBH + tyl) * 2, x0 = (bx * g.TBW + txl) * 2;
     const bool ok00 = blk_ok && y0 < g.H && x0 < g.W, ok01 = ok00 && x0 + 1 < g.W, ok10 = ok00 && y0 + 1 < g.H, ok11 = ok10 && x0 + 1 < g.W;
-    const long p00 = ((long)(b * g.H + y0) * g.W + x0) * N;
-    const long rowN = (long)g.W * N;
+    // output in the C4 layout: the lane's two float4 (ct = 0, 1) are channel quads n0 / 4 + 2 lg + ct = two planes
+    const long pl_f = (long)g.H * g.W * 4;   // floats per channel-quad plane
+    const long p00 = (((long)(b * (N >> 2) + (n0 >> 2) + 2 * lg) * g.H + y0) * g.W + x0) * 4;
+    const long rowN = (long)g.W * 4;
     unsigned mbits = 0xffffffffu;
 
     // [position][column tile]: M_p[n0 + 8 lg + 4 ct + r][tile lj] -- row m = 4 lg + r of column tile ct stands for output channel
@@ -152,8 +155,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(Wino2Args a) {
     }
 
     float4 st[W2_SLOTS];
+    const unsigned plane2_b = (unsigned)g.H * (unsigned)g.W * 32u;   // bytes of two channel-quad planes = the eight channels of a half-phase
     auto gload1 = [&](int hp, int i) {
-        if (i < W2_PSLOTS) st[i] = wbufload(rx, voff[i], (unsigned)hp * 32u);
+        if (i < W2_PSLOTS) st[i] = wbufload(rx, voff[i], (unsigned)hp * plane2_b);
         else st[i] = wbufload(rw, vsrc + (unsigned)(i - W2_PSLOTS) * 4096u, (unsigned)hp * (W2_VHALF * 4));
     };
     auto lstore = [&](int q, int i) {
@@ -250,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(Wino2Args a) {
 #pragma unroll
                 for (int bb = 0; bb < 2; ++bb) {
                     const bool ok = aa == 0 ? (bb == 0 ? ok00 : ok01) : (bb == 0 ? ok10 : ok11);
-                    const float4 m = ok ? *reinterpret_cast<const float4*>(a.aux + p00 + aa * rowN + bb * N + n0 + 8 * lg + 4 * ct) : f4zero();
+                    const float4 m = ok ? *reinterpret_cast<const float4*>(a.aux + p00 + ct * pl_f + aa * rowN + bb * 4) : f4zero();
                     const unsigned bits = (m.x > 0.f ? 1u : 0u) | (m.y > 0.f ? 2u : 0u) | (m.z > 0.f ? 4u : 0u) | (m.w > 0.f ? 8u : 0u);
                     mbits |= bits << (16 * ct + 8 * aa + 4 * bb);
                 }
@@ -276,7 +280,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(Wino2Args a) {
 #undef WSB
 
     // ---- output transform + epilogue: acc[p][ct][r] = M_p[column n0 + 8 lg + 4 ct + r][tile lj]
-    unsigned obits = 0u, pcode = 0u;
+    unsigned obits = 0u;
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
         const int col = n0 + 8 * lg + 4 * ct;
@@ -332,28 +336,30 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(Wino2Args a) {
                     obits |= bits << (16 * ct + 8 * aa + 4 * bb);
                 }
         }
-        if (ok00) *reinterpret_cast<float4*>(a.out + p00 + col) = Y[0][0];
-        if (ok01) *reinterpret_cast<float4*>(a.out + p00 + N + col) = Y[0][1];
-        if (ok10) *reinterpret_cast<float4*>(a.out + p00 + rowN + col) = Y[1][0];
-        if (ok11) *reinterpret_cast<float4*>(a.out + p00 + rowN + N + col) = Y[1][1];
+        float* oq = a.out + p00 + ct * pl_f;
+        if (ok00) *reinterpret_cast<float4*>(oq) = Y[0][0];
+        if (ok01) *reinterpret_cast<float4*>(oq + 4) = Y[0][1];
+        if (ok10) *reinterpret_cast<float4*>(oq + rowN) = Y[1][0];
+        if (ok11) *reinterpret_cast<float4*>(oq + rowN + 4) = Y[1][1];
         if (POOL && ok11) {
             float4 m;
             m.x = fmaxf(fmaxf(Y[0][0].x, Y[0][1].x), fmaxf(Y[1][0].x, Y[1][1].x));
             m.y = fmaxf(fmaxf(Y[0][0].y, Y[0][1].y), fmaxf(Y[1][0].y, Y[1][1].y));
             m.z = fmaxf(fmaxf(Y[0][0].z, Y[0][1].z), fmaxf(Y[1][0].z, Y[1][1].z));
             m.w = fmaxf(fmaxf(Y[0][0].w, Y[0][1].w), fmaxf(Y[1][0].w, Y[1][1].w));
-            *reinterpret_cast<float4*>(a.pool + ((long)(b * (g.H >> 1) + (y0 >> 1)) * (g.W >> 1) + (x0 >> 1)) * N + col) = m;
+            const size_t pp = (((size_t)(b * (N >> 2) + (col >> 2)) * (g.H >> 1) + (y0 >> 1)) * (g.W >> 1) + (x0 >> 1)) * 4;
+            *reinterpret_cast<float4*>(a.pool + pp) = m;
             if (a.pbits) {   // where MaxPoolGrad will send the gradient (vc_maxpool2x2_bwd_bits_f32): first maximum in row-major order, valid if > 0
                 auto code = [](float v00, float v01, float v10, float v11, float mx) -> unsigned {
                     return (v00 == mx ? 0u : v01 == mx ? 1u : v10 == mx ? 2u : 3u) | (mx > 0.f ? 4u : 0u);
                 };
-                pcode |= (code(Y[0][0].x, Y[0][1].x, Y[1][0].x, Y[1][1].x, m.x) | code(Y[0][0].y, Y[0][1].y, Y[1][0].y, Y[1][1].y, m.y) << 4 |
-                          code(Y[0][0].z, Y[0][1].z, Y[1][0].z, Y[1][1].z, m.z) << 8 | code(Y[0][0].w, Y[0][1].w, Y[1][0].w, Y[1][1].w, m.w) << 12) << (16 * ct);
+                const unsigned c16 = code(Y[0][0].x, Y[0][1].x, Y[1][0].x, Y[1][1].x, m.x) | code(Y[0][0].y, Y[0][1].y, Y[1][0].y, Y[1][1].y, m.y) << 4 |
+                                     code(Y[0][0].z, Y[0][1].z, Y[1][0].z, Y[1][1].z, m.z) << 8 | code(Y[0][0].w, Y[0][1].w, Y[1][0].w, Y[1][1].w, m.w) << 12;
+                reinterpret_cast<unsigned short*>(a.pbits)[pp >> 2] = (unsigned short)c16;   // one half-word per (channel quad, pooled pixel)
             }
         }
     }
     if (KIND == W2_FWD && a.mask) a.mask[(size_t)id * 256 + tid] = obits;
-    if (POOL && a.pbits && ok11) a.pbits[(((size_t)(b * (g.H >> 1) + (y0 >> 1)) * (g.W >> 1) + (x0 >> 1)) * N + n0 + 8 * lg) >> 3] = pcode;
 }
 
 // w [3][3][Ci][Co] (HWIO) -> V = G g G^T, G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1], packed

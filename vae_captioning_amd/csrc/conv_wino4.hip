@@ -66,13 +66,13 @@ struct Wino4Geom {
 
 struct Wino4Args {
     Wino4Geom g;
-    const float* x;      // [P, C]
+    const float* x;      // [B][C/4][H][W][4] (the C4 activation layout, vaecap.h)
     const float* wp;     // packed [N/32][C/4][group 2][pq 9][g 4][n 16][pp 4]
-    float* out;          // [P, N]
-    const float* aux;    // fwd: bias [N] or null; dgrad: ReLU source [P, N] or null
-    float* pool;         // fwd: also max_pool2x2(out) [B, H/2, W/2, N] (null: none)
-    unsigned* pbits;     // fwd + pool: MaxPoolGrad routing codes, the format of conv_wino.hip ([B,H/2,W/2,N/8] words, 4 bits per pooled element:
-                         // position of the first maximum of its window | 4 if it is > 0); a lane owns four channels = half a word
+    float* out;          // [B][N/4][H][W][4]
+    const float* aux;    // fwd: bias [N] or null; dgrad: ReLU source, layout of out, or null
+    float* pool;         // fwd: also max_pool2x2(out) [B][N/4][H/2][W/2][4] (null: none)
+    unsigned* pbits;     // fwd + pool: MaxPoolGrad routing codes, the format of conv_wino.hip ([B][N/4][H/2][W/2] half-words, 4 bits per pooled element:
+                         // position of the first maximum of its window | 4 if it is > 0); a lane owns four channels = one half-word
     unsigned* mask;      // [workgroups][256 threads][2]: (out > 0) of each lane's 4 x 4 pixels x 4 channels as 64 bits -- written by the forward
                          // (null: not wanted), read by the data gradient of the NEXT layer instead of the float source (same shape => same lanes)
     int relu;
@@ -146,7 +146,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
         const unsigned by = wino_div(rem, g.m_bx_n), bx = rem - by * (unsigned)g.bx_n;
         const int y = (int)(by * 16u + py) - 1, x = (int)(bx * 16u + px) - 1;
         const bool ok = live && (unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W;
-        voff[j] = ok ? (((b * (unsigned)g.H + (unsigned)y) * (unsigned)g.W + (unsigned)x) * (unsigned)C) * 4u : WOOB;
+        // C4 layout [B][C/4][H][W][4]: the pixel's four channels of phase h are 16 bytes at channel plane h (soffset h * plane bytes);
+        // consecutive lanes = consecutive pixels of a patch row = consecutive 16-byte pieces (288-byte runs: ~3 cache lines per row)
+        voff[j] = ok ? (((b * (unsigned)(C >> 2) * (unsigned)g.H + (unsigned)y) * (unsigned)g.W + (unsigned)x)) * 16u : WOOB;
         if (W4_ABL & 256) voff[j] = (unsigned)((tm * 648 + (int)s) * 16) % (unsigned)(g.B * g.H * g.W * C * 4 - 4096);   // timing only: consecutive lanes, consecutive 16-byte pieces
         pst[j] = s < (unsigned)W4_NPIX ? W4_POFF + (int)blk * W4_BLKF + (int)py * W4_PITCH + (int)px : W4_DUMP + (tid & 15);
     }
@@ -176,8 +178,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
     const int ob = (int)wino_div((unsigned)gboc, g.m_blocks_img), orem = gboc - ob * g.blocks_img;
     const int oby = (int)wino_div((unsigned)orem, g.m_bx_n), obx = orem - oby * g.bx_n;
     const int y0 = oby * 16 + 4 * ty, x0 = obx * 16 + 4 * tx;
-    const long rowN = (long)g.W * N;
-    const long p00 = ((long)(ob * g.H + y0) * g.W + x0) * N + nc0;
+    // output in the C4 layout: this lane's channel quad nc0 / 4 is one plane; a tile row = 64 consecutive bytes
+    const long p00 = (((long)(ob * (N >> 2) + (nc0 >> 2)) * g.H + y0) * g.W + x0) * 4;
     // data gradient: the ReLU mask of the lane's outputs as 64 bits (bit 16 aa + 4 bb + c), from the producer's forward (one 8-byte
     // load) or from the float activation (sixteen loads that overlap the first patch loads)
     unsigned mb0 = 0xffffffffu, mb1 = 0xffffffffu;
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
 #pragma unroll
             for (int bb = 0; bb < 4; ++bb) {
                 const bool ok = blk_ok && y0 + aa < g.H && x0 + bb < g.W;
-                const float4 m = ok ? *reinterpret_cast<const float4*>(a.aux + p00 + aa * rowN + bb * N) : f4zero();
+                const float4 m = ok ? *reinterpret_cast<const float4*>(a.aux + p00 + (aa * g.W + bb) * 4) : f4zero();
                 const unsigned bits = (m.x > 0.f ? 1u : 0u) | (m.y > 0.f ? 2u : 0u) | (m.z > 0.f ? 4u : 0u) | (m.w > 0.f ? 8u : 0u);
                 if (aa < 2) mb0 |= bits << (16 * aa + 4 * bb);
                 else mb1 |= bits << (16 * (aa - 2) + 4 * bb);
@@ -215,7 +217,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
             for (int c = 0; c < 6; ++c) { HA[r][c] = 1.f + lane + r; HB[r][c] = 2.f + lane + c; rr[c] = 0.5f * lane; U[c] = 1.f * lane; }
     }
 
-    auto pload = [&](int i, int hp) { if (!(W4_ABL & (8 | 32))) st[i] = wbufload(rx, voff[i], (unsigned)hp * 16u); };
+    const unsigned plane_b = (unsigned)g.H * (unsigned)g.W * 16u;   // bytes of one channel-quad plane of an image
+    auto pload = [&](int i, int hp) { if (!(W4_ABL & (8 | 32))) st[i] = wbufload(rx, voff[i], (unsigned)hp * plane_b); };
     auto pstore = [&](int i, int pq) {
         if (W4_ABL & 8) return;
         float* d = &smem[pst[i] + pq * W4_PBUF];
@@ -380,7 +383,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
                 if (!(mb & 4u)) v.z = 0.f;
                 if (!(mb & 8u)) v.w = 0.f;
             }
-            if (ok) *reinterpret_cast<float4*>(a.out + p00 + aa * rowN + bb * N) = v;
+            if (ok) *reinterpret_cast<float4*>(a.out + p00 + (aa * g.W + bb) * 4) = v;
         }
     if (KIND == W4_FWD && a.mask) *reinterpret_cast<uint2*>(a.mask + ((size_t)id * 256 + tid) * 2) = make_uint2(ob0, ob1);
     if (POOL) {   // a 4 x 4 tile is 2 x 2 pooling windows: register math, no LDS, no separate pooling pass
@@ -396,7 +399,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
                 m.y = fmaxf(fmaxf(v00.y, v01.y), fmaxf(v10.y, v11.y));
                 m.z = fmaxf(fmaxf(v00.z, v01.z), fmaxf(v10.z, v11.z));
                 m.w = fmaxf(fmaxf(v00.w, v01.w), fmaxf(v10.w, v11.w));
-                const size_t pp = ((size_t)(ob * HP + (y0 >> 1) + pa) * WP + (x0 >> 1) + pc) * N + nc0;
+                const size_t pp = (((size_t)(ob * (N >> 2) + (nc0 >> 2)) * HP + (y0 >> 1) + pa) * WP + (x0 >> 1) + pc) * 4;
                 *reinterpret_cast<float4*>(a.pool + pp) = m;
                 if (a.pbits) {   // where MaxPoolGrad will send the gradient (vc_maxpool2x2_bwd_bits_f32): first maximum in row-major order, valid if > 0
                     auto code = [](float a00, float a01, float a10, float a11, float mx) -> unsigned {
@@ -404,7 +407,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
                     };
                     const unsigned c16 = code(v00.x, v01.x, v10.x, v11.x, m.x) | code(v00.y, v01.y, v10.y, v11.y, m.y) << 4 |
                                          code(v00.z, v01.z, v10.z, v11.z, m.z) << 8 | code(v00.w, v01.w, v10.w, v11.w, m.w) << 12;
-                    reinterpret_cast<unsigned short*>(a.pbits)[pp >> 2] = (unsigned short)c16;   // half-word (pp / 8) * 2 + (channel / 4) % 2
+                    reinterpret_cast<unsigned short*>(a.pbits)[pp >> 2] = (unsigned short)c16;   // one half-word per (channel quad, pooled pixel): [B][N/4][H/2][W/2]
                 }
             }
     }

@@ -12,10 +12,12 @@
 
 namespace vc {
 
+constexpr int WG_XPL = 724, WG_YPL = 516;   // LDS plane pitches (floats) of the x patch (>= 4 * 180) and the dy block (>= 4 * 128)
+
 struct WinoWgArgs {
     WinoGeom g;          // C = input channels (x), N = output channels (dy)
-    const float* x;      // [P, C]
-    const float* dy;     // [P, N]
+    const float* x;      // [B][C/4][H][W][4] (the C4 activation layout, vaecap.h)
+    const float* dy;     // [B][N/4][H][W][4]
     float* ws;           // [split][16][C][N] position sums, then [split][N] bias partials
     int ncb, nnb, nsplit, cps;
 };
@@ -24,7 +26,12 @@ template <int TBH, int TBW>
 __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(WinoWgArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int PW = 2 * TBW + 2, PH = 2 * TBH + 2, DW = 2 * TBW, DH = 2 * TBH, NS = (TBH / 2) * TBW;
-    constexpr int XPF = 180 * 64, BUF = XPF + 128 * 64;   // floats: x patch, dy tile block; two buffers
+    // LDS: per buffer the x halo patch and the dy block as sixteen CHANNEL-QUAD PLANES [quad][pixel][4] -- the staging writes are
+    // 16-byte pieces of consecutive pixels (what the C4 layout delivers: consecutive lanes = consecutive pixels of a patch row), the operand
+    // reads (one float per lane: channel li of 32, ds_read_b32, banks mod 32) are conflict-free because the plane pitches are 4 mod 8 dwords x 4
+    constexpr int NPX = PW * PH, NDY = DW * DH;
+    constexpr int XPL = WG_XPL, YPL = WG_YPL;            // plane pitches in floats (724 = 20 mod 32, 516 = 4 mod 32)
+    constexpr int XPF = 16 * XPL, BUF = XPF + 16 * YPL;   // floats: x patch, dy tile block; two buffers
     static_assert(PW * PH <= 180 && DW * DH <= 128 && NS <= 16 && NS >= 8, "block shape");
     const WinoGeom& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
@@ -39,8 +46,8 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(WinoWgArgs a) {
     int nch = g.nblocks - blk0;
     if (nch > a.cps) nch = a.cps;
 
-    // staging slots: x patch 180 pixels x 16 channel quads = 2880 float4 (slots 0..11 of a thread), dy 128 pixels x 16 quads = 2048
-    // (slots 12..19); slot i of a thread: float4 index tid + 256 i (x) / tid + 256 (i - 12) (dy): pixel index / 16, quad index % 16
+    // staging slots: x patch 16 channel quads x NPX <= 180 pixels = 2880 float4 (slots 0..11 of a thread), dy 16 quads x NDY <= 128 pixels
+    // (slots 12..19); slot i of a thread: float4 index s = tid + 256 i (x) / tid + 256 (i - 12) (dy): quad s / pixels, pixel s % pixels
     float4 st[10];
     int by0 = 0, bx0 = 0, bimg = 0;   // current block to LOAD (uniform)
     auto set_block = [&](int blk) {
@@ -50,26 +57,28 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(WinoWgArgs a) {
     };
     auto gload1 = [&](int i, int k) {   // slot i into st[k]
         if (i < 12) {
-            const int s = tid + 256 * i, pix = s >> 4, quad = s & 15;
+            const int s = tid + 256 * i, quad = s / NPX, pix = s - quad * NPX;
             const int py = pix / PW, px = pix - py * PW;
             const int y = by0 - 1 + py, x = bx0 - 1 + px;
-            const bool ok = s < 180 * 16 && pix < PW * PH && (unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W;
-            const unsigned off = ok ? (unsigned)((((bimg * g.H + y) * g.W + x) * C + cb * 64 + quad * 4) * 4) : WOOB;
+            const bool ok = s < 16 * NPX && (unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W;
+            const unsigned off = ok ? (unsigned)(((((bimg * (C >> 2) + cb * 16 + quad) * g.H + y) * g.W + x)) * 16) : WOOB;
             st[k] = wbufload(rx, off, 0);
         } else {
-            const int s = tid + 256 * (i - 12), pix = s >> 4, quad = s & 15;
+            const int s = tid + 256 * (i - 12), quad = s / NDY, pix = s - quad * NDY;
             const int py = pix / DW, px = pix - py * DW;
             const int y = by0 + py, x = bx0 + px;
-            const bool ok = pix < DW * DH && y < g.H && x < g.W;
-            const unsigned off = ok ? (unsigned)((((bimg * g.H + y) * g.W + x) * N + nb * 64 + quad * 4) * 4) : WOOB;
+            const bool ok = s < 16 * NDY && y < g.H && x < g.W;
+            const unsigned off = ok ? (unsigned)(((((bimg * (N >> 2) + nb * 16 + quad) * g.H + y) * g.W + x)) * 16) : WOOB;
             st[k] = wbufload(ry, off, 0);
         }
     };
     auto lstore1 = [&](int buf, int i, int k) {
         if (i < 12) {
-            if (i < 11 || tid + 256 * i < 180 * 16) *reinterpret_cast<float4*>(&smem[buf * BUF + (tid + 256 * i) * 4]) = st[k];
+            const int s = tid + 256 * i, quad = s / NPX, pix = s - quad * NPX;
+            if (s < 16 * NPX) *reinterpret_cast<float4*>(&smem[buf * BUF + quad * XPL + pix * 4]) = st[k];
         } else {
-            *reinterpret_cast<float4*>(&smem[buf * BUF + XPF + (tid + 256 * (i - 12)) * 4]) = st[k];
+            const int s = tid + 256 * (i - 12), quad = s / NDY, pix = s - quad * NDY;
+            if (s < 16 * NDY) *reinterpret_cast<float4*>(&smem[buf * BUF + XPF + quad * YPL + pix * 4]) = st[k];
         }
     };
 
@@ -82,8 +91,8 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(WinoWgArgs a) {
 
     // operands of one step: ua[p] = U_p[tile][c], eb[p] = E_p[tile][n]; dv / ev: raw reads; tc[j][xi]: vertical transform of patch column j
     float ua[2][16], eb[2][16], dv[4][4], ev[2][2], tc[4][4], tv[2][4];
-    const int xbase = ((2 * lh) * PW) * 64 + cw * 32 + li;          // + buf * BUF + ((4 r + i) * PW + 2 tx + j) * 64
-    const int ybase = XPF + ((2 * lh) * DW) * 64 + nw * 32 + li;    // + buf * BUF + ((4 r + a) * DW + 2 tx + b) * 64
+    const int xbase = ((2 * lh) * PW) * 4 + (cw * 8 + (li >> 2)) * XPL + (li & 3);          // + buf * BUF + ((4 r + i) * PW + 2 tx + j) * 4
+    const int ybase = XPF + ((2 * lh) * DW) * 4 + (nw * 8 + (li >> 2)) * YPL + (li & 3);    // + buf * BUF + ((4 r + a) * DW + 2 tx + b) * 4
     // micro-operation k of preparing step sn (from LDS buffer `buf`) into operand set ob
     auto prep = [&](int buf, int sn, int ob, int k) {
         const int r = sn / TBW, tx = sn - r * TBW;
@@ -92,14 +101,14 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(WinoWgArgs a) {
         if (k < nread) {
             const int idx = fresh ? k : 8 + k, j = idx >> 2, i = idx & 3;
             if (WG_ABL & 2) return;
-            dv[i][j] = smem[buf * BUF + xbase + ((4 * r + i) * PW + 2 * tx + j) * 64];
+            dv[i][j] = smem[buf * BUF + xbase + ((4 * r + i) * PW + 2 * tx + j) * 4];
             return;
         }
         k -= nread;
         if (k < 4) {
             const int aa = k >> 1, bb = k & 1;
             if (WG_ABL & 2) return;
-            ev[aa][bb] = smem[buf * BUF + ybase + ((4 * r + aa) * DW + 2 * tx + bb) * 64];
+            ev[aa][bb] = smem[buf * BUF + ybase + ((4 * r + aa) * DW + 2 * tx + bb) * 4];
             return;
         }
         k -= 4;
@@ -198,7 +207,7 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(WinoWgArgs a) {
     }
 }
 
-constexpr int WINO_WG_LDS_BYTES = 2 * (180 * 64 + 128 * 64) * 4;
+constexpr int WINO_WG_LDS_BYTES = 2 * 16 * (WG_XPL + WG_YPL) * 4;   // 158 720
 
 template <int TBH, int TBW>
 static int launch_wino_wgrad(hipStream_t st, const WinoWgArgs& a) {

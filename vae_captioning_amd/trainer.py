@@ -52,12 +52,14 @@ class VggEngine(object):
         # the weight gradient of layer l and the data-gradient chain (layer l, then l-1 ...) are independent:
         # wgrads run on a side stream so that the tail of one kernel (the last partial round of workgroups)
         # is filled by the other instead of idling the chip
-        # Convolution dispatch ("which kernel runs which layer"):
+        # Convolution dispatch ("which kernel runs which layer").  Activations between conv1_1 and pool5 are in the
+        # C4 layout [B][C/4][H][W][4] (include/vaecap.h); the reference's NHWC order is restored at the fc1 boundary.
         #   conv1_1 (3 -> 64 channels, HBM-bound)      csrc/conv_first.hip
-        #   every other 3x3 layer, all three passes    Winograd F(2x2,3x3) / F(3x3,2x2) in fp32 (csrc/conv_wino.hip, conv_wino_wgrad.hip)
-        #   VC_CONV_WINO=0 (A/B runs, tests)           the direct patch-staged kernels (csrc/conv_patch.hip), same layers
-        #   shapes neither takes                       the implicit-GEMM kernels of csrc/conv.hip (also the independent checker of tests/)
-        self.use_patch = True
+        #   every other 3x3 layer, forward / dgrad     Winograd F(4x4,3x3) (csrc/conv_wino4.hip) where vc_conv3x3_wino4_preferred, else F(2x2,3x3) (conv_wino.hip)
+        #   weight gradient                            Winograd F(3x3,2x2) (csrc/conv_wino_wgrad.hip)
+        #   VC_CONV_WINO=0, or shapes neither takes    the NHWC implicit-GEMM kernels of csrc/conv.hip behind layout conversions (slow; also the
+        #                                              independent checker of tests/)
+        self.use_conv1 = True
         self.use_wino = os.environ.get("VC_CONV_WINO", "1") != "0"
         # Streams: 3 = two half-batch convolution chains + the weight gradients on a third stream (the tail of one launch is filled by
         # another stream's launch; the data-parallel gradient buckets are issued from the weight-gradient stream), 1 = serial
@@ -115,8 +117,7 @@ class VggEngine(object):
             lib, need, H, W = self.lib, 0, 224, 224
             for name, ci, co in spec.VGG_CONV:
                 cie = 4 if ci == 3 else ci
-                need = max(need, lib.vc_conv3x3_fwd_workspace_bytes(nb, H, W, cie, co), lib.vc_conv3x3_dgrad_workspace_bytes(nb, H, W, cie, co),
-                           lib.vc_conv3x3_packed_workspace_bytes(nb, H, W, cie, co, 0), lib.vc_conv3x3_packed_workspace_bytes(nb, H, W, cie, co, 1))
+                need = max(need, lib.vc_conv3x3_fwd_workspace_bytes(nb, H, W, cie, co), lib.vc_conv3x3_dgrad_workspace_bytes(nb, H, W, cie, co))
                 if name in spec.VGG_POOL_AFTER:
                     H, W = H // 2, W // 2
             t = self.tail_ws[key] = torch.empty(max(need, 16) // 4 + 16, dtype=torch.float32, device=self.dev)
@@ -133,14 +134,14 @@ class VggEngine(object):
             fn()
 
     def _pack_weights(self, backward, H=224, W=224, nb=1):
-        """[tap][C/4][N][4] copies of the 3x3 kernels for the patch-staged convolutions (forward layout, and the flipped
+        """Transformed (G g G^T) copies of the 3x3 kernels in the Winograd kernels' operand order (forward layout, and the flipped
         + transposed one of the data gradient when a backward pass follows).  Runs on the weight-gradient stream, which is
         idle during the forward pass: the forward copies first, in layer order, each followed by the event its layer's
         launches wait for (returned as {layer: event}; conv1_1 needs none), then the data-gradient copies, which only the
         backward pass waits for (self.packed_bwd)."""
         self.packed_bwd = None
         self.wino4 = set()   # layers on the F(4x4,3x3) kernels this step
-        if not self.use_patch:
+        if not self.use_wino:
             return None
         lib, S = self.lib, self.store
         main = torch.cuda.current_stream()
@@ -156,17 +157,17 @@ class VggEngine(object):
                 for name, ci, co in spec.VGG_CONV:
                     if ci % 32 == 0:
                         w = S.param(spec.vgg_var_names(name)[0])
-                        if self.use_wino and bool(lib.vc_conv3x3_wino4_preferred(nb, h, w_, ci, co)):
+                        made = True
+                        if bool(lib.vc_conv3x3_wino4_preferred(nb, h, w_, ci, co)):
                             # F(4x4,3x3) where it is the faster form for launches over nb images (every layer of a block between two pools has
                             # the same H x W and at least 64 channels, so a block stays in one family: the ReLU bits pass from layer to layer)
                             self.wino4.add(name)
                             lib.vc_conv3x3_wino4_pack_f32(sh, ci, co, P(w), dgrad, P(self._b(("vpt_" if dgrad else "vp_") + name, (36 * ci * co,))))
-                        elif self.use_wino and bool(lib.vc_conv3x3_wino_supported(1, h, w_, ci, co, dgrad)):
-                            # G g G^T of every filter, in the Winograd kernel's operand order
+                        elif bool(lib.vc_conv3x3_wino_supported(1, h, w_, ci, co, dgrad)):
                             lib.vc_conv3x3_wino_pack_f32(sh, ci, co, P(w), dgrad, P(self._b(("vpt_" if dgrad else "vp_") + name, (16 * ci * co,))))
-                        else:    # direct patch kernels: [tap][C/4][N][4]
-                            lib.vc_conv3x3_pack_f32(sh, ci, co, P(w), dgrad, P(self._b(("wpt_" if dgrad else "wp_") + name, (9 * ci * co,))))
-                        if not dgrad:
+                        else:    # neither family takes the shape: csrc/conv.hip reads the HWIO kernel itself
+                            made = False
+                        if not dgrad and made:
                             evs[name] = torch.cuda.Event()
                             evs[name].record(torch.cuda.current_stream())
                     if name in spec.VGG_POOL_AFTER:
@@ -175,9 +176,6 @@ class VggEngine(object):
                 self.packed_bwd = torch.cuda.Event()
                 self.packed_bwd.record(torch.cuda.current_stream())
         return evs
-
-    def _patch_ok(self, nb, H, W, ci, co, dgrad):
-        return self.use_patch and ci % 32 == 0 and bool(self.lib.vc_conv3x3_patch_supported(nb, H, W, ci, co, dgrad))
 
     def _wino_ok(self, name, nb, H, W, ci, co, dgrad):
         ok = self.lib.vc_conv3x3_wino4_supported if name in self.wino4 else self.lib.vc_conv3x3_wino_supported
@@ -226,14 +224,20 @@ class VggEngine(object):
             self._b(k, a.shape).copy_(torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)))
 
     # ------------------------------------------------------------------ forward
+    def _to_nhwc(self, tag, t, nb, H, W, C):
+        """NHWC copy of the C4 tensor t (fallback path: the kernels of csrc/conv.hip are NHWC)."""
+        out = self._b("nhwc_" + tag, (nb, H, W, C))
+        self.lib.vc_c4_to_nhwc_f32(_stream(), nb, H, W, C, P(t), P(out))
+        return out
+
     def forward(self, images, step=None):
         """images [B, 224, 224, 3] float32 RGB 0..255 on device -> fc2 [B, 4096]."""
         lib, st, S = self.lib, _stream(), self.store
         B, H, W = int(images.shape[0]), int(images.shape[1]), int(images.shape[2])
         self.B = B
-        x = self._b("x0", (B, H, W, 4))
+        x = self._b("x0", (B, H, W, 4))   # NHWC4 == C4 with one channel quad
         lib.vc_vgg_preprocess_f32(st, P(images), B, H, W, P(x))
-        c1 = bool(self.use_patch and lib.vc_conv1_supported(B, H, W))  # conv1_1 through csrc/conv_first.hip (unpadded weights)
+        c1 = bool(self.use_conv1 and self.use_wino and lib.vc_conv1_supported(B, H, W))  # conv1_1 through csrc/conv_first.hip (unpadded weights)
         w4 = self._b("w1_4", (3, 3, 4, 64))
         if not c1:
             lib.vc_pad_dim_f32(st, P(S.param("cnn/conv1_1/weights")), 9, 3, 4, 64, P(w4))
@@ -242,7 +246,7 @@ class VggEngine(object):
         self.mask_geom = {}  # layer name -> (images per launch, launches): forward launches that left their ReLU mask as bits
         # The conv / pool chain of one image is independent of every other image: with two streams the
         # batch is pushed through as two half-batch chains so that the tail of each kernel (its last partial
-        # round of workgroups) overlaps the other chain's kernels.  Halves are contiguous NHWC slices.
+        # round of workgroups) overlaps the other chain's kernels.  Halves are contiguous slices of the leading (image) dimension.
         main = torch.cuda.current_stream()
         side = self.side if (self.side is not None and B % 2 == 0 and B >= 2) else None
         halves = [(0, B // 2, main), (B // 2, B // 2, side)] if side is not None else [(0, B, main)]
@@ -252,9 +256,9 @@ class VggEngine(object):
             wn, bn = spec.vgg_var_names(name)
             cie = 4 if ci == 3 else ci
             w = w4 if ci == 3 else S.param(wn)
-            y = self._b("y_" + name, (B, H, W, co))
+            y = self._b("y_" + name, (B, co // 4, H, W, 4))
             pooled = name in spec.VGG_POOL_AFTER
-            yp = self._b("p_" + name, (B, H // 2, W // 2, co)) if pooled else None
+            yp = self._b("p_" + name, (B, co // 4, H // 2, W // 2, 4)) if pooled else None
             pool_bits = None   # set when every chain's forward of this pooled layer left routing codes
             for ch, (b0, nb, strm) in enumerate(halves):
                 tws = self._chain_ws(ch, nb)
@@ -265,7 +269,7 @@ class VggEngine(object):
                                     lambda: lib.vc_conv1_fwd_f32(sh, nb, H, W, P(x[b0:]), P(S.param(wn)), P(S.param(bn)), P(y[b0:]), 1))
                         continue
                     fl = 2.0 * nb * H * W * 9 * ci * co
-                    if packed is not None and name in packed:   # this layer's packed / transformed weights of this step are ready
+                    if packed is not None and name in packed:   # this layer's transformed weights of this step are ready
                         torch.cuda.current_stream().wait_event(packed[name])
                     if self._wino_ok(name, nb, H, W, cie, co, 0):   # Winograd (calls over 2 GiB are cut into image ranges inside the library)
                         if self.train and not pooled and lib.vc_conv3x3_wino_single_launch_supported(nb, H, W, cie, co):
@@ -286,19 +290,14 @@ class VggEngine(object):
                             self._timed("conv_fwd", fl, lambda: self._wino(name, "fwd_f32")(
                                 sh, nb, H, W, cie, co, P(x[b0:]), P(self.buf["vp_" + name]), P(S.param(bn)), P(y[b0:]), P(yp[b0:]) if pooled else None, 1))
                         continue
-                    wp = self.buf.get("wp_" + name)
-                    if wp is not None and self._patch_ok(nb, H, W, cie, co, 0):   # direct patch-staged kernels (VC_CONV_WINO=0)
-                        if pooled and W % 8 == 0 and H % 4 == 0:  # 2x2 max-pool fused into the epilogue (4 x 8 sub-tile tiling)
-                            self._timed("conv_fwd", fl, lambda: lib.vc_conv3x3_fwd_pool_packed_f32(
-                                sh, nb, H, W, cie, co, P(x[b0:]), P(wp), P(S.param(bn)), P(y[b0:]), P(yp[b0:]), 1, P(tws), tws.numel() * 4))
-                            continue
-                        self._timed("conv_fwd", fl, lambda: lib.vc_conv3x3_fwd_packed_f32(
-                            sh, nb, H, W, cie, co, P(x[b0:]), P(wp), P(S.param(bn)), P(y[b0:]), 1, P(tws), tws.numel() * 4))
-                    else:   # implicit-GEMM kernels of csrc/conv.hip: any shape
-                        self._timed("conv_fwd", fl, lambda: lib.vc_conv3x3_fwd_f32(
-                            sh, nb, H, W, cie, co, P(x[b0:]), P(w), P(S.param(bn)), P(y[b0:]), 1, P(tws), tws.numel() * 4))
-                    if pooled:
-                        lib.vc_maxpool2x2_fwd_f32(sh, nb, H, W, co, P(y[b0:]), P(yp[b0:]))
+                    # NHWC implicit-GEMM kernels of csrc/conv.hip behind layout conversions: any shape (VC_CONV_WINO=0, odd image sizes)
+                    xn = self._to_nhwc("x_%d" % ch, x[b0:], nb, H, W, cie)
+                    yn = self._b("nhwc_y_%d" % ch, (nb, H, W, co))
+                    self._timed("conv_fwd", fl, lambda: lib.vc_conv3x3_fwd_f32(
+                        sh, nb, H, W, cie, co, P(xn), P(w), P(S.param(bn)), P(yn), 1, P(tws), tws.numel() * 4))
+                    lib.vc_nhwc_to_c4_f32(sh, nb, H, W, co, P(yn), P(y[b0:]))
+                    if pooled:   # (B * co / 4 planes of H x W four-channel pixels: the NHWC kernel on C4 data)
+                        lib.vc_maxpool2x2_fwd_f32(sh, nb * (co // 4), H, W, 4, P(y[b0:]), P(yp[b0:]))
             self.acts.append((name, x, H, W, cie, co, w))
             x = y
             if pooled:
@@ -307,9 +306,13 @@ class VggEngine(object):
                 H, W = H // 2, W // 2
         if side is not None:
             main.wait_stream(side)
-        flat = x  # [B, 7, 7, 512] NHWC == [B, 25088] (image_embeddings.py:222)
+        # pool5 in the reference's order: [B, 7, 7, 512] NHWC == [B, 25088] (image_embeddings.py:222); 6.4 MB at 64 images
+        co = int(x.shape[1]) * 4
+        self.pool5 = x
+        flat = self._b("flat", (B, H, W, co))
+        lib.vc_c4_to_nhwc_f32(st, B, H, W, co, P(x), P(flat))
         self.flat = flat
-        F1 = H * W * 512
+        F1 = H * W * co
         fc1 = self._b("fc1", (B, 4096))
         fc1_bytes = 4.0 * (F1 * 4096 + B * F1 + B * 4096)   # the weight matrix (411 MB) + both activations: the product is HBM-bound at B <= 64
         self._timed("hbm_fc1_gemm", fc1_bytes,
@@ -364,13 +367,15 @@ class VggEngine(object):
         fc1_bytes = 4.0 * (F1 * 4096 + B * F1 + B * 4096)
         self._timed("hbm_fc1_gemm", fc1_bytes, lambda: self.gemm(1, 0, F1, 4096, B, self.flat, F1, d1, 4096, S.grad("cnn/fc1/weights"), 4096))
         self.colsum(d1, B, 4096, S.grad("cnn/fc1/biases"))
-        d = self._b("d_pool5", tuple(self.flat.shape))
-        self._timed("hbm_fc1_gemm", fc1_bytes, lambda: self.gemm(0, 1, B, F1, 4096, d1, 4096, S.param("cnn/fc1/weights"), 4096, d, F1))
+        dn = self._b("d_pool5", tuple(self.flat.shape))
+        self._timed("hbm_fc1_gemm", fc1_bytes, lambda: self.gemm(0, 1, B, F1, 4096, d1, 4096, S.param("cnn/fc1/weights"), 4096, dn, F1))
+        d = self._b("d_pool5_c4", tuple(self.pool5.shape))   # back into the convolution layers' C4 layout
+        lib.vc_nhwc_to_c4_f32(st, B, int(dn.shape[1]), int(dn.shape[2]), int(dn.shape[3]), P(dn), P(d))
         if after_fc is not None:
             after_fc()
         dw4 = self._b("dw1_4", (3, 3, 4, 64))
         self._need_ws(max(lib.vc_conv1_wgrad_workspace_bytes(),
-                          max(max(lib.vc_conv3x3_wgrad_workspace_bytes(B, a[2], a[3], a[4], a[5]), lib.vc_conv3x3_wgrad_patch_workspace_bytes(B, a[2], a[3], a[4], a[5]),
+                          max(max(lib.vc_conv3x3_wgrad_workspace_bytes(B, a[2], a[3], a[4], a[5]),
                                   lib.vc_conv3x3_wino_wgrad_workspace_bytes(B, a[2], a[3], a[4], a[5]) if self._wino_wgrad_ok(B, a[2], a[3], a[4], a[5]) else 0)
                               for a in self.acts if a[0] != "P")))
         main = torch.cuda.current_stream()
@@ -387,13 +392,13 @@ class VggEngine(object):
         for li in range(len(self.acts) - 1, -1, -1):
             name, x, H, W, ci, co, w = self.acts[li]
             if name == "P":
-                dx = self._b("dx_%d" % li, (B, H, W, co))
+                dx = self._b("dx_%d" % li, (B, co // 4, H, W, 4))
                 for b0, nb, strm in halves:
                     with torch.cuda.stream(strm):  # + ReluGrad of the conv that made x
                         if w is not None:   # routing codes from the pooled Winograd forward: no read of x
                             lib.vc_maxpool2x2_bwd_bits_f32(_stream(), nb, H, W, co, P(w[b0 * (H // 2) * (W // 2) * (co // 8):]), P(d[b0:]), P(dx[b0:]))
-                        else:
-                            lib.vc_maxpool2x2_bwd_f32(_stream(), nb, H, W, co, P(x[b0:]), P(d[b0:]), P(dx[b0:]), 1)
+                        else:   # (planes of four-channel pixels: the NHWC kernel on C4 data)
+                            lib.vc_maxpool2x2_bwd_f32(_stream(), nb * (co // 4), H, W, 4, P(x[b0:]), P(d[b0:]), P(dx[b0:]), 1)
                 d = dx
                 continue
             wn, bn = spec.vgg_var_names(name)
@@ -402,17 +407,16 @@ class VggEngine(object):
 
             def wgrad(x=x, d=d, wn=wn, bn=bn, ci=ci, co=co, H=H, W=W, fl=fl):
                 sw = _stream()
-                if ci == 4 and self.use_patch and lib.vc_conv1_supported(B, H, W):
+                if ci == 4 and self.use_conv1 and self.use_wino and lib.vc_conv1_supported(B, H, W):
                     self._timed("conv_wgrad", fl, lambda: lib.vc_conv1_wgrad_f32(sw, B, H, W, P(x), P(d), P(S.grad(wn)), P(S.grad(bn)), 0, P(self.ws), self.ws_bytes))
-                elif ci == 4:
-                    self._timed("conv_wgrad", fl, lambda: lib.vc_conv3x3_wgrad_f32(sw, B, H, W, ci, co, P(x), P(d), P(dw4), P(S.grad(bn)), 0, P(self.ws), self.ws_bytes))
-                    lib.vc_pad_dim_f32(sw, P(dw4), 9, 4, 3, 64, P(S.grad(wn)))
-                elif self._wino_wgrad_ok(B, H, W, ci, co):   # Winograd F(3x3,2x2): both operands transformed in registers, K = the 2x2 tiles
+                elif ci != 4 and self._wino_wgrad_ok(B, H, W, ci, co):   # Winograd F(3x3,2x2): both operands transformed in registers, K = the 2x2 tiles
                     self._timed("conv_wgrad", fl, lambda: lib.vc_conv3x3_wino_wgrad_f32(sw, B, H, W, ci, co, P(x), P(d), P(S.grad(wn)), P(S.grad(bn)), 0, P(self.ws), self.ws_bytes))
-                elif self.use_patch and lib.vc_conv3x3_wgrad_patch_supported(B, H, W, ci, co):
-                    self._timed("conv_wgrad", fl, lambda: lib.vc_conv3x3_wgrad_patch_f32(sw, B, H, W, ci, co, P(x), P(d), P(S.grad(wn)), P(S.grad(bn)), 0, P(self.ws), self.ws_bytes))
-                else:
-                    self._timed("conv_wgrad", fl, lambda: lib.vc_conv3x3_wgrad_f32(sw, B, H, W, ci, co, P(x), P(d), P(S.grad(wn)), P(S.grad(bn)), 0, P(self.ws), self.ws_bytes))
+                else:   # csrc/conv.hip on NHWC copies (conv1_1: zero-padded 4-channel weights)
+                    xn, dn_ = self._to_nhwc("wx", x, B, H, W, ci), self._to_nhwc("wd", d, B, H, W, co)
+                    self._timed("conv_wgrad", fl, lambda: lib.vc_conv3x3_wgrad_f32(sw, B, H, W, ci, co, P(xn), P(dn_), P(dw4 if ci == 4 else S.grad(wn)), P(S.grad(bn)), 0,
+                                                                                   P(self.ws), self.ws_bytes))
+                    if ci == 4:
+                        lib.vc_pad_dim_f32(sw, P(dw4), 9, 4, 3, 64, P(S.grad(wn)))
             if wst is not None:
                 wst.wait_stream(main)  # d (this layer's pre-activation gradient) is final on the chain stream(s)
                 if split:
@@ -427,7 +431,7 @@ class VggEngine(object):
                     after_layer[1]()
             if li > 0:
                 prev_is_pool = self.acts[li - 1][0] == "P"
-                dx = self._b("dx_%d" % li, (B, H, W, ci))
+                dx = self._b("dx_%d" % li, (B, ci // 4, H, W, 4))
                 for ch, (b0, nb, strm) in enumerate(halves):
                     tws = self._chain_ws(ch, nb)
                     with torch.cuda.stream(strm):
@@ -442,13 +446,13 @@ class VggEngine(object):
                         elif self._wino_ok(name, nb, H, W, ci, co, 1):
                             self._timed("conv_dgrad", fl * nb / B, lambda: self._wino(name, "dgrad_f32")(
                                 sh, nb, H, W, ci, co, P(d[b0:]), P(self.buf["vpt_" + name]), None if prev_is_pool else P(x[b0:]), P(dx[b0:])))
-                        elif self._patch_ok(nb, H, W, ci, co, 1) and ("wpt_" + name) in self.buf:
-                            wpt = self.buf["wpt_" + name]
-                            self._timed("conv_dgrad", fl * nb / B, lambda: lib.vc_conv3x3_dgrad_packed_f32(
-                                sh, nb, H, W, ci, co, P(d[b0:]), P(wpt), None if prev_is_pool else P(x[b0:]), P(dx[b0:]), P(tws), tws.numel() * 4))
-                        else:
+                        else:   # csrc/conv.hip on NHWC copies
+                            dn_ = self._to_nhwc("d_%d" % ch, d[b0:], nb, H, W, co)
+                            xn = None if prev_is_pool else self._to_nhwc("x_%d" % ch, x[b0:], nb, H, W, ci)
+                            dxn = self._b("nhwc_dx_%d" % ch, (nb, H, W, ci))
                             self._timed("conv_dgrad", fl * nb / B, lambda: lib.vc_conv3x3_dgrad_f32(
-                                sh, nb, H, W, ci, co, P(d[b0:]), P(w), None if prev_is_pool else P(x[b0:]), P(dx[b0:]), P(tws), tws.numel() * 4))
+                                sh, nb, H, W, ci, co, P(dn_), P(w), P(xn), P(dxn), P(tws), tws.numel() * 4))
+                            lib.vc_nhwc_to_c4_f32(sh, nb, H, W, ci, P(dxn), P(dx[b0:]))
                 d = dx
         if split:
             main.wait_stream(side)
