@@ -10,9 +10,9 @@ Workloads (BASELINE.json configs):
         -> global batch 512 on 8 GPUs (weak scaling).
   cfg2: Normal CVAE, precomputed 4096-d features, 256 images (1280 rows) per GPU.
   cfg3: AG-CVAE with cluster vectors, 256 images per GPU.   cfg1: LSTM baseline, 32 images.
-A "step" = one pass of the whole hot path over one batch.  One process per GPU; for N > 1
-launch with torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the env).
-Prints ONE JSON line on rank 0.
+A "step" = one pass of the whole hot path over one batch.  One process per GPU: under
+torch.distributed.run the ranks read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the env; a bare
+`python bench.py --gpus N` (N > 1, no WORLD_SIZE) starts the N ranks itself.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -157,8 +157,8 @@ def main():
                          "dominant kernels can be bracketed by HIP events inside the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--strong-n1", type=int, default=1,
-                    help="cfg4 at N = 1 (weak): after the timed region also run the 512-image GLOBAL batch on this one GPU (1 warm-up + 3 timed "
-                         "steps, ~1 s) and report it as `strong_n1` -- SURVEY.md section 8d's single-GPU point of the strong-scaling curve")
+                    help="cfg4 at N = 1 (weak): after the timed region also run the 512-image GLOBAL batch on this one GPU (3 warm-up + 10 timed "
+                         "steps, ~3 s) and report it as `strong_n1` -- SURVEY.md section 8d's single-GPU point of the strong-scaling curve")
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--images-per-gpu", type=int, default=0, help="override the workload's images per GPU (sweeps; the default is BASELINE's)")
     ap.add_argument("--fresh-batch", type=int, default=0, metavar="K",
@@ -172,6 +172,8 @@ def main():
     ap.add_argument("--variable-len", action="store_true", help="caption lengths ~ clip(N(11,3), 6, 20) instead of all 20 (secondary line)")
     ap.add_argument("--num-captions", type=int, default=0, help="captions per image (secondary line nc = 1; default: the reference's 5)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args.gpus)
 
     import torch
     import torch.distributed as dist
@@ -181,7 +183,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node %d, or without a launcher)" % (args.gpus, world, args.gpus))
     # one process per GPU.  (VC_DIST_BACKEND=gloo lets two ranks share ONE GPU: used only by the
     # single-GPU test of the N > 1 code path, tests/test_gpu_cli.py.)
     backend = os.environ.get("VC_DIST_BACKEND", "nccl")
@@ -351,7 +354,24 @@ def main():
         dist.destroy_process_group()
 
 
-def strong_n1_point(args, lib, w, vocab, steps=3, warmup=1):
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU under torch.distributed.run,
+    rendezvous on 127.0.0.1 at a free port) with the same arguments; rank 0's JSON line is the only thing on stdout, the exit code is
+    the launcher's."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def strong_n1_point(args, lib, w, vocab, steps=10, warmup=3):
     """The 512-image global batch of cfg4 on ONE GPU (the N = 1 point of the strong-scaling curve): a fresh
     Trainer at 8 x the per-GPU batch, `warmup` untimed + `steps` timed steps in the same process as the headline line."""
     import torch

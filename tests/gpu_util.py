@@ -85,3 +85,12 @@ def dev_c4(x, dtype=None):
 def host_c4(t, shape):
     """device tensor holding a C4 activation -> NHWC numpy array of `shape` [B,H,W,C]."""
     return from_c4(host(t), shape)
+
+
+def grads_only(tr):
+    """Trainer.gall with the two REPORTING scalars of the data-parallel step (ce_num, kl_sum: tail slots 1 and 2, written only when
+    collectives are on) zeroed -- what must be identical between a collective and a collective-free step."""
+    g = tr.gall.clone()
+    n = tr.cap.store.n
+    g[n + 1:n + 3] = 0
+    return g

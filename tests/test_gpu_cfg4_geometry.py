@@ -277,3 +277,50 @@ def test_cfg4_step_on_three_streams_equals_one_stream_bit_for_bit(lib):
     for i, what in ((1, "gradients"), (2, "caption parameters"), (3, "VGG16 parameters")):
         assert torch.equal(res[0][i], res[1][i]), "%s differ: max |d| %.3e" % (what, float((res[0][i] - res[1][i]).abs().max()))
     assert float(res[0][1].abs().max()) > 0
+
+
+def test_step_at_168_images_one_stream_cut_launches_equals_three_streams(lib):
+    """A Trainer step whose conv1_x tensors exceed 2 GiB (168 images x 224 x 224 x 64 x 4 B = 2.16 GB), the geometry of the
+    512-image `strong_n1` step of bench.py: on ONE stream the conv1_1 / conv1_2 calls are cut into launches over image ranges by the
+    library and conv1_2's data gradient takes its ReLU mask from the float activation (the mask bits are per tile of ONE launch);
+    on three streams the same 168 images run as two 84-image chains: single launches, mask bits.  An image's tiles do not depend on
+    the launch it is in: the losses and the whole caption-side gradient (it hangs on fc2 of every image) are identical bit for
+    bit, and so is the data-gradient chain -- the convolution weight gradients sum image ranges in another order: 1e-5 of their
+    maximum per variable."""
+    from vae_captioning_amd import spec, synth
+    from vae_captioning_amd.trainer import Trainer
+    from vae_captioning_amd.utils.parameters import Parameters
+    p = Parameters()
+    p.fine_tune, p.batch_size = True, 168
+    V, T, B = 2000, 12, 168
+    assert B * 224 * 224 * 64 * 4 > 2 ** 31 and lib.vc_conv3x3_wino_single_launch_supported(B, 224, 224, 64, 64) == 0
+    rng = np.random.default_rng(168)
+    batch = synth.make_batch(rng, B, p.num_captions, T, V, images=True)
+    P0 = {**spec.init_caption_params(p, V, seed=1), **spec.init_vgg_params(seed=2)}
+    res = []
+    old = os.environ.get("VC_VGG_STREAMS")
+    try:
+        for streams in ("1", "3"):
+            os.environ["VC_VGG_STREAMS"] = streams
+            tr = Trainer(p, V, lib=lib, seed=23, wgrad_stream=streams == "3")
+            tr.load_state_dict(P0)
+            tr.set_batch(batch)
+            tr.train_step()
+            torch.cuda.synchronize()
+            res.append((tr.losses(), tr.gall.clone(), tr.n_cap, {n: tr.vgg.store.grad(n).clone() for n in tr.vgg.store.names()}))
+            del tr
+            torch.cuda.empty_cache()
+    finally:
+        if old is None:
+            os.environ.pop("VC_VGG_STREAMS", None)
+        else:
+            os.environ["VC_VGG_STREAMS"] = old
+    (l1, g1, n_cap, v1), (l3, g3, _, v3) = res
+    assert l1 == l3 and all(np.isfinite(l1)), (l1, l3)
+    assert torch.equal(g1[:n_cap], g3[:n_cap]), "caption-side gradients differ"
+    for n in v1:
+        if "fc" in n:      # fc1 / fc2: one GEMM over all 168 rows in both schedules
+            assert torch.equal(v1[n], v3[n]), n
+        else:
+            _maxerr(v1[n], v3[n], 1e-5, n)
+    assert float(v1["cnn/conv1_1/weights"].abs().max()) > 0

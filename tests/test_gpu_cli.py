@@ -145,6 +145,51 @@ def test_reference_call_sequence_with_arrays_as_arguments(lib, kw):
         np.testing.assert_array_equal(a[k], b2[k], err_msg=k)
 
 
+def test_facade_arrays_refilled_in_place_and_direct_set_batch_between(lib):
+    """session.bind uploads what the facades hold at EVERY step: (1) a caller that refills preallocated arrays in place trains on
+    the new contents (object identity says nothing), (2) a direct Trainer.set_batch between two facade steps (a validation batch)
+    does not leave that batch resident for the next facade step, (3) facades rebuilt with None forget the earlier arrays."""
+    from vae_captioning_amd import layers
+    rng = np.random.default_rng(9)
+    p1, p2 = _params(prior="Normal"), _params(prior="Normal")
+    V = 90
+    P0 = spec.init_caption_params(p1, V, seed=4)
+    bs = [synth.make_batch(rng, 3, 2, 6, V, variable_len=True, feature_size=48) for _ in range(3)]
+    ref = Trainer(p1, V, lib=lib, seed=5)
+    ref.load_state_dict(P0)
+    want = []
+    for b in (bs[0], bs[1], bs[0]):
+        ref.set_batch(b)
+        ref.train_step()
+        want.append(ref.losses())
+    tr = session.get(p2)
+    tr.cap.seed = 5
+    tr.load_state_dict(P0)
+    hold = {k: np.array(bs[0][k]) for k in ("features", "cap_enc", "cap_dec", "lengths")}   # the caller's preallocated arrays
+    images_fv = layers.dense(hold["features"], p2.embed_size, name="imf_emb", params=p2)
+    enc = Encoder(images_fv, hold["cap_enc"], hold["lengths"], p2)
+    dec = Decoder(images_fv, hold["cap_dec"], hold["lengths"], p2, None)
+    optimize, _, _ = optimizers.non_cnn_optimizer(None, p2)
+
+    def step():
+        z, _, _ = enc.q_net()
+        dec.px_z_fi({"z": z})
+        tr.cap.fw_loss()
+        optimize()
+        return tr.losses()
+    got = [step()]
+    for k in hold:                      # (1) refill in place: the same ndarray objects, other contents
+        hold[k][...] = bs[1][k]
+    got.append(step())
+    tr.set_batch(bs[2])                 # (2) somebody uploads another batch directly ...
+    for k in hold:
+        hold[k][...] = bs[0][k]         # ... and the facades' arrays go back to the first contents
+    got.append(step())
+    assert got == want, (got, want)
+    Encoder(None, None, None, p2)       # (3)
+    assert "cap_enc" not in session.staged(p2) and "lengths" not in session.staged(p2)
+
+
 def test_facades_refuse_incomplete_or_embedded_inputs(lib):
     from vae_captioning_amd import layers
     p = _params(prior="Normal")
@@ -252,6 +297,25 @@ def test_bench_two_ranks_through_torchrun_on_one_gpu(tmp_path):
     assert "libvaecap communicator not available on every rank" in r.stdout and "ncclCommInitRank failed" in r.stdout
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert d["n_gpus"] == 2 and np.isfinite(d["final_losses"]["rec_loss"]) and d["data_parallel"]["collectives"].startswith("torch.distributed")
+
+
+def test_bench_gpus_2_without_a_launcher(tmp_path):
+    """`python bench.py --gpus 2 ...` with no torchrun wrapper and no WORLD_SIZE: bench.py starts its two ranks itself
+    (bench.self_launch), rank 0 prints the ONE JSON line, exit code 0.  Two ranks share the one GPU over gloo."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(PYTHONPATH=ROOT, VC_DIST_BACKEND="gloo")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "cfg4",
+           "--images-per-gpu", "2", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=tmp_path, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["config"]["global_caption_rows"] == 20
+    assert d["value"] > 0 and np.isfinite(d["final_losses"]["rec_loss"])
+    # a launcher whose world size disagrees with --gpus is an error message, not a traceback
+    r = subprocess.run(cmd, cwd=tmp_path, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "--gpus 2 but WORLD_SIZE=1" in r.stderr
 
 
 def test_gen_caption_cli_single_image(tmp_path, lib):

@@ -34,8 +34,11 @@ class FakeGroup(object):
         self.world = world
         self.bar = threading.Barrier(world)
         self.slot = {}
+        self.calls = {r: [] for r in range(world)}   # per rank: (collective, elements) in issue order
 
     def hooks(self, rank):
+        log = self.calls[rank]
+
         def exchange(t):
             self.slot[rank] = t.clone()
             self.bar.wait()
@@ -44,12 +47,15 @@ class FakeGroup(object):
             return parts
 
         def reduce_fn(t):
+            log.append(("all_reduce", t.numel()))
             t.copy_(sum(exchange(t)))
 
         def gather_fn(out, inp):
+            log.append(("all_gather", inp.numel()))
             out.copy_(torch.cat(exchange(inp), 0).view_as(out))
 
         def rscatter_fn(out, inp):
+            log.append(("reduce_scatter", out.numel()))
             n = out.shape[0]
             out.copy_(sum(p[rank * n:(rank + 1) * n] for p in exchange(inp)))
         return reduce_fn, gather_fn, rscatter_fn
@@ -99,6 +105,12 @@ def test_two_emulated_ranks_equal_the_global_batch_oracle(lib, q1_mode, prior):
     [t.start() for t in th]
     [t.join() for t in th]
     assert not errs, errs
+    # the collectives of ONE data-parallel step: the flat gradient all-reduce (ce_num / kl_sum / sum ||dX||^2 in its tail) + either
+    # the label count on its own (tower mix) or ONE all-gather of [mean | std | count] and ONE reduce-scatter of [dmean | dstd]
+    N, L = B * p.num_captions // world, p.latent_size
+    want = ([("all_reduce", 1), ("all_reduce", trs[0].gall.numel())] if q1_mode == "tower" else
+            [("all_gather", 2 * N * L + 4), ("reduce_scatter", 2 * N * L), ("all_reduce", trs[0].gall.numel())])
+    assert fg.calls[0] == want and fg.calls[1] == want, fg.calls
     G = trs[0].cap.grads_dict()  # the all-reduced gradient, identical on both replicas
     for k, g in ref.grads.items():
         assert np.abs(G[k] - g).max() <= 2e-4 * (np.abs(g).max() + 1e-12), k

@@ -138,6 +138,42 @@ def test_fine_tune_step_matches_oracle(lib):
         assert rel_l2(new[n] - PV[n], PVn[n] - PV[n]) < 2e-2, (n, rel_l2(new[n] - PV[n], PVn[n] - PV[n]), upd)
 
 
+def test_cached_weight_norm_is_dropped_when_somebody_else_writes_the_parameters(lib):
+    """The Adam update of the cnn/* variables leaves per-block sums of w^2 for the next step's regulariser term (no second pass over
+    0.54 GB).  The cache must be USED on an undisturbed run, and dropped as soon as the parameters are written behind the
+    optimiser's back (store.p.copy_, a view's in-place edit, load_state_dict): the next step's reported loss then carries the new
+    weights' norm."""
+    p = Parameters()
+    p.fine_tune, p.num_captions, p.gen_z_samples = True, 2, 4
+    V, B, T = 300, 1, 5
+    rng = np.random.default_rng(6)
+    batch = synth.make_batch(rng, B, p.num_captions, T, V, images=True, variable_len=True)
+    tr = Trainer(p, V, lib=lib, seed=3)
+    tr.load_state_dict({**spec.init_caption_params(p, V, seed=1), **spec.init_vgg_params(seed=3)})
+    tr.set_batch(batch)
+    tr.train_step()
+    vg = tr.vgg
+    assert vg.w2_valid and vg.store.p._version == vg._w2_version      # nothing in a step writes the parameters through torch
+    tr.train_step()
+    assert vg.w2_valid and vg.store.p._version == vg._w2_version
+    red = torch.zeros(2, device="cuda")
+
+    def both():   # (cached or recomputed by reg_sumsq, always recomputed here)
+        vg.reg_sumsq(red.data_ptr())
+        torch.cuda.synchronize()
+        return float(red[0].item()), float((vg.store.p.double() ** 2).sum().item())
+    got, want = both()
+    assert abs(got - want) <= 1e-5 * want
+    vg.store.param("cnn/fc1/weights").mul_(1.5)                        # an edit through a view of the flat buffer
+    got, want2 = both()
+    assert want2 > 1.2 * want and abs(got - want2) <= 1e-5 * want2, (got, want2, want)
+    tr.train_step()                                                    # the next Adam update makes the cache valid again
+    assert vg.w2_valid and vg.store.p._version == vg._w2_version
+    vg.store.p.copy_(vg.store.p * 0.5)
+    got, want3 = both()
+    assert abs(got - want3) <= 1e-5 * want3 and want3 < 0.3 * want2
+
+
 def test_fallback_kernels_without_the_winograd_path(lib, monkeypatch):
     """use_wino = False: every layer through the NHWC implicit-GEMM kernels of csrc/conv.hip behind layout conversions (conv1_1 on zero-padded
     4-channel weights, separate max-pool launches) -- the path taken for geometries the Winograd / conv1 kernels do not support, and an

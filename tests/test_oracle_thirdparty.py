@@ -254,3 +254,93 @@ def test_crc32c_matches_an_independent_implementation():
         data = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
         assert tb.crc32c(data) == bitwise(data)
     assert tb.crc32c(bytes(32)) == 0x8a9136aa and tb.crc32c(b"\xff" * 32) == 0x62a8ab43 and tb.crc32c(bytes(range(32))) == 0x46dd794e
+
+
+def test_reader_on_a_checkpoint_written_by_an_independent_writer(tmp_path):
+    """f3 (main.py:186-191, gen_caption.py:113-115): a V2 checkpoint (`.index` + `.data-00000-of-00001`) of the reference's variable
+    names WRITTEN HERE without tf_bundle's writer -- BundleHeaderProto / BundleEntryProto serialised by google.protobuf from the
+    published schema, the index as a LevelDB table assembled per table_format.md the way TensorFlow's TableBuilder does it (keys
+    prefix-compressed against their predecessor, a restart point every 16 entries, several data blocks, index-block keys = the last
+    key of each block, which the format allows in place of a shortest separator) -- and read back by tf_bundle.read_bundle /
+    list_bundle / latest_checkpoint.  What this pins: the READER follows the published formats beyond what its own writer emits
+    (shared key prefixes, multi-restart blocks).  What it does not: no file here was written by TensorFlow itself (absent from this
+    image) -- "self-consistent + proto-exact + format-spec reader", nothing more."""
+    import struct
+    from vae_captioning_amd import spec, tf_bundle as tb
+    from vae_captioning_amd.utils.parameters import Parameters
+    Header, Entry = _bundle_messages()
+    p = Parameters()
+    p.prior, p.use_c_v = "Normal", False
+    p.embed_size, p.encoder_hidden, p.decoder_hidden, p.latent_size, p.gen_z_samples, p.cnn_feature_size = 8, 32, 32, 5, 3, 16
+    rng = np.random.default_rng(11)
+    tensors = {n: rng.standard_normal(s).astype(np.float32) for n, s in spec.caption_variables(p, 37)}
+    tensors["global_step"] = np.array(1234, np.int64)                         # a scalar, another dtype
+    names = sorted(tensors, key=lambda s: s.encode())
+    assert len(names) > 16                                                    # more than one restart interval
+    # ---- data file + entries
+    u32 = lambda v: struct.pack("<I", v)
+    DT = {np.dtype(np.float32): 1, np.dtype(np.int64): 9}
+    items, blob = [], b""
+    h = Header()
+    h.num_shards = 1
+    h.version.producer = 1
+    items.append((b"", h.SerializeToString(deterministic=True)))
+    for n in names:
+        a = tensors[n]
+        e = Entry()
+        e.dtype = DT[a.dtype]
+        e.shape.SetInParent()
+        for s in a.shape:
+            e.shape.dim.add().size = s
+        e.offset, e.size, e.crc32c = len(blob), a.nbytes, tb.mask_crc(tb.crc32c(a.tobytes()))
+        blob += a.tobytes()
+        items.append((n.encode(), e.SerializeToString(deterministic=True)))
+
+    def varint(v):
+        out = b""
+        while v >= 128:
+            out += bytes([v & 127 | 128])
+            v >>= 7
+        return out + bytes([v])
+
+    def block(entries, interval=16):
+        body, restarts, prev = b"", [], b""
+        for i, (k, v) in enumerate(entries):
+            shared = 0
+            if i % interval == 0:
+                restarts.append(len(body))
+            else:
+                while shared < min(len(k), len(prev)) and k[shared] == prev[shared]:
+                    shared += 1
+            body += varint(shared) + varint(len(k) - shared) + varint(len(v)) + k[shared:] + v
+            prev = k
+        return body + b"".join(u32(r) for r in restarts) + u32(len(restarts))
+
+    out, index_entries = b"", []
+
+    def emit(blk):
+        nonlocal out
+        off = len(out)
+        out += blk + b"\x00" + u32(tb.mask_crc(tb.crc32c(blk + b"\x00")))
+        return varint(off) + varint(len(blk))
+    per = 20                                                                  # entries per data block: two restarts in a block
+    for i in range(0, len(items), per):
+        chunk = items[i:i + per]
+        assert any(a[0][:4] == b[0][:4] for a, b in zip(chunk[1:], chunk[2:]))   # keys that share a prefix with their predecessor
+        index_entries.append((chunk[-1][0], emit(block(chunk))))
+    meta = emit(block([]))
+    idx = emit(block(index_entries, interval=1))
+    footer = meta + idx
+    out += footer + b"\x00" * (40 - len(footer)) + bytes.fromhex("57fb808b247547db")
+    prefix = str(tmp_path / "model.ckpt")
+    open(prefix + ".index", "wb").write(out)
+    open(prefix + ".data-00000-of-00001", "wb").write(blob)
+    open(tmp_path / "checkpoint", "w").write('model_checkpoint_path: "model.ckpt"\nall_model_checkpoint_paths: "model.ckpt"\n')
+    # ---- the product's reader
+    assert tb.latest_checkpoint(str(tmp_path)) == prefix
+    header, entries = tb.list_bundle(prefix)
+    assert header["num_shards"] == 1 and sorted(entries, key=lambda s: s.encode()) == names
+    got = tb.read_bundle(prefix)
+    for n in names:
+        assert got[n].dtype == tensors[n].dtype and got[n].shape == tensors[n].shape and np.array_equal(got[n], tensors[n]), n
+    assert "decoder/rnn_logits/kernel" in got and got["global_step"] == 1234

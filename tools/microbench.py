@@ -132,65 +132,6 @@ def conv():
             print("conv%s %-10s B=%d H=%3d %3d->%3d: %8.3f ms  %6.1f TFLOP/s" % (name, nm, B, H, ci, co, med, fl / med))
 
 
-def convp():
-    """patch-staged forward / data gradient (conv_patch.hip) against the implicit-GEMM kernels (conv.hip), VGG16 layer shapes"""
-    for B in (64, 32):
-        for (name, H, ci, co) in [("1_2", 224, 64, 64), ("2_1", 112, 64, 128), ("2_2", 112, 128, 128), ("3_1", 56, 128, 256), ("3_2", 56, 256, 256),
-                                  ("4_1", 28, 256, 512), ("4_2", 28, 512, 512), ("5_2", 14, 512, 512)]:
-            x, w, bias = rnd(B, H, H, ci), rnd(3, 3, ci, co), rnd(co)
-            y, dx = torch.empty(B, H, H, co, device="cuda"), torch.empty(B, H, H, ci, device="cuda")
-            dy = rnd(B, H, H, co)
-            wp, wpt = torch.empty(9 * ci * co, device="cuda"), torch.empty(9 * ci * co, device="cuda")
-            lib.vc_conv3x3_pack_f32(st(), ci, co, P(w), 0, P(wp))
-            lib.vc_conv3x3_pack_f32(st(), ci, co, P(w), 1, P(wpt))
-            tw = torch.empty(max(lib.vc_conv3x3_fwd_workspace_bytes(B, H, H, ci, co), lib.vc_conv3x3_dgrad_workspace_bytes(B, H, H, ci, co),
-                                 lib.vc_conv3x3_packed_workspace_bytes(B, H, H, ci, co, 0), lib.vc_conv3x3_packed_workspace_bytes(B, H, H, ci, co, 1), 16) // 4 + 4, device="cuda")
-            tb = tw.numel() * 4 if os.environ.get("VC_NO_TAIL") != "1" else 0
-            fl = 2e-9 * B * H * H * 9 * ci * co
-            res = {}
-            for nm, fn in (("fwd", lambda: lib.vc_conv3x3_fwd_f32(st(), B, H, H, ci, co, P(x), P(w), P(bias), P(y), 1, P(tw), tb)),
-                           ("fwd-patch", lambda: lib.vc_conv3x3_fwd_packed_f32(st(), B, H, H, ci, co, P(x), P(wp), P(bias), P(y), 1, P(tw), tb)),
-                           ("dgrad", lambda: lib.vc_conv3x3_dgrad_f32(st(), B, H, H, ci, co, P(dy), P(w), P(x), P(dx), P(tw), tb)),
-                           ("dgrad-patch", lambda: lib.vc_conv3x3_dgrad_packed_f32(st(), B, H, H, ci, co, P(dy), P(wpt), P(x), P(dx), P(tw), tb)),
-                           ("pack", lambda: lib.vc_conv3x3_pack_f32(st(), ci, co, P(w), 1, P(wpt)))):
-                med, mn = timeit(fn, reps=5)
-                res[nm] = med
-                print("conv%s %-12s B=%d H=%3d %3d->%3d: %8.3f ms  %6.1f TFLOP/s" % (name, nm, B, H, ci, co, med, fl / med), flush=True)
-            print("conv%s B=%d speed-up fwd %.3f dgrad %.3f" % (name, B, res["fwd"] / res["fwd-patch"], res["dgrad"] / res["dgrad-patch"]), flush=True)
-
-
-def wino():
-    """Winograd F(2x2,3x3) forward / data gradient (conv_wino.hip) against the patch-staged direct kernels, VGG16 layer shapes at 64 images;
-    TFLOP/s are ALGORITHMIC (direct-convolution flops / time)"""
-    B = 64
-    for (name, H, ci, co) in [("1_2", 224, 64, 64), ("2_1", 112, 64, 128), ("2_2", 112, 128, 128), ("3_1", 56, 128, 256), ("3_2", 56, 256, 256),
-                              ("4_1", 28, 256, 512), ("4_2", 28, 512, 512), ("5_2", 14, 512, 512)]:
-        x, w, bias = rnd(B, H, H, ci), rnd(3, 3, ci, co), rnd(co)
-        y, dx = torch.empty(B, H, H, co, device="cuda"), torch.empty(B, H, H, ci, device="cuda")
-        yp = torch.empty(B, H // 2, H // 2, co, device="cuda")
-        dy = rnd(B, H, H, co)
-        wp, wpt = torch.empty(9 * ci * co, device="cuda"), torch.empty(9 * ci * co, device="cuda")
-        vp, vpt = torch.empty(16 * ci * co, device="cuda"), torch.empty(16 * ci * co, device="cuda")
-        lib.vc_conv3x3_pack_f32(st(), ci, co, P(w), 0, P(wp))
-        lib.vc_conv3x3_pack_f32(st(), ci, co, P(w), 1, P(wpt))
-        lib.vc_conv3x3_wino_pack_f32(st(), ci, co, P(w), 0, P(vp))
-        lib.vc_conv3x3_wino_pack_f32(st(), ci, co, P(w), 1, P(vpt))
-        tw = torch.empty(max(lib.vc_conv3x3_packed_workspace_bytes(B, H, H, ci, co, 0), lib.vc_conv3x3_packed_workspace_bytes(B, H, H, ci, co, 1), 16) // 4 + 4, device="cuda")
-        tb = tw.numel() * 4
-        fl = 2e-9 * B * H * H * 9 * ci * co
-        res = {}
-        for nm, fn in (("fwd-patch", lambda: lib.vc_conv3x3_fwd_packed_f32(st(), B, H, H, ci, co, P(x), P(wp), P(bias), P(y), 1, P(tw), tb)),
-                       ("fwd-wino", lambda: lib.vc_conv3x3_wino_fwd_f32(st(), B, H, H, ci, co, P(x), P(vp), P(bias), P(y), None, 1)),
-                       ("fwd-wino-pool", lambda: lib.vc_conv3x3_wino_fwd_f32(st(), B, H, H, ci, co, P(x), P(vp), P(bias), P(y), P(yp), 1)),
-                       ("dgrad-patch", lambda: lib.vc_conv3x3_dgrad_packed_f32(st(), B, H, H, ci, co, P(dy), P(wpt), P(x), P(dx), P(tw), tb)),
-                       ("dgrad-wino", lambda: lib.vc_conv3x3_wino_dgrad_f32(st(), B, H, H, ci, co, P(dy), P(vpt), P(x), P(dx))),
-                       ("wino-pack", lambda: lib.vc_conv3x3_wino_pack_f32(st(), ci, co, P(w), 1, P(vpt)))):
-            med, mn = timeit(fn, reps=5)
-            res[nm] = med
-            print("conv%s %-13s B=%d H=%3d %3d->%3d: %8.3f ms  %6.1f TFLOP/s" % (name, nm, B, H, ci, co, med, fl / med), flush=True)
-        print("conv%s speed-up fwd %.3f dgrad %.3f" % (name, res["fwd-patch"] / res["fwd-wino"], res["dgrad-patch"] / res["dgrad-wino"]), flush=True)
-
-
 def winoab():
     """Winograd forward / data gradient only, VGG16 layer shapes at 64 and 32 images (round 3 A/B: profiles/r03_wino_fwd_dgrad_round2_kernel.txt keeps the round-2 32x32x2 kernel's
     numbers from the same program); algorithmic TFLOP/s"""
@@ -242,59 +183,19 @@ def winowq():
 
 
 def winow():
-    """Winograd F(3x3,2x2) weight gradient against the patch-staged direct kernel, VGG16 layer shapes at 64 images (algorithmic TFLOP/s)"""
+    """Winograd F(3x3,2x2) weight gradient, VGG16 layer shapes at 64 images (algorithmic TFLOP/s); the last line sums the twelve layers"""
     B = 64
+    tot = 0.0
     for (name, H, ci, co) in [("1_2", 224, 64, 64), ("2_1", 112, 64, 128), ("2_2", 112, 128, 128), ("3_1", 56, 128, 256), ("3_2", 56, 256, 256),
                               ("4_1", 28, 256, 512), ("4_2", 28, 512, 512), ("5_2", 14, 512, 512)]:
         x, dy, bias = rnd(B, H, H, ci), rnd(B, H, H, co), rnd(co)
         dw = torch.empty(3, 3, ci, co, device="cuda")
-        ws = torch.empty(max(lib.vc_conv3x3_wgrad_patch_workspace_bytes(B, H, H, ci, co), lib.vc_conv3x3_wino_wgrad_workspace_bytes(B, H, H, ci, co)) // 4 + 4, device="cuda")
+        ws = torch.empty(lib.vc_conv3x3_wino_wgrad_workspace_bytes(B, H, H, ci, co) // 4 + 4, device="cuda")
         fl = 2e-9 * B * H * H * 9 * ci * co
-        res = {}
-        for nm, fn in (("wgrad-patch", lambda: lib.vc_conv3x3_wgrad_patch_f32(st(), B, H, H, ci, co, P(x), P(dy), P(dw), P(bias), 0, P(ws), ws.numel() * 4)),
-                       ("wgrad-wino", lambda: lib.vc_conv3x3_wino_wgrad_f32(st(), B, H, H, ci, co, P(x), P(dy), P(dw), P(bias), 0, P(ws), ws.numel() * 4))):
-            med, mn = timeit(fn, reps=5)
-            res[nm] = med
-            print("conv%s %-12s B=%d H=%3d %3d->%3d: %8.3f ms  %6.1f TFLOP/s" % (name, nm, B, H, ci, co, med, fl / med), flush=True)
-        print("conv%s speed-up wgrad %.3f" % (name, res["wgrad-patch"] / res["wgrad-wino"]), flush=True)
-
-
-def convsweep():
-    """tile-count sweep of the patch forward kernel (conv4_2 / conv3_2 shapes, batch varied): how launch time depends on
-    tiles / resident workgroups, with (tail) and without (single) the K-split tail launch"""
-    for (H, ci, co) in [(28, 512, 512), (56, 256, 256), (14, 512, 512)]:
-        w, bias = rnd(3, 3, ci, co), rnd(co)
-        wp = torch.empty(9 * ci * co, device="cuda")
-        lib.vc_conv3x3_pack_f32(st(), ci, co, P(w), 0, P(wp))
-        for B in ([4, 8, 10, 12, 16, 20, 21, 24, 28, 32, 40, 42, 48, 56, 63, 64] if H == 28 else [2, 4, 5, 6, 8, 10, 12, 16, 32] if H == 56 else [16, 32, 40, 64, 84, 128]):
-            x, y = rnd(B, H, H, ci), torch.empty(B, H, H, co, device="cuda")
-            tw = torch.empty(max(lib.vc_conv3x3_packed_workspace_bytes(B, H, H, ci, co, 0), lib.vc_conv3x3_fwd_workspace_bytes(B, H, H, ci, co), 16) // 4 + 4, device="cuda")
-            fl = 2e-9 * B * H * H * 9 * ci * co
-            t1, _ = timeit(lambda: lib.vc_conv3x3_fwd_packed_f32(st(), B, H, H, ci, co, P(x), P(wp), P(bias), P(y), 1, None, 0), reps=5)
-            t2, _ = timeit(lambda: lib.vc_conv3x3_fwd_packed_f32(st(), B, H, H, ci, co, P(x), P(wp), P(bias), P(y), 1, P(tw), tw.numel() * 4), reps=5)
-            t3, _ = timeit(lambda: lib.vc_conv3x3_fwd_f32(st(), B, H, H, ci, co, P(x), P(w), P(bias), P(y), 1, P(tw), tw.numel() * 4), reps=5)
-            tiles = (B * H * H + 127) // 128 * (co // 128)
-            print("sweep H=%d %d->%d B=%3d tiles %5d (%.2f x 512): single %7.3f ms %6.1f TF | tail %7.3f ms %6.1f TF | old %7.3f ms %6.1f TF" % (
-                H, ci, co, B, tiles, tiles / 512.0, t1, fl / t1, t2, fl / t2, t3, fl / t3), flush=True)
-
-
-def convw():
-    """patch-staged weight gradient against the implicit-GEMM one, VGG16 layer shapes"""
-    for B in (64, 32):
-        for (name, H, ci, co) in [("1_2", 224, 64, 64), ("2_1", 112, 64, 128), ("2_2", 112, 128, 128), ("3_1", 56, 128, 256), ("3_2", 56, 256, 256),
-                                  ("4_1", 28, 256, 512), ("4_2", 28, 512, 512), ("5_2", 14, 512, 512)]:
-            x, dy, bias = rnd(B, H, H, ci), rnd(B, H, H, co), rnd(co)
-            dw = torch.empty(3, 3, ci, co, device="cuda")
-            ws = torch.empty(max(lib.vc_conv3x3_wgrad_workspace_bytes(B, H, H, ci, co), lib.vc_conv3x3_wgrad_patch_workspace_bytes(B, H, H, ci, co)) // 4 + 4, device="cuda")
-            fl = 2e-9 * B * H * H * 9 * ci * co
-            res = {}
-            for nm, fn in (("wgrad", lambda: lib.vc_conv3x3_wgrad_f32(st(), B, H, H, ci, co, P(x), P(dy), P(dw), P(bias), 0, P(ws), ws.numel() * 4)),
-                           ("wgrad-patch", lambda: lib.vc_conv3x3_wgrad_patch_f32(st(), B, H, H, ci, co, P(x), P(dy), P(dw), P(bias), 0, P(ws), ws.numel() * 4)),
-                           ("wgrad-patch-nb", lambda: lib.vc_conv3x3_wgrad_patch_f32(st(), B, H, H, ci, co, P(x), P(dy), P(dw), None, 0, P(ws), ws.numel() * 4))):
-                med, mn = timeit(fn, reps=5)
-                res[nm] = med
-                print("conv%s %-14s B=%d H=%3d %3d->%3d: %8.3f ms  %6.1f TFLOP/s" % (name, nm, B, H, ci, co, med, fl / med), flush=True)
-            print("conv%s B=%d speed-up wgrad %.3f" % (name, B, res["wgrad"] / res["wgrad-patch"]), flush=True)
+        med, mn = timeit(lambda: lib.vc_conv3x3_wino_wgrad_f32(st(), B, H, H, ci, co, P(x), P(dy), P(dw), P(bias), 0, P(ws), ws.numel() * 4), reps=5)
+        tot += med * {"1_2": 1, "2_1": 1, "2_2": 1, "3_1": 1, "3_2": 2, "4_1": 1, "4_2": 2, "5_2": 3}[name]
+        print("conv%s %-12s B=%d H=%3d %3d->%3d: %8.3f ms  %6.1f TFLOP/s" % (name, "wgrad-wino", B, H, ci, co, med, fl / med), flush=True)
+    print("sum over the twelve layers B=%d wgrad %8.3f ms" % (B, tot))
 
 
 def lstm():

@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(WinoWgArgs a) {
     constexpr int NPX = PW * PH, NDY = DW * DH;
     constexpr int XPL = WG_XPL, YPL = WG_YPL;            // plane pitches in floats (724 = 20 mod 32, 516 = 4 mod 32)
     constexpr int XPF = 16 * XPL, BUF = XPF + 16 * YPL;   // floats: x patch, dy tile block; two buffers
-    static_assert(PW * PH <= 180 && DW * DH <= 128 && NS <= 16 && NS >= 8, "block shape");
+    static_assert(PW * PH <= 180 && DW * DH <= 128 && NS <= 16 && NS >= 13, "block shape (the staging schedule runs to step 11, before the barrier of step NS - 1)");
     const WinoGeom& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
     const int cw = wave >> 1, nw = wave & 1;
@@ -46,39 +46,36 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(WinoWgArgs a) {
     int nch = g.nblocks - blk0;
     if (nch > a.cps) nch = a.cps;
 
-    // staging slots: x patch 16 channel quads x NPX <= 180 pixels = 2880 float4 (slots 0..11 of a thread), dy 16 quads x NDY <= 128 pixels
-    // (slots 12..19); slot i of a thread: float4 index s = tid + 256 i (x) / tid + 256 (i - 12) (dy): quad s / pixels, pixel s % pixels
-    float4 st[10];
-    int by0 = 0, bx0 = 0, bimg = 0;   // current block to LOAD (uniform)
+    // staging slots: a thread owns ONE pixel of the x halo patch (pixel tid < NPX <= 180) and ONE pixel of the dy block (pixel tid & 127
+    // < NDY <= 128, channel-quad parity tid >> 7): per block TWO voffsets (the pixel's 16 bytes in channel-quad plane 0 of the tile, or
+    // WOOB) and the quad as a SCALAR plane offset -- slot i < 16: x quad i; slot 16 + i, i < 8: dy quad 2 i + (tid >> 7).  (Slots that were
+    // float4 index tid + 256 i of [quad][pixel] cost two divisions and a bounds check per slot and block: + 0.4 ms per step, round 4.)
+    float4 st[8];
+    const int xpy = tid / PW, xpx = tid - xpy * PW;                 // (compile-time divisors)
+    const int ypix = tid & 127, ypy = ypix / DW, ypx = ypix - ypy * DW;
+    const bool xlive = tid < NPX, ylive = ypix < NDY;
+    const unsigned plane_b = (unsigned)g.H * (unsigned)g.W * 16u;   // bytes of one channel-quad plane of an image
+    const int xq0 = cb * 16, yq0 = nb * 16 + (tid >> 7);
+    const int xst = tid * 4, yst = XPF + (tid >> 7) * YPL + ypix * 4;   // LDS float index of the thread's pixel in plane 0 (+ buf * BUF + quad * pitch)
+    unsigned xvoff = WOOB, yvoff = WOOB;   // of the block to LOAD
     auto set_block = [&](int blk) {
         const unsigned b = (unsigned)blk / (unsigned)g.blocks_img, rem = (unsigned)blk - b * (unsigned)g.blocks_img;
         const unsigned by = rem / (unsigned)g.bx_n, bx = rem - by * (unsigned)g.bx_n;
-        bimg = (int)b; by0 = (int)by * DH; bx0 = (int)bx * DW;   // first output pixel of the block
+        const int y = (int)by * DH - 1 + xpy, x = (int)bx * DW - 1 + xpx;
+        xvoff = (xlive && (unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W)
+                    ? (unsigned)((((int)b * (C >> 2) + xq0) * g.H + y) * g.W + x) * 16u : WOOB;
+        const int yy = (int)by * DH + ypy, yx = (int)bx * DW + ypx;
+        yvoff = (ylive && yy < g.H && yx < g.W) ? (unsigned)((((int)b * (N >> 2) + yq0) * g.H + yy) * g.W + yx) * 16u : WOOB;
     };
     auto gload1 = [&](int i, int k) {   // slot i into st[k]
-        if (i < 12) {
-            const int s = tid + 256 * i, quad = s / NPX, pix = s - quad * NPX;
-            const int py = pix / PW, px = pix - py * PW;
-            const int y = by0 - 1 + py, x = bx0 - 1 + px;
-            const bool ok = s < 16 * NPX && (unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W;
-            const unsigned off = ok ? (unsigned)(((((bimg * (C >> 2) + cb * 16 + quad) * g.H + y) * g.W + x)) * 16) : WOOB;
-            st[k] = wbufload(rx, off, 0);
-        } else {
-            const int s = tid + 256 * (i - 12), quad = s / NDY, pix = s - quad * NDY;
-            const int py = pix / DW, px = pix - py * DW;
-            const int y = by0 + py, x = bx0 + px;
-            const bool ok = s < 16 * NDY && y < g.H && x < g.W;
-            const unsigned off = ok ? (unsigned)(((((bimg * (N >> 2) + nb * 16 + quad) * g.H + y) * g.W + x)) * 16) : WOOB;
-            st[k] = wbufload(ry, off, 0);
-        }
+        if (i < 16) st[k] = wbufload(rx, xvoff, (unsigned)i * plane_b);
+        else st[k] = wbufload(ry, yvoff, (unsigned)(2 * (i - 16)) * plane_b);
     };
     auto lstore1 = [&](int buf, int i, int k) {
-        if (i < 12) {
-            const int s = tid + 256 * i, quad = s / NPX, pix = s - quad * NPX;
-            if (s < 16 * NPX) *reinterpret_cast<float4*>(&smem[buf * BUF + quad * XPL + pix * 4]) = st[k];
+        if (i < 16) {
+            if (xlive) *reinterpret_cast<float4*>(&smem[buf * BUF + xst + i * XPL]) = st[k];
         } else {
-            const int s = tid + 256 * (i - 12), quad = s / NDY, pix = s - quad * NDY;
-            if (s < 16 * NDY) *reinterpret_cast<float4*>(&smem[buf * BUF + XPF + quad * YPL + pix * 4]) = st[k];
+            if (ylive) *reinterpret_cast<float4*>(&smem[buf * BUF + yst + 2 * (i - 16) * YPL]) = st[k];
         }
     };
 
@@ -149,11 +146,11 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(WinoWgArgs a) {
     if (nch > 0) {
         set_block(blk0);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < 3; ++h) {
 #pragma unroll
-            for (int k = 0; k < 10; ++k) gload1(10 * h + k, k);
+            for (int k = 0; k < 8; ++k) gload1(8 * h + k, k);
 #pragma unroll
-            for (int k = 0; k < 10; ++k) lstore1(0, 10 * h + k, k);
+            for (int k = 0; k < 8; ++k) lstore1(0, 8 * h + k, k);
         }
         __syncthreads();
 #pragma unroll
@@ -181,11 +178,13 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(WinoWgArgs a) {
                     for (int k2 = 0; k2 < 5; ++k2)
                         if (k2 < per && m * per + k2 < total) prep(nbuf, sn, nob, m * per + k2);
                 }
-                if (more && m < 10 && !(WG_ABL & 4)) {   // the next block's data: two batches of ten slots, loaded early, written a few steps later
+                if (more && m < 8 && !(WG_ABL & 4)) {   // the next block's data: three batches of eight slots, each loaded three steps before it is written
                     if (s == 0) gload1(m, m);
-                    if (s == NS / 2 - 2) lstore1(buf ^ 1, m, m);
-                    if (s == NS / 2 - 1) gload1(10 + m, m);
-                    if (s == NS - 3) lstore1(buf ^ 1, 10 + m, m);
+                    if (s == 3) lstore1(buf ^ 1, m, m);
+                    if (s == 4) gload1(8 + m, m);
+                    if (s == 7) lstore1(buf ^ 1, 8 + m, m);
+                    if (s == 8) gload1(16 + m, m);
+                    if (s == 11) lstore1(buf ^ 1, 16 + m, m);
                 }
                 WSB();
             }

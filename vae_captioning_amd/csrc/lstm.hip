@@ -755,7 +755,8 @@ __global__ __launch_bounds__(512, 1) void lstm_rec8_fwd_kernel(LstmFwdArgs a, co
 // GEMM + 8.2 us gate kernel backward).
 static int g_lstm_mode = 2;
 static bool rec_ok(int N, int H) { return H == 512 && (long)(N + 96) * 4 * H * 4 < 0x7fffffffL; }
-static bool rec8_rows(int N) { return N > 400; }  // forward: the eight-wave 16-unit kernel above (19.7 vs 17.1 us at 320 rows, 26.2 vs 31.9 at 640, 47.9 vs 58.9 at 1280)
+static int lstm_env(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+static bool rec8_rows(int N) { static const int thr = lstm_env("VC_LSTM_REC8_ROWS", 400); return N > thr; }  // forward: the eight-wave 16-unit kernel above (19.7 vs 17.1 us at 320 rows, 26.2 vs 31.9 at 640, 47.9 vs 58.9 at 1280)
 constexpr size_t REC_PACK_BYTES = (size_t)512 * 2048 * sizeof(float);
 
 static int rec_cus() {
@@ -777,7 +778,8 @@ static int rec_lds(K kern) {  // 66 KB of dynamic LDS: above the 64 KB a kernel 
 
 // row groups: as many as keep one workgroup per CU (UG column slices x RG <= CUs), at least 16 rows each
 static int rec_row_groups(int N, int UG) {
-    int rg = rec_cus() / UG;
+    static const int occ = lstm_env("VC_LSTM_WGS_PER_CU", 1);   // (experiment knob: workgroups of the four-wave kernels per CU)
+    int rg = occ * rec_cus() / UG;
     if (rg < 1) rg = 1;
     const int cap = cdiv(N, 16);
     return rg < cap ? rg : cap;

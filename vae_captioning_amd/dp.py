@@ -3,23 +3,28 @@
 One process per GPU, replicated parameters, the minibatch sharded BY IMAGE (an image's nc
 caption rows, its cluster-vector rows and its noise slices stay together).  Per step:
 
-  1. all-reduce(sum) of ONE float: the number of non-PAD labels.  The CE loss divides by the
-     GLOBAL count (main.py:156-157), and the backward pass needs it as its scale.
+  1. the number of non-PAD labels of the GLOBAL batch: the CE loss divides by it (main.py:156-157) and the backward pass needs it
+     as its scale.  With the global Q1 mix (below) it rides in that exchange's all-gather; otherwise (tower mix, --no_encoder) it
+     is an all-reduce(sum) of ONE float.
   2. every rank runs forward + backward on its shard with the scales of `scales()`, so that
      the SUM over ranks of the local gradients is the gradient of the global-batch loss.
   3. ONE all-reduce(sum) of the flat gradient buffer (caption grads | tail scalars | VGG
-     grads).  The tail carries sum ||dX||^2 of the embedding IndexedSlices values (the
-     un-deduplicated term of the global norm, quirk Q5); ce_num and kl_sum are reduced with
-     the count for reporting.
+     grads; with VGG fine-tuning issued as four asynchronous pieces, `gradient_buckets`).  The tail carries sum ||dX||^2 of the
+     embedding IndexedSlices values (the un-deduplicated term of the global norm, quirk Q5) and the two REPORTING scalars ce_num
+     and kl_sum: the reported losses are finalised behind the all-reduce (engine.apply_gradients), they have no collective of
+     their own.
   4. identical clip + optimiser step on every replica (parameter-only terms such as the L2
      regulariser's gradient are applied once, inside the optimiser kernel).
+
+Collectives per step: caption-only 3 with the global Q1 mix (all-gather, reduce-scatter, gradient all-reduce), 2 without; VGG16
+fine-tuning 6 (all-gather, reduce-scatter, four gradient pieces).  STILL UNMEASURED on more than one GPU.
 
 The one place the reference graph is not separable over rows is the Q1 reshape
 (vae_model/decoder.py:109-110), which mixes the z samples of different batch rows.  Default
 (q1_mode="global"): bit-for-bit the single-GPU semantics on the concatenated batch -- the per-row
-mean/std [N, L] are all-gathered (2 x 1.5 MB at 2560 rows), each rank samples the flat range
+[mean | std | label count] of every rank are all-gathered in ONE call (3 MB at 2560 rows), each rank samples the flat range
 q in [rank*Nl*S, (rank+1)*Nl*S) of the global [S, Ng, L] tensor (q = s*Ng + n) that forms its own
-z_rnn rows, and the [Ng, L] partial gradient sums are reduce-scattered back to the owning ranks.
+z_rnn rows, and the [Ng, L] partial gradient sums [dmean | dstd] are reduce-scattered back to the owning ranks in ONE call.
 q1_mode="tower" mixes inside each rank's shard instead (what N towers of the reference graph
 would compute; equals the oracle with q1_groups = N) and needs no extra exchange.
 """

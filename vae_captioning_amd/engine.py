@@ -629,7 +629,11 @@ class CaptionEngine(object):
         lib.vc_lstm_seq_fwd_f32(st, Te, N, E, He, P(Xe), P(S.param(spec.ENC_CELL + "kernel")), P(S.param(spec.ENC_CELL + "bias")),
                                 P(self.buf["lens_e"]), P(act_e), P(cs_e), P(hs_e), ws, wsb)
         hT = hs_e[Te]
-        mean, std = self._b("mean", (N, L)), self._b("std", (N, L))
+        # [mean | std | non-PAD label count, 0, 0, 0]: one buffer, so that the data-parallel exchange of the global Q1 mix is ONE
+        # all-gather (fw_encode_sample)
+        msc = self._b("mean_std_cnt", (2 * N * L + 4,))
+        mean, std = msc[:N * L].view(N, L), msc[N * L:2 * N * L].view(N, L)
+        self.buf["mean"], self.buf["std"] = mean, std
         if p.prior == "Normal":
             logstd = self._b("logstd", (N, L))
             self.gemm(0, 0, N, L, He, hT, He, S.param("encoder/dense/kernel"), L, mean, L, S.param("encoder/dense/bias"))
@@ -657,11 +661,22 @@ class CaptionEngine(object):
             mu_p = self._b("mu_p", (N, L))
             self.gemm(0, 0, N, L, K_CL, cv, K_CL, self.c_means, L, mu_p, L)
         z = self._b("z", (Sm, N, L))
+        self._den_gathered = False
         if self._q1_global():
-            Ng = N * self.world
+            # ONE all-gather per step in front of the sample: every rank's [mean | std | count of non-PAD labels].  The count is a
+            # function of the batch alone; gathered here, its sum (in rank order: identical on every rank) is the global CE
+            # denominator of main.py:156-157 and fw_loss needs no collective of its own.
+            Ng, W, M = N * self.world, self.world, 2 * N * L + 4
+            msc = self.buf["mean_std_cnt"]
+            lib.vc_count_nonzero_i32(st, P(self.buf["cap_enc_t"]), T * N, msc.data_ptr() + 8 * N * L)
+            gath = self._b("mean_std_cnt_g", (W * M,))
+            self.gather_fn(gath, msc)
+            gv = gath.view(W, M)
             mg, sg = self._b("mean_g", (Ng, L)), self._b("std_g", (Ng, L))
-            self.gather_fn(mg, mean)
-            self.gather_fn(sg, std)
+            mg.view(W, N * L).copy_(gv[:, :N * L])
+            sg.view(W, N * L).copy_(gv[:, N * L:2 * N * L])
+            torch.sum(gv[:, 2 * N * L], dim=0, keepdim=True, out=self.red[1:2])
+            self._den_gathered = True
             # this rank's z_rnn rows = flat range [rank*N*S, (rank+1)*N*S) of the global [S, Ng, L] tensor
             lib.vc_latent_sample_mixed_f32(st, Ng, L, self.rank * N * Sm, N * Sm, P(mg), P(sg), P(self.buf["eps"]), P(z))
         else:
@@ -716,9 +731,10 @@ class CaptionEngine(object):
         kl_sum = self.kl_sum
         labels = self.buf["cap_enc_t"]
         den = self.red[1:2]
-        lib.vc_count_nonzero_i32(st, P(labels), T * N, P(den))
-        if self.collectives:
-            self.reduce_fn(den)
+        if not (self.collectives and getattr(self, "_den_gathered", False)):  # (global Q1 mix: the count came with the all-gather)
+            lib.vc_count_nonzero_i32(st, P(labels), T * N, P(den))
+            if self.collectives:
+                self.reduce_fn(den)
         vector_loss = self.enc and p.prior == "AG"  # Q3
         Ng = N * self.world
         gscale = dp.scales(N, self.world, vector_loss)[0]
@@ -726,12 +742,17 @@ class CaptionEngine(object):
         self._timed("hbm_softmax_xent", 8.0 * T * N * V,  # logits read once, d(logits) written in place
                     lambda: lib.vc_softmax_xent_f32(st, P(logits), P(labels), T * N, V, _round(V, 4), P(den), gscale, P(row_loss), 1 if train else 0))
         lib.vc_reduce_sum_f32(st, P(row_loss), T * N, 1.0, P(self.red), 0)
-        self._finalize_losses(kl_sum, Ng, ann)
+        # Data-parallel training step: ce_num and kl_sum are needed for REPORTING only (the gradient's scales are the global count
+        # and row number), so they ride in the tail of the gradient all-reduce (pack_tail) and the losses are finalised behind it
+        # (apply_gradients) -- no collective of their own.  Without a backward pass (train=False) they are reduced here.
+        self._losses_deferred = bool(self.collectives and train)
+        if not self._losses_deferred:
+            self._finalize_losses(kl_sum, Ng, ann, reduce=self.collectives)
         return self.out
 
-    def _finalize_losses(self, kl_sum, Ng, ann):
+    def _finalize_losses(self, kl_sum, Ng, ann, reduce=False):
         lib, st = self.lib, _stream()
-        if self.collectives:  # ce_num and kl_sum summed over ranks (reporting only)
+        if reduce:  # ce_num and kl_sum summed over ranks (reporting only)
             r2 = self._b("red2", (2,), zero=True)
             r2[0:1].copy_(self.red[0:1])
             if kl_sum is not None:
@@ -792,14 +813,17 @@ class CaptionEngine(object):
             dz = self._b("dz", (Sm, N, L))
             self.gemm(0, 1, N, Sm * L, E, dz_dec, E, S.param("decoder/net/z_rnn/kernel"), E, dz, Sm * L)
             mean, std = self.buf["mean"], self.buf["std"]
-            dmean, dstd = self._b("dmean", (N, L)), self._b("dstd", (N, L))
+            dms = self._b("dmean_dstd", (2, N, L))
+            dmean, dstd = dms[0], dms[1]
             Sb = Sm
-            if self._q1_global():  # partial sums over this rank's q range for EVERY global row, then reduce-scatter
-                Ng = N * self.world
+            if self._q1_global():  # partial sums over this rank's q range for EVERY global row, then ONE reduce-scatter of [dmean | dstd]
+                Ng, W = N * self.world, self.world
                 pm, ps = self._b("dmean_g", (Ng, L)), self._b("dstd_g", (Ng, L))
                 lib.vc_latent_sums_mixed_f32(st, Ng, L, self.rank * N * Sm, N * Sm, P(dz), P(self.buf["eps"]), P(pm), P(ps))
-                self.rscatter_fn(dmean, pm)
-                self.rscatter_fn(dstd, ps)
+                pin = self._b("dmean_dstd_g", (W, 2, N * L))   # rank r's piece = [dmean rows of r | dstd rows of r]
+                pin[:, 0].copy_(pm.view(W, N * L))
+                pin[:, 1].copy_(ps.view(W, N * L))
+                self.rscatter_fn(dms.view(-1), pin.view(-1))
                 Sb = 0
             _, kl_n, kl_ag, _ = dp.scales(N, self.world, p.prior == "AG")
             hT = self.buf["hs_e"][Te]
@@ -877,10 +901,19 @@ class CaptionEngine(object):
         lib, st, nb = self.lib, _stream(), self.nb
         tail = self.store.g[self.store.n:]
         lib.vc_reduce_sum_f32(st, self.part.data_ptr() + nb * 4, 2 * nb, 1.0, P(tail), 0)  # sum ||dX||^2 (both tables)
+        if getattr(self, "_losses_deferred", False):  # reporting scalars of the data-parallel step: ce_num, kl_sum
+            tail[1:2].copy_(self.red[0:1])
+            tail[2:3].copy_(self.red[2:3])
 
     def apply_gradients(self):
         """non_cnn_optimizer (ops/optimizers.py:3-47): global-norm clip 5.0 + Adam / SGD / Momentum."""
         p, lib, st, S, nb = self.p, self.lib, _stream(), self.store, self.nb
+        if getattr(self, "_losses_deferred", False):  # the tail has been summed over the ranks: finalise the reported losses
+            self._losses_deferred = False
+            self.red[0:1].copy_(S.g[S.n + 1:S.n + 2])
+            if self.kl_sum is not None:
+                self.red[2:3].copy_(S.g[S.n + 2:S.n + 3])
+            self._finalize_losses(self.kl_sum, self.N * self.world, self.scal[1:2])
         lib.vc_sumsq_partial_f32(st, P(S.g), self.n_dense, P(self.part))
         self.part[nb:nb + 1].copy_(S.g[S.n:S.n + 1])
         lib.vc_clip_finalize_f32(st, P(self.part), nb + 1, float(p.lstm_clip_by_norm), P(self.ns))

@@ -35,11 +35,14 @@ class Staged(object):
 
 
 def stage(params, **arrays):
-    """Record the arrays a facade was constructed with (None = not given)."""
+    """Record the arrays a facade was constructed with.  None = not given: it also forgets what an EARLIER facade staged under that
+    name, so facades rebuilt with None arguments are back on the caller-uploads contract instead of a left-over array."""
     st = params.__dict__.setdefault("_vc_staged", {})
     for k, v in arrays.items():
         if v is not None:
             st[k] = v
+        else:
+            st.pop(k, None)
     return st
 
 
@@ -47,21 +50,13 @@ def staged(params):
     return params.__dict__.get("_vc_staged", {})
 
 
-def _same(a, b):
-    import torch
-    if a is b:
-        return True
-    if isinstance(a, torch.Tensor) or isinstance(b, torch.Tensor):
-        return False   # device tensors are compared by identity only
-    a, b = np.asarray(a), np.asarray(b)
-    return a.shape == b.shape and np.array_equal(a, b)
-
-
 def bind(params):
     """Make the staged arrays the engine's resident batch: builds the Trainer.set_batch dict from what Encoder / Decoder / layers.dense
-    / vgg16 were given and uploads it unless the identical arrays are already resident.  Returns the device feature tensor the step
-    must use (fc2 of the session's VGG16 when fine-tuning) or None (uploaded precomputed features).  Raises if the staged set is
-    incomplete or inconsistent -- a step never silently trains on a stale batch."""
+    / vgg16 were given and uploads it -- ALWAYS: the copy is one asynchronous H2D transfer, and neither object identity (a caller may
+    refill a preallocated array in place) nor a remembered earlier upload (Trainer.set_batch may have replaced it since) says what
+    is resident.  Returns the device feature tensor the step must use (fc2 of the session's VGG16 when fine-tuning) or None
+    (uploaded precomputed features).  Raises if the staged set is incomplete or inconsistent -- a step never silently trains on a
+    stale batch."""
     tr = get(params)
     st = staged(params)
     if not st:
@@ -105,13 +100,8 @@ def bind(params):
         if cv is None:
             raise ValueError("facade inputs incomplete: the cluster vectors were not given (decoder.c_i_ph / encoder.c_i_ph, main.py:108-116)")
         batch["c_v"] = np.asarray(cv, np.float32)
-    if feats_dev is not None and "images" in st:
-        batch["images"] = st["images"]   # (kept for the resident-batch comparison only)
-    prev = getattr(tr, "_bound", None)
-    if prev is None or set(prev) != set(batch) or not all(_same(prev[k], batch[k]) for k in batch):
-        if feats_dev is not None:   # the images are on the device already (vgg16 facade): only the caption side is uploaded
-            tr.cap.set_batch({k: v for k, v in batch.items() if k != "images"})
-        else:
-            tr.set_batch(batch)
-        tr._bound = batch
+    if feats_dev is not None:   # the images are on the device already (vgg16 facade): only the caption side is uploaded
+        tr.cap.set_batch(batch)
+    else:
+        tr.set_batch(batch)
     return feats_dev

@@ -80,6 +80,8 @@ class VggEngine(object):
         self.w2_blocks = (self.lib.vc_adam_blocks(self.o_fc), self.lib.vc_adam_blocks(self.store.n - self.o_fc))
         self.w2_part = torch.zeros(sum(self.w2_blocks), dtype=torch.float32, device=device)
         self.w2_valid = False
+        self.w2_cache = True     # False: always recompute sum(w^2) (a captured step: parameters restored behind the graph's back would go unnoticed)
+        self._w2_version = -1
 
     @property
     def side(self):
@@ -339,7 +341,10 @@ class VggEngine(object):
     def reg_sumsq(self, out_ptr):
         """sum(w^2) over every cnn/* variable (main.py:69-74, Q9: biases included) -> device scalar."""
         lib, st = self.lib, _stream()
-        if self.w2_valid:   # left by the previous step's Adam update
+        # the partial sums the previous step's Adam update left are good only while nobody else has written the parameters: torch
+        # bumps the flat buffer's version counter on every in-place write through it or a view of it (load_state_dict, p.copy_, ...),
+        # the library's own kernels do not
+        if self.w2_valid and self.w2_cache and self.store.p._version == self._w2_version:
             lib.vc_reduce_sum_f32(st, P(self.w2_part), self.w2_part.numel(), 1.0, out_ptr, 0)
             return
         lib.vc_sumsq_partial_f32(st, P(self.store.p), self.store.n, P(self.part))
@@ -482,6 +487,14 @@ class VggEngine(object):
                 lib.vc_momentum_f32(st, sl(S.p), sl(S.g), sl(S.slot("a")), n, scal.data_ptr() + 16, None, 0.9, self.wd, None, 0)
         # (every block of both halves has written its sum by the time the next forward pass reads them, whatever the order)
         self.w2_valid = p.cnn_optimizer == "Adam" and bool(self.wd)
+        self._w2_version = self.store.p._version
+
+
+class _NoPending(object):
+    """Handle of a muted collective (Trainer.mute_collectives)."""
+
+    def wait(self):
+        pass
 
 
 class Trainer(object):
@@ -664,22 +677,27 @@ class Trainer(object):
     def reduce_async_fn(self):
         if getattr(self.cap, "_fake_collectives", False):
             return None
+        if getattr(self, "_muted", False):   # mute_collectives: same bucket / stream structure, nothing on the wire
+            return lambda t: _NoPending()
         if self.comm is not None:
             return self.comm.all_reduce_async
         return lambda t: torch.distributed.all_reduce(t, group=self.group, async_op=True)
 
     def mute_collectives(self):
         """Replace every collective of the step by a no-op (timing only: bench.py measures the compute-only step to report the
-        exposed communication time = step - compute-only step).  Returns the function that restores them."""
+        exposed communication time = step - compute-only step).  The step keeps its structure -- the four gradient pieces are still
+        "issued" and "waited for" where the real ones are, so the optimisers overlap the VGG16 backward pass exactly as in the real
+        step.  Returns the function that restores the collectives."""
         cap = self.cap
-        saved = (cap.reduce_fn, cap.gather_fn, cap.rscatter_fn, cap.__dict__.get("_fake_collectives", False))
+        saved = (cap.reduce_fn, cap.gather_fn, cap.rscatter_fn)
         cap.reduce_fn = lambda t: None
-        cap.gather_fn = lambda out, inp: None
+        cap.gather_fn = lambda out, inp: out.view(self.world, -1).copy_(inp.view(1, -1).expand(self.world, -1))
         cap.rscatter_fn = lambda out, inp: out.copy_(inp.view(-1)[:out.numel()].view_as(out))
-        cap._fake_collectives = True   # (no asynchronous bucket pieces either)
+        self._muted = True
 
         def restore():
-            cap.reduce_fn, cap.gather_fn, cap.rscatter_fn, cap._fake_collectives = saved
+            cap.reduce_fn, cap.gather_fn, cap.rscatter_fn = saved
+            self._muted = False
         return restore
 
     def all_reduce_grads(self):
@@ -700,6 +718,7 @@ class Trainer(object):
         if self.fine:
             self.images = self.cap.buf["images"]
         if self.vgg is not None:
+            self.vgg.w2_cache = False
             self.vgg.one_stream = True   # (see VggEngine.__init__; the buffers of the one-chain geometry are made by the un-captured steps below)
             warmup = max(warmup, 1)
         s = torch.cuda.Stream()
