@@ -173,3 +173,65 @@ def test_gradient_buckets_are_disjoint_and_cover_the_flat_buffer():
     assert inside("cnn/conv3_1/weights", bk[2]) and inside("cnn/conv5_3/biases_conv", bk[2]) and not inside("cnn/conv2_2/weights", bk[2])
     assert inside("cnn/conv1_1/weights", bk[3]) and inside("cnn/conv2_2/biases", bk[3])
     assert dp.gradient_buckets(n_cap, n_cap) == [(0, n_cap)]        # caption-only runs: the single all-reduce
+
+
+def _handshake_worker(rank, world, port, case, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sys.path.insert(0, ROOT)
+        import types
+        from vae_captioning_amd import abi, dp
+        from vae_captioning_amd.trainer import Trainer
+
+        class Lib(object):   # the three entries the handshake touches, failing where the case says
+            def vc_comm_available(self):
+                return 0 if (case == "unavailable_on_1" and rank == 1) else 1
+
+            def vc_comm_unique_id(self, buf):
+                if case == "id_fails":
+                    raise abi.VaecapError("vc_comm_unique_id: no RCCL (test)")
+                buf.raw = bytes(range(128))
+
+        made = []
+
+        class FakeComm(object):
+            def __init__(self, lib, world_, rank_, dev, uid):
+                if case == "init_fails_on_0" and rank_ == 0:
+                    raise abi.VaecapError("ncclCommInitRank failed (test)")
+                assert bytes(uid) == bytes(range(128)) and world_ == world and rank_ == rank
+                made.append(self)
+                self.destroyed = False
+
+            unique_id = staticmethod(dp.AbiComm.unique_id)
+
+            def destroy(self):
+                self.destroyed = True
+        real = dp.AbiComm
+        dp.AbiComm = FakeComm
+        try:
+            me = types.SimpleNamespace(lib=Lib(), world=world, rank=rank, group=None)
+            comm = Trainer._agree_on_abi_comm(me, 0)
+        finally:
+            dp.AbiComm = real
+        ret[rank] = (comm is not None, [c.destroyed for c in made])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["ok", "unavailable_on_1", "id_fails", "init_fails_on_0"])
+def test_ranks_agree_on_the_communicator_whatever_fails_where(case):
+    """Trainer._agree_on_abi_comm on two gloo ranks with the library's three entries stubbed: either both ranks get a communicator
+    or both fall back to torch.distributed -- an RCCL that cannot be bound on one rank, a unique id that rank 0 cannot create, an
+    init that fails on one rank only (the communicator the other rank did get is destroyed).  Nobody hangs."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_handshake_worker, args=(2, _free_port(), case, ret), nprocs=2, join=True)
+    got = [ret[0], ret[1]]
+    if case == "ok":
+        assert got == [(True, [False]), (True, [False])]
+    elif case == "init_fails_on_0":
+        assert got == [(False, []), (False, [True])]
+    else:
+        assert got == [(False, []), (False, [])]

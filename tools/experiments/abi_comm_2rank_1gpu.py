@@ -14,7 +14,9 @@ torch.cuda.set_device(0)
 dist.init_process_group("gloo", rank=rank, world_size=world)
 lib = abi.load()
 try:
-    comm = dp.AbiComm.from_store(lib, world, rank, 0)
+    msg = [dp.AbiComm.unique_id(lib) if rank == 0 else None]
+    dist.broadcast_object_list(msg, src=0)
+    comm = dp.AbiComm(lib, world, rank, 0, msg[0])
     t = torch.full((1000,), float(rank + 1), device="cuda")
     comm.all_reduce(t)
     g = torch.empty(2 * 8, device="cuda")

@@ -30,6 +30,8 @@ extern "C" int vc_device_check(int device) {
 // roctx ranges (tracing): named ranges around the phases of a step, visible to `rocprofv3 --marker-trace`.
 // the roctx library is bound at run time (no link-time dependency; without it the calls are no-ops that still return 0).
 #include <dlfcn.h>
+
+#include <mutex>
 namespace vc {
 struct Roctx {
     int (*push)(const char*) = nullptr;
@@ -37,9 +39,8 @@ struct Roctx {
 };
 static Roctx* roctx() {
     static Roctx r;
-    static bool tried = false;
-    if (!tried) {
-        tried = true;
+    static std::once_flag once;
+    std::call_once(once, [] {
         // rocprofv3 (rocprofiler-sdk) sees the ranges of ITS roctx library; the roctracer-era libroctx64 is the fallback
         const char* names[] = {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "/opt/rocm/lib/librocprofiler-sdk-roctx.so.1",
                                "libroctx64.so.4", "libroctx64.so", "/opt/rocm/lib/libroctx64.so.4"};
@@ -49,7 +50,7 @@ static Roctx* roctx() {
             *(void**)(&r.push) = dlsym(h, "roctxRangePushA");
             *(void**)(&r.pop) = dlsym(h, "roctxRangePop");
         }
-    }
+    });
     return (r.push && r.pop) ? &r : nullptr;
 }
 }  // namespace vc

@@ -6,13 +6,23 @@
 // (PyTorch-ROCm bundles one) must not end up with two -- the already-loaded library is preferred (RTLD_NOLOAD by soname), then the
 // ROCm install; VC_RCCL_LIB overrides.  Every RCCL failure becomes a non-zero return code with ncclGetErrorString in vc_last_error.
 #include <dlfcn.h>
-#include <rccl/rccl.h>
 #include <stdlib.h>
 
 #include <mutex>
 
 #include "common.h"
 #include "vaecap.h"
+
+// The part of the NCCL API (rccl.h) this file binds, declared HERE: libvaecap builds on a ROCm install without the RCCL development
+// headers (the library is bound at run time, see above).  Values as published in rccl.h / nccl.h and stable across their releases:
+// ncclUniqueId is 128 opaque bytes, ncclSuccess = 0, ncclInProgress = 7, ncclSum = 0, ncclFloat32 = 7.
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0, ncclInProgress = 7 } ncclResult_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+typedef enum { ncclFloat32 = 7 } ncclDataType_t;
+}
 
 namespace vc {
 

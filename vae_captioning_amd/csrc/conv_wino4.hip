@@ -54,7 +54,9 @@ constexpr int W4_WGRP = 9 * 256;             // floats of one channel group's we
 constexpr int W4_WBUF = 2 * W4_WGRP;         // 18 KB
 constexpr int W4_POFF = 2 * W4_WBUF;         // LDS: two weight buffers, then two patch buffers
 constexpr int W4_DUMP = W4_POFF + 360;       // plane padding of block 0: where the staging slots past the data write
-constexpr int WINO4_LDS_BYTES = (2 * W4_WBUF + 2 * W4_PBUF) * 4;   // 61 440: two workgroups per CU
+constexpr int W4_MAIN_BYTES = (2 * W4_WBUF + 2 * W4_PBUF) * 4;     // 61 440: the main loop's buffers
+constexpr int WINO4_LDS_BYTES = 4 * 16 * 64 * 16;                  // 65 536: the epilogue's exchange of partial outputs (four waves x 16 float4 per lane); two workgroups per CU
+static_assert(W4_MAIN_BYTES <= WINO4_LDS_BYTES, "LDS");
 constexpr int W4_WPH = W4_WBUF * 4;          // bytes of a phase's packed weights per 32-channel tile
 constexpr int W4_NPIX = W4_NBLK * 324;       // patch pixels of a workgroup
 
@@ -79,28 +81,12 @@ struct Wino4Args {
     int tiles_n, ntiles, nphases;
 };
 
-// one 1-D input transform B^T (6 -> 6) in twelve operations, step by step (so that the caller can spread them over MFMA gaps):
+// one 1-D input transform B^T (6 -> 6) in twelve operations:
 //   o0 = 4 d0 - 5 d2 + d4      o1 = (d4 - 4 d2) + (d3 - 4 d1)     o2 = (d4 - 4 d2) - (d3 - 4 d1)
 //   o5 = 4 d1 - 5 d3 + d5      o3 = (d4 - d2) + 2 (d3 - d1)       o4 = (d4 - d2) - 2 (d3 - d1)
-// Two orders of the same twelve operations:
-//   w4_bstep_h (rows, from the raw pixels): the raw inputs are dead after step 7, so the next row may be read over them;
-//   w4_bstep_v (columns, into the MFMA operands): output o_j is not written before step 2 j -- a column transform running two steps
-//   per gap beside the six MFMAs of the previous column writes o_j over the operand that MFMA j has just consumed (single-buffered U).
-__device__ __forceinline__ void w4_bstep_h(int k, const float& d0, const float& d1, const float& d2, const float& d3, const float& d4, const float& d5,
-                                           float* o, float* t) {
-    if (k == 0) t[0] = __builtin_fmaf(-4.f, d2, d4);
-    if (k == 1) t[1] = __builtin_fmaf(-4.f, d1, d3);
-    if (k == 2) t[2] = d4 - d2;
-    if (k == 3) t[3] = d3 - d1;
-    if (k == 4) t[4] = __builtin_fmaf(-5.f, d2, d4);
-    if (k == 5) o[0] = __builtin_fmaf(4.f, d0, t[4]);
-    if (k == 6) t[4] = __builtin_fmaf(-5.f, d3, d5);
-    if (k == 7) o[5] = __builtin_fmaf(4.f, d1, t[4]);
-    if (k == 8) o[1] = t[0] + t[1];
-    if (k == 9) o[2] = t[0] - t[1];
-    if (k == 10) o[3] = __builtin_fmaf(2.f, t[3], t[2]);
-    if (k == 11) o[4] = __builtin_fmaf(-2.f, t[3], t[2]);
-}
+// w4_bstep_v (columns, into the MFMA operands), step by step so that the caller can spread the steps over MFMA gaps: output o_j is not
+// written before step 2 j -- a column transform running ONE step per gap beside the twelve MFMAs of the previous column (six positions
+// x two channel groups) writes o_j over the operand that the MFMAs of position j have consumed (single-buffered U).
 __device__ __forceinline__ void w4_bstep_v(int k, const float& d0, const float& d1, const float& d2, const float& d3, const float& d4, const float& d5,
                                            float* o, float* t) {
     if (k == 0) t[0] = __builtin_fmaf(-4.f, d2, d4);
@@ -116,17 +102,39 @@ __device__ __forceinline__ void w4_bstep_v(int k, const float& d0, const float& 
     if (k == 10) o[4] = __builtin_fmaf(-2.f, t[3], t[2]);
     if (k == 11) o[5] = __builtin_fmaf(4.f, d1, t[4]);
 }
+// w4_hstep<HF> (rows, from the raw pixels): the HALF of the row transform a wave needs -- HF = 0: outputs o0 o1 o2 (horizontal indices
+// v = 0, 1, 2), HF = 1: o3 o4 o5 (v = 3, 4, 5) -- in six operations; the raw inputs are dead after step 3.
+template <int HF>
+__device__ __forceinline__ void w4_hstep(int k, const float* d, float* o, float* t) {
+    if (HF == 0) {
+        if (k == 0) t[0] = __builtin_fmaf(-4.f, d[2], d[4]);
+        if (k == 1) t[1] = __builtin_fmaf(-4.f, d[1], d[3]);
+        if (k == 2) t[2] = __builtin_fmaf(-5.f, d[2], d[4]);
+        if (k == 3) o[0] = __builtin_fmaf(4.f, d[0], t[2]);
+        if (k == 4) o[1] = t[0] + t[1];
+        if (k == 5) o[2] = t[0] - t[1];
+    } else {
+        if (k == 0) t[0] = d[4] - d[2];
+        if (k == 1) t[1] = d[3] - d[1];
+        if (k == 2) t[2] = __builtin_fmaf(-5.f, d[3], d[5]);
+        if (k == 3) o[2] = __builtin_fmaf(4.f, d[1], t[2]);
+        if (k == 4) o[0] = __builtin_fmaf(2.f, t[1], t[0]);
+        if (k == 5) o[1] = __builtin_fmaf(-2.f, t[1], t[0]);
+    }
+}
 
 template <int KIND, bool POOL>
 __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const Wino4Geom& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lj = lane & 15, lg = lane >> 4;
-    const int wb = wave >> 1, cg = wave & 1;
+    // wave = 2 block + half: the two waves of a block split the 36 POSITIONS (half 0: horizontal indices v = 0..2, half 1: v = 3..5) and
+    // each multiplies its eighteen against BOTH channel groups; the epilogue exchanges partial outputs and wave `hf` finishes channel group hf
+    const int wb = wave >> 1, hf = wave & 1;
     const int id = xcd_remap(blockIdx.x, a.ntiles);
     const int tm = id / a.tiles_n, nt = id - tm * a.tiles_n;
     const int C = g.C, N = g.N;
-    const int nc0 = nt * 32 + cg * 16 + 4 * lg;   // this lane's four output channels
+    const int nc0 = nt * 32 + hf * 16 + 4 * lg;   // the four output channels this lane FINISHES
 
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)((long)g.B * g.H * g.W * C * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, (int)(36L * C * N * 4), 0x00020000);
@@ -147,9 +155,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
         const int y = (int)(by * 16u + py) - 1, x = (int)(bx * 16u + px) - 1;
         const bool ok = live && (unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W;
         // C4 layout [B][C/4][H][W][4]: the pixel's four channels of phase h are 16 bytes at channel plane h (soffset h * plane bytes);
-        // consecutive lanes = consecutive pixels of a patch row = consecutive 16-byte pieces (288-byte runs: ~3 cache lines per row)
+        // consecutive lanes = consecutive pixels of a patch row = consecutive 16-byte pieces (288-byte runs)
         voff[j] = ok ? (((b * (unsigned)(C >> 2) * (unsigned)g.H + (unsigned)y) * (unsigned)g.W + (unsigned)x)) * 16u : WOOB;
-        if (W4_ABL & 256) voff[j] = (unsigned)((tm * 648 + (int)s) * 16) % (unsigned)(g.B * g.H * g.W * C * 4 - 4096);   // timing only: consecutive lanes, consecutive 16-byte pieces
         pst[j] = s < (unsigned)W4_NPIX ? W4_POFF + (int)blk * W4_BLKF + (int)py * W4_PITCH + (int)px : W4_DUMP + (tid & 15);
     }
     // weight slots: piece i of the phase's 18 KB = float4 tid + 256 i < 1152
@@ -158,17 +165,23 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
 
     const int ty = lj >> 2, tx = lj & 3;
     const int rbase = W4_POFF + wb * W4_BLKF + lg * W4_PLANE + (4 * ty) * W4_PITCH + 4 * tx;   // + buffer + 4 * PLANE (odd phase) + r * PITCH
-    const int vbase = cg * W4_WGRP + (lg * 16 + lj) * 4;                                       // + wq * WBUF + k * 256
+    const int vbase = (lg * 16 + lj) * 4;                                                      // + group * WGRP + wq * WBUF + pq * 256
 
-    // M_p[channel nc0 + r][tile lj], p = 6 v + u (u: vertical index, v: horizontal index)
-    f32x4 acc[36];
+    // M_p[channel 32 nt + 16 gi + 4 lg + r][tile lj] for the wave's positions p = 18 hf + pos, pos = 6 vl + u (u: vertical index, vl: the
+    // wave's horizontal index v - 3 hf) and BOTH channel groups gi
+    f32x4 acc[2][18];
 #pragma unroll
-    for (int p = 0; p < 36; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // forward: the bias rides in the accumulator of position (1, 1): column 1 of A^T is (1, 1, 1, 1), so A^T M A adds M_(1,1) to all
-    // sixteen outputs of the tile
-    if (KIND == W4_FWD && a.aux) {
-        const float4 bv = *reinterpret_cast<const float4*>(a.aux + nc0);
-        acc[7] = f32x4{bv.x, bv.y, bv.z, bv.w};
+    for (int gi = 0; gi < 2; ++gi)
+#pragma unroll
+        for (int p = 0; p < 18; ++p) acc[gi][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // forward: the bias rides in the accumulator of position (1, 1) (half 0): column 1 of A^T is (1, 1, 1, 1), so A^T M A adds M_(1,1) to
+    // all sixteen outputs of the tile
+    if (KIND == W4_FWD && a.aux && hf == 0) {
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) {
+            const float4 bv = *reinterpret_cast<const float4*>(a.aux + nt * 32 + gi * 16 + 4 * lg);
+            acc[gi][7] = f32x4{bv.x, bv.y, bv.z, bv.w};
+        }
     }
 
     // this lane's 4 x 4 output pixels
@@ -200,168 +213,214 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
             }
     }
 
-    float4 st[4 + W4_B_REG];    // staging registers
-    float HA[6][6], HB[6][6];   // [patch row r][horizontal index v]: rows transformed horizontally (B^T over the pixels of a row)
-    float U[6];                 // one column v of B^T d B = the B operands of the unit's six MFMAs
-    float4 vf[2];               // weight fragments: fragment k = positions 4 k .. 4 k + 3
-    float rr[6];                // the raw patch row in flight
-    float tv[5], th[5];
-    if (W4_ABL) {   // ablated builds read registers nobody wrote: give them values
-#pragma unroll
-        for (int i = 0; i < 4 + W4_B_REG; ++i) st[i] = make_float4(1.f, 2.f, 3.f, 4.f);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) vf[i] = make_float4(1.f + lane, 2.f, 3.f, 4.f);
-#pragma unroll
-        for (int r = 0; r < 6; ++r)
-#pragma unroll
-            for (int c = 0; c < 6; ++c) { HA[r][c] = 1.f + lane + r; HB[r][c] = 2.f + lane + c; rr[c] = 0.5f * lane; U[c] = 1.f * lane; }
-    }
-
     const unsigned plane_b = (unsigned)g.H * (unsigned)g.W * 16u;   // bytes of one channel-quad plane of an image
-    auto pload = [&](int i, int hp) { if (!(W4_ABL & (8 | 32))) st[i] = wbufload(rx, voff[i], (unsigned)hp * plane_b); };
-    auto pstore = [&](int i, int pq) {
-        if (W4_ABL & 8) return;
-        float* d = &smem[pst[i] + pq * W4_PBUF];
-        d[0] = st[i].x; d[W4_PLANE] = st[i].y; d[2 * W4_PLANE] = st[i].z; d[3 * W4_PLANE] = st[i].w;
-    };
-    auto wload = [&](int si, int i, int hp) { if (!(W4_ABL & (8 | 32))) st[si] = wbufload(rw, (i == 4 && !w4ok) ? WOOB : vsrc + (unsigned)i * 4096u, (unsigned)hp * (unsigned)W4_WPH); };
-    auto wstore = [&](int si, int i, int wq) {
-        if (W4_ABL & 8) return;
-        const int dst = (i == 4 && !w4ok) ? W4_DUMP + 4 * (tid & 3) : wq * W4_WBUF + (tid + 256 * i) * 4;
-        *reinterpret_cast<float4*>(&smem[dst]) = st[si];
-    };
-    auto rdrow = [&](int off, int r) {   // off: float offset of the patch buffer whose rows are read
-        if (W4_ABL & 2) return;
-        const float4 v = *reinterpret_cast<const float4*>(&smem[rbase + off + r * W4_PITCH]);
-        const float2 w = *reinterpret_cast<const float2*>(&smem[rbase + off + r * W4_PITCH + 4]);
-        rr[0] = v.x; rr[1] = v.y; rr[2] = v.z; rr[3] = v.w; rr[4] = w.x; rr[5] = w.y;
-    };
+    float4 Y[4][4];   // the lane's finished outputs (channel group hf)
+
+    // ---- main loop + partial output transform, compiled once per position half
+    auto body = [&](auto hfc) {
+        constexpr int HF = decltype(hfc)::value;
+        float4 st[4];               // staging registers
+        float HA[6][3], HB[6][3];   // [patch row r][local horizontal index vl]: rows transformed horizontally (the wave's half of B^T over a row)
+        float U[6];                 // one column of B^T d B = the B operands of twelve MFMAs
+        float4 vf[2][2];            // weight fragments [slot][channel group]: fragment f = positions 4 (4 HF + f) .. + 3 of the packed order
+        float rr[2][6];             // raw patch rows in flight (row r in set r & 1)
+        float tv[5], th[3];
+        if (W4_ABL) {   // ablated builds read registers nobody wrote: give them values
+#pragma unroll
+            for (int i = 0; i < 4; ++i) st[i] = make_float4(1.f, 2.f, 3.f, 4.f);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { vf[i][0] = make_float4(1.f + lane, 2.f, 3.f, 4.f); vf[i][1] = make_float4(2.f + lane, 2.f, 3.f, 4.f); }
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { HA[r][c] = 1.f + lane + r; HB[r][c] = 2.f + lane + c; rr[c & 1][r] = 0.5f * lane; U[r] = 1.f * lane; }
+        }
+        auto pload = [&](int i, int hp) { if (!(W4_ABL & 8)) st[i] = wbufload(rx, voff[i], (unsigned)hp * plane_b); };
+        auto pstore = [&](int i, int pq) {
+            if (W4_ABL & 8) return;
+            float* d = &smem[pst[i] + pq * W4_PBUF];
+            d[0] = st[i].x; d[W4_PLANE] = st[i].y; d[2 * W4_PLANE] = st[i].z; d[3 * W4_PLANE] = st[i].w;
+        };
+        auto wload = [&](int si, int i, int hp) { if (!(W4_ABL & 8)) st[si] = wbufload(rw, (i == 4 && !w4ok) ? WOOB : vsrc + (unsigned)i * 4096u, (unsigned)hp * (unsigned)W4_WPH); };
+        auto wstore = [&](int si, int i, int wq) {
+            if (W4_ABL & 8) return;
+            const int dst = (i == 4 && !w4ok) ? W4_DUMP + 4 * (tid & 3) : wq * W4_WBUF + (tid + 256 * i) * 4;
+            *reinterpret_cast<float4*>(&smem[dst]) = st[si];
+        };
+        auto rdrow = [&](int off, int r) {   // off: float offset of the patch buffer whose rows are read; row r lands in set r & 1
+            if (W4_ABL & 2) return;
+            const float4 v = *reinterpret_cast<const float4*>(&smem[rbase + off + r * W4_PITCH]);
+            const float2 w = *reinterpret_cast<const float2*>(&smem[rbase + off + r * W4_PITCH + 4]);
+            float* d = rr[r & 1];
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; d[4] = w.x; d[5] = w.y;
+        };
+        auto rdfrag = [&](int f, int slot, int wq) {   // fragment f of weight buffer wq, both channel groups
+            if (W4_ABL & 4) return;
+#pragma unroll
+            for (int gi = 0; gi < 2; ++gi)
+                vf[slot][gi] = *reinterpret_cast<const float4*>(&smem[vbase + gi * W4_WGRP + wq * W4_WBUF + (4 * HF + f) * 256]);
+        };
 #define WSB() __builtin_amdgcn_sched_barrier(0)
 
-    // One phase (index h, parity q) = 36 MFMAs on the columns of Hc.  Beside them the next phase's rows are read (patch buffer q ^ 1)
-    // and transformed into Hn, the next phase's weights are staged into weight buffer q ^ 1 and the patches of the phase after it into
-    // patch buffer q (free: this phase's rows were read during the previous one); the barrier at gap 28 publishes the writes and
-    // closes this phase's reads.
-    auto phase = [&](auto qc, float (&Hc)[6][6], float (&Hn)[6][6], bool stP, bool stW, int h) {
-        constexpr int q = decltype(qc)::value;
-        const bool nxt = stW;   // a next phase exists exactly when its weights are still to be staged
-        const bool rd0ok = stP;
-        constexpr int rdo = (q ^ 1) * W4_PBUF, rd0 = q * W4_PBUF;
+        // One phase (index h, parity q) = 36 MFMAs: the wave's eighteen positions x two channel groups, column by column of Hc (twelve
+        // MFMAs per column).  Beside them the next phase's rows are read (patch buffer q ^ 1) and transformed into Hn (gaps 1 .. 24), the
+        // next column is transformed vertically (one step per gap), the next phase's weights are staged into weight buffer q ^ 1 and the
+        // patches of the phase after it into patch buffer q; the barrier at gap 28 publishes the writes and closes this phase's reads.
+        auto phase = [&](auto qc, float (&Hc)[6][3], float (&Hn)[6][3], bool stP, bool stW, int h) {
+            constexpr int q = decltype(qc)::value;
+            const bool nxt = stW;   // a next phase exists exactly when its weights are still to be staged
+            const bool rd0ok = stP;
+            constexpr int rdo = (q ^ 1) * W4_PBUF, rd0 = q * W4_PBUF;
 #pragma unroll
-        for (int m = 0; m < 36; ++m) {
-            const int v = m / 6, u = m % 6;
-            {   // fragment k = m / 4 lives in vf[(k + q) & 1]: nine fragments per phase, so the parity flips with the phase
-                const float4& f = vf[((m >> 2) + q) & 1];
-                const float av = (m & 3) == 0 ? f.x : (m & 3) == 1 ? f.y : (m & 3) == 2 ? f.z : f.w;
-                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, U[u], acc[m], 0, 0, 0);
-            }
-            WSB();
-            // (A) vertical transform of the next unit's column, two steps per gap, written over the operands just consumed
-            if (W4_ABL & 1) {
-            } else if (v < 5) {
+            for (int m = 0; m < 36; ++m) {
+                const int pos = m >> 1, gi = m & 1, vl = pos / 6, u = pos % 6;
+                {   // packed position p = 18 HF + pos lives in fragment f = p / 4 - 4 HF, slot (f + q) & 1 (five fragments per phase: the parity flips with the phase)
+                    const int pp = 18 * HF + pos, f = (pp >> 2) - 4 * HF;
+                    const float4& fr = vf[(f + q) & 1][gi];
+                    const float av = (pp & 3) == 0 ? fr.x : (pp & 3) == 1 ? fr.y : (pp & 3) == 2 ? fr.z : fr.w;
+                    acc[gi][pos] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, U[u], acc[gi][pos], 0, 0, 0);
+                }
+                WSB();
+                // (A) vertical transform of the next column, one step per gap, written over the operands just consumed
+                if (W4_ABL & 1) {
+                } else if (vl < 2) {
+                    w4_bstep_v(m % 12, Hc[0][vl + 1], Hc[1][vl + 1], Hc[2][vl + 1], Hc[3][vl + 1], Hc[4][vl + 1], Hc[5][vl + 1], U, tv);
+                } else if (nxt) {
+                    w4_bstep_v(m % 12, Hn[0][0], Hn[1][0], Hn[2][0], Hn[3][0], Hn[4][0], Hn[5][0], U, tv);
+                }
+                // (B) horizontal transform of the next phase's rows: 36 steps over gaps 1 .. 24 (row r: gaps 4 r + 1 .. 4 r + 4, done
+                // before its column 0 is wanted at gap 24)
+                if (nxt && m >= 1 && m <= 24 && !(W4_ABL & 1)) {
 #pragma unroll
-                for (int k = 2 * u; k < 2 * u + 2; ++k) w4_bstep_v(k, Hc[0][v + 1], Hc[1][v + 1], Hc[2][v + 1], Hc[3][v + 1], Hc[4][v + 1], Hc[5][v + 1], U, tv);
-            } else if (nxt) {
-#pragma unroll
-                for (int k = 2 * u; k < 2 * u + 2; ++k) w4_bstep_v(k, Hn[0][0], Hn[1][0], Hn[2][0], Hn[3][0], Hn[4][0], Hn[5][0], U, tv);
-            }
-            // (B) horizontal transform of the next phase's rows: 72 steps over gaps 1 .. 30 (row r: gaps 5 r + 1 .. 5 r + 5)
-            if (nxt && m >= 1 && m <= 30 && !(W4_ABL & 1)) {
-#pragma unroll
-                for (int S = (m - 1) * 72 / 30; S < m * 72 / 30; ++S) w4_bstep_h(S % 12, rr[0], rr[1], rr[2], rr[3], rr[4], rr[5], Hn[S / 12], th);
-            }
-            // (C) row reads: the raw row is dead after step 7 of its transform (gap 5 r + 3); row r + 1 is read at gap 5 r + 4, row 0 of
-            // the phase after the next at gap 34 (behind the barrier)
-            if (nxt && m >= 4 && m <= 24 && (m - 4) % 5 == 0) rdrow(rdo, (m - 4) / 5 + 1);
-            if (rd0ok && m == 34) rdrow(rd0, 0);
-            // (D) weight fragments: fragment k >= 1 of this phase at gap 4 k - 3; fragment 0 of the next phase at gap 33
-            if (m >= 1 && m <= 29 && (m - 1) % 4 == 0 && !(W4_ABL & 4)) {
-                const int k = (m - 1) / 4 + 1;
-                vf[(k + q) & 1] = *reinterpret_cast<const float4*>(&smem[vbase + q * W4_WBUF + k * 256]);
-            }
-            if (nxt && m == 33 && !(W4_ABL & 4)) vf[(q ^ 1) & 1] = *reinterpret_cast<const float4*>(&smem[vbase + (q ^ 1) * W4_WBUF]);
-            // (E) staging: group A = the three patch slots + weight piece 0, group B = weight pieces 1 .. 4
-            if (!(W4_ABL & 64)) {
+                    for (int S = (m - 1) * 3 / 2; S < m * 3 / 2; ++S) w4_hstep<HF>(S % 6, rr[(S / 6) & 1], Hn[S / 6], th);
+                }
+                // (C) row reads: rows 0 and 1 were read at the end of the previous phase; the raw row r is dead after gap 4 r + 3, row
+                // r + 2 is read into its registers at gap 4 r + 4; rows 0, 1 of the phase after the next at gaps 34, 35 (behind the barrier)
+                if (nxt && m >= 4 && m <= 16 && (m & 3) == 0) rdrow(rdo, m / 4 + 1);
+                if (rd0ok && m == 34) rdrow(rd0, 0);
+                if (rd0ok && m == 35) rdrow(rd0, 1);
+                // (D) weight fragments: fragment f >= 1 of this phase once the slot's previous fragment is consumed; fragment 0 of the
+                // next phase at gap 33.  Half 0 uses fragment f at MFMAs 8 f .. 8 f + 7, half 1 at 8 f - 4 .. 8 f + 3.
+                {
+                    constexpr int first = HF ? 0 : 1;
+                    if (m >= first && m <= first + 24 && ((m - first) & 7) == 0) {
+                        const int f = (m - first) / 8 + 1;
+                        rdfrag(f, (f + q) & 1, q);
+                    }
+                }
+                if (nxt && m == 33) rdfrag(0, (q ^ 1) & 1, q ^ 1);
+                // (E) staging: group A = the three patch slots + weight piece 0, group B = weight pieces 1 .. 4
                 if (m >= W4_A_LD && m < W4_A_LD + 3 && stP) pload(m - W4_A_LD, h + 2);
                 if (m == W4_A_LD + 3 && stW) wload(3, 0, h + 1);
                 if (m >= W4_A_ST && m < W4_A_ST + 3 && stP) pstore(m - W4_A_ST, q);
                 if (m == W4_A_ST + 3 && stW) wstore(3, 0, q ^ 1);
+                if (m >= W4_B_LD && m < W4_B_LD + 4 && stW) wload(m - W4_B_LD, m - W4_B_LD + 1, h + 1);
+                if (m >= W4_B_ST && m < W4_B_ST + 4 && stW) wstore(m - W4_B_ST, m - W4_B_ST + 1, q ^ 1);
+                // (F)
+                if (m == 28 && nxt && !(W4_ABL & 16)) __syncthreads();
+                WSB();
             }
-            if (!(W4_ABL & 128)) {
-                if (m >= W4_B_LD && m < W4_B_LD + 4 && stW) wload(m - W4_B_LD + W4_B_REG, m - W4_B_LD + 1, h + 1);
-                if (m >= W4_B_ST && m < W4_B_ST + 4 && stW) wstore(m - W4_B_ST + W4_B_REG, m - W4_B_ST + 1, q ^ 1);
-            }
-            // (F)
-            if (m == 28 && nxt && !(W4_ABL & 16)) __syncthreads();
-            WSB();
+        };
+
+        // ---- prologue: phases 0 (patches + weights) and 1 (patches) into the LDS, rows of phase 0 transformed
+#pragma unroll
+        for (int i = 0; i < 3; ++i) pload(i, 0);
+        wload(3, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) pstore(i, 0);
+        wstore(3, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wload(i, i + 1, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wstore(i, i + 1, 0);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) pload(i, 1);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) pstore(i, 1);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            rdrow(0, r);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) w4_hstep<HF>(k, rr[r & 1], HA[r], th);
         }
-    };
+#pragma unroll
+        for (int k = 0; k < 12; ++k) w4_bstep_v(k, HA[0][0], HA[1][0], HA[2][0], HA[3][0], HA[4][0], HA[5][0], U, tv);
+        rdfrag(0, 0, 0);
+        rdrow(W4_PBUF, 0);   // rows 0, 1 of phase 1
+        rdrow(W4_PBUF, 1);
+        __syncthreads();     // (nobody stages over rows that somebody still reads)
+        WSB();
 
-    // ---- prologue: phases 0 (patches + weights) and 1 (patches) into the LDS, rows of phase 0 transformed
-#pragma unroll
-    for (int i = 0; i < 3; ++i) pload(i, 0);
-    wload(3, 0, 0);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) pstore(i, 0);
-    wstore(3, 0, 0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) wload(i, i + 1, 0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) wstore(i, i + 1, 0);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) pload(i, 1);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) pstore(i, 1);
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 6; ++r) {
-        rdrow(0, r);
-#pragma unroll
-        for (int k = 0; k < 12; ++k) w4_bstep_h(k, rr[0], rr[1], rr[2], rr[3], rr[4], rr[5], HA[r], th);
-    }
-#pragma unroll
-    for (int k = 0; k < 12; ++k) w4_bstep_v(k, HA[0][0], HA[1][0], HA[2][0], HA[3][0], HA[4][0], HA[5][0], U, tv);
-    if (!(W4_ABL & 4)) vf[0] = *reinterpret_cast<const float4*>(&smem[vbase]);
-    rdrow(W4_PBUF, 0);   // row 0 of phase 1
-    __syncthreads();     // (nobody stages over rows that somebody still reads)
-    WSB();
-
-    using Q0 = std::integral_constant<int, 0>;
-    using Q1 = std::integral_constant<int, 1>;
-    int h = 0;
-    for (; h + 2 < a.nphases; h += 2) {
-        phase(Q0{}, HA, HB, true, true, h);
-        phase(Q1{}, HB, HA, true, true, h + 1);
-    }
-    phase(Q0{}, HA, HB, false, true, h);
-    phase(Q1{}, HB, HA, false, false, h + 1);
+        using Q0 = std::integral_constant<int, 0>;
+        using Q1 = std::integral_constant<int, 1>;
+        int h = 0;
+        for (; h + 2 < a.nphases; h += 2) {
+            phase(Q0{}, HA, HB, true, true, h);
+            phase(Q1{}, HB, HA, true, true, h + 1);
+        }
+        phase(Q0{}, HA, HB, false, true, h);
+        phase(Q1{}, HB, HA, false, false, h + 1);
 #undef WSB
 
-    // ---- output transform A^T M A (6 x 6 -> 4 x 4) and epilogue
-    //   y0 = m0 + m1 + m2 + m3 + m4   y1 = (m1 - m2) + 2 (m3 - m4)   y2 = (m1 + m2) + 4 (m3 + m4)   y3 = (m1 - m2) + 8 (m3 - m4) + m5
-    float4 Y[4][4];
+        // ---- output transform A^T M A (6 x 6 -> 4 x 4): rows of A^T
+        //   y0 = m0 + m1 + m2 + m3 + m4   y1 = (m1 - m2) + 2 (m3 - m4)   y2 = (m1 + m2) + 4 (m3 + m4)   y3 = (m1 - m2) + 8 (m3 - m4) + m5
+        // The vertical pass (over u) is whole inside a wave; of the horizontal pass (over v) a wave holds three of the six terms: PARTIAL
+        // outputs, summed with the other half's through the LDS -- each wave sends the partials of the channel group it does not finish.
+        __syncthreads();   // (the main loop's LDS reads are behind every wave)
+        float4* xch = reinterpret_cast<float4*>(smem);
+        auto partial = [&](int gi, float4 (&Pq)[4][4]) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        float T[4][6];
+            for (int r = 0; r < 4; ++r) {
+                float T[4][3];
 #pragma unroll
-        for (int v = 0; v < 6; ++v) {
-            const float m0 = acc[6 * v + 0][r], m1 = acc[6 * v + 1][r], m2 = acc[6 * v + 2][r], m3 = acc[6 * v + 3][r], m4 = acc[6 * v + 4][r], m5 = acc[6 * v + 5][r];
-            const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
-            T[0][v] = m0 + s1 + s2;
-            T[1][v] = __builtin_fmaf(2.f, d2, d1);
-            T[2][v] = __builtin_fmaf(4.f, s2, s1);
-            T[3][v] = __builtin_fmaf(8.f, d2, d1) + m5;
+                for (int vl = 0; vl < 3; ++vl) {
+                    const float m0 = acc[gi][6 * vl + 0][r], m1 = acc[gi][6 * vl + 1][r], m2 = acc[gi][6 * vl + 2][r], m3 = acc[gi][6 * vl + 3][r],
+                                m4 = acc[gi][6 * vl + 4][r], m5 = acc[gi][6 * vl + 5][r];
+                    const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+                    T[0][vl] = m0 + s1 + s2;
+                    T[1][vl] = __builtin_fmaf(2.f, d2, d1);
+                    T[2][vl] = __builtin_fmaf(4.f, s2, s1);
+                    T[3][vl] = __builtin_fmaf(8.f, d2, d1) + m5;
+                }
+#pragma unroll
+                for (int aa = 0; aa < 4; ++aa) {
+                    float o0, o1, o2, o3;
+                    if (HF == 0) {   // v = 0, 1, 2: m0, m1, m2 of the row
+                        const float s1 = T[aa][1] + T[aa][2], d1 = T[aa][1] - T[aa][2];
+                        o0 = T[aa][0] + s1; o1 = d1; o2 = s1; o3 = d1;
+                    } else {         // v = 3, 4, 5: m3, m4, m5
+                        const float s2 = T[aa][0] + T[aa][1], d2 = T[aa][0] - T[aa][1];
+                        o0 = s2; o1 = 2.f * d2; o2 = 4.f * s2; o3 = __builtin_fmaf(8.f, d2, T[aa][2]);
+                    }
+                    if (r == 0) { Pq[aa][0].x = o0; Pq[aa][1].x = o1; Pq[aa][2].x = o2; Pq[aa][3].x = o3; }
+                    if (r == 1) { Pq[aa][0].y = o0; Pq[aa][1].y = o1; Pq[aa][2].y = o2; Pq[aa][3].y = o3; }
+                    if (r == 2) { Pq[aa][0].z = o0; Pq[aa][1].z = o1; Pq[aa][2].z = o2; Pq[aa][3].z = o3; }
+                    if (r == 3) { Pq[aa][0].w = o0; Pq[aa][1].w = o1; Pq[aa][2].w = o2; Pq[aa][3].w = o3; }
+                }
+            }
+        };
+        {
+            float4 S[4][4];
+            partial(1 - HF, S);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) xch[(wave * 16 + k) * 64 + lane] = S[k >> 2][k & 3];
         }
+        partial(HF, Y);
+        __syncthreads();
 #pragma unroll
-        for (int aa = 0; aa < 4; ++aa) {
-            const float s1 = T[aa][1] + T[aa][2], d1 = T[aa][1] - T[aa][2], s2 = T[aa][3] + T[aa][4], d2 = T[aa][3] - T[aa][4];
-            const float o0 = T[aa][0] + s1 + s2, o1 = __builtin_fmaf(2.f, d2, d1), o2 = __builtin_fmaf(4.f, s2, s1), o3 = __builtin_fmaf(8.f, d2, d1) + T[aa][5];
-            if (r == 0) { Y[aa][0].x = o0; Y[aa][1].x = o1; Y[aa][2].x = o2; Y[aa][3].x = o3; }
-            if (r == 1) { Y[aa][0].y = o0; Y[aa][1].y = o1; Y[aa][2].y = o2; Y[aa][3].y = o3; }
-            if (r == 2) { Y[aa][0].z = o0; Y[aa][1].z = o1; Y[aa][2].z = o2; Y[aa][3].z = o3; }
-            if (r == 3) { Y[aa][0].w = o0; Y[aa][1].w = o1; Y[aa][2].w = o2; Y[aa][3].w = o3; }
+        for (int k = 0; k < 16; ++k) {
+            const float4 o = xch[((wave ^ 1) * 16 + k) * 64 + lane];
+            float4& y = Y[k >> 2][k & 3];
+            // (always half 0's partial + half 1's, so that both waves of a block round alike)
+            if (HF == 0) { y.x = y.x + o.x; y.y = y.y + o.y; y.z = y.z + o.z; y.w = y.w + o.w; }
+            else { y.x = o.x + y.x; y.y = o.y + y.y; y.z = o.z + y.z; y.w = o.w + y.w; }
         }
-    }
+    };
+    if (hf) body(std::integral_constant<int, 1>{});
+    else body(std::integral_constant<int, 0>{});
+
+    // ---- epilogue
     unsigned ob0 = 0u, ob1 = 0u;
 #pragma unroll
     for (int aa = 0; aa < 4; ++aa)

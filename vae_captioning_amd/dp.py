@@ -99,7 +99,7 @@ class _Pending(object):
 class AbiComm(object):
     """The step's collectives through libvaecap's own RCCL entries (include/vaecap.h: vc_comm_*, vc_allreduce_sum_f32,
     vc_allgather_f32, vc_reducescatter_sum_f32) -- what a maintainer binding the C ABI gets; torch.distributed is not involved in
-    the data path (it may carry the 128-byte unique id to the other ranks, `from_store`).  Every collective of the communicator runs
+    the data path (it carries the 128-byte unique id to the other ranks: Trainer._agree_on_abi_comm).  Every collective of the communicator runs
     on ONE dedicated HIP stream in issue order; it waits for the issuing stream's work, and the issuing stream waits for it (blocking
     form) or for its event (`*_async(...).wait()`).  A failing call raises abi.VaecapError with RCCL's message: the step aborts."""
     _serial = 0
@@ -123,20 +123,6 @@ class AbiComm(object):
         buf = ctypes.create_string_buffer(128)
         lib.vc_comm_unique_id(buf)
         return buf.raw
-
-    @classmethod
-    def from_store(cls, lib, world, rank, device):
-        """Rank 0 creates the unique id; it travels through torch.distributed's rendezvous store (host side, any backend)."""
-        import torch.distributed as dist
-        store = dist.distributed_c10d._get_default_store()
-        key = "vc_rccl_unique_id_%d" % cls._serial
-        cls._serial += 1
-        if rank == 0:
-            uid = cls.unique_id(lib)
-            store.set(key, uid)
-        else:
-            uid = store.get(key)
-        return cls(lib, world, rank, device, uid)
 
     @classmethod
     def single(cls, lib, device=0):

@@ -565,23 +565,54 @@ class Trainer(object):
                 if self.world == 1:
                     self.comm = dp.AbiComm.single(self.lib, dev)
                 else:
-                    # every rank must end up on the same path: the ranks agree (through the process group) whether the communicator came
-                    # up everywhere; if not (e.g. RCCL refuses two ranks on one GPU), all of them use torch.distributed instead
-                    err = None
-                    try:
-                        self.comm = dp.AbiComm.from_store(self.lib, self.world, self.rank, dev)
-                    except abi.VaecapError as e:
-                        err = e
-                    flag = torch.tensor([0.0 if err else 1.0], device="cuda" if dist.get_backend(self.group) == "nccl" else "cpu")
-                    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
-                    if float(flag.item()) == 0.0:
-                        if self.comm is not None:
-                            self.comm.destroy()
-                            self.comm = None
-                        if self.rank == 0:
-                            print("libvaecap communicator not available on every rank (%s): collectives through torch.distributed" % (err or "another rank failed"), flush=True)
+                    self.comm = self._agree_on_abi_comm(dev)
         if self.comm is not None:   # the engine's collective hooks go through the C ABI
             self.cap.reduce_fn, self.cap.gather_fn, self.cap.rscatter_fn = self.comm.all_reduce, self.comm.all_gather, self.comm.reduce_scatter
+
+    def _agree_on_abi_comm(self, dev):
+        """The libvaecap communicator for world > 1, or None with every rank on torch.distributed -- the ranks must end up on the
+        SAME path whatever fails where, so each stage is agreed on through the process group before the next one starts:
+          1. vc_comm_available() on every rank (an RCCL library can be bound);
+          2. rank 0 creates the unique id and broadcasts it -- or the error text -- to the group (broadcast_object_list: the group's
+             own transport, no private store, nobody waits on a key that never appears);
+          3. ncclCommInitRank on every rank (RCCL refuses e.g. two ranks on one GPU: an error on all of them), then a last MIN.
+        (A rank that dies INSIDE the collective init still hangs the others -- that is RCCL's contract, not something a handshake
+        in front of it can repair.)"""
+        import torch.distributed as dist
+        from . import dp
+        on_gpu = dist.get_backend(self.group) == "nccl"
+
+        def all_ok(ok):
+            flag = torch.tensor([1.0 if ok else 0.0], device="cuda" if on_gpu else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            return float(flag.item()) == 1.0
+
+        def give_up(why):
+            if self.rank == 0:
+                print("libvaecap communicator not available on every rank (%s): collectives through torch.distributed" % why, flush=True)
+            return None
+        if not all_ok(bool(self.lib.vc_comm_available())):
+            return give_up("no RCCL library could be bound on some rank")
+        msg = [None]
+        if self.rank == 0:
+            try:
+                msg = [("id", dp.AbiComm.unique_id(self.lib))]
+            except abi.VaecapError as e:
+                msg = [("error", str(e))]
+        src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+        dist.broadcast_object_list(msg, src=src, group=self.group)
+        if msg[0][0] != "id":
+            return give_up(msg[0][1])
+        comm, err = None, None
+        try:
+            comm = dp.AbiComm(self.lib, self.world, self.rank, dev, msg[0][1])
+        except abi.VaecapError as e:
+            err = e
+        if not all_ok(err is None):
+            if comm is not None:
+                comm.destroy()
+            return give_up(err or "another rank failed")
+        return comm
 
     def set_batch(self, batch, noise=None):
         extra = [("images", np.asarray(batch["images"], np.float32), torch.float32)] if self.fine else []
