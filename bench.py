@@ -470,11 +470,12 @@ def wino_executed_ratio(images, wino4=True):
     """Executed MFMA FLOPs / algorithmic FLOPs of one cfg4 step's 3x3 convolution calls when the Winograd kernels run (default):
     F(2x2,3x3) / F(3x3,2x2) multiply 16 times per 2x2 tile and channel pair where the direct form multiplies 36 times, F(4x4,3x3) 36
     times per 4x4 tile where the direct form multiplies 144 times; tile blocks that stick out of the image add padding work.  Forward /
-    data gradient: F(4x4,3x3) on blocks of 16 x 16 pixels (csrc/conv_wino4.hip) where vc_conv3x3_wino4_preferred says so -- coverage
-    >= 0.85 x the F(2x2,3x3) blocks' coverage: the 224-, 112-, 28-, 14-wide layers --, else F(2x2,3x3) on blocks of 16 tile slots whose
-    halo patch fits 100 pixels (csrc/conv_wino.hip plan_wino2: the 56-wide layers); weight gradient (conv_wino_wgrad.hip
+    data gradient: F(4x4,3x3) on blocks of 16 x 16 pixels (csrc/conv_wino4.hip) where vc_conv3x3_wino4_preferred says so -- since round 4
+    every VGG16 layer behind conv1_1 --, else F(2x2,3x3) on blocks of 16 tile slots whose halo patch fits 100 pixels
+    (csrc/conv_wino.hip plan_wino2); weight gradient (conv_wino_wgrad.hip
     plan_wino_wgrad): F(3x3,2x2) on 4x8 / 4x7 / 2x14 tiles.  conv1_1 (3 input channels) stays on its direct HBM-bound kernels."""
-    from vae_captioning_amd import spec
+    from vae_captioning_amd import abi, spec
+    prefers4 = abi.load().vc_conv3x3_wino4_preferred   # the library's own rule (block coverage; csrc/conv_wino4.hip)
     slots, maxpix = 16, 100
     H = 224
     alg = ex = 0.0
@@ -493,7 +494,7 @@ def wino_executed_ratio(images, wino4=True):
                 best = max(best, tw * th / (_cdiv(tw, tbw) * _cdiv(th, tbh) * float(slots)))
             effw = max(tw * th / (_cdiv(tw, bw) * _cdiv(th, bh) * float(bh * bw)) for bh, bw in ((4, 8), (4, 7), (2, 14)))
             eff4 = H * H / (_cdiv(H, 16) ** 2 * 256.0)
-            fd = (36.0 / 144.0) / eff4 if (wino4 and eff4 >= 0.85 * best) else (16.0 / 36.0) / best
+            fd = (36.0 / 144.0) / eff4 if (wino4 and prefers4(images, H, H, ci, co)) else (16.0 / 36.0) / best
             alg += 3 * fl
             ex += 2 * fl * fd + fl * (16.0 / 36.0) / effw
         if name in spec.VGG_POOL_AFTER:

@@ -236,17 +236,17 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
                 for (int c = 0; c < 3; ++c) { HA[r][c] = 1.f + lane + r; HB[r][c] = 2.f + lane + c; rr[c & 1][r] = 0.5f * lane; U[r] = 1.f * lane; }
         }
         auto pload = [&](int i, int hp) { if (!(W4_ABL & 8)) st[i] = wbufload(rx, voff[i], (unsigned)hp * plane_b); };
-        auto pstore = [&](int i, int pq) {
-            if (W4_ABL & 8) return;
+        auto pput = [&](const float4& v, int i, int pq) {   // patch slot i into patch buffer pq: one pixel, four channel planes
             float* d = &smem[pst[i] + pq * W4_PBUF];
-            d[0] = st[i].x; d[W4_PLANE] = st[i].y; d[2 * W4_PLANE] = st[i].z; d[3 * W4_PLANE] = st[i].w;
+            d[0] = v.x; d[W4_PLANE] = v.y; d[2 * W4_PLANE] = v.z; d[3 * W4_PLANE] = v.w;
         };
-        auto wload = [&](int si, int i, int hp) { if (!(W4_ABL & 8)) st[si] = wbufload(rw, (i == 4 && !w4ok) ? WOOB : vsrc + (unsigned)i * 4096u, (unsigned)hp * (unsigned)W4_WPH); };
-        auto wstore = [&](int si, int i, int wq) {
-            if (W4_ABL & 8) return;
+        auto wput = [&](const float4& v, int i, int wq) {   // weight piece i into weight buffer wq
             const int dst = (i == 4 && !w4ok) ? W4_DUMP + 4 * (tid & 3) : wq * W4_WBUF + (tid + 256 * i) * 4;
-            *reinterpret_cast<float4*>(&smem[dst]) = st[si];
+            *reinterpret_cast<float4*>(&smem[dst]) = v;
         };
+        auto pstore = [&](int i, int pq) { if (!(W4_ABL & 8)) pput(st[i], i, pq); };
+        auto wload = [&](int si, int i, int hp) { if (!(W4_ABL & 8)) st[si] = wbufload(rw, (i == 4 && !w4ok) ? WOOB : vsrc + (unsigned)i * 4096u, (unsigned)hp * (unsigned)W4_WPH); };
+        auto wstore = [&](int si, int i, int wq) { if (!(W4_ABL & 8)) wput(st[si], i, wq); };
         auto rdrow = [&](int off, int r) {   // off: float offset of the patch buffer whose rows are read; row r lands in set r & 1
             if (W4_ABL & 2) return;
             const float4 v = *reinterpret_cast<const float4*>(&smem[rbase + off + r * W4_PITCH]);
@@ -322,21 +322,23 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
             }
         };
 
-        // ---- prologue: phases 0 (patches + weights) and 1 (patches) into the LDS, rows of phase 0 transformed
+        // ---- prologue: phases 0 (patches + weights) and 1 (patches) into the LDS, rows of phase 0 transformed.  All eleven loads are
+        // issued before the first store: one memory round trip instead of three (a workgroup of conv1_2 lives for sixteen phases only)
+        if (!(W4_ABL & 8)) {
+            float4 pr[11];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) pload(i, 0);
-        wload(3, 0, 0);
+            for (int i = 0; i < 3; ++i) pr[i] = wbufload(rx, voff[i], 0u);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) pstore(i, 0);
-        wstore(3, 0, 0);
+            for (int i = 0; i < 5; ++i) pr[3 + i] = wbufload(rw, (i == 4 && !w4ok) ? WOOB : vsrc + (unsigned)i * 4096u, 0u);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) wload(i, i + 1, 0);
+            for (int i = 0; i < 3; ++i) pr[8 + i] = wbufload(rx, voff[i], plane_b);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) wstore(i, i + 1, 0);
+            for (int i = 0; i < 3; ++i) pput(pr[i], i, 0);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) pload(i, 1);
+            for (int i = 0; i < 5; ++i) wput(pr[3 + i], i, 0);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) pstore(i, 1);
+            for (int i = 0; i < 3; ++i) pput(pr[8 + i], i, 1);
+        }
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
@@ -558,15 +560,17 @@ extern "C" int vc_conv3x3_wino4_supported(int B, int H, int W, int Cin, int Cout
     return nb > 0 && (dgrad ? vc::plan_wino4(nb, H, W, Cout, Cin, g) : vc::plan_wino4(nb, H, W, Cin, Cout, g)) ? 1 : 0;
 }
 
-// 1 when this kernel is the faster Winograd form for the layer: its 16 x 16-pixel blocks must cover the image nearly as well as the
-// F(2x2,3x3) kernel's blocks of sixteen 2 x 2 tiles do (>= 0.85 x).  Decided on the training step itself, block of layers by block
-// (cfg4 at 64 images, three streams, ms per step; profiles/r03_wino4_layers.txt): none 31.76; conv1_2 31.43; + conv2_x 31.08; + conv4_x
-// 31.04; + conv5_x 30.89; the 56-wide conv3_x on top 31.03 (77 % coverage against 100 %) -- although, kernel by kernel at 32 images, conv3_x
-// gains 2-11 % and conv5_x loses 10 %: beside the other streams' launches the ranking is not the stand-alone one.
+// 1 when this kernel is the faster Winograd form for the layer: its 16 x 16-pixel blocks must cover the image at least 0.75 x as well as
+// the F(2x2,3x3) kernel's blocks of sixteen 2 x 2 tiles do.  Decided on the training step itself (cfg4 at 64 images, three streams, ms per
+// step).  Round 3 (each wave transformed the whole 6 x 6 patch; profiles/r03_wino4_layers.txt): the rule was 0.85 -- the 56-wide conv3_x (77 %
+// coverage against 100 %) lost 0.14 ms on F(4x4,3x3).  Round 4 (the two waves of a block split the positions, half the transform each):
+// conv3_x gains 2-12 % kernel by kernel and 0.16 ms in the step (28.74 -> 28.58, profiles/r04_wino4_layers.txt), so every VGG16 layer
+// behind conv1_1 now runs this kernel; VC_WINO4_MIN_COVERAGE overrides the ratio for A/B runs.
 extern "C" int vc_conv3x3_wino4_preferred(int B, int H, int W, int Cin, int Cout) {
     if (!vc_conv3x3_wino4_supported(B, H, W, Cin, Cout, 0) || !vc_conv3x3_wino4_supported(B, H, W, Cin, Cout, 1) || (H & 1) || (W & 1)) return 0;
     const double e4 = (double)H * W / ((double)vc::cdiv(H, 16) * vc::cdiv(W, 16) * 256.0);
-    return e4 >= 0.85 * vc::wino2_coverage(H, W) ? 1 : 0;
+    static const double ratio = getenv("VC_WINO4_MIN_COVERAGE") ? atof(getenv("VC_WINO4_MIN_COVERAGE")) : 0.75;   // (A/B runs of the rule)
+    return e4 >= ratio * vc::wino2_coverage(H, W) ? 1 : 0;
 }
 
 extern "C" int vc_conv3x3_wino4_pack_f32(void* stream, int Cin, int Cout, const float* w, int transpose, float* wp) {
