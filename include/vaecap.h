@@ -266,7 +266,7 @@ int vc_pad_dim_f32(void* stream, const float* src, long outer, int c_src, int c_
  * pixels, a pixel = 16 bytes = four consecutive channels (element (b, y, x, c) at float index (((b * C/4 + c/4) * H + y) * W + x) * 4 + c%4).
  * Why: the kernels gather 16-byte pieces (a pixel's four channels of one Winograd phase) for the pixels of a halo patch; in NHWC the
  * pixels of a patch row are 4 C bytes apart, one wave load touches 64 cache lines and the L1's tag rate bounds the kernel (measured:
- * DESIGN.md section 4g); in C4 a patch row is 288 consecutive bytes.  Images stay contiguous (image ranges, data-parallel shards and the
+ * HISTORY.md section 4g); in C4 a patch row is 288 consecutive bytes.  Images stay contiguous (image ranges, data-parallel shards and the
  * > 2 GiB cuts are slices of the leading dimension as before); C = 4 (conv1_1's zero-padded RGB input) is the same memory in both
  * layouts.  The reference's NHWC order (utils/image_embeddings.py:222: pool5 flattened as (h, w, c)) is restored at the fc1 boundary.
  * vc_maxpool2x2_fwd_f32 / vc_maxpool2x2_bwd_f32 work on C4 tensors when called with (B * C/4, H, W, 4). */

@@ -1,5 +1,5 @@
 #!/bin/bash
-# EXPERIMENT report -> profiles/r03_wino4_experiment.txt.  Build first (in the container):
+# EXPERIMENT report (HISTORY.md section 4g) -> profiles/r03_wino4_experiment.txt.  Build first (in the container):
 #   make -C vae_captioning_amd/csrc wino4; for n in 1 8 32 64 128 15 256; do make -C vae_captioning_amd/csrc wino4 W4FLAGS=-DW4_ABL=$n && \
 #     cp vae_captioning_amd/lib/libvaecap_wino4.so vae_captioning_amd/lib/libvaecap_wino4_abl$n.so; done; make -C vae_captioning_amd/csrc wino4
 #   hipcc -w --offload-arch=gfx950 -O3 -std=c++17 tools/probes/mfma16_f43.hip -o build/probes/mfma16_f43   (and mfma_specialised)

@@ -1,4 +1,4 @@
-"""the Winograd F(4x4,3x3) forward / data gradient of csrc/conv_wino4.hip against the
+"""HISTORY.md section 4g: the Winograd F(4x4,3x3) forward / data gradient of csrc/conv_wino4.hip against the
 library's F(2x2,3x3) kernel -- values and time on the VGG16 layer shapes.  Run: python tools/experiments/wino4_try.py [images] [dgrad|bits]; ablations: make -C vae_captioning_amd/csrc wino4abl W4FLAGS=-DW4_ABL=n, then
 VC_LIB=vae_captioning_amd/lib/libvaecap_wino4abl.so
 (W4_ONLY=conv2_2,conv4_2 restricts the layers)."""

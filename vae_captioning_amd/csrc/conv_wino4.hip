@@ -5,7 +5,7 @@
 //
 // Used where vc_conv3x3_wino4_preferred says so (block coverage: the 224-, 112-, 28- and 14-wide layers of VGG16; the 56-wide block
 // stays on conv_wino.hip): kernel by kernel 7-30 % faster there, 0.9 ms of the 31.8 ms cfg4 step (profiles/r03_wino4_layers.txt).
-// Why a second Winograd kernel (tools/probes/mfma16_f43.hip, mfma_specialised.hip): on one SIMD a VALU
+// Why a second Winograd kernel (tools/probes/mfma16_f43.hip, mfma_specialised.hip; HISTORY.md section 4g): on one SIMD a VALU
 // instruction and the matrix pipe do NOT overlap -- beside back-to-back v_mfma_f32_16x16x4_f32 a partner wave gets ~0.5 VALU issues
 // per MFMA, inside one stream every VALU operation costs 4-8 cycles of matrix time -- so the F(2x2,3x3) kernel's 71 % MFMA-busy is its
 // instruction mix, not its LDS traffic, and the way down is fewer MFMAs per output: the 36 positions of F(4x4,3x3) cost 36 / 16 = 2.25
@@ -26,8 +26,7 @@
 #include "conv_wino.h"
 
 // `make wino4abl W4FLAGS=-DW4_ABL=n` builds this file with W4_ABL = a bit mask that REMOVES parts of the main loop (results are then wrong; timing only):
-// 1 transform arithmetic, 2 patch-row reads, 4 weight-fragment reads, 8 staging (global loads + LDS writes), 16 barriers,
-// 256 the patch loads made contiguous over the lanes (what a channel-blocked activation layout would give the L1), 32 the global loads only (the LDS writes store stale registers), 64 staging group A (patches + weight piece 0), 128 staging group B
+// 1 transform arithmetic, 2 patch-row reads, 4 weight-fragment reads, 8 staging (global loads + LDS writes), 16 barriers, 32 the patch loads wrapped into a cache-resident 1 MB window (same pattern),
 #ifndef W4_ABL
 #define W4_ABL 0
 #endif
@@ -157,6 +156,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
         // C4 layout [B][C/4][H][W][4]: the pixel's four channels of phase h are 16 bytes at channel plane h (soffset h * plane bytes);
         // consecutive lanes = consecutive pixels of a patch row = consecutive 16-byte pieces (288-byte runs)
         voff[j] = ok ? (((b * (unsigned)(C >> 2) * (unsigned)g.H + (unsigned)y) * (unsigned)g.W + (unsigned)x)) * 16u : WOOB;
+        if ((W4_ABL & 32) && ok) voff[j] &= 0xfffffu;   // timing only: the same access pattern inside a 1 MB window (cache-resident patches)
         pst[j] = s < (unsigned)W4_NPIX ? W4_POFF + (int)blk * W4_BLKF + (int)py * W4_PITCH + (int)px : W4_DUMP + (tid & 15);
     }
     // weight slots: piece i of the phase's 18 KB = float4 tid + 256 i < 1152
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) { HA[r][c] = 1.f + lane + r; HB[r][c] = 2.f + lane + c; rr[c & 1][r] = 0.5f * lane; U[r] = 1.f * lane; }
         }
-        auto pload = [&](int i, int hp) { if (!(W4_ABL & 8)) st[i] = wbufload(rx, voff[i], (unsigned)hp * plane_b); };
+        auto pload = [&](int i, int hp) { if (!(W4_ABL & 8)) st[i] = wbufload(rx, voff[i], (unsigned)((W4_ABL & 32) ? (hp & 1) : hp) * plane_b); };
         auto pput = [&](const float4& v, int i, int pq) {   // patch slot i into patch buffer pq: one pixel, four channel planes
             float* d = &smem[pst[i] + pq * W4_PBUF];
             d[0] = v.x; d[W4_PLANE] = v.y; d[2 * W4_PLANE] = v.z; d[3 * W4_PLANE] = v.w;

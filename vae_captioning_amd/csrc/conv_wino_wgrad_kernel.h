@@ -2,6 +2,7 @@
 // shape is instantiated in its own translation unit (conv_wino_wgrad_<shape>.hip): a fully unrolled K-chunk of 256 MFMAs with their
 // hand-placed fillers takes hipcc about a minute per instantiation.
 #pragma once
+#include <type_traits>
 #include "conv_wino.h"
 
 // `make ablate-wgrad` builds the kernels with WG_ABL = a bit mask that REMOVES parts of the main loop (results wrong; timing only):
@@ -35,7 +36,7 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(WinoWgArgs a) {
     static_assert(PW * PH <= 180 && DW * DH <= 128 && NS <= 16 && NS >= 13, "block shape (the staging schedule runs to step 11, before the barrier of step NS - 1)");
     const WinoGeom& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
-    const int cw = wave >> 1, nw = wave & 1;
+    const int cw = wave >> 1, ph = wave & 1;
     const int cn = blockIdx.x % (a.ncb * a.nnb), split = blockIdx.x / (a.ncb * a.nnb);
     const int cb = cn / a.nnb, nb = cn - cb * a.nnb;
     const int C = g.C, N = g.N;
@@ -79,131 +80,159 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(WinoWgArgs a) {
         }
     };
 
-    f32x16 acc[16];
+    // wave = (input-channel tile cw, position half ph): 32 input channels x BOTH 32-column output tiles x the eight positions p = 4 xi + nu
+    // with xi (the vertical index) in {2 ph, 2 ph + 1}.  Round 3's wave owned one output tile and all sixteen positions, so the two waves
+    // of an input-channel tile each ran the whole x transform; now a wave needs three of the four patch rows and runs HALF of it (vertical
+    // 2 of 4 outputs per column, horizontal 8 of 16), and the dy transform of its half of the positions for both output tiles costs what
+    // one tile's full transform did: 24 instead of 36 arithmetic operations per step beside the same sixteen MFMAs.  The raw position sums
+    // go to the workspace as before (a wave writes its eight positions of both tiles); nothing is exchanged between the waves.
+    f32x16 acc[2][8];
 #pragma unroll
-    for (int p = 0; p < 16; ++p)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
-    float dbacc = 0.f;
+        for (int p = 0; p < 8; ++p)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][p][r] = 0.f;
+    float dbacc[2] = {0.f, 0.f};
 
-    // operands of one step: ua[p] = U_p[tile][c], eb[p] = E_p[tile][n]; dv / ev: raw reads; tc[j][xi]: vertical transform of patch column j
-    float ua[2][16], eb[2][16], dv[4][4], ev[2][2], tc[4][4], tv[2][4];
-    const int xbase = ((2 * lh) * PW) * 4 + (cw * 8 + (li >> 2)) * XPL + (li & 3);          // + buf * BUF + ((4 r + i) * PW + 2 tx + j) * 4
-    const int ybase = XPF + ((2 * lh) * DW) * 4 + (nw * 8 + (li >> 2)) * YPL + (li & 3);    // + buf * BUF + ((4 r + a) * DW + 2 tx + b) * 4
-    // micro-operation k of preparing step sn (from LDS buffer `buf`) into operand set ob
-    auto prep = [&](int buf, int sn, int ob, int k) {
-        const int r = sn / TBW, tx = sn - r * TBW;
-        const bool fresh = tx == 0;
-        const int nread = fresh ? 16 : 8;
-        if (k < nread) {
-            const int idx = fresh ? k : 8 + k, j = idx >> 2, i = idx & 3;
-            if (WG_ABL & 2) return;
-            dv[i][j] = smem[buf * BUF + xbase + ((4 * r + i) * PW + 2 * tx + j) * 4];
-            return;
-        }
-        k -= nread;
-        if (k < 4) {
-            const int aa = k >> 1, bb = k & 1;
-            if (WG_ABL & 2) return;
-            ev[aa][bb] = smem[buf * BUF + ybase + ((4 * r + aa) * DW + 2 * tx + bb) * 4];
-            return;
-        }
-        k -= 4;
-        if (WG_ABL & 1) return;
-        if (k < nread) {   // vertical transforms of the new patch columns (the two older ones carry over from the previous step)
-            const int idx = fresh ? k : 8 + k, j = idx >> 2, xi = idx & 3;
-            if (!fresh && k == 0) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { tc[0][q] = tc[2][q]; tc[1][q] = tc[3][q]; }
+    const int xbase = ((2 * lh) * PW) * 4 + (cw * 8 + (li >> 2)) * XPL + (li & 3);   // + buf * BUF + ((4 r + i) * PW + 2 tx + j) * 4
+    const int ybase = XPF + ((2 * lh) * DW) * 4 + (li >> 2) * YPL + (li & 3);          // + t * 8 * YPL + buf * BUF + ((4 r + a) * DW + 2 tx + b) * 4
+
+    auto body = [&](auto phc) {
+        constexpr int PH = decltype(phc)::value;
+        // operands of one step, double-buffered by ob: ua[ob][4 xl + nu] = U_p[tile][c] (xl = xi - 2 PH); the dy side keeps its raw values
+        // e, the vertical terms v and the two computed horizontal terms per xl -- the MFMA takes whichever register holds E_p (no copies)
+        float ua[2][8], dv[3][4], tc[4][2];
+        float ey[2][2][2][2], vy[2][2][2], hy[2][2][2][2];   // [ob][tile]: e[aa][bb]; v[bb]; h[xl][0: sum, 1: difference]
+        auto evalue = [&](int ob, int t, int pl) -> float {   // E_p of tile t, p = 4 (2 PH + xl) + nu, from the registers above
+            const int xl = pl >> 2, nu = pl & 3;
+            // row term of bb: PH 0: xi 0 -> e[0][bb], xi 1 -> v[bb] = e0 + e1;  PH 1: xi 2 -> v[bb] = e0 - e1, xi 3 -> e[1][bb]
+            auto row = [&](int bb) -> float { return PH == 0 ? (xl == 0 ? ey[ob][t][0][bb] : vy[ob][t][bb]) : (xl == 0 ? vy[ob][t][bb] : ey[ob][t][1][bb]); };
+            return nu == 0 ? row(0) : nu == 3 ? row(1) : hy[ob][t][xl][nu - 1];
+        };
+        // micro-operation k of preparing step sn (from LDS buffer `buf`) into operand set ob
+        auto prep = [&](int buf, int sn, int ob, int k) {
+            const int r = sn / TBW, tx = sn - r * TBW;
+            const bool fresh = tx == 0;
+            const int ncol = fresh ? 4 : 2, nread = 3 * ncol;
+            if (k < nread) {   // patch rows PH .. PH + 2 of the new columns
+                const int idx = fresh ? k : 6 + k, j = idx / 3, i = idx % 3;
+                if (WG_ABL & 2) return;
+                dv[i][j] = smem[buf * BUF + xbase + ((4 * r + PH + i) * PW + 2 * tx + j) * 4];
+                return;
             }
-            tc[j][xi] = xi == 0 ? dv[0][j] - dv[2][j] : xi == 1 ? dv[1][j] + dv[2][j] : xi == 2 ? dv[2][j] - dv[1][j] : dv[1][j] - dv[3][j];
-            return;
-        }
-        k -= nread;
-        if (k < 16) {
-            const int xi = k >> 2, nu = k & 3;
-            ua[ob][k] = nu == 0 ? tc[0][xi] - tc[2][xi] : nu == 1 ? tc[1][xi] + tc[2][xi] : nu == 2 ? tc[2][xi] - tc[1][xi] : tc[1][xi] - tc[3][xi];
-            return;
-        }
-        k -= 16;
-        if (k < 4) {       // vertical G' of dy column bb = k >> 1: rows 1 (sum), 2 (difference); rows 0 and 3 are e[0][bb], e[1][bb]
-            const int bb = k >> 1;
-            if (k & 1) tv[bb][2] = ev[0][bb] - ev[1][bb];
-            else { tv[bb][1] = ev[0][bb] + ev[1][bb]; tv[bb][0] = ev[0][bb]; tv[bb][3] = ev[1][bb]; }
-            return;
-        }
-        k -= 4;
-        if (k < 8) {
-            const int xi = k >> 1;
-            if (k & 1) eb[ob][xi * 4 + 2] = tv[0][xi] - tv[1][xi];
-            else { eb[ob][xi * 4 + 1] = tv[0][xi] + tv[1][xi]; eb[ob][xi * 4 + 0] = tv[0][xi]; eb[ob][xi * 4 + 3] = tv[1][xi]; }
-            return;
-        }
-        k -= 8;
-        if (k == 0) dbacc += eb[ob][5];   // E_(1,1) = the sum of the tile's four dy values
-    };
+            k -= nread;
+            if (k < 8) {
+                const int t = k >> 2, aa = (k >> 1) & 1, bb = k & 1;
+                if (WG_ABL & 2) return;
+                ey[ob][t][aa][bb] = smem[buf * BUF + ybase + t * 8 * YPL + ((4 * r + aa) * DW + 2 * tx + bb) * 4];
+                return;
+            }
+            k -= 8;
+            if (WG_ABL & 1) return;
+            if (k < 2 * ncol) {   // vertical transforms of the new patch columns (the two older ones carry over from the previous step)
+                const int idx = fresh ? k : 4 + k, j = idx >> 1, xl = idx & 1;
+                if (!fresh && k == 0) { tc[0][0] = tc[2][0]; tc[0][1] = tc[2][1]; tc[1][0] = tc[3][0]; tc[1][1] = tc[3][1]; }
+                // B^T rows: xi 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3; dv[i] = patch row PH + i
+                if (PH == 0) tc[j][xl] = xl == 0 ? dv[0][j] - dv[2][j] : dv[1][j] + dv[2][j];
+                else tc[j][xl] = xl == 0 ? dv[1][j] - dv[0][j] : dv[0][j] - dv[2][j];
+                return;
+            }
+            k -= 2 * ncol;
+            if (k < 8) {
+                const int xl = k >> 2, nu = k & 3;
+                ua[ob][k] = nu == 0 ? tc[0][xl] - tc[2][xl] : nu == 1 ? tc[1][xl] + tc[2][xl] : nu == 2 ? tc[2][xl] - tc[1][xl] : tc[1][xl] - tc[3][xl];
+                return;
+            }
+            k -= 8;
+            if (k < 4) {   // vertical G' of dy column bb of tile t: the one computed term of this position half
+                const int t = k >> 1, bb = k & 1;
+                vy[ob][t][bb] = PH == 0 ? ey[ob][t][0][bb] + ey[ob][t][1][bb] : ey[ob][t][0][bb] - ey[ob][t][1][bb];
+                return;
+            }
+            k -= 4;
+            if (k < 8) {   // horizontal G': sum and difference of the two row terms
+                const int t = k >> 2, xl = (k >> 1) & 1, sd = k & 1;
+                const float r0 = PH == 0 ? (xl == 0 ? ey[ob][t][0][0] : vy[ob][t][0]) : (xl == 0 ? vy[ob][t][0] : ey[ob][t][1][0]);
+                const float r1 = PH == 0 ? (xl == 0 ? ey[ob][t][0][1] : vy[ob][t][1]) : (xl == 0 ? vy[ob][t][1] : ey[ob][t][1][1]);
+                hy[ob][t][xl][sd] = sd == 0 ? r0 + r1 : r0 - r1;
+                return;
+            }
+            k -= 8;
+            if (PH == 0 && k < 2) dbacc[k] += hy[ob][k][1][0];   // E_(1,1) = the sum of the tile's four dy values
+        };
 #define WSB() __builtin_amdgcn_sched_barrier(0)
-    if (nch > 0) {
-        set_block(blk0);
+        constexpr int TOT_F = 12 + 8 + 8 + 8 + 4 + 8 + 2, TOT_C = 6 + 8 + 4 + 8 + 4 + 8 + 2;   // micro-operations of a fresh / a carried step
+        if (nch > 0) {
+            set_block(blk0);
 #pragma unroll
-        for (int h = 0; h < 3; ++h) {
+            for (int h = 0; h < 3; ++h) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) gload1(8 * h + k, k);
+                for (int k = 0; k < 8; ++k) gload1(8 * h + k, k);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) lstore1(0, 8 * h + k, k);
+                for (int k = 0; k < 8; ++k) lstore1(0, 8 * h + k, k);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < TOT_F; ++k) prep(0, 0, 0, k);
+            WSB();
         }
-        __syncthreads();
+        for (int ci = 0; ci < nch; ++ci) {
+            const int buf = ci & 1;
+            const bool more = ci + 1 < nch;
+            if (more) set_block(blk0 + ci + 1);
 #pragma unroll
-        for (int k = 0; k < 65; ++k) prep(0, 0, 0, k);
-        WSB();
-    }
-    for (int ci = 0; ci < nch; ++ci) {
-        const int buf = ci & 1;
-        const bool more = ci + 1 < nch;
-        if (more) set_block(blk0 + ci + 1);
+            for (int s = 0; s < NS; ++s) {
+                const int ob = s & 1;
+                const bool last_step = s == NS - 1;
+                if (last_step && more) __syncthreads();   // this buffer's last reads are behind every wave, the other buffer is written
+                const bool nxt = !last_step || more;
+                const int sn = last_step ? 0 : s + 1, nbuf = last_step ? buf ^ 1 : buf, nob = ob ^ 1;
+                const int total = (sn % TBW) == 0 ? TOT_F : TOT_C, per = (total + 15) / 16;
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const int ob = s & 1;
-            const bool last_step = s == NS - 1;
-            if (last_step && more) __syncthreads();   // this buffer's last reads are behind every wave, the other buffer is written
-            const bool nxt = !last_step || more;
-            const int sn = last_step ? 0 : s + 1, nbuf = last_step ? buf ^ 1 : buf, nob = (NS & 1) && last_step ? ob ^ 1 : ob ^ 1;
-            const int total = (sn % TBW) == 0 ? 65 : 49, per = (total + 15) / 16;
+                for (int m = 0; m < 16; ++m) {
+                    const int pl = m >> 1, t = m & 1;
+                    acc[t][pl] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[ob][pl], evalue(ob, t, pl), acc[t][pl], 0, 0, 0);
+                    WSB();
+                    if (nxt) {
 #pragma unroll
-            for (int m = 0; m < 16; ++m) {
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[ob][m], eb[ob][m], acc[m], 0, 0, 0);
-                WSB();
-                if (nxt) {
-#pragma unroll
-                    for (int k2 = 0; k2 < 5; ++k2)
-                        if (k2 < per && m * per + k2 < total) prep(nbuf, sn, nob, m * per + k2);
+                        for (int k2 = 0; k2 < 4; ++k2)
+                            if (k2 < per && m * per + k2 < total) prep(nbuf, sn, nob, m * per + k2);
+                    }
+                    if (more && m < 8 && !(WG_ABL & 4)) {   // the next block's data: three batches of eight slots, each loaded three steps before it is written
+                        if (s == 0) gload1(m, m);
+                        if (s == 3) lstore1(buf ^ 1, m, m);
+                        if (s == 4) gload1(8 + m, m);
+                        if (s == 7) lstore1(buf ^ 1, 8 + m, m);
+                        if (s == 8) gload1(16 + m, m);
+                        if (s == 11) lstore1(buf ^ 1, 16 + m, m);
+                    }
+                    WSB();
                 }
-                if (more && m < 8 && !(WG_ABL & 4)) {   // the next block's data: three batches of eight slots, each loaded three steps before it is written
-                    if (s == 0) gload1(m, m);
-                    if (s == 3) lstore1(buf ^ 1, m, m);
-                    if (s == 4) gload1(8 + m, m);
-                    if (s == 7) lstore1(buf ^ 1, 8 + m, m);
-                    if (s == 8) gload1(16 + m, m);
-                    if (s == 11) lstore1(buf ^ 1, 16 + m, m);
-                }
-                WSB();
             }
         }
-    }
 #undef WSB
-    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+        asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
 
-    // raw position sums of this split: acc[p][r] = S_p[c0 + 8 (r >> 2) + 4 lh + (r & 3)][n0 + li]
-    const int c0 = cb * 64 + cw * 32, n0 = nb * 64 + nw * 32;
-    float* o = a.ws + (long)split * 16 * C * N + (long)n0 + li;
+        // raw position sums of this split: acc[t][pl][r] = S_p[c0 + 8 (r >> 2) + 4 lh + (r & 3)][n0 + 32 t + li], p = 8 PH + pl
+        const int c0 = cb * 64 + cw * 32, n0 = nb * 64;
+        float* o = a.ws + (long)split * 16 * C * N + (long)n0 + li;
 #pragma unroll
-    for (int p = 0; p < 16; ++p)
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[((long)p * C + c0 + 8 * (r >> 2) + 4 * lh + (r & 3)) * N] = acc[p][r];
-    if (cb == 0 && cw == 0) {
-        const float v = dbacc + __shfl_xor(dbacc, 32, 64);
-        if (lh == 0) a.ws[(long)a.nsplit * 16 * C * N + (long)split * N + n0 + li] = v;
-    }
+            for (int pl = 0; pl < 8; ++pl)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[((long)(8 * PH + pl) * C + c0 + 8 * (r >> 2) + 4 * lh + (r & 3)) * N + 32 * t] = acc[t][pl][r];
+        if (PH == 0 && cb == 0 && cw == 0) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const float v = dbacc[t] + __shfl_xor(dbacc[t], 32, 64);
+                if (lh == 0) a.ws[(long)a.nsplit * 16 * C * N + (long)split * N + n0 + 32 * t + li] = v;
+            }
+        }
+    };
+    if (ph) body(std::integral_constant<int, 1>{});
+    else body(std::integral_constant<int, 0>{});
 }
 
 constexpr int WINO_WG_LDS_BYTES = 2 * 16 * (WG_XPL + WG_YPL) * 4;   // 158 720
