@@ -24,19 +24,27 @@ struct WinoWgArgs {
 };
 
 template <int TBH, int TBW>
-__global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(WinoWgArgs a) {
+__global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(WinoWgArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int PW = 2 * TBW + 2, PH = 2 * TBH + 2, DW = 2 * TBW, DH = 2 * TBH, NS = (TBH / 2) * TBW;
+    constexpr int PW = 2 * TBW + 2, PHT = 2 * TBH + 2, DW = 2 * TBW, DH = 2 * TBH, NS = (TBH / 2) * TBW;
     // LDS: per buffer the x halo patch and the dy block as sixteen CHANNEL-QUAD PLANES [quad][pixel][4] -- the staging writes are
     // 16-byte pieces of consecutive pixels (what the C4 layout delivers: consecutive lanes = consecutive pixels of a patch row), the operand
-    // reads (one float per lane: channel li of 32, ds_read_b32, banks mod 32) are conflict-free because the plane pitches are 4 mod 8 dwords x 4
-    constexpr int NPX = PW * PH, NDY = DW * DH;
+    // reads (one float per lane: channel li of 32, ds_read_b32) spread over the banks because the plane pitches are 4 mod 8 dwords x 4
+    constexpr int NPX = PW * PHT, NDY = DW * DH;
     constexpr int XPL = WG_XPL, YPL = WG_YPL;            // plane pitches in floats (724 = 20 mod 32, 516 = 4 mod 32)
     constexpr int XPF = 16 * XPL, BUF = XPF + 16 * YPL;   // floats: x patch, dy tile block; two buffers
-    static_assert(PW * PH <= 180 && DW * DH <= 128 && NS <= 16 && NS >= 13, "block shape (the staging schedule runs to step 11, before the barrier of step NS - 1)");
+    static_assert(PW * PHT <= 180 && DW * DH <= 128 && NS <= 16 && NS >= 13, "block shape (the staging schedule runs to step 11, before the barrier of step NS - 1)");
     const WinoGeom& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
-    const int cw = wave >> 1, ph = wave & 1;
+    // EIGHT waves, two per SIMD: wave = (input-channel tile cw, output-channel tile nw, position half ph) owns 32 x 32 channels x the
+    // eight positions p = 4 xi + nu with xi (the vertical index) in {2 ph, 2 ph + 1} = eight 32 x 32 accumulators = 128 registers.
+    // Round 3's four waves (one per SIMD, sixteen positions = 256 accumulator registers each) left every LDS-read and barrier wait of a
+    // wave exposed -- the ablation (profiles/r04_wgrad_ablation.txt) charges 21 % of the kernel to the operand reads and their waits, 4 %
+    // to staging, and a third fewer transform operations alone (positions split over FOUR waves, 256 registers each) bought 1.8 % -- so
+    // the positions are split to HALVE THE ACCUMULATORS: a second wave per SIMD issues MFMAs while the first waits.  A wave needs three
+    // of the four patch rows and runs half of the x transform (vertical 2 of 4 outputs per column, horizontal 8 of 16) and half of its
+    // tile's dy transform.  Raw position sums go to the workspace as before; nothing is exchanged between the waves.
+    const int cw = wave >> 2, nw = (wave >> 1) & 1, ph = wave & 1;
     const int cn = blockIdx.x % (a.ncb * a.nnb), split = blockIdx.x / (a.ncb * a.nnb);
     const int cb = cn / a.nnb, nb = cn - cb * a.nnb;
     const int C = g.C, N = g.N;
@@ -47,17 +55,18 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(WinoWgArgs a) {
     int nch = g.nblocks - blk0;
     if (nch > a.cps) nch = a.cps;
 
-    // staging slots: a thread owns ONE pixel of the x halo patch (pixel tid < NPX <= 180) and ONE pixel of the dy block (pixel tid & 127
-    // < NDY <= 128, channel-quad parity tid >> 7): per block TWO voffsets (the pixel's 16 bytes in channel-quad plane 0 of the tile, or
-    // WOOB) and the quad as a SCALAR plane offset -- slot i < 16: x quad i; slot 16 + i, i < 8: dy quad 2 i + (tid >> 7).  (Slots that were
-    // float4 index tid + 256 i of [quad][pixel] cost two divisions and a bounds check per slot and block: + 0.4 ms per step, round 4.)
-    float4 st[8];
-    const int xpy = tid / PW, xpx = tid - xpy * PW;                 // (compile-time divisors)
+    // staging slots: a thread owns ONE pixel of the x halo patch (pixel tid & 255 < NPX <= 180, channel-quad parity tid >> 8) and ONE pixel
+    // of the dy block (pixel tid & 127 < NDY <= 128, channel quad mod 4 = tid >> 7): per block TWO voffsets (the pixel's 16 bytes in the
+    // thread's first channel-quad plane, or WOOB) and the further quads as SCALAR plane offsets -- slot i < 8: x quad 2 i + (tid >> 8);
+    // slot 8 + i, i < 4: dy quad 4 i + (tid >> 7).  (Slots that were float4 index tid + 256 i of [quad][pixel] cost two divisions and a
+    // bounds check per slot and block: + 0.4 ms per step, round 4.)
+    float4 st[4];
+    const int xpix = tid & 255, xpy = xpix / PW, xpx = xpix - xpy * PW;   // (compile-time divisors)
     const int ypix = tid & 127, ypy = ypix / DW, ypx = ypix - ypy * DW;
-    const bool xlive = tid < NPX, ylive = ypix < NDY;
+    const bool xlive = xpix < NPX, ylive = ypix < NDY;
     const unsigned plane_b = (unsigned)g.H * (unsigned)g.W * 16u;   // bytes of one channel-quad plane of an image
-    const int xq0 = cb * 16, yq0 = nb * 16 + (tid >> 7);
-    const int xst = tid * 4, yst = XPF + (tid >> 7) * YPL + ypix * 4;   // LDS float index of the thread's pixel in plane 0 (+ buf * BUF + quad * pitch)
+    const int xq0 = cb * 16 + (tid >> 8), yq0 = nb * 16 + (tid >> 7);
+    const int xst = (tid >> 8) * XPL + xpix * 4, yst = XPF + (tid >> 7) * YPL + ypix * 4;   // LDS float index of the thread's first plane (+ buf * BUF + further quads)
     unsigned xvoff = WOOB, yvoff = WOOB;   // of the block to LOAD
     auto set_block = [&](int blk) {
         const unsigned b = (unsigned)blk / (unsigned)g.blocks_img, rem = (unsigned)blk - b * (unsigned)g.blocks_img;
@@ -69,46 +78,38 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(WinoWgArgs a) {
         yvoff = (ylive && yy < g.H && yx < g.W) ? (unsigned)((((int)b * (N >> 2) + yq0) * g.H + yy) * g.W + yx) * 16u : WOOB;
     };
     auto gload1 = [&](int i, int k) {   // slot i into st[k]
-        if (i < 16) st[k] = wbufload(rx, xvoff, (unsigned)i * plane_b);
-        else st[k] = wbufload(ry, yvoff, (unsigned)(2 * (i - 16)) * plane_b);
+        if (i < 8) st[k] = wbufload(rx, xvoff, (unsigned)(2 * i) * plane_b);
+        else st[k] = wbufload(ry, yvoff, (unsigned)(4 * (i - 8)) * plane_b);
     };
     auto lstore1 = [&](int buf, int i, int k) {
-        if (i < 16) {
-            if (xlive) *reinterpret_cast<float4*>(&smem[buf * BUF + xst + i * XPL]) = st[k];
+        if (i < 8) {
+            if (xlive) *reinterpret_cast<float4*>(&smem[buf * BUF + xst + 2 * i * XPL]) = st[k];
         } else {
-            if (ylive) *reinterpret_cast<float4*>(&smem[buf * BUF + yst + 2 * (i - 16) * YPL]) = st[k];
+            if (ylive) *reinterpret_cast<float4*>(&smem[buf * BUF + yst + 4 * (i - 8) * YPL]) = st[k];
         }
     };
 
-    // wave = (input-channel tile cw, position half ph): 32 input channels x BOTH 32-column output tiles x the eight positions p = 4 xi + nu
-    // with xi (the vertical index) in {2 ph, 2 ph + 1}.  Round 3's wave owned one output tile and all sixteen positions, so the two waves
-    // of an input-channel tile each ran the whole x transform; now a wave needs three of the four patch rows and runs HALF of it (vertical
-    // 2 of 4 outputs per column, horizontal 8 of 16), and the dy transform of its half of the positions for both output tiles costs what
-    // one tile's full transform did: 24 instead of 36 arithmetic operations per step beside the same sixteen MFMAs.  The raw position sums
-    // go to the workspace as before (a wave writes its eight positions of both tiles); nothing is exchanged between the waves.
-    f32x16 acc[2][8];
+    f32x16 acc[8];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int p = 0; p < 8; ++p)
 #pragma unroll
-        for (int p = 0; p < 8; ++p)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][p][r] = 0.f;
-    float dbacc[2] = {0.f, 0.f};
+        for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+    float dbacc = 0.f;
 
-    const int xbase = ((2 * lh) * PW) * 4 + (cw * 8 + (li >> 2)) * XPL + (li & 3);   // + buf * BUF + ((4 r + i) * PW + 2 tx + j) * 4
-    const int ybase = XPF + ((2 * lh) * DW) * 4 + (li >> 2) * YPL + (li & 3);          // + t * 8 * YPL + buf * BUF + ((4 r + a) * DW + 2 tx + b) * 4
+    const int xbase = ((2 * lh) * PW) * 4 + (cw * 8 + (li >> 2)) * XPL + (li & 3);          // + buf * BUF + ((4 r + i) * PW + 2 tx + j) * 4
+    const int ybase = XPF + ((2 * lh) * DW) * 4 + (nw * 8 + (li >> 2)) * YPL + (li & 3);    // + buf * BUF + ((4 r + a) * DW + 2 tx + b) * 4
 
     auto body = [&](auto phc) {
         constexpr int PH = decltype(phc)::value;
         // operands of one step, double-buffered by ob: ua[ob][4 xl + nu] = U_p[tile][c] (xl = xi - 2 PH); the dy side keeps its raw values
         // e, the vertical terms v and the two computed horizontal terms per xl -- the MFMA takes whichever register holds E_p (no copies)
         float ua[2][8], dv[3][4], tc[4][2];
-        float ey[2][2][2][2], vy[2][2][2], hy[2][2][2][2];   // [ob][tile]: e[aa][bb]; v[bb]; h[xl][0: sum, 1: difference]
-        auto evalue = [&](int ob, int t, int pl) -> float {   // E_p of tile t, p = 4 (2 PH + xl) + nu, from the registers above
+        float ey[2][2][2], vy[2][2], hy[2][2][2];   // [ob]: e[aa][bb]; v[bb]; h[xl][0: sum, 1: difference]
+        auto evalue = [&](int ob, int pl) -> float {   // E_p, p = 4 (2 PH + xl) + nu, from the registers above
             const int xl = pl >> 2, nu = pl & 3;
             // row term of bb: PH 0: xi 0 -> e[0][bb], xi 1 -> v[bb] = e0 + e1;  PH 1: xi 2 -> v[bb] = e0 - e1, xi 3 -> e[1][bb]
-            auto row = [&](int bb) -> float { return PH == 0 ? (xl == 0 ? ey[ob][t][0][bb] : vy[ob][t][bb]) : (xl == 0 ? vy[ob][t][bb] : ey[ob][t][1][bb]); };
-            return nu == 0 ? row(0) : nu == 3 ? row(1) : hy[ob][t][xl][nu - 1];
+            auto row = [&](int bb) -> float { return PH == 0 ? (xl == 0 ? ey[ob][0][bb] : vy[ob][bb]) : (xl == 0 ? vy[ob][bb] : ey[ob][1][bb]); };
+            return nu == 0 ? row(0) : nu == 3 ? row(1) : hy[ob][xl][nu - 1];
         };
         // micro-operation k of preparing step sn (from LDS buffer `buf`) into operand set ob
         auto prep = [&](int buf, int sn, int ob, int k) {
@@ -122,13 +123,13 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(WinoWgArgs a) {
                 return;
             }
             k -= nread;
-            if (k < 8) {
-                const int t = k >> 2, aa = (k >> 1) & 1, bb = k & 1;
+            if (k < 4) {
+                const int aa = k >> 1, bb = k & 1;
                 if (WG_ABL & 2) return;
-                ey[ob][t][aa][bb] = smem[buf * BUF + ybase + t * 8 * YPL + ((4 * r + aa) * DW + 2 * tx + bb) * 4];
+                ey[ob][aa][bb] = smem[buf * BUF + ybase + ((4 * r + aa) * DW + 2 * tx + bb) * 4];
                 return;
             }
-            k -= 8;
+            k -= 4;
             if (WG_ABL & 1) return;
             if (k < 2 * ncol) {   // vertical transforms of the new patch columns (the two older ones carry over from the previous step)
                 const int idx = fresh ? k : 4 + k, j = idx >> 1, xl = idx & 1;
@@ -145,32 +146,31 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(WinoWgArgs a) {
                 return;
             }
             k -= 8;
-            if (k < 4) {   // vertical G' of dy column bb of tile t: the one computed term of this position half
-                const int t = k >> 1, bb = k & 1;
-                vy[ob][t][bb] = PH == 0 ? ey[ob][t][0][bb] + ey[ob][t][1][bb] : ey[ob][t][0][bb] - ey[ob][t][1][bb];
+            if (k < 2) {   // vertical G' of dy column bb: the one computed term of this position half
+                vy[ob][k] = PH == 0 ? ey[ob][0][k] + ey[ob][1][k] : ey[ob][0][k] - ey[ob][1][k];
+                return;
+            }
+            k -= 2;
+            if (k < 4) {   // horizontal G': sum and difference of the two row terms
+                const int xl = k >> 1, sd = k & 1;
+                const float r0 = PH == 0 ? (xl == 0 ? ey[ob][0][0] : vy[ob][0]) : (xl == 0 ? vy[ob][0] : ey[ob][1][0]);
+                const float r1 = PH == 0 ? (xl == 0 ? ey[ob][0][1] : vy[ob][1]) : (xl == 0 ? vy[ob][1] : ey[ob][1][1]);
+                hy[ob][xl][sd] = sd == 0 ? r0 + r1 : r0 - r1;
                 return;
             }
             k -= 4;
-            if (k < 8) {   // horizontal G': sum and difference of the two row terms
-                const int t = k >> 2, xl = (k >> 1) & 1, sd = k & 1;
-                const float r0 = PH == 0 ? (xl == 0 ? ey[ob][t][0][0] : vy[ob][t][0]) : (xl == 0 ? vy[ob][t][0] : ey[ob][t][1][0]);
-                const float r1 = PH == 0 ? (xl == 0 ? ey[ob][t][0][1] : vy[ob][t][1]) : (xl == 0 ? vy[ob][t][1] : ey[ob][t][1][1]);
-                hy[ob][t][xl][sd] = sd == 0 ? r0 + r1 : r0 - r1;
-                return;
-            }
-            k -= 8;
-            if (PH == 0 && k < 2) dbacc[k] += hy[ob][k][1][0];   // E_(1,1) = the sum of the tile's four dy values
+            if (PH == 0 && k == 0) dbacc += hy[ob][1][0];   // E_(1,1) = the sum of the tile's four dy values
         };
 #define WSB() __builtin_amdgcn_sched_barrier(0)
-        constexpr int TOT_F = 12 + 8 + 8 + 8 + 4 + 8 + 2, TOT_C = 6 + 8 + 4 + 8 + 4 + 8 + 2;   // micro-operations of a fresh / a carried step
+        constexpr int TOT_F = 12 + 4 + 8 + 8 + 2 + 4 + 1, TOT_C = 6 + 4 + 4 + 8 + 2 + 4 + 1;   // micro-operations of a fresh / a carried step
         if (nch > 0) {
             set_block(blk0);
 #pragma unroll
             for (int h = 0; h < 3; ++h) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) gload1(8 * h + k, k);
+                for (int k = 0; k < 4; ++k) gload1(4 * h + k, k);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) lstore1(0, 8 * h + k, k);
+                for (int k = 0; k < 4; ++k) lstore1(0, 4 * h + k, k);
             }
             __syncthreads();
 #pragma unroll
@@ -188,24 +188,23 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(WinoWgArgs a) {
                 if (last_step && more) __syncthreads();   // this buffer's last reads are behind every wave, the other buffer is written
                 const bool nxt = !last_step || more;
                 const int sn = last_step ? 0 : s + 1, nbuf = last_step ? buf ^ 1 : buf, nob = ob ^ 1;
-                const int total = (sn % TBW) == 0 ? TOT_F : TOT_C, per = (total + 15) / 16;
+                const int total = (sn % TBW) == 0 ? TOT_F : TOT_C, per = (total + 7) / 8;
 #pragma unroll
-                for (int m = 0; m < 16; ++m) {
-                    const int pl = m >> 1, t = m & 1;
-                    acc[t][pl] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[ob][pl], evalue(ob, t, pl), acc[t][pl], 0, 0, 0);
+                for (int m = 0; m < 8; ++m) {
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[ob][m], evalue(ob, m), acc[m], 0, 0, 0);
                     WSB();
                     if (nxt) {
 #pragma unroll
-                        for (int k2 = 0; k2 < 4; ++k2)
+                        for (int k2 = 0; k2 < 5; ++k2)
                             if (k2 < per && m * per + k2 < total) prep(nbuf, sn, nob, m * per + k2);
                     }
-                    if (more && m < 8 && !(WG_ABL & 4)) {   // the next block's data: three batches of eight slots, each loaded three steps before it is written
+                    if (more && m < 4 && !(WG_ABL & 4)) {   // the next block's data: three batches of four slots, each loaded three steps before it is written
                         if (s == 0) gload1(m, m);
                         if (s == 3) lstore1(buf ^ 1, m, m);
-                        if (s == 4) gload1(8 + m, m);
-                        if (s == 7) lstore1(buf ^ 1, 8 + m, m);
-                        if (s == 8) gload1(16 + m, m);
-                        if (s == 11) lstore1(buf ^ 1, 16 + m, m);
+                        if (s == 4) gload1(4 + m, m);
+                        if (s == 7) lstore1(buf ^ 1, 4 + m, m);
+                        if (s == 8) gload1(8 + m, m);
+                        if (s == 11) lstore1(buf ^ 1, 8 + m, m);
                     }
                     WSB();
                 }
@@ -214,21 +213,16 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(WinoWgArgs a) {
 #undef WSB
         asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
 
-        // raw position sums of this split: acc[t][pl][r] = S_p[c0 + 8 (r >> 2) + 4 lh + (r & 3)][n0 + 32 t + li], p = 8 PH + pl
-        const int c0 = cb * 64 + cw * 32, n0 = nb * 64;
+        // raw position sums of this split: acc[pl][r] = S_p[c0 + 8 (r >> 2) + 4 lh + (r & 3)][n0 + li], p = 8 PH + pl
+        const int c0 = cb * 64 + cw * 32, n0 = nb * 64 + nw * 32;
         float* o = a.ws + (long)split * 16 * C * N + (long)n0 + li;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int pl = 0; pl < 8; ++pl)
 #pragma unroll
-            for (int pl = 0; pl < 8; ++pl)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[((long)(8 * PH + pl) * C + c0 + 8 * (r >> 2) + 4 * lh + (r & 3)) * N + 32 * t] = acc[t][pl][r];
+            for (int r = 0; r < 16; ++r) o[((long)(8 * PH + pl) * C + c0 + 8 * (r >> 2) + 4 * lh + (r & 3)) * N] = acc[pl][r];
         if (PH == 0 && cb == 0 && cw == 0) {
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const float v = dbacc[t] + __shfl_xor(dbacc[t], 32, 64);
-                if (lh == 0) a.ws[(long)a.nsplit * 16 * C * N + (long)split * N + n0 + 32 * t + li] = v;
-            }
+            const float v = dbacc + __shfl_xor(dbacc, 32, 64);
+            if (lh == 0) a.ws[(long)a.nsplit * 16 * C * N + (long)split * N + n0 + li] = v;
         }
     };
     if (ph) body(std::integral_constant<int, 1>{});
@@ -244,7 +238,7 @@ static int launch_wino_wgrad(hipStream_t st, const WinoWgArgs& a) {
         return e == hipSuccess ? 0 : fail((int)e, "%s: hipFuncSetAttribute failed", "wino wgrad kernel");
     }();
     if (once) return once;
-    hipLaunchKernelGGL((wino_wgrad_kernel<TBH, TBW>), dim3(a.ncb * a.nnb * a.nsplit), dim3(256), WINO_WG_LDS_BYTES, st, a);
+    hipLaunchKernelGGL((wino_wgrad_kernel<TBH, TBW>), dim3(a.ncb * a.nnb * a.nsplit), dim3(512), WINO_WG_LDS_BYTES, st, a);
     return launch_status("conv wino wgrad");
 }
 
