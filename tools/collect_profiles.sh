@@ -28,8 +28,10 @@ for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; d
   (cd /tmp && VC_VGG_STREAMS=1 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $D -- python $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --strong-n1 0 > $OUT/${TAG}_pmc_$(echo $C | cut -d' ' -f1).log 2>&1)
 done
 python tools/pmc_summary.py /tmp/pmc $OUT/${TAG}_traffic_cfg4.json > $OUT/${TAG}_cfg4_pmc.md
-# 4. comparison points: the implicit-GEMM kernels of round 1 (VC_CONV_PATCH=0), the direct patch kernels (VC_CONV_WINO=0), one stream, the 16x16x4 variant
+# 4. comparison points: the NHWC implicit-GEMM kernels behind layout conversions (VC_CONV_WINO=0: the checker / fallback path), one stream,
+#    F(2x2,3x3) on the 56-wide layers (the round-3 preference rule)
 VC_CONV_WINO=0 python bench.py --no-cpu-baseline --strong-n1 0 > $OUT/${TAG}_bench_nowino.json 2>/dev/null
+VC_WINO4_MIN_COVERAGE=0.85 python bench.py --no-cpu-baseline --strong-n1 0 > $OUT/${TAG}_bench_conv3_f23.json 2>/dev/null
 VC_VGG_STREAMS=1 python bench.py --no-cpu-baseline --strong-n1 0 > $OUT/${TAG}_bench_1stream.json 2>/dev/null
 # 5. the step a user runs: fresh host batches through set_batch inside the timed region
 python bench.py --no-cpu-baseline --strong-n1 0 --fresh-batch 4 > $OUT/${TAG}_bench_fresh_cfg4.json 2>/dev/null
@@ -42,7 +44,12 @@ python bench.py --no-cpu-baseline --workload cfg2 --num-captions 1 > $OUT/${TAG}
 python bench.py --no-cpu-baseline --workload cfg1 > $OUT/${TAG}_bench_cfg1.json 2>/dev/null
 python bench.py --no-cpu-baseline --workload cfg3 > $OUT/${TAG}_bench_cfg3.json 2>/dev/null
 python bench.py --no-cpu-baseline --workload cfg5 --steps 5 --warmup 1 > $OUT/${TAG}_bench_cfg5.json 2>/dev/null
-# 7. per-layer tables: Winograd kernels against the direct patch kernels (forward / data gradient, weight gradient)
-python tools/microbench.py winoab winow > $OUT/${TAG}_wino_layers.txt 2>/dev/null
+# 7. per-layer tables: F(2x2,3x3) forward / data gradient and the F(3x3,2x2) weight gradient; F(4x4,3x3) against F(2x2,3x3) per layer
+#    (forward, data gradient with the float mask, data gradient with mask bits); LSTM recurrence steps (default, two workgroups per CU)
+python tools/microbench.py winoab winow 2>/dev/null | grep -v amdgpu.ids > $OUT/${TAG}_wino_layers.txt
+(for v in fwd dgrad bits; do echo "== python tools/experiments/wino4_try.py 64 $v"; python tools/experiments/wino4_try.py 64 $v 2>&1 | grep "^conv\|^sum"; done
+ for v in fwd bits; do echo "== python tools/experiments/wino4_try.py 32 $v"; python tools/experiments/wino4_try.py 32 $v 2>&1 | grep "^conv\|^sum"; done) > $OUT/${TAG}_wino4_layers.txt
+(echo "== python tools/microbench.py lstm (VC_LSTM_MODES=3,1)"; python tools/microbench.py lstm 2>&1 | grep "^lstm"
+ echo "== VC_LSTM_WGS_PER_CU=2 (two workgroups of the four-wave recurrence kernels per CU; measured, not adopted)"; VC_LSTM_WGS_PER_CU=2 VC_LSTM_MODES=3 python tools/microbench.py lstm 2>&1 | grep "^lstm") > $OUT/${TAG}_lstm_steps.txt
 # 8. SQ counters of the Winograd forward / data-gradient kernel per layer shape
 bash tools/sq_probe_wino.sh ${TAG} > /dev/null 2>&1
