@@ -66,9 +66,9 @@ def conv_algorithmic_bytes(images):
     """Algorithmic HBM bytes of one cfg4 step's 3x3 convolution calls (fp32), the denominator of roofline.traffic_over_algorithmic:
       forward        x [B,H,W,Ci] read + y [B,H,W,Co] written (+ the pooled copy [B,H/2,W/2,Co] behind conv1_2 / 2_2 / 3_3 / 4_3 / 5_3:
                      the fused max-pool writes it from the same kernel) + the layer's 9 Ci Co weights + Co biases
-      data gradient  dy [B,H,W,Co] read + dx [B,H,W,Ci] written + the ReLU source: 1 bit per element of dx where the producer's forward
-                     left mask bits, else the float tensor [B,H,W,Ci]; none behind a pool (MaxPoolGrad applies it); no data gradient
-                     for conv1_1
+      data gradient  dy [B,H,W,Co] read + dx [B,H,W,Ci] written + the ReLU source: 1 bit per element of dx (the producer's forward
+                     leaves mask bits: the Winograd forwards and, since round 4, conv1_1's); none behind a pool (MaxPoolGrad applies
+                     it); no data gradient for conv1_1
       weight grad    x and dy read, 9 Ci Co + Co written
     Saved activations are the forward's y (counted once, as its write); Winograd-transformed tensors never touch HBM and do not count;
     transformed WEIGHTS (16 Ci Co, re-packed once per step) count as the 9 Ci Co they stand for."""
@@ -84,9 +84,7 @@ def conv_algorithmic_bytes(images):
         pooled = name in spec.VGG_POOL_AFTER
         tot += 4 * (px * cie + px * co + (px / 4 * co if pooled else 0) + wts)          # forward
         if not first:
-            mask = 0.0 if prev_pool else px * ci / 8.0 / 4.0                             # bits (in units of 4 bytes); the conv1_2 float mask below
-            if name == "conv1_2":
-                mask = px * ci
+            mask = 0.0 if prev_pool else px * ci / 8.0 / 4.0                             # bits (in units of 4 bytes; conv1_2's come from conv1_1's forward)
             tot += 4 * (px * co + px * ci + mask + wts)                                  # data gradient
         tot += 4 * (px * cie + px * co + wts)                                           # weight gradient
         first = False

@@ -352,6 +352,10 @@ int vc_conv3x3_wino_wgrad_f32(void* stream, int B, int H, int W, int Cin, int Co
 int vc_conv1_supported(int B, int H, int W);
 size_t vc_conv1_wgrad_workspace_bytes(void);
 int vc_conv1_fwd_f32(void* stream, int B, int H, int W, const float* x4, const float* w, const float* bias, float* y, int relu);
+/* The forward with ReLU, also leaving (y > 0) as bits for the F(4x4,3x3) data gradient of the next layer (conv1_2): mask_out =
+ * vc_conv3x3_wino4_mask_words(B, H, W, 64) words, to be passed to vc_conv3x3_wino4_dgrad_bits_f32(B, H, W, 64, Cout, ...); bit-identical
+ * to that entry's float-mask form on y.  One launch (B images within 2 GiB), H % 16 == 0, W % 32 == 0. */
+int vc_conv1_fwd_mask_f32(void* stream, int B, int H, int W, const float* x4, const float* w, const float* bias, float* y, uint32_t* mask_out);
 int vc_conv1_wgrad_f32(void* stream, int B, int H, int W, const float* x4, const float* dy, float* dw, float* db, int accumulate,
                        float* ws, size_t ws_bytes);
 

@@ -226,3 +226,32 @@ def test_wino4_calls_over_the_launch_limit_are_cut_into_image_ranges(tmp_path):
     for k in ("y", "yp", "y2", "yp2", "bits", "dx"):
         assert np.array_equal(out["one"][k], out["cut"][k]), k
     assert np.array_equal(out["one"]["y"], out["one"]["y2"]) and np.abs(out["one"]["dx"]).max() > 0 and out["one"]["bits"].any()
+
+
+@pytest.mark.parametrize("case", [(3, 32, 64), (2, 224, 224), (1, 16, 32)], ids=lambda c: "x".join(map(str, c)))
+def test_conv1_forward_leaves_the_mask_bits_of_conv1_2s_data_gradient(lib, case):
+    """vc_conv1_fwd_mask_f32: conv1_1's forward (its own kernel: a lane = one pixel x eight channel quads) also writes (y > 0) as bits in
+    the lane order of the F(4x4,3x3) data gradient with 64 produced channels (a lane = a 4 x 4-pixel tile x one channel quad): the same
+    y as vc_conv1_fwd_f32, and vc_conv3x3_wino4_dgrad_bits_f32 on those bits equals vc_conv3x3_wino4_dgrad_f32 on the float activation
+    bit for bit (utils/image_embeddings.py:36-63: ReluGrad of conv1_1's output inside conv1_2's backward)."""
+    B, H, W = case
+    g = torch.Generator(device="cuda").manual_seed(B * H + W)
+    x4 = torch.rand(B, H, W, 4, device="cuda", generator=g) * 255 - 120
+    x4[..., 3] = 0
+    w = (torch.rand(3, 3, 3, 64, device="cuda", generator=g) - 0.5) * 0.02
+    b = torch.rand(64, device="cuda", generator=g) - 0.5
+    y1, y2 = zeros(B, 16, H, W, 4), zeros(B, 16, H, W, 4)
+    bits = torch.full((lib.vc_conv3x3_wino4_mask_words(B, H, W, 64),), -1, dtype=torch.int32, device="cuda")   # (every word must be written)
+    lib.vc_conv1_fwd_f32(stream(), B, H, W, P(x4), P(w), P(b), P(y1), 1)
+    lib.vc_conv1_fwd_mask_f32(stream(), B, H, W, P(x4), P(w), P(b), P(y2), P(bits))
+    assert torch.equal(y1, y2) and 0.2 < float((y1 > 0).float().mean()) < 0.8
+    w2 = (torch.rand(3, 3, 64, 64, device="cuda", generator=g) - 0.5) * 0.1
+    wpt = torch.empty(36 * 64 * 64, device="cuda")
+    lib.vc_conv3x3_wino4_pack_f32(stream(), 64, 64, P(w2), 1, P(wpt))
+    dy = torch.rand(B, 16, H, W, 4, device="cuda", generator=g) - 0.5
+    dxa, dxb = zeros(B, 16, H, W, 4), zeros(B, 16, H, W, 4)
+    lib.vc_conv3x3_wino4_dgrad_f32(stream(), B, H, W, 64, 64, P(dy), P(wpt), P(y1), P(dxa))
+    lib.vc_conv3x3_wino4_dgrad_bits_f32(stream(), B, H, W, 64, 64, P(dy), P(wpt), P(bits), P(dxb))
+    assert torch.equal(dxa, dxb) and float(dxa.abs().max()) > 0
+    with pytest.raises(Exception):
+        lib.vc_conv1_fwd_mask_f32(stream(), B, H + 8, W, P(x4), P(w), P(b), P(y2), P(bits))   # H % 16 != 0 is refused

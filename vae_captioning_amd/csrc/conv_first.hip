@@ -43,6 +43,9 @@ struct Conv1Args {
     int B, H, W, relu;
     int groups;         // B * H * W / 32
     int segs;           // W / 32
+    unsigned* mask;     // forward, optional: (y > 0) as bits in the lane order of conv_wino4.hip's data gradient with N = 64 produced channels
+                        // ([workgroup id = 2 (block / 2) + column tile][256 threads][2 words], bit 16 aa + 4 bb + c of a lane's 4 x 4 pixels x 4 channels)
+    int blocks_img, bx_n;   // 16 x 16-pixel blocks per image / per image row (H, W multiples of 16)
 };
 
 __global__ __launch_bounds__(256, 3) void conv1_fwd_kernel(Conv1Args a) {
@@ -118,6 +121,21 @@ __global__ __launch_bounds__(256, 3) void conv1_fwd_kernel(Conv1Args a) {
                 float4 v = make_float4(acc[tm][4 * q], acc[tm][4 * q + 1], acc[tm][4 * q + 2], acc[tm][4 * q + 3]);
                 if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 *reinterpret_cast<float4*>(yp + (8 * tm + 2 * q) * qstep) = v;
+                if (a.mask) {
+                    // the ReLU mask of conv1_2's data gradient as bits (that kernel then loads 8 bytes per lane instead of sixteen float4):
+                    // this lane's nibble = (v > 0) of its pixel and channel quad 8 tm + 2 q + lh; the four pixels of a tile row are four
+                    // neighbouring lanes -> one half-word per (tile, quad, tile row aa), written by the lane of the row's first pixel
+                    unsigned nb4 = (v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u);
+                    nb4 |= (unsigned)__shfl_down((int)nb4, 1, 64) << 4;
+                    nb4 |= (unsigned)__shfl_down((int)nb4, 2, 64) << 8;
+                    if ((li & 3) == 0) {
+                        const int yy = row - bi * H;
+                        const int gb = bi * a.blocks_img + (yy >> 4) * a.bx_n + (xs >> 4);
+                        const int thr = ((gb & 1) * 2 + (q >> 1)) * 64 + (2 * (q & 1) + lh) * 16 + ((yy >> 2) & 3) * 4 + ((xs >> 2) & 3);
+                        const long word = ((long)((gb >> 1) * 2 + tm) * 256 + thr) * 2 + ((yy >> 1) & 1);
+                        reinterpret_cast<unsigned short*>(a.mask)[word * 2 + (yy & 1)] = (unsigned short)(nb4 & 0xffffu);
+                    }
+                }
             }
     }
 }
@@ -236,6 +254,27 @@ extern "C" int vc_conv1_fwd_f32(void* stream, int B, int H, int W, const float* 
         if (rc) return rc;
     }
     return 0;
+}
+
+// The same forward, also leaving (y > 0) as bits for the F(4x4,3x3) data gradient of the NEXT layer (conv1_2: Cin = 64):
+// mask_out = vc_conv3x3_wino4_mask_words(B, H, W, 64) words in the layout vc_conv3x3_wino4_fwd_mask_f32 writes, to be passed to
+// vc_conv3x3_wino4_dgrad_bits_f32(B, H, W, 64, Cout, ...) -- bit-identical to its float-mask form on y.  One launch only (the bits
+// are per tile of ONE launch of B images), H and W multiples of 16 (whole blocks: every half-word is written).
+extern "C" int vc_conv1_fwd_mask_f32(void* stream, int B, int H, int W, const float* x4, const float* w, const float* bias, float* y,
+                                     uint32_t* mask_out) {
+    using namespace vc;
+    VC_CHECK_ARG(conv1_ok(B, H, W) && conv1_images_per_launch(B, H, W) >= B && H % 16 == 0 && W % 16 == 0,
+                 "unsupported geometry (one launch, H % 16 == 0, W % 32 == 0 required)");
+    VC_CHECK_ARG(x4 && w && bias && y && mask_out, "null pointer");
+    VC_CHECK_ARG((((uintptr_t)x4 | (uintptr_t)y | (uintptr_t)bias | (uintptr_t)mask_out) & 15) == 0, "x4 / y / bias / mask_out must be 16-byte aligned");
+    Conv1Args a{};
+    a.x4 = x4; a.w = w; a.bias = bias; a.y = y; a.B = B; a.H = H; a.W = W; a.relu = 1;
+    a.segs = W / 32; a.groups = B * H * a.segs;
+    a.mask = mask_out; a.bx_n = W / 16; a.blocks_img = (H / 16) * a.bx_n;
+    int wgs = cdiv(a.groups, 4);
+    if (wgs > 2048) wgs = 2048;
+    hipLaunchKernelGGL(conv1_fwd_kernel, dim3(wgs), dim3(256), 0, (hipStream_t)stream, a);
+    return launch_status(__func__);
 }
 
 // dw [3,3,3,64] (+)= sum over pixels of patch x dy; db [64] (+)= sum of dy (may be null); dy is the gradient w.r.t. the layer's

@@ -26,7 +26,7 @@
 #include "conv_wino.h"
 
 // `make wino4abl W4FLAGS=-DW4_ABL=n` builds this file with W4_ABL = a bit mask that REMOVES parts of the main loop (results are then wrong; timing only):
-// 1 transform arithmetic, 2 patch-row reads, 4 weight-fragment reads, 8 staging (global loads + LDS writes), 16 barriers, 32 the patch loads wrapped into a cache-resident 1 MB window (same pattern),
+// 1 transform arithmetic, 2 patch-row reads, 4 weight-fragment reads, 8 staging (global loads + LDS writes), 16 barriers, 32 the patch loads wrapped into a cache-resident 1 MB window (same pattern), 64 no output stores, 128 no exchange of the partial outputs
 #ifndef W4_ABL
 #define W4_ABL 0
 #endif
@@ -406,12 +406,14 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
             float4 S[4][4];
             partial(1 - HF, S);
 #pragma unroll
-            for (int k = 0; k < 16; ++k) xch[(wave * 16 + k) * 64 + lane] = S[k >> 2][k & 3];
+            for (int k = 0; k < 16; ++k)
+                if (!(W4_ABL & 128)) xch[(wave * 16 + k) * 64 + lane] = S[k >> 2][k & 3];
         }
         partial(HF, Y);
-        __syncthreads();
+        if (!(W4_ABL & 128)) __syncthreads();
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
+            if (W4_ABL & 128) break;
             const float4 o = xch[((wave ^ 1) * 16 + k) * 64 + lane];
             float4& y = Y[k >> 2][k & 3];
             // (always half 0's partial + half 1's, so that both waves of a block round alike)
@@ -444,7 +446,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
                 if (!(mb & 4u)) v.z = 0.f;
                 if (!(mb & 8u)) v.w = 0.f;
             }
-            if (ok) *reinterpret_cast<float4*>(a.out + p00 + (aa * g.W + bb) * 4) = v;
+            if (ok && !((W4_ABL & 64) && v.x != 12345.f)) *reinterpret_cast<float4*>(a.out + p00 + (aa * g.W + bb) * 4) = v;
         }
     if (KIND == W4_FWD && a.mask) *reinterpret_cast<uint2*>(a.mask + ((size_t)id * 256 + tid) * 2) = make_uint2(ob0, ob1);
     if (POOL) {   // a 4 x 4 tile is 2 x 2 pooling windows: register math, no LDS, no separate pooling pass

@@ -246,6 +246,7 @@ class VggEngine(object):
         packed = self._pack_weights(self.train, H, W, B // 2 if (self.side is not None and B % 2 == 0 and B >= 2) else B)
         self.acts = []  # (layer name, input tensor, H, W, Cin_eff, Cout, weights used)
         self.mask_geom = {}  # layer name -> (images per launch, launches): forward launches that left their ReLU mask as bits
+        self.mask_family = {}  # layer name -> 4 / 2: the Winograd family whose data gradient can read those bits (its lane order)
         # The conv / pool chain of one image is independent of every other image: with two streams the
         # batch is pushed through as two half-batch chains so that the tail of each kernel (its last partial
         # round of workgroups) overlaps the other chain's kernels.  Halves are contiguous slices of the leading (image) dimension.
@@ -267,8 +268,16 @@ class VggEngine(object):
                 with torch.cuda.stream(strm):
                     sh = _stream()
                     if ci == 3 and c1:  # conv1_1: its own HBM-bound kernel, unpadded weights
-                        self._timed("conv_fwd", 2.0 * nb * H * W * 9 * ci * co,
-                                    lambda: lib.vc_conv1_fwd_f32(sh, nb, H, W, P(x[b0:]), P(S.param(wn)), P(S.param(bn)), P(y[b0:]), 1))
+                        if (self.train and "conv1_2" in self.wino4 and H % 16 == 0 and W % 16 == 0
+                                and lib.vc_conv3x3_wino_single_launch_supported(nb, H, W, co, co)):
+                            # conv1_2's F(4x4,3x3) data gradient takes its ReLU mask as bits from here instead of re-reading this activation
+                            mk = self._b("mk_%s_%d" % (name, ch), (lib.vc_conv3x3_wino4_mask_words(nb, H, W, co),), dtype=torch.int32)
+                            self.mask_geom[name], self.mask_family[name] = (nb, len(halves)), 4
+                            self._timed("conv_fwd", 2.0 * nb * H * W * 9 * ci * co,
+                                        lambda: lib.vc_conv1_fwd_mask_f32(sh, nb, H, W, P(x[b0:]), P(S.param(wn)), P(S.param(bn)), P(y[b0:]), P(mk)))
+                        else:
+                            self._timed("conv_fwd", 2.0 * nb * H * W * 9 * ci * co,
+                                        lambda: lib.vc_conv1_fwd_f32(sh, nb, H, W, P(x[b0:]), P(S.param(wn)), P(S.param(bn)), P(y[b0:]), 1))
                         continue
                     fl = 2.0 * nb * H * W * 9 * ci * co
                     if packed is not None and name in packed:   # this layer's transformed weights of this step are ready
@@ -278,6 +287,7 @@ class VggEngine(object):
                             # the next layer is a convolution on this output: leave (y > 0) as bits in the lane order of ITS data gradient
                             mk = self._b("mk_%s_%d" % (name, ch), (self._wino(name, "mask_words")(nb, H, W, co),), dtype=torch.int32)
                             self.mask_geom[name] = (nb, len(halves))   # the bits are per tile of THIS launch geometry
+                            self.mask_family[name] = 4 if name in self.wino4 else 2
                             self._timed("conv_fwd", fl, lambda: self._wino(name, "fwd_mask_f32")(
                                 sh, nb, H, W, cie, co, P(x[b0:]), P(self.buf["vp_" + name]), P(S.param(bn)), P(y[b0:]), 1, P(mk)))
                         elif pooled and self.train:
@@ -443,7 +453,7 @@ class VggEngine(object):
                         sh = _stream()
                         if (self._wino_ok(name, nb, H, W, ci, co, 1) and not prev_is_pool
                               and self.mask_geom.get(self.acts[li - 1][0]) == (nb, len(halves))
-                              and (self.acts[li - 1][0] in self.wino4) == (name in self.wino4)   # (bits are in their family's lane order)
+                              and self.mask_family.get(self.acts[li - 1][0]) == (4 if name in self.wino4 else 2)   # (bits are in their family's lane order)
                               and lib.vc_conv3x3_wino_single_launch_supported(nb, H, W, ci, co)):
                             # ReluGrad from the bits the previous layer's forward left (one 8-byte load per lane instead of sixteen 16-byte ones)
                             self._timed("conv_dgrad", fl * nb / B, lambda: self._wino(name, "dgrad_bits_f32")(
