@@ -491,7 +491,7 @@ def wino_executed_ratio(images, wino4=True):
                     continue
                 best = max(best, tw * th / (_cdiv(tw, tbw) * _cdiv(th, tbh) * float(slots)))
             effw = max(tw * th / (_cdiv(tw, bw) * _cdiv(th, bh) * float(bh * bw)) for bh, bw in ((4, 8), (4, 7), (2, 14)))
-            eff4 = H * H / (_cdiv(H, 16) ** 2 * 256.0)
+            eff4 = H * H / (_cdiv(H, 4) ** 2 * 16.0) if _cdiv(images * _cdiv(H, 4) ** 2, 16) < images * _cdiv(H, 16) ** 2 else H * H / (_cdiv(H, 16) ** 2 * 256.0)   # linear tiles (csrc/conv_wino4.hip plan_wino4) / square blocks
             fd = (36.0 / 144.0) / eff4 if (wino4 and prefers4(images, H, H, ci, co)) else (16.0 / 36.0) / best
             alg += 3 * fl
             ex += 2 * fl * fd + fl * (16.0 / 36.0) / effw

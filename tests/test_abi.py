@@ -91,13 +91,14 @@ def test_product_code_never_touches_the_oracle_or_the_reference():
 def test_bench_executed_ratio_of_the_winograd_kernels():
     """bench.py prices the Winograd kernels' executed MFMA work as a fraction of the algorithmic (direct-convolution) FLOPs.  Forward /
     data gradient: F(4x4,3x3) = 36 / 144 per layer and pass on every layer behind conv1_1 (csrc/conv_wino4.hip: blocks of
-    16 x 16 pixels -- exact at 224 / 112, (56 / 64)^2 = (28 / 32)^2 = (14 / 16)^2 = 49 / 64 of the slots real at 56, 28 and 14; the library's own
-    preference rule, which bench.py asks, takes all of them since round 4); weight gradient F(3x3,2x2) = 16 / 36 over plan_wino_wgrad's
+    16 x 16 pixels -- exact at 224 / 112; linear blocks of sixteen consecutive tiles at 56 / 28: every slot real; one block per image with
+    (14 / 16)^2 = 49 / 64 of the slots real at 14; the library's own preference rule, which bench.py asks, takes all of them since round 4);
+    weight gradient F(3x3,2x2) = 16 / 36 over plan_wino_wgrad's
     block coverage; conv1_1 stays direct.  Hand-worked for the VGG16 shapes at 224 x 224; the F(2x2,3x3)-only figure is kept beside it."""
     import bench
     r, r2 = bench.wino_executed_ratio(64), bench.wino_executed_ratio(64, wino4=False)
     # per layer: (forward / data-gradient multiplications per direct multiplication, weight-gradient block coverage)
-    fd = {224: 0.25, 112: 0.25, 56: 0.25 / (49.0 / 64.0), 28: 0.25 / (49.0 / 64.0), 14: 0.25 / (49.0 / 64.0)}
+    fd = {224: 0.25, 112: 0.25, 56: 0.25, 28: 0.25, 14: 0.25 / (49.0 / 64.0)}   # (56 / 28: linear tiles fill every slot; 14: 3.5 tiles per side)
     fd2 = {224: 16.0 / 36.0, 112: 16.0 / 36.0, 56: 16.0 / 36.0, 28: (16.0 / 36.0) / 0.875, 14: (16.0 / 36.0) / (49.0 / 64.0)}
     effw = {224: 1.0, 112: 1.0, 56: 1.0, 28: 1.0, 14: 0.875}
     layers = [(224, 3, 64), (224, 64, 64), (112, 64, 128), (112, 128, 128), (56, 128, 256), (56, 256, 256), (56, 256, 256),
@@ -114,7 +115,7 @@ def test_bench_executed_ratio_of_the_winograd_kernels():
             ex += 2 * fl * fd[H] + fl * (16.0 / 36.0) / effw[H]
             ex2 += 2 * fl * fd2[H] + fl * (16.0 / 36.0) / effw[H]
     assert abs(r - ex / alg) < 1e-9 and abs(r2 - ex2 / alg) < 1e-9
-    assert 0.34 < r < 0.36 and 0.46 < r2 < 0.49
+    assert 0.31 < r < 0.34 and 0.46 < r2 < 0.49
 
 
 def test_bench_algorithmic_bytes_of_the_convolution_calls():

@@ -118,10 +118,11 @@ def test_wino4_unsupported_shapes_are_refused_and_preference_follows_the_block_c
     x, wp, y = zeros(2, 8, 8, 32), zeros(36 * 32 * 48), zeros(2, 8, 8, 48)
     with pytest.raises(VaecapError):
         lib.vc_conv3x3_wino4_fwd_f32(stream(), 2, 8, 8, 32, 48, P(x), P(wp), None, P(y), None, 0)
-    # VGG16 at 224 x 224: every 3x3 layer behind conv1_1, the 56-wide block included since round 4 (4 x 4-tile blocks cover 56 x 56 to 77 %,
-    # the 2 x 2-tile blocks to 100 %: above the 0.75 the rule asks for); a 40-wide image (3 x 3 blocks: 69 % against 100 %) is turned down
-    pref = {H: lib.vc_conv3x3_wino4_preferred(32, H, H, 64, 64) for H in (224, 112, 56, 28, 14, 40)}
-    assert pref == {224: 1, 112: 1, 56: 1, 28: 1, 14: 1, 40: 0}, pref
+    # VGG16 at 224 x 224: every 3x3 layer behind conv1_1 since round 4.  With linear tiles (blocks of sixteen consecutive tiles: the 56-, 28-
+    # and 40-wide images below) only the padding inside the 4 x 4 tiles of the right / bottom edge is left over: 14 x 14 -> 77 % of the slots,
+    # above the 0.75 x F(2x2,3x3)'s coverage the rule asks for; odd sizes stay with the other kernels (no fused pool)
+    pref = {H: lib.vc_conv3x3_wino4_preferred(32, H, H, 64, 64) for H in (224, 112, 56, 28, 14, 40, 27)}
+    assert pref == {224: 1, 112: 1, 56: 1, 28: 1, 14: 1, 40: 1, 27: 0}, pref
     assert lib.vc_conv3x3_wino4_preferred(32, 224, 224, 4, 64) == 0
 
 

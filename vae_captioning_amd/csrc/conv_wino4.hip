@@ -30,17 +30,6 @@
 #ifndef W4_ABL
 #define W4_ABL 0
 #endif
-// gaps (0 .. 35, behind MFMA m of a phase) at which the two staging groups load from global memory and write to the LDS
-#ifndef W4_A_LD
-#define W4_A_LD 0
-#define W4_A_ST 12
-#define W4_B_LD 16
-#define W4_B_ST 24
-#endif
-#ifndef W4_B_REG
-#define W4_B_REG 0   // 4: group B has its own staging registers (the groups may then be in flight together)
-#endif
-
 namespace vc {
 
 enum { W4_FWD = 0, W4_DGRAD = 1 };
@@ -56,13 +45,28 @@ constexpr int W4_DUMP = W4_POFF + 360;       // plane padding of block 0: where 
 constexpr int W4_MAIN_BYTES = (2 * W4_WBUF + 2 * W4_PBUF) * 4;     // 61 440: the main loop's buffers
 constexpr int WINO4_LDS_BYTES = 4 * 16 * 64 * 16;                  // 65 536: the epilogue's exchange of partial outputs (four waves x 16 float4 per lane); two workgroups per CU
 static_assert(W4_MAIN_BYTES <= WINO4_LDS_BYTES, "LDS");
+// LINEAR TILES (template flag LT): a block = sixteen CONSECUTIVE 4 x 4 tiles of the launch in raster order (image, tile row, tile
+// column) instead of a 4 x 4 square of them.  On the 56- and 28-wide layers (14 x 14 and 7 x 7 tiles per image) square blocks leave 23 %
+// of their tile slots -- and of the MFMAs -- outside the image; linear blocks fill every slot (196 and 49 tiles per image, 64 images:
+// whole blocks).  The price is the patch: every tile stages its own 6 x 6 pixels (576 per block against the shared 18 x 18 = 324), as
+// four planes [tile 16][row 6][pixel 6] of 578 floats (pitch 2 mod 4: the two lane groups a ds_read_b64 serves together then hit
+// different banks); a patch row = three ds_read_b64.  Everything behind the patch -- transforms, MFMAs, weights, epilogue -- is the same.
+constexpr int W4L_PLANE = 578;
+constexpr int W4L_BLKF = 4 * W4L_PLANE;
+constexpr int W4L_PBUF = W4_NBLK * W4L_BLKF;                       // 18.5 KB
+constexpr int W4L_DUMP = W4_POFF + 2 * W4L_PBUF;                   // sixteen floats behind the patch buffers
+constexpr int W4L_NPIX = W4_NBLK * 576;
+constexpr int WINO4L_LDS_BYTES = (2 * W4_WBUF + 2 * W4L_PBUF + 16) * 4;   // 73 920: two workgroups per CU
+static_assert(WINO4L_LDS_BYTES >= WINO4_LDS_BYTES, "the exchange area");
 constexpr int W4_WPH = W4_WBUF * 4;          // bytes of a phase's packed weights per 32-channel tile
 constexpr int W4_NPIX = W4_NBLK * 324;       // patch pixels of a workgroup
 
 struct Wino4Geom {
     int B, H, W, C, N;
-    int bx_n, by_n, blocks_img, nblocks;     // blocks of 16 x 16 output pixels
+    int bx_n, by_n, blocks_img, nblocks;     // blocks of 16 x 16 output pixels (linear tiles: blocks_img unused, nblocks = ceil(tiles / 16))
     unsigned m_blocks_img, m_bx_n;
+    int lt, tw, tiles_img, ntiles_all;       // linear tiles: tiles per image row / per image / in the launch
+    unsigned m_tiles_img, m_tw;
 };
 
 struct Wino4Args {
@@ -122,8 +126,10 @@ __device__ __forceinline__ void w4_hstep(int k, const float* d, float* o, float*
     }
 }
 
-template <int KIND, bool POOL>
+template <int KIND, bool POOL, bool LT>
 __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
+    constexpr int NPS = LT ? 5 : 3;                                    // patch slots per thread and phase
+    constexpr int PBUF = LT ? W4L_PBUF : W4_PBUF, BLKF = LT ? W4L_BLKF : W4_BLKF, PLANE = LT ? W4L_PLANE : W4_PLANE;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const Wino4Geom& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lj = lane & 15, lg = lane >> 4;
@@ -138,33 +144,49 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)((long)g.B * g.H * g.W * C * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, (int)(36L * C * N * 4), 0x00020000);
 
-    // patch slots: slot s = tid + 256 j < 648 = (block s / 324, patch pixel s % 324); one float4 = the phase's four channels of the pixel
-    unsigned voff[3];
-    int pst[3];
+    // patch slots: slot s = tid + 256 j; one float4 = the phase's four channels of a pixel.  Square blocks: s < 648 = (block s / 324, patch
+    // pixel s % 324 of its 18 x 18); linear tiles: s < 1152 = (block s / 576, tile (s % 576) / 36, pixel of its 6 x 6)
+    unsigned voff[NPS];
+    int pst[NPS];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
+    for (int j = 0; j < NPS; ++j) {
         const unsigned s = (unsigned)tid + 256u * j;
-        const unsigned blk = s >= 324u ? 1u : 0u, pix = s - blk * 324u;
-        const unsigned py = pix / 18u, px = pix - py * 18u;
-        const unsigned gb = (unsigned)tm * W4_NBLK + blk;
-        const bool live = s < (unsigned)W4_NPIX && gb < (unsigned)g.nblocks;
-        const unsigned gbc = live ? gb : 0u;
-        const unsigned b = wino_div(gbc, g.m_blocks_img), rem = gbc - b * (unsigned)g.blocks_img;
-        const unsigned by = wino_div(rem, g.m_bx_n), bx = rem - by * (unsigned)g.bx_n;
-        const int y = (int)(by * 16u + py) - 1, x = (int)(bx * 16u + px) - 1;
-        const bool ok = live && (unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W;
-        // C4 layout [B][C/4][H][W][4]: the pixel's four channels of phase h are 16 bytes at channel plane h (soffset h * plane bytes);
-        // consecutive lanes = consecutive pixels of a patch row = consecutive 16-byte pieces (288-byte runs)
-        voff[j] = ok ? (((b * (unsigned)(C >> 2) * (unsigned)g.H + (unsigned)y) * (unsigned)g.W + (unsigned)x)) * 16u : WOOB;
-        if ((W4_ABL & 32) && ok) voff[j] &= 0xfffffu;   // timing only: the same access pattern inside a 1 MB window (cache-resident patches)
-        pst[j] = s < (unsigned)W4_NPIX ? W4_POFF + (int)blk * W4_BLKF + (int)py * W4_PITCH + (int)px : W4_DUMP + (tid & 15);
+        if constexpr (LT) {
+            const unsigned blk = s >= 576u ? 1u : 0u, rem = s - blk * 576u;
+            const unsigned tl = rem / 36u, pp = rem - tl * 36u, py = pp / 6u, px = pp - py * 6u;
+            const unsigned T = ((unsigned)tm * W4_NBLK + blk) * 16u + tl;
+            const bool live = s < (unsigned)W4L_NPIX && T < (unsigned)g.ntiles_all;
+            const unsigned Tc = live ? T : 0u;
+            const unsigned b = wino_div(Tc, g.m_tiles_img), r2 = Tc - b * (unsigned)g.tiles_img;
+            const unsigned tyy = wino_div(r2, g.m_tw), txx = r2 - tyy * (unsigned)g.tw;
+            const int y = (int)(tyy * 4u + py) - 1, x = (int)(txx * 4u + px) - 1;
+            const bool ok = live && (unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W;
+            voff[j] = ok ? (((b * (unsigned)(C >> 2) * (unsigned)g.H + (unsigned)y) * (unsigned)g.W + (unsigned)x)) * 16u : WOOB;
+            pst[j] = s < (unsigned)W4L_NPIX ? W4_POFF + (int)blk * W4L_BLKF + (int)(tl * 36u + pp) : W4L_DUMP + (tid & 15);
+        } else {
+            const unsigned blk = s >= 324u ? 1u : 0u, pix = s - blk * 324u;
+            const unsigned py = pix / 18u, px = pix - py * 18u;
+            const unsigned gb = (unsigned)tm * W4_NBLK + blk;
+            const bool live = s < (unsigned)W4_NPIX && gb < (unsigned)g.nblocks;
+            const unsigned gbc = live ? gb : 0u;
+            const unsigned b = wino_div(gbc, g.m_blocks_img), rem = gbc - b * (unsigned)g.blocks_img;
+            const unsigned by = wino_div(rem, g.m_bx_n), bx = rem - by * (unsigned)g.bx_n;
+            const int y = (int)(by * 16u + py) - 1, x = (int)(bx * 16u + px) - 1;
+            const bool ok = live && (unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W;
+            // C4 layout [B][C/4][H][W][4]: the pixel's four channels of phase h are 16 bytes at channel plane h (soffset h * plane bytes);
+            // consecutive lanes = consecutive pixels of a patch row = consecutive 16-byte pieces (288-byte runs)
+            voff[j] = ok ? (((b * (unsigned)(C >> 2) * (unsigned)g.H + (unsigned)y) * (unsigned)g.W + (unsigned)x)) * 16u : WOOB;
+            pst[j] = s < (unsigned)W4_NPIX ? W4_POFF + (int)blk * W4_BLKF + (int)py * W4_PITCH + (int)px : W4_DUMP + (tid & 15);
+        }
+        if ((W4_ABL & 32) && voff[j] != WOOB) voff[j] &= 0xfffffu;   // timing only: the same access pattern inside a 1 MB window (cache-resident patches)
     }
     // weight slots: piece i of the phase's 18 KB = float4 tid + 256 i < 1152
     const unsigned vsrc = (unsigned)nt * (unsigned)a.nphases * (unsigned)W4_WPH + (unsigned)tid * 16u;
     const bool w4ok = tid < 128;   // piece 4: only the first half of the workgroup has one
 
     const int ty = lj >> 2, tx = lj & 3;
-    const int rbase = W4_POFF + wb * W4_BLKF + lg * W4_PLANE + (4 * ty) * W4_PITCH + 4 * tx;   // + buffer + 4 * PLANE (odd phase) + r * PITCH
+    // + buffer + r * (row pitch): the lane's patch row r in plane lg
+    const int rbase = LT ? W4_POFF + wb * W4L_BLKF + lg * W4L_PLANE + lj * 36 : W4_POFF + wb * W4_BLKF + lg * W4_PLANE + (4 * ty) * W4_PITCH + 4 * tx;
     const int vbase = (lg * 16 + lj) * 4;                                                      // + group * WGRP + wq * WBUF + pq * 256
 
     // M_p[channel 32 nt + 16 gi + 4 lg + r][tile lj] for the wave's positions p = 18 hf + pos, pos = 6 vl + u (u: vertical index, vl: the
@@ -186,11 +208,23 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
 
     // this lane's 4 x 4 output pixels
     const int gbo = tm * W4_NBLK + wb;
-    const bool blk_ok = gbo < g.nblocks;
-    const int gboc = blk_ok ? gbo : 0;
-    const int ob = (int)wino_div((unsigned)gboc, g.m_blocks_img), orem = gboc - ob * g.blocks_img;
-    const int oby = (int)wino_div((unsigned)orem, g.m_bx_n), obx = orem - oby * g.bx_n;
-    const int y0 = oby * 16 + 4 * ty, x0 = obx * 16 + 4 * tx;
+    bool blk_ok;
+    int ob, y0, x0;
+    if constexpr (LT) {
+        const int T = gbo * 16 + lj;
+        blk_ok = T < g.ntiles_all;
+        const int Tc = blk_ok ? T : 0;
+        ob = (int)wino_div((unsigned)Tc, g.m_tiles_img);
+        const int r2 = Tc - ob * g.tiles_img, tyy = (int)wino_div((unsigned)r2, g.m_tw);
+        y0 = 4 * tyy; x0 = 4 * (r2 - tyy * g.tw);
+    } else {
+        blk_ok = gbo < g.nblocks;
+        const int gboc = blk_ok ? gbo : 0;
+        ob = (int)wino_div((unsigned)gboc, g.m_blocks_img);
+        const int orem = gboc - ob * g.blocks_img;
+        const int oby = (int)wino_div((unsigned)orem, g.m_bx_n), obx = orem - oby * g.bx_n;
+        y0 = oby * 16 + 4 * ty; x0 = obx * 16 + 4 * tx;
+    }
     // output in the C4 layout: this lane's channel quad nc0 / 4 is one plane; a tile row = 64 consecutive bytes
     const long p00 = (((long)(ob * (N >> 2) + (nc0 >> 2)) * g.H + y0) * g.W + x0) * 4;
     // data gradient: the ReLU mask of the lane's outputs as 64 bits (bit 16 aa + 4 bb + c), from the producer's forward (one 8-byte
@@ -219,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
     // ---- main loop + partial output transform, compiled once per position half
     auto body = [&](auto hfc) {
         constexpr int HF = decltype(hfc)::value;
-        float4 st[4];               // staging registers
+        float4 st[5];               // staging registers: the patch slots, then the five weight pieces
         float HA[6][3], HB[6][3];   // [patch row r][local horizontal index vl]: rows transformed horizontally (the wave's half of B^T over a row)
         float U[6];                 // one column of B^T d B = the B operands of twelve MFMAs
         float4 vf[2][2];            // weight fragments [slot][channel group]: fragment f = positions 4 (4 HF + f) .. + 3 of the packed order
@@ -227,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
         float tv[5], th[3];
         if (W4_ABL) {   // ablated builds read registers nobody wrote: give them values
 #pragma unroll
-            for (int i = 0; i < 4; ++i) st[i] = make_float4(1.f, 2.f, 3.f, 4.f);
+            for (int i = 0; i < 5; ++i) st[i] = make_float4(1.f, 2.f, 3.f, 4.f);
 #pragma unroll
             for (int i = 0; i < 2; ++i) { vf[i][0] = make_float4(1.f + lane, 2.f, 3.f, 4.f); vf[i][1] = make_float4(2.f + lane, 2.f, 3.f, 4.f); }
 #pragma unroll
@@ -237,11 +271,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
         }
         auto pload = [&](int i, int hp) { if (!(W4_ABL & 8)) st[i] = wbufload(rx, voff[i], (unsigned)((W4_ABL & 32) ? (hp & 1) : hp) * plane_b); };
         auto pput = [&](const float4& v, int i, int pq) {   // patch slot i into patch buffer pq: one pixel, four channel planes
-            float* d = &smem[pst[i] + pq * W4_PBUF];
-            d[0] = v.x; d[W4_PLANE] = v.y; d[2 * W4_PLANE] = v.z; d[3 * W4_PLANE] = v.w;
+            float* d = &smem[pst[i] + pq * PBUF];
+            d[0] = v.x; d[PLANE] = v.y; d[2 * PLANE] = v.z; d[3 * PLANE] = v.w;
         };
         auto wput = [&](const float4& v, int i, int wq) {   // weight piece i into weight buffer wq
-            const int dst = (i == 4 && !w4ok) ? W4_DUMP + 4 * (tid & 3) : wq * W4_WBUF + (tid + 256 * i) * 4;
+            const int dst = (i == 4 && !w4ok) ? (LT ? W4L_DUMP : W4_DUMP) + 4 * (tid & 3) : wq * W4_WBUF + (tid + 256 * i) * 4;
             *reinterpret_cast<float4*>(&smem[dst]) = v;
         };
         auto pstore = [&](int i, int pq) { if (!(W4_ABL & 8)) pput(st[i], i, pq); };
@@ -249,10 +283,17 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
         auto wstore = [&](int si, int i, int wq) { if (!(W4_ABL & 8)) wput(st[si], i, wq); };
         auto rdrow = [&](int off, int r) {   // off: float offset of the patch buffer whose rows are read; row r lands in set r & 1
             if (W4_ABL & 2) return;
-            const float4 v = *reinterpret_cast<const float4*>(&smem[rbase + off + r * W4_PITCH]);
-            const float2 w = *reinterpret_cast<const float2*>(&smem[rbase + off + r * W4_PITCH + 4]);
             float* d = rr[r & 1];
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; d[4] = w.x; d[5] = w.y;
+            if constexpr (LT) {
+                const float2 v0 = *reinterpret_cast<const float2*>(&smem[rbase + off + r * 6]);
+                const float2 v1 = *reinterpret_cast<const float2*>(&smem[rbase + off + r * 6 + 2]);
+                const float2 v2 = *reinterpret_cast<const float2*>(&smem[rbase + off + r * 6 + 4]);
+                d[0] = v0.x; d[1] = v0.y; d[2] = v1.x; d[3] = v1.y; d[4] = v2.x; d[5] = v2.y;
+            } else {
+                const float4 v = *reinterpret_cast<const float4*>(&smem[rbase + off + r * W4_PITCH]);
+                const float2 w = *reinterpret_cast<const float2*>(&smem[rbase + off + r * W4_PITCH + 4]);
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; d[4] = w.x; d[5] = w.y;
+            }
         };
         auto rdfrag = [&](int f, int slot, int wq) {   // fragment f of weight buffer wq, both channel groups
             if (W4_ABL & 4) return;
@@ -270,7 +311,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
             constexpr int q = decltype(qc)::value;
             const bool nxt = stW;   // a next phase exists exactly when its weights are still to be staged
             const bool rd0ok = stP;
-            constexpr int rdo = (q ^ 1) * W4_PBUF, rd0 = q * W4_PBUF;
+            constexpr int rdo = (q ^ 1) * PBUF, rd0 = q * PBUF;
 #pragma unroll
             for (int m = 0; m < 36; ++m) {
                 const int pos = m >> 1, gi = m & 1, vl = pos / 6, u = pos % 6;
@@ -309,13 +350,12 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
                     }
                 }
                 if (nxt && m == 33) rdfrag(0, (q ^ 1) & 1, q ^ 1);
-                // (E) staging: group A = the three patch slots + weight piece 0, group B = weight pieces 1 .. 4
-                if (m >= W4_A_LD && m < W4_A_LD + 3 && stP) pload(m - W4_A_LD, h + 2);
-                if (m == W4_A_LD + 3 && stW) wload(3, 0, h + 1);
-                if (m >= W4_A_ST && m < W4_A_ST + 3 && stP) pstore(m - W4_A_ST, q);
-                if (m == W4_A_ST + 3 && stW) wstore(3, 0, q ^ 1);
-                if (m >= W4_B_LD && m < W4_B_LD + 4 && stW) wload(m - W4_B_LD, m - W4_B_LD + 1, h + 1);
-                if (m >= W4_B_ST && m < W4_B_ST + 4 && stW) wstore(m - W4_B_ST, m - W4_B_ST + 1, q ^ 1);
+                // (E) staging: the patch slots of phase h + 2 (loaded at gaps 0 .., written ten gaps later), then the five weight pieces of
+                // phase h + 1 (loaded at 16 .. 20, written at 23 .. 27), through the same registers
+                if (m < NPS && stP) pload(m, h + 2);
+                if (m >= 10 && m < 10 + NPS && stP) pstore(m - 10, q);
+                if (m >= 16 && m < 21 && stW) wload(m - 16, m - 16, h + 1);
+                if (m >= 23 && m < 28 && stW) wstore(m - 23, m - 23, q ^ 1);
                 // (F)
                 if (m == 28 && nxt && !(W4_ABL & 16)) __syncthreads();
                 WSB();
@@ -325,19 +365,19 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
         // ---- prologue: phases 0 (patches + weights) and 1 (patches) into the LDS, rows of phase 0 transformed.  All eleven loads are
         // issued before the first store: one memory round trip instead of three (a workgroup of conv1_2 lives for sixteen phases only)
         if (!(W4_ABL & 8)) {
-            float4 pr[11];
+            float4 pr[2 * NPS + 5];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) pr[i] = wbufload(rx, voff[i], 0u);
+            for (int i = 0; i < NPS; ++i) pr[i] = wbufload(rx, voff[i], 0u);
 #pragma unroll
-            for (int i = 0; i < 5; ++i) pr[3 + i] = wbufload(rw, (i == 4 && !w4ok) ? WOOB : vsrc + (unsigned)i * 4096u, 0u);
+            for (int i = 0; i < 5; ++i) pr[NPS + i] = wbufload(rw, (i == 4 && !w4ok) ? WOOB : vsrc + (unsigned)i * 4096u, 0u);
 #pragma unroll
-            for (int i = 0; i < 3; ++i) pr[8 + i] = wbufload(rx, voff[i], plane_b);
+            for (int i = 0; i < NPS; ++i) pr[NPS + 5 + i] = wbufload(rx, voff[i], plane_b);
 #pragma unroll
-            for (int i = 0; i < 3; ++i) pput(pr[i], i, 0);
+            for (int i = 0; i < NPS; ++i) pput(pr[i], i, 0);
 #pragma unroll
-            for (int i = 0; i < 5; ++i) wput(pr[3 + i], i, 0);
+            for (int i = 0; i < 5; ++i) wput(pr[NPS + i], i, 0);
 #pragma unroll
-            for (int i = 0; i < 3; ++i) pput(pr[8 + i], i, 1);
+            for (int i = 0; i < NPS; ++i) pput(pr[NPS + 5 + i], i, 1);
         }
         __syncthreads();
 #pragma unroll
@@ -349,8 +389,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
 #pragma unroll
         for (int k = 0; k < 12; ++k) w4_bstep_v(k, HA[0][0], HA[1][0], HA[2][0], HA[3][0], HA[4][0], HA[5][0], U, tv);
         rdfrag(0, 0, 0);
-        rdrow(W4_PBUF, 0);   // rows 0, 1 of phase 1
-        rdrow(W4_PBUF, 1);
+        rdrow(PBUF, 0);   // rows 0, 1 of phase 1
+        rdrow(PBUF, 1);
         __syncthreads();     // (nobody stages over rows that somebody still reads)
         WSB();
 
@@ -521,6 +561,13 @@ static bool plan_wino4(int B, int H, int W, int C, int N, Wino4Geom& g) {
     g.nblocks = B * g.blocks_img;
     if ((long)g.nblocks * g.blocks_img >= 0x100000000L) return false;
     g.m_blocks_img = wino_magic(g.blocks_img); g.m_bx_n = wino_magic(g.bx_n);
+    // linear tiles where they need fewer blocks than the square ones (VGG16: the 56- and 28-wide layers; a 14-wide image is one block either way)
+    const int th = cdiv(H, 4);
+    g.tw = cdiv(W, 4); g.tiles_img = th * g.tw; g.ntiles_all = B * g.tiles_img;
+    g.m_tiles_img = wino_magic(g.tiles_img); g.m_tw = wino_magic(g.tw);
+    static const int lt_on = getenv("VC_WINO4_LINEAR") ? atoi(getenv("VC_WINO4_LINEAR")) : 1;   // (A/B runs)
+    g.lt = (lt_on && (long)B * g.tiles_img < 0x7ffffff0L && cdiv(g.ntiles_all, 16) < g.nblocks) ? 1 : 0;
+    if (g.lt) g.nblocks = cdiv(g.ntiles_all, 16);
     return true;
 }
 
@@ -528,9 +575,13 @@ static int wino4_attr() {
     static int once = [] {
         hipError_t e = hipSuccess;
         auto set = [&](const void* f) { if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, WINO4_LDS_BYTES); };
-        set(reinterpret_cast<const void*>(conv_wino4_kernel<W4_FWD, false>));
-        set(reinterpret_cast<const void*>(conv_wino4_kernel<W4_FWD, true>));
-        set(reinterpret_cast<const void*>(conv_wino4_kernel<W4_DGRAD, false>));
+        set(reinterpret_cast<const void*>(conv_wino4_kernel<W4_FWD, false, false>));
+        set(reinterpret_cast<const void*>(conv_wino4_kernel<W4_FWD, true, false>));
+        set(reinterpret_cast<const void*>(conv_wino4_kernel<W4_DGRAD, false, false>));
+        auto setl = [&](const void* f) { if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, WINO4L_LDS_BYTES); };
+        setl(reinterpret_cast<const void*>(conv_wino4_kernel<W4_FWD, false, true>));
+        setl(reinterpret_cast<const void*>(conv_wino4_kernel<W4_FWD, true, true>));
+        setl(reinterpret_cast<const void*>(conv_wino4_kernel<W4_DGRAD, false, true>));
         return e == hipSuccess ? 0 : fail((int)e, "%s: hipFuncSetAttribute failed", "conv wino4 kernel");
     }();
     return once;
@@ -547,9 +598,13 @@ static int wino4_launch(hipStream_t st, int kind, int nb, int H, int W, int C, i
     a.tiles_n = N / 32;
     a.nphases = C / 4;
     a.ntiles = cdiv(a.g.nblocks, W4_NBLK) * a.tiles_n;
-    if (kind == W4_DGRAD) hipLaunchKernelGGL((conv_wino4_kernel<W4_DGRAD, false>), dim3(a.ntiles), dim3(256), WINO4_LDS_BYTES, st, a);
-    else if (pool) hipLaunchKernelGGL((conv_wino4_kernel<W4_FWD, true>), dim3(a.ntiles), dim3(256), WINO4_LDS_BYTES, st, a);
-    else hipLaunchKernelGGL((conv_wino4_kernel<W4_FWD, false>), dim3(a.ntiles), dim3(256), WINO4_LDS_BYTES, st, a);
+    if (a.g.lt) {
+        if (kind == W4_DGRAD) hipLaunchKernelGGL((conv_wino4_kernel<W4_DGRAD, false, true>), dim3(a.ntiles), dim3(256), WINO4L_LDS_BYTES, st, a);
+        else if (pool) hipLaunchKernelGGL((conv_wino4_kernel<W4_FWD, true, true>), dim3(a.ntiles), dim3(256), WINO4L_LDS_BYTES, st, a);
+        else hipLaunchKernelGGL((conv_wino4_kernel<W4_FWD, false, true>), dim3(a.ntiles), dim3(256), WINO4L_LDS_BYTES, st, a);
+    } else if (kind == W4_DGRAD) hipLaunchKernelGGL((conv_wino4_kernel<W4_DGRAD, false, false>), dim3(a.ntiles), dim3(256), WINO4_LDS_BYTES, st, a);
+    else if (pool) hipLaunchKernelGGL((conv_wino4_kernel<W4_FWD, true, false>), dim3(a.ntiles), dim3(256), WINO4_LDS_BYTES, st, a);
+    else hipLaunchKernelGGL((conv_wino4_kernel<W4_FWD, false, false>), dim3(a.ntiles), dim3(256), WINO4_LDS_BYTES, st, a);
     return launch_status("conv wino4");
 }
 
@@ -570,7 +625,8 @@ extern "C" int vc_conv3x3_wino4_supported(int B, int H, int W, int Cin, int Cout
 // behind conv1_1 now runs this kernel; VC_WINO4_MIN_COVERAGE overrides the ratio for A/B runs.
 extern "C" int vc_conv3x3_wino4_preferred(int B, int H, int W, int Cin, int Cout) {
     if (!vc_conv3x3_wino4_supported(B, H, W, Cin, Cout, 0) || !vc_conv3x3_wino4_supported(B, H, W, Cin, Cout, 1) || (H & 1) || (W & 1)) return 0;
-    const double e4 = (double)H * W / ((double)vc::cdiv(H, 16) * vc::cdiv(W, 16) * 256.0);
+    // share of the tile slots that hold pixels of the image: linear tiles leave only the padding INSIDE the 4 x 4 tiles of the right / bottom edge
+    const double e4 = (double)H * W / ((double)vc::cdiv(H, 4) * vc::cdiv(W, 4) * 16.0);
     static const double ratio = getenv("VC_WINO4_MIN_COVERAGE") ? atof(getenv("VC_WINO4_MIN_COVERAGE")) : 0.75;   // (A/B runs of the rule)
     return e4 >= ratio * vc::wino2_coverage(H, W) ? 1 : 0;
 }
@@ -624,7 +680,7 @@ extern "C" int vc_conv3x3_wino4_fwd_pool_f32(void* stream, int B, int H, int W, 
 extern "C" size_t vc_conv3x3_wino4_mask_words(int B, int H, int W, int C) {
     vc::Wino4Geom g;
     if (!vc::plan_wino4(B, H, W, 8, C, g)) return 0;
-    return (size_t)vc::cdiv(g.nblocks, vc::W4_NBLK) * (C / 32) * 512;
+    return (size_t)vc::cdiv(B * g.blocks_img, vc::W4_NBLK) * (C / 32) * 512;   // (the square-block count: never less than the linear one)
 }
 
 extern "C" int vc_conv3x3_wino4_fwd_mask_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const float* wp,
