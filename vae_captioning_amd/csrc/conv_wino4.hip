@@ -3,22 +3,26 @@
 //
 //   Y = A^T [ sum_c (G g_c G^T) (.) (B^T d_c B) ] A     per 4 x 4 output tile: d = its 6 x 6 input patch, g = the 3 x 3 filter
 //
-// Used where vc_conv3x3_wino4_preferred says so (block coverage: the 224-, 112-, 28- and 14-wide layers of VGG16; the 56-wide block
-// stays on conv_wino.hip): kernel by kernel 7-30 % faster there, 0.9 ms of the 31.8 ms cfg4 step (profiles/r03_wino4_layers.txt).
-// Why a second Winograd kernel (tools/probes/mfma16_f43.hip, mfma_specialised.hip; HISTORY.md section 4g): on one SIMD a VALU
-// instruction and the matrix pipe do NOT overlap -- beside back-to-back v_mfma_f32_16x16x4_f32 a partner wave gets ~0.5 VALU issues
-// per MFMA, inside one stream every VALU operation costs 4-8 cycles of matrix time -- so the F(2x2,3x3) kernel's 71 % MFMA-busy is its
-// instruction mix, not its LDS traffic, and the way down is fewer MFMAs per output: the 36 positions of F(4x4,3x3) cost 36 / 16 = 2.25
-// MFMAs per output where F(2x2,3x3) spends 16 / 4 = 4.  The input transform is heavier (144 operations per tile and channel against
-// 32), which is why the kernel is built around the instruction count: 12-operation 1-D transforms (FMA with the constants 4, 5, 2),
-// a lane owns ONE tile and ONE input channel of a four-channel phase.
+// Since round 4 every 3x3 layer of VGG16 behind conv1_1 runs here (vc_conv3x3_wino4_preferred; profiles/r04_wino4_layers.txt).
+// Why this kernel looks the way it does (tools/probes/mfma16_f43.hip, mfma_specialised.hip; HISTORY.md section 4g): on gfx950 the fp32
+// MFMA rate equals the fp32 vector rate and on one SIMD a VALU instruction and the matrix pipe do NOT overlap -- every VALU operation
+// costs 4-8 cycles of matrix time -- so a Winograd kernel's speed is its instruction count per MFMA.  F(4x4,3x3) spends 36 / 16 = 2.25
+// MFMAs per output where F(2x2,3x3) spends 4, but its input transform is heavier (144 operations per tile and channel against 32);
+// the kernel is built around that count: 12-operation 1-D transforms (FMA with the constants 4, 5, 2), a lane owns ONE tile and ONE
+// input channel of a four-channel phase, and (round 4) the TWO WAVES OF A BLOCK SPLIT THE 36 POSITIONS: wave `hf` takes the horizontal
+// indices v = 3 hf .. 3 hf + 2, runs half of the horizontal pass (6 operations per patch row) and three column transforms -- 72
+// operations per phase instead of 144 --, multiplies its eighteen positions against BOTH groups of sixteen output channels (the same 36
+// MFMAs per phase, one B operand feeding two MFMAs), and the partial outputs meet once, in the epilogue.
 //
-// Structure: workgroup = four waves = TWO blocks of 4 x 4 tiles (16 x 16 output pixels each) x TWO groups of sixteen output channels
-// (wave = 2 block + group); 36 accumulators of four registers per wave (16 tiles x 16 channels x 36 positions), two workgroups per CU.
-// A phase = four input channels = ONE k-step: 36 MFMAs per wave.  LDS per phase: the blocks' 18 x 18 halo patches as four channel
-// planes [g 4][row 18][pixel, pitch 20] (a lane's patch row = ds_read_b128 + ds_read_b64, conflict-free: the plane stride is a
-// multiple of 64 floats) and the phase's transformed weights [group 2][position / 4][g 4][n 16][position % 4] (a lane's fragment of
-// four positions = one ds_read_b128, 1 KB contiguous per wave); both double-buffered, 60 KB per workgroup.
+// Structure: workgroup = four waves = TWO blocks of sixteen 4 x 4 tiles x 32 output channels, wave = (block, position half); 36
+// accumulators of four registers per wave, two workgroups per CU.  A phase = four input channels = ONE k-step.  LDS per phase: the
+// blocks' patches as four channel planes and the phase's transformed weights [group 2][position / 4][g 4][n 16][position % 4] (a lane's
+// fragment of four positions = one ds_read_b128, 1 KB contiguous per wave); both double-buffered.  A block is either a 4 x 4 SQUARE of
+// tiles with a shared 18 x 18 halo patch ([g 4][row 18][pixel, pitch 20]: a lane's patch row = ds_read_b128 + ds_read_b64) or, where
+// squares would leave slots empty (the 56- and 28-wide layers), sixteen CONSECUTIVE tiles in raster order with a 6 x 6 patch each
+// (template flag LT below).  Epilogue: A^T over u in registers, the wave's three terms of the sum over v, one exchange of sixteen
+// float4 per lane through the LDS, then wave `hf` holds the finished outputs of channel group hf -- bias (it rode in the accumulator
+// of position (1, 1)), ReLU, mask bits, 2 x 2 max-pool + routing codes and the C4 stores are register math.
 // Rounding: the transforms' constants (4, 5, 8; 1/4, 1/6, 1/24 in the weights) cost about a decimal digit against F(2x2,3x3):
 // ~1e-5 of the tensor maximum (tests/test_gpu_conv_wino4.py against the fp64 oracle).
 #include <stdlib.h>
