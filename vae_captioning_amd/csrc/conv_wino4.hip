@@ -354,12 +354,22 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
                     }
                 }
                 if (nxt && m == 33) rdfrag(0, (q ^ 1) & 1, q ^ 1);
-                // (E) staging: the patch slots of phase h + 2 (loaded at gaps 0 .., written ten gaps later), then the five weight pieces of
-                // phase h + 1 (loaded at 16 .. 20, written at 23 .. 27), through the same registers
-                if (m < NPS && stP) pload(m, h + 2);
-                if (m >= 10 && m < 10 + NPS && stP) pstore(m - 10, q);
-                if (m >= 16 && m < 21 && stW) wload(m - 16, m - 16, h + 1);
-                if (m >= 23 && m < 28 && stW) wstore(m - 23, m - 23, q ^ 1);
+                // (E) staging through shared registers.  Square blocks: group A = the three patch slots of phase h + 2 + weight piece 0 of
+                // phase h + 1 (loaded at gaps 0 .. 3, written at 12 .. 15), group B = weight pieces 1 .. 4 (16 .. 19 -> 24 .. 27).  Linear tiles:
+                // the five patch slots (0 .. 4 -> 11 .. 15), then the five weight pieces (16 .. 20 -> 23 .. 27).
+                if constexpr (!LT) {
+                    if (m < 3 && stP) pload(m, h + 2);
+                    if (m == 3 && stW) wload(3, 0, h + 1);
+                    if (m >= 12 && m < 15 && stP) pstore(m - 12, q);
+                    if (m == 15 && stW) wstore(3, 0, q ^ 1);
+                    if (m >= 16 && m < 20 && stW) wload(m - 16, m - 15, h + 1);
+                    if (m >= 24 && m < 28 && stW) wstore(m - 24, m - 23, q ^ 1);
+                } else {   // (own registers for the weight pieces, both groups in flight together: measured, no gain)
+                    if (m < 5 && stP) pload(m, h + 2);
+                    if (m >= 11 && m < 16 && stP) pstore(m - 11, q);
+                    if (m >= 16 && m < 21 && stW) wload(m - 16, m - 16, h + 1);
+                    if (m >= 23 && m < 28 && stW) wstore(m - 23, m - 23, q ^ 1);
+                }
                 // (F)
                 if (m == 28 && nxt && !(W4_ABL & 16)) __syncthreads();
                 WSB();
