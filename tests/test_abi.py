@@ -143,3 +143,36 @@ def test_bench_algorithmic_bytes_of_the_convolution_calls():
     got = bench.conv_algorithmic_bytes(B)
     assert abs(got - (acts + weights)) < 1e-3 * got
     assert 16.7e9 < got < 17.7e9   # ~17.2 GB per 64-image step = 269 MB per image
+
+
+def test_bench_without_a_launcher_starts_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus 4 ...` with no WORLD_SIZE in the environment (the shape of the driver's scaling command if it does not wrap
+    it in torchrun): bench.self_launch re-runs the same arguments under torch.distributed.run with one process per GPU, rendezvous on
+    127.0.0.1 at a free port, and exits with the launcher's code.  (The two-rank run itself: tests/test_gpu_cli.py.)"""
+    import subprocess
+    import sys
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1", "--workload", "cfg2"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[0] == sys.executable and cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    i = cmd.index(os.path.abspath(bench.__file__))
+    assert cmd[i + 1:] == ["--gpus", "4", "--steps", "3", "--warmup", "1", "--workload", "cfg2"]
+    assert "OMP_NUM_THREADS" in seen["env"]
+    # under a launcher (WORLD_SIZE set) bench.py does not launch again; a world size that disagrees with --gpus is an error message
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    seen.clear()
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert not seen and "--gpus 4 but WORLD_SIZE=2" in str(e.value.code)
