@@ -86,6 +86,7 @@ struct Wino4Args {
                          // (null: not wanted), read by the data gradient of the NEXT layer instead of the float source (same shape => same lanes)
     int relu;
     int tiles_n, ntiles, nphases;
+    int tg, per_chunk;   // workgroup order: [chunk of tg channel tiles][block pair][channel tile of the chunk] (tg divides tiles_n; per_chunk = block pairs * tg)
 };
 
 // one 1-D input transform B^T (6 -> 6) in twelve operations:
@@ -141,7 +142,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
     // each multiplies its eighteen against BOTH channel groups; the epilogue exchanges partial outputs and wave `hf` finishes channel group hf
     const int wb = wave >> 1, hf = wave & 1;
     const int id = xcd_remap(blockIdx.x, a.ntiles);
-    const int tm = id / a.tiles_n, nt = id - tm * a.tiles_n;
+    const int chunk = id / a.per_chunk, cr = id - chunk * a.per_chunk;
+    const int tm = cr / a.tg, nt = chunk * a.tg + (cr - tm * a.tg);
     const int C = g.C, N = g.N;
     const int nc0 = nt * 32 + hf * 16 + 4 * lg;   // the four output channels this lane FINISHES
 
@@ -612,6 +614,15 @@ static int wino4_launch(hipStream_t st, int kind, int nb, int H, int W, int C, i
     a.tiles_n = N / 32;
     a.nphases = C / 4;
     a.ntiles = cdiv(a.g.nblocks, W4_NBLK) * a.tiles_n;
+    // Workgroup order (the kernel's id -> (block pair, channel tile)): the 64 workgroups an XCD holds at a time share its 4 MB L2; with all
+    // N / 32 channel tiles of a block pair side by side (the order up to round 4) the 512-channel layers keep 16 x 2.4 MB of packed weights
+    // in flight per XCD and re-fetch them for every four block pairs: 12-13 x the algorithmic bytes on conv4_x.  Chunks of FOUR channel
+    // tiles (16 block pairs x 4 tiles per XCD) balance patch and weight re-fetches: 10.1 -> 6.6 GB per forward pass over the twelve
+    // layers, data gradient 9.9 -> 7.0 (profiles/r04_traffic_layers.md; 8: 7.7, 2: 8.3); the time does not change (the Infinity Cache
+    // serves the re-fetches either way).  VC_WINO4_TG=<n>: another chunk width, 0 = all tiles of a block pair together.
+    static const int tg_env = getenv("VC_WINO4_TG") ? atoi(getenv("VC_WINO4_TG")) : 4;
+    a.tg = (tg_env > 0 && a.tiles_n % tg_env == 0) ? tg_env : a.tiles_n;
+    a.per_chunk = cdiv(a.g.nblocks, W4_NBLK) * a.tg;
     if (a.g.lt) {
         if (kind == W4_DGRAD) hipLaunchKernelGGL((conv_wino4_kernel<W4_DGRAD, false, true>), dim3(a.ntiles), dim3(256), WINO4L_LDS_BYTES, st, a);
         else if (pool) hipLaunchKernelGGL((conv_wino4_kernel<W4_FWD, true, true>), dim3(a.ntiles), dim3(256), WINO4L_LDS_BYTES, st, a);

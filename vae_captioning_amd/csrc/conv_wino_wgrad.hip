@@ -142,6 +142,8 @@ extern "C" int vc_conv3x3_wino_wgrad_f32(void* stream, int B, int H, int W, int 
         WinoWgArgs a;
         a.g = p.g; a.x = x + (size_t)b0 * H * W * Cin; a.dy = dy + (size_t)b0 * H * W * Cout; a.ws = ws;
         a.ncb = p.ncb; a.nnb = p.nnb; a.nsplit = p.nsplit; a.cps = p.cps;
+        static const int xcd_on = getenv("VC_WGRAD_XCD") ? atoi(getenv("VC_WGRAD_XCD")) : 1;   // (A/B runs)
+        a.xcd = xcd_on;
         int rc = p.shape == 0 ? launch_wino_wgrad_4x8((hipStream_t)stream, a) : p.shape == 1 ? launch_wino_wgrad_4x7((hipStream_t)stream, a)
                                                                                              : launch_wino_wgrad_2x14((hipStream_t)stream, a);
         if (rc) return rc;

@@ -21,6 +21,7 @@ struct WinoWgArgs {
     const float* dy;     // [B][N/4][H][W][4]
     float* ws;           // [split][16][C][N] position sums, then [split][N] bias partials
     int ncb, nnb, nsplit, cps;
+    int xcd;             // 1: workgroup order by XCD (below)
 };
 
 template <int TBH, int TBW>
@@ -45,7 +46,12 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(WinoWgArgs a) {
     // of the four patch rows and runs half of the x transform (vertical 2 of 4 outputs per column, horizontal 8 of 16) and half of its
     // tile's dy transform.  Raw position sums go to the workspace as before; nothing is exchanged between the waves.
     const int cw = wave >> 2, nw = (wave >> 1) & 1, ph = wave & 1;
-    const int cn = blockIdx.x % (a.ncb * a.nnb), split = blockIdx.x / (a.ncb * a.nnb);
+    // Workgroup order: the hardware deals consecutive workgroups round the eight XCDs, each with its own L2; logical id = xcd_remap(...)
+    // gives XCD i a CONTIGUOUS range of (split, tile) ids -- whole K splits (x and dy of a split are then fetched by one XCD only), or,
+    // on the 64-tile layers, half the tiles of one split (four input-channel tiles x all eight output-channel tiles) -- instead of one
+    // residue class mod 8 = one output-channel tile of EVERY split, which fetched x eight times (profiles/r04_traffic_layers.md).
+    const int wid = a.xcd ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int cn = wid % (a.ncb * a.nnb), split = wid / (a.ncb * a.nnb);
     const int cb = cn / a.nnb, nb = cn - cb * a.nnb;
     const int C = g.C, N = g.N;
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)((long)g.B * g.H * g.W * C * 4), 0x00020000);
