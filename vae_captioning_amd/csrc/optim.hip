@@ -5,6 +5,7 @@
 //
 // HBM-bound: Adam touches 4 reads + 3 writes x 4 B = 28 B per parameter.
 #include "common.h"
+#include <stdlib.h>
 #include "vaecap.h"
 
 namespace vc {
@@ -17,6 +18,12 @@ static inline int grid_for(long work_items, int per_block = 256, int cap = 2048)
 }
 
 constexpr int SUMSQ_BLOCKS = 512;
+
+// Workgroups of an Adam launch (grid-stride, all resident at once).  (VC_ADAM_BLOCKS: A/B runs)
+static inline int adam_grid(long n) {
+    static const int cap = getenv("VC_ADAM_BLOCKS") ? atoi(getenv("VC_ADAM_BLOCKS")) : 2048;
+    return grid_for(n / 4 + 1, 256, cap > 0 ? cap : 2048);
+}
 
 // partial[b] = sum over a fixed grid-stride slice of x^2: deterministic for a fixed n.
 __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ x, long n, float* __restrict__ partial) {
@@ -240,18 +247,18 @@ extern "C" int vc_adam_f32(void* stream, float* p, const float* g, float* m, flo
     VC_CHECK_ARG(p && g && m && v && lr_t && n >= 0, "bad argument");
     VC_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "buffers must be 16-byte aligned");
     if (n == 0) return 0;
-    hipLaunchKernelGGL(adam_kernel<false>, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr_t, scale, beta1, beta2, eps, l2, nullptr);
+    hipLaunchKernelGGL(adam_kernel<false>, dim3(adam_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr_t, scale, beta1, beta2, eps, l2, nullptr);
     VC_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int vc_adam_blocks(long n) { return grid_for(n / 4 + 1); }
+extern "C" int vc_adam_blocks(long n) { return adam_grid(n); }
 
 extern "C" int vc_adam_sumsq_f32(void* stream, float* p, const float* g, float* m, float* v, long n, const float* lr_t,
                                  const float* scale, float beta1, float beta2, float eps, float l2, float* sumsq_partial) {
     VC_CHECK_ARG(p && g && m && v && lr_t && sumsq_partial && n > 0, "bad argument");
     VC_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "buffers must be 16-byte aligned");
-    hipLaunchKernelGGL(adam_kernel<true>, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr_t, scale, beta1, beta2, eps, l2, sumsq_partial);
+    hipLaunchKernelGGL(adam_kernel<true>, dim3(adam_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr_t, scale, beta1, beta2, eps, l2, sumsq_partial);
     VC_LAUNCH_CHECK();
     return 0;
 }

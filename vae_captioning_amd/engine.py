@@ -14,6 +14,7 @@ Layout decisions (MI355X-first):
     a reference-named checkpoint is exported).
 """
 import contextlib
+import os
 
 import numpy as np
 import torch
@@ -781,8 +782,20 @@ class CaptionEngine(object):
         dhs = self._b("dhs_d", (Td + 1, N, Hd))  # external gradient w.r.t. every decoder state; init steps stay 0
         douts = dhs[nid + 1:]
         self.gemm(0, 1, T * N, Hd, Vp, dlogits, Vp, S.param("decoder/rnn_logits/kernel"), Vp, douts, Hd)
-        with self.off_chain():
+        # The [Hd, V] kernel gradient of the logits layer (a chip-filling 65 GFLOP product at cfg4) is issued at the END of this pass:
+        # next to the BPTT it takes every CU's LDS and the recurrence's first step kernel waits for the whole product (0.5 ms on the
+        # gradient chain); issued last it runs under the VGG16 backward pass (cfg4 26.53 -> 26.28 ms; caption-only workloads: no
+        # difference).  VC_LOGITS_DW=now: the former order (A/B runs).
+        logits_dw_late = os.environ.get("VC_LOGITS_DW", "end") != "now"
+
+        def side(fn):   # weight-gradient work on the weight-gradient stream
+            with self.off_chain():
+                fn()
+
+        def logits_dw():
             self.dense_bwd_w(outs, T * N, Hd, Vp, dlogits, "decoder/rnn_logits/kernel", "decoder/rnn_logits/bias")  # padding columns of dlogits are 0
+        if not logits_dw_late:
+            side(logits_dw)
         if p.dec_lstm_drop < 1:
             lib.vc_dropout_f32(st, P(douts), P(self.buf["drop_out"]), p.dec_lstm_drop, T * N * Hd, P(douts))
         # running state gradients of both LSTMs: one buffer, one fill ([dH_d | dC_d | dC_e])
@@ -796,20 +809,20 @@ class CaptionEngine(object):
         if p.dec_keep_rate < 1:
             lib.vc_dropout_f32(st, P(dxw), P(self.buf["drop_in"]), p.dec_keep_rate, T * N * E, P(dxw))
         nb = self.nb
-        with self.off_chain():
+        def dec_w(dG=dG, dxw=dxw):
             ws, wsb = self._need_ws(lib.vc_lstm_seq_workspace_bytes(Td, N, E, Hd))
             lib.vc_lstm_seq_bwd_weights_f32(_stream(), Td, N, E, Hd, P(self.buf["Xd"]), P(self.buf["hs_d"]), P(dG),
                                             P(S.grad(spec.DEC_CELL + "kernel")), P(S.grad(spec.DEC_CELL + "bias")), ws, wsb)
             self._embedding_grad("decoder/net/dec_embeddings", "dec", dxw)
             lib.vc_sumsq_partial_f32(_stream(), P(dxw), T * N * E, self.part.data_ptr() + nb * 4)  # IndexedSlices.values (Q5)
+        side(dec_w)
         d_imfv = dXd[0]       # [N, E] gradient w.r.t. images_fv (decoder part)
         d_ci = dXd[1] if self.feed_cv else None
         if self.enc:
             zi = nid - 1
             dz_dec = dXd[zi]
             z = self.buf["z"]
-            with self.off_chain():
-                self.dense_bwd_w(z, N, Sm * L, E, dz_dec, "decoder/net/z_rnn/kernel", "decoder/net/z_rnn/bias")
+            side(lambda: self.dense_bwd_w(z, N, Sm * L, E, dz_dec, "decoder/net/z_rnn/kernel", "decoder/net/z_rnn/bias"))
             dz = self._b("dz", (Sm, N, L))
             self.gemm(0, 1, N, Sm * L, E, dz_dec, E, S.param("decoder/net/z_rnn/kernel"), E, dz, Sm * L)
             mean, std = self.buf["mean"], self.buf["std"]
@@ -830,9 +843,8 @@ class CaptionEngine(object):
             dhT = self._b("dH_e", (N, He))
             if p.prior == "Normal":
                 lib.vc_latent_bwd_f32(st, Sb, N, L, 0, 1, P(dz), P(self.buf["eps"]), P(mean), P(std), None, P(ann), kl_n, P(dmean), P(dstd))
-                with self.off_chain():
-                    self.dense_bwd_w(hT, N, He, L, dmean, "encoder/dense/kernel", "encoder/dense/bias")
-                    self.dense_bwd_w(hT, N, He, L, dstd, "encoder/dense_1/kernel", "encoder/dense_1/bias")
+                side(lambda: (self.dense_bwd_w(hT, N, He, L, dmean, "encoder/dense/kernel", "encoder/dense/bias"),
+                              self.dense_bwd_w(hT, N, He, L, dstd, "encoder/dense_1/kernel", "encoder/dense_1/bias")))
                 self.gemm(0, 1, N, He, L, dmean, L, S.param("encoder/dense/kernel"), L, dhT, He)
                 self.gemm(0, 1, N, He, L, dstd, L, S.param("encoder/dense_1/kernel"), L, dhT, He, None, 2)
             else:
@@ -845,8 +857,7 @@ class CaptionEngine(object):
                 dheads = self._b("dheads", (N, 2 * K_CL * L))
                 lib.vc_heads_mix_bwd_f32(st, N, K_CL, L, P(heads), None if gmm else P(self.buf["c_v"]), P(self.buf["gmm_idx"]) if gmm else None,
                                          P(dmean), P(dstd), P(dheads))
-                with self.off_chain():
-                    self.dense_bwd_w(hT, N, He, 2 * K_CL * L, dheads, "encoder/heads/kernel", "encoder/heads/bias")
+                side(lambda: self.dense_bwd_w(hT, N, He, 2 * K_CL * L, dheads, "encoder/heads/kernel", "encoder/heads/bias"))
                 self.gemm(0, 1, N, He, 2 * K_CL * L, dheads, 2 * K_CL * L, S.param("encoder/heads/kernel"), 2 * K_CL * L, dhT, He)
             dC = self.buf["dstate0"][2 * N * Hd:].view(N, He)
             dG, dXe = self._b("dG_e", (Te, N, 4 * He)), self._b("dXe", (Te, N, E))
@@ -857,15 +868,18 @@ class CaptionEngine(object):
             if self.feed_cv:
                 lib.vc_axpy_f32(st, 1.0, P(dXe[1]), N * E, P(d_ci))
             dxe = dXe[self.n_init_e]
-            with self.off_chain():
+            def enc_w(dG=dG, dxe=dxe):
                 ws, wsb = self._need_ws(lib.vc_lstm_seq_workspace_bytes(Te, N, E, He))
                 lib.vc_lstm_seq_bwd_weights_f32(_stream(), Te, N, E, He, P(self.buf["Xe"]), P(self.buf["hs_e"]), P(dG),
                                                 P(S.grad(spec.ENC_CELL + "kernel")), P(S.grad(spec.ENC_CELL + "bias")), ws, wsb)
                 self._embedding_grad("encoder/enc_embeddings", "enc", dxe)
                 lib.vc_sumsq_partial_f32(_stream(), P(dxe), T * N * E, self.part.data_ptr() + 2 * nb * 4)
+            side(enc_w)
         else:
             with self.off_chain():
                 self.part[2 * nb:3 * nb].zero_()
+        if logits_dw_late:
+            side(logits_dw)
         dimf = self._b("dimf", (B, E))
         if nc > 1:
             lib.vc_segment_sum_rows_f32(st, P(d_imfv), B, nc, E, P(dimf), 0)
