@@ -452,7 +452,9 @@ def hbm_from_timer(timer):
     MI355X_MICROARCH.md."""
     sm = timer.summary()
     out = {}
-    for tag in ("hbm_embedding_gather", "hbm_softmax_xent", "hbm_adam", "hbm_fc1_gemm"):
+    # (fc1_gemm: the forward product, alone on the chip; fc1_gemm_bwd: its two backward products, which share the chip with the logits
+    # layer's weight gradient on the weight-gradient stream since round 4 -- their event pairs include that)
+    for tag in ("hbm_embedding_gather", "hbm_softmax_xent", "hbm_adam", "hbm_fc1_gemm", "hbm_fc1_gemm_bwd"):
         if tag in sm and sm[tag]["seconds"] > 0:
             gbs = sm[tag]["flops"] / sm[tag]["seconds"] / 1e9
             out[tag[4:]] = {"launches": sm[tag]["launches"], "avg_us": round(1e6 * sm[tag]["seconds"] / sm[tag]["launches"], 2),
@@ -525,10 +527,10 @@ def roofline_from_timer(timer, fine_tune, images=0):
     if not fine_tune:
         kern = "vc::gemm_kernel<128x128,MK,KM> (logits)"
     elif wino:
-        kern = ("vc::conv_wino4_kernel (Winograd F(4x4,3x3) forward / data gradient; the 56-wide layers: vc::conv_wino2_kernel, F(2x2,3x3)) / "
+        kern = ("vc::conv_wino4_kernel (Winograd F(4x4,3x3) forward / data gradient of conv1_2 ... conv5_3) / "
                 "vc::wino_wgrad_kernel (F(3x3,2x2) weight gradient) (+ vc::conv1_fwd_kernel / vc::conv1_wgrad_kernel for conv1_1)")
     else:
-        kern = "vc::conv_patch_kernel / vc::wgrad_patch_kernel (+ vc::conv1_fwd_kernel / vc::conv1_wgrad_kernel for conv1_1)"
+        kern = "vc::conv_kernel<fwd|dgrad|wgrad> (NHWC implicit GEMM behind layout conversions: the checker path)"
     ex = ach * ratio
     return {"bound": "mfma", "kernel": kern,
             # achieved / frac: the FLOPs the MFMAs EXECUTE per second against the dense fp32 MFMA peak (a fraction of the roofline, < 1)

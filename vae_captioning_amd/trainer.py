@@ -380,10 +380,10 @@ class VggEngine(object):
         lib.vc_relu_bwd_f32(st, P(d1), P(self.buf["fc1"]), m1, self.keep, B * 4096, P(d1))
         F1 = self.flat.numel() // B
         fc1_bytes = 4.0 * (F1 * 4096 + B * F1 + B * 4096)
-        self._timed("hbm_fc1_gemm", fc1_bytes, lambda: self.gemm(1, 0, F1, 4096, B, self.flat, F1, d1, 4096, S.grad("cnn/fc1/weights"), 4096))
+        self._timed("hbm_fc1_gemm_bwd", fc1_bytes, lambda: self.gemm(1, 0, F1, 4096, B, self.flat, F1, d1, 4096, S.grad("cnn/fc1/weights"), 4096))
         self.colsum(d1, B, 4096, S.grad("cnn/fc1/biases"))
         dn = self._b("d_pool5", tuple(self.flat.shape))
-        self._timed("hbm_fc1_gemm", fc1_bytes, lambda: self.gemm(0, 1, B, F1, 4096, d1, 4096, S.param("cnn/fc1/weights"), 4096, dn, F1))
+        self._timed("hbm_fc1_gemm_bwd", fc1_bytes, lambda: self.gemm(0, 1, B, F1, 4096, d1, 4096, S.param("cnn/fc1/weights"), 4096, dn, F1))
         d = self._b("d_pool5_c4", tuple(self.pool5.shape))   # back into the convolution layers' C4 layout
         lib.vc_nhwc_to_c4_f32(st, B, int(dn.shape[1]), int(dn.shape[2]), int(dn.shape[3]), P(dn), P(d))
         if after_fc is not None:
