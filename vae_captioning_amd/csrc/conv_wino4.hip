@@ -30,7 +30,7 @@
 #include "conv_wino.h"
 
 // `make wino4abl W4FLAGS=-DW4_ABL=n` builds this file with W4_ABL = a bit mask that REMOVES parts of the main loop (results are then wrong; timing only):
-// 1 transform arithmetic, 2 patch-row reads, 4 weight-fragment reads, 8 staging (global loads + LDS writes), 16 barriers, 32 the patch loads wrapped into a cache-resident 1 MB window (same pattern), 64 no output stores, 128 no exchange of the partial outputs
+// 1 transform arithmetic, 2 patch-row reads, 4 weight-fragment reads, 8 staging (global loads + LDS writes), 16 barriers, 32 the patch loads wrapped into a cache-resident 1 MB window (same pattern), 64 no output stores, 128 no exchange of the partial outputs (NOT a valid ablation: the compiler then drops the MFMAs of the unsent channel group), 256 the output stores wrapped into a cache-resident 1 MB window
 #ifndef W4_ABL
 #define W4_ABL 0
 #endif
@@ -502,8 +502,31 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
                 if (!(mb & 4u)) v.z = 0.f;
                 if (!(mb & 8u)) v.w = 0.f;
             }
-            if (ok && !((W4_ABL & 64) && v.x != 12345.f)) *reinterpret_cast<float4*>(a.out + p00 + (aa * g.W + bb) * 4) = v;
+            // linear tile blocks: the lane's own sixteen 16-byte stores (a tile row = 64 consecutive bytes, four instructions)
+            if (LT && ok && !((W4_ABL & 64) && v.x != 12345.f)) *reinterpret_cast<float4*>(a.out + ((W4_ABL & 256) ? ((p00 + (aa * g.W + bb) * 4) & 0x3fffcL) : (p00 + (aa * g.W + bb) * 4))) = v;   // (256: timing only, every store inside a 1 MB window)
         }
+    if constexpr (!LT) {
+        // Square blocks: the wave's 16 x 16 pixels x four channel quads leave through its 16 KB of the exchange area so that a store
+        // instruction writes four 256-byte ROWS (lane = (quad, pixel of the row)) instead of 64 scattered 16-byte pieces -- the scattered
+        // form cost 0.08 ms of conv1_2's 0.90 even with every store hitting the cache (W4_ABL=256).  slot(quad, y, x) = quad * 256 + 16 y +
+        // ((x + 2 (y >> 2)) & 15): the rotation keeps the eight lanes of a ds_write_b128 group (four tile columns x two tile rows) on four
+        // bank quads (2-way, hidden behind the instruction's own 13 cycles); a row read is 256 contiguous bytes, rotated.
+        __syncthreads();   // the partner wave has read this wave's partial outputs
+        float4* T = reinterpret_cast<float4*>(smem) + wave * 1024;
+#pragma unroll
+        for (int aa = 0; aa < 4; ++aa)
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) T[lg * 256 + (4 * ty + aa) * 16 + ((4 * tx + bb + 2 * ty) & 15)] = Y[aa][bb];
+        const int by0 = y0 - 4 * ty, bx0 = x0 - 4 * tx, xx = lj;   // (lane = 16 quad + pixel: quad = lg, pixel = lj)
+        const long pb = (((long)(ob * (N >> 2) + (nc0 >> 2)) * g.H + by0) * g.W + bx0 + xx) * 4;
+        const bool okx = blk_ok && bx0 + xx < g.W;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float4 v = T[lg * 256 + i * 16 + ((xx + 2 * (i >> 2)) & 15)];
+            const long po = pb + (long)i * g.W * 4;
+            if (okx && by0 + i < g.H && !((W4_ABL & 64) && v.x != 12345.f)) *reinterpret_cast<float4*>(a.out + ((W4_ABL & 256) ? (po & 0x3fffcL) : po)) = v;
+        }
+    }
     if (KIND == W4_FWD && a.mask) *reinterpret_cast<uint2*>(a.mask + ((size_t)id * 256 + tid) * 2) = make_uint2(ob0, ob1);
     if (POOL) {   // a 4 x 4 tile is 2 x 2 pooling windows: register math, no LDS, no separate pooling pass
         const int HP = g.H >> 1, WP = g.W >> 1;
