@@ -502,8 +502,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
                 if (!(mb & 4u)) v.z = 0.f;
                 if (!(mb & 8u)) v.w = 0.f;
             }
-            // linear tile blocks: the lane's own sixteen 16-byte stores (a tile row = 64 consecutive bytes, four instructions)
-            if (LT && ok && !((W4_ABL & 64) && v.x != 12345.f)) *reinterpret_cast<float4*>(a.out + ((W4_ABL & 256) ? ((p00 + (aa * g.W + bb) * 4) & 0x3fffcL) : (p00 + (aa * g.W + bb) * 4))) = v;   // (256: timing only, every store inside a 1 MB window)
+            (void)ok;
         }
     if constexpr (!LT) {
         // Square blocks: the wave's 16 x 16 pixels x four channel quads leave through its 16 KB of the exchange area so that a store
@@ -524,8 +523,38 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
         for (int i = 0; i < 16; ++i) {
             const float4 v = T[lg * 256 + i * 16 + ((xx + 2 * (i >> 2)) & 15)];
             const long po = pb + (long)i * g.W * 4;
-            if (okx && by0 + i < g.H && !((W4_ABL & 64) && v.x != 12345.f)) *reinterpret_cast<float4*>(a.out + ((W4_ABL & 256) ? (po & 0x3fffcL) : po)) = v;
+            if (okx && by0 + i < g.H && !((W4_ABL & 64) && v.x != 12345.f)) *reinterpret_cast<float4*>(a.out + ((W4_ABL & 256) ? (po & 0x3fffcL) : po)) = v;   // (256: timing only, every store inside a 1 MB window)
         }
+    } else {
+        // Linear tile blocks: sixteen consecutive tiles in raster order = runs of up to `tw` adjacent tiles of one tile row.  The same
+        // hand-over: slot(quad, aa, tile, bb) = ((quad * 4 + aa) * 16 + tile) * 4 + ((bb + (tile >> 1)) & 3) (the rotation spreads the eight
+        // lanes of a ds_write_b128 group over all banks); store instruction (quad, aa): lane = 4 tile + bb, i.e. the pixel row aa of all
+        // sixteen tiles -- one to three contiguous runs (896 bytes per tile row at 56 pixels) instead of 64 pieces.
+        __syncthreads();
+        float4* T = reinterpret_cast<float4*>(smem) + wave * 1024;
+#pragma unroll
+        for (int aa = 0; aa < 4; ++aa)
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) T[((lg * 4 + aa) * 16 + lj) * 4 + ((bb + (lj >> 1)) & 3)] = Y[aa][bb];
+        const int rt = lane >> 2, rb = lane & 3;          // the tile and pixel column this lane STORES
+        const int Tr = gbo * 16 + rt;
+        const bool rok = Tr < g.ntiles_all;
+        const int Trc = rok ? Tr : 0;
+        const int rob = (int)wino_div((unsigned)Trc, g.m_tiles_img);
+        const int rr2 = Trc - rob * g.tiles_img, rty = (int)wino_div((unsigned)rr2, g.m_tw);
+        const int ry0 = 4 * rty, rx = 4 * (rr2 - rty * g.tw) + rb;
+        const long pr = (((long)(rob * (N >> 2) + (nt * 8 + hf * 4)) * g.H + ry0) * g.W + rx) * 4;   // quad 0, row 0
+        const bool rokx = rok && rx < g.W;
+        const long planef = (long)g.H * g.W * 4;
+        const int rslot = rt * 4 + ((rb + (rt >> 1)) & 3);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int aa = 0; aa < 4; ++aa) {
+                const float4 v = T[(q * 4 + aa) * 64 + rslot];
+                const long po = pr + q * planef + (long)aa * g.W * 4;
+                if (rokx && ry0 + aa < g.H && !((W4_ABL & 64) && v.x != 12345.f)) *reinterpret_cast<float4*>(a.out + ((W4_ABL & 256) ? (po & 0x3fffcL) : po)) = v;
+            }
     }
     if (KIND == W4_FWD && a.mask) *reinterpret_cast<uint2*>(a.mask + ((size_t)id * 256 + tid) * 2) = make_uint2(ob0, ob1);
     if (POOL) {   // a 4 x 4 tile is 2 x 2 pooling windows: register math, no LDS, no separate pooling pass
