@@ -30,7 +30,7 @@
 #include "conv_wino.h"
 
 // `make wino4abl W4FLAGS=-DW4_ABL=n` builds this file with W4_ABL = a bit mask that REMOVES parts of the main loop (results are then wrong; timing only):
-// 1 transform arithmetic, 2 patch-row reads, 4 weight-fragment reads, 8 staging (global loads + LDS writes), 16 barriers, 32 the patch loads wrapped into a cache-resident 1 MB window (same pattern), 64 no output stores, 128 no exchange of the partial outputs (NOT a valid ablation: the compiler then drops the MFMAs of the unsent channel group), 256 the output stores wrapped into a cache-resident 1 MB window
+// 1 transform arithmetic, 2 patch-row reads, 4 weight-fragment reads, 8 staging (global loads + LDS writes), 16 barriers, 32 the patch loads wrapped into a cache-resident 1 MB window (same pattern), 64 no output stores, 128 no exchange of the partial outputs (NOT a valid ablation: the compiler then drops the MFMAs of the unsent channel group), 256 the output stores wrapped into a cache-resident 1 MB window, 512 no global loads of the staging (its LDS writes stay), 1024 no LDS writes of the staging (its loads stay)
 #ifndef W4_ABL
 #define W4_ABL 0
 #endif
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) { HA[r][c] = 1.f + lane + r; HB[r][c] = 2.f + lane + c; rr[c & 1][r] = 0.5f * lane; U[r] = 1.f * lane; }
         }
-        auto pload = [&](int i, int hp) { if (!(W4_ABL & 8)) st[i] = wbufload(rx, voff[i], (unsigned)((W4_ABL & 32) ? (hp & 1) : hp) * plane_b); };
+        auto pload = [&](int i, int hp) { if (!(W4_ABL & (8 | 512))) st[i] = wbufload(rx, voff[i], (unsigned)((W4_ABL & 32) ? (hp & 1) : hp) * plane_b); };
         auto pput = [&](const float4& v, int i, int pq) {   // patch slot i into patch buffer pq: one pixel, four channel planes
             float* d = &smem[pst[i] + pq * PBUF];
             d[0] = v.x; d[PLANE] = v.y; d[2 * PLANE] = v.z; d[3 * PLANE] = v.w;
@@ -284,9 +284,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
             const int dst = (i == 4 && !w4ok) ? (LT ? W4L_DUMP : W4_DUMP) + 4 * (tid & 3) : wq * W4_WBUF + (tid + 256 * i) * 4;
             *reinterpret_cast<float4*>(&smem[dst]) = v;
         };
-        auto pstore = [&](int i, int pq) { if (!(W4_ABL & 8)) pput(st[i], i, pq); };
-        auto wload = [&](int si, int i, int hp) { if (!(W4_ABL & 8)) st[si] = wbufload(rw, (i == 4 && !w4ok) ? WOOB : vsrc + (unsigned)i * 4096u, (unsigned)hp * (unsigned)W4_WPH); };
-        auto wstore = [&](int si, int i, int wq) { if (!(W4_ABL & 8)) wput(st[si], i, wq); };
+        auto keep = [&](const float4& v) { asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); };   // (ablation 1024: the loads stay, their LDS writes go)
+        auto pstore = [&](int i, int pq) { if (W4_ABL & 1024) keep(st[i]); else if (!(W4_ABL & 8)) pput(st[i], i, pq); };
+        auto wload = [&](int si, int i, int hp) { if (!(W4_ABL & (8 | 512))) st[si] = wbufload(rw, (i == 4 && !w4ok) ? WOOB : vsrc + (unsigned)i * 4096u, (unsigned)hp * (unsigned)W4_WPH); };
+        auto wstore = [&](int si, int i, int wq) { if (W4_ABL & 1024) keep(st[si]); else if (!(W4_ABL & 8)) wput(st[si], i, wq); };
         auto rdrow = [&](int off, int r) {   // off: float offset of the patch buffer whose rows are read; row r lands in set r & 1
             if (W4_ABL & 2) return;
             float* d = rr[r & 1];
