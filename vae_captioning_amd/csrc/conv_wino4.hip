@@ -22,7 +22,8 @@
 // squares would leave slots empty (the 56- and 28-wide layers), sixteen CONSECUTIVE tiles in raster order with a 6 x 6 patch each
 // (template flag LT below).  Epilogue: A^T over u in registers, the wave's three terms of the sum over v, one exchange of sixteen
 // float4 per lane through the LDS, then wave `hf` holds the finished outputs of channel group hf -- bias (it rode in the accumulator
-// of position (1, 1)), ReLU, mask bits, 2 x 2 max-pool + routing codes and the C4 stores are register math.
+// of position (1, 1)), ReLU, mask bits, 2 x 2 max-pool + routing codes are register math; the outputs themselves pass through the LDS once
+// more (the wave's own 16 KB, no barrier between its write and its read) so that a store instruction writes pixel ROWS of the C4 planes.
 // Rounding: the transforms' constants (4, 5, 8; 1/4, 1/6, 1/24 in the weights) cost about a decimal digit against F(2x2,3x3):
 // ~1e-5 of the tensor maximum (tests/test_gpu_conv_wino4.py against the fp64 oracle).
 #include <stdlib.h>
