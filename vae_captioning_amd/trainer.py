@@ -530,7 +530,7 @@ class Trainer(object):
         self.gall = torch.zeros(n_cap + n_vgg, dtype=torch.float32, device=device)  # THE all-reduce buffer
         self.cap = CaptionEngine(p, vocab, device, self.lib, grad_backing=self.gall[:n_cap], world=world, rank=rank, group=group, seed=seed,
                                  force_collectives=force_collectives)
-        self.cap.enable_wgrad_stream(bool(wgrad_stream))
+        self.cap.enable_wgrad_stream(bool(wgrad_stream) and os.environ.get("VC_WGRAD_STREAM", "1") != "0")   # (VC_WGRAD_STREAM=0: A/B runs)
         self.vgg = None
         if self.fine:
             self.vgg = VggEngine(p, device, self.lib, grad_backing=self.gall[n_cap:], seed=seed, rank=rank)
@@ -546,7 +546,6 @@ class Trainer(object):
         # (caption side | fc1+fc2, 478 MB | conv3_1..conv5_3, 58 MB | conv1_1..conv2_2, 1 MB) so that RCCL
         # overlaps the convolution backward and only the last megabyte is exposed
         # (VC_DP_BUCKETS=0 forces the single blocking call).
-        import os
         self.buckets = os.environ.get("VC_DP_BUCKETS", "1") != "0"
         self.off_fc = n_cap + self.vgg.store.offset("cnn/fc1/weights") if self.vgg is not None else None
         self.off_c3 = n_cap + self.vgg.store.offset("cnn/conv3_1/weights") if self.vgg is not None else None
