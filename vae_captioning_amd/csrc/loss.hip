@@ -303,7 +303,15 @@ __global__ __launch_bounds__(256) void latent_bwd_kernel(const float* __restrict
     for (long j = (long)blockIdx.x * 256 + threadIdx.x; j < NL; j += (long)gridDim.x * 256) {
         // S == 0: dmean / dstd already hold the sums over the samples (vc_latent_sums_mixed_f32)
         float dm = S ? 0.f : dmean[j], ds = S ? 0.f : dstd[j];
-        for (int s = 0; s < S; ++s) {
+        int s = 0;
+        for (; s + 8 <= S; s += 8) {   // sixteen loads in flight, the sums in the same order as the plain loop (a thread per element is all
+            float g[8], e[8];          // the parallelism N * L = 48 000 gives: with one load pair at a time the launch took 65 us at cfg4)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { g[k] = dz[(long)(s + k) * NL + j]; e[k] = eps[(long)(s + k) * NL + j]; }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { dm += g[k]; ds += g[k] * e[k]; }
+        }
+        for (; s < S; ++s) {
             const float g = dz[(long)s * NL + j];
             dm += g;
             ds += g * eps[(long)s * NL + j];
