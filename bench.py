@@ -187,6 +187,9 @@ def main():
     # single-GPU test of the N > 1 code path, tests/test_gpu_cli.py.)
     backend = os.environ.get("VC_DIST_BACKEND", "nccl")
     local = local % torch.cuda.device_count() if backend != "nccl" else local
+    if local >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d wants GPU %d but this node shows %d (one process per GPU; --gpus %d needs %d GPUs)" % (
+            rank, local, torch.cuda.device_count(), args.gpus, args.gpus))
     torch.cuda.set_device(local)
     lib = abi.load()  # raises if the HIP library is missing: no fallback
     lib.vc_device_check(local)
