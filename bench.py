@@ -144,6 +144,36 @@ def cpu_baseline(workload, w, seed):
     return out
 
 
+def _blas_threads():
+    try:
+        import threadpoolctl
+        return int(max([i.get("num_threads", 1) for i in threadpoolctl.threadpool_info()] + [1]))
+    except Exception:
+        return int(os.cpu_count() or 1)
+
+
+def cpu_baseline_generate(kind, p, feats, cv, eps, beam=5, images=8):
+    """BASELINE.md section 3's generation legs on the host: the numpy oracle's per-image decode (own CPU restatement of
+    vae_model/decoder.py:145-320, NOT TF1) on the first `images` images of the batch the GPU decodes -- cfg1: greedy, 32 images;
+    cfg5: beam search, 8 images.  Returns (cpu_baseline dict, the oracle's outputs for a token-id comparison in the same run)."""
+    from oracle import decode as od
+    from vae_captioning_amd import spec, synth
+    P = spec.init_caption_params(p, VOCAB, seed=1)
+    t0 = time.perf_counter()
+    outs = []
+    for b in range(images):
+        e = eps[:, b:b + 1] if eps is not None else None
+        c = cv[b] if cv is not None else None
+        if kind == "greedy":
+            outs.append(od.greedy(P, p, feats[b], c, e, synth.BOS, synth.EOS, max_len=p.gen_max_len))
+        else:
+            outs.append(od.beam_search(P, p, feats[b], c, e, synth.BOS, synth.EOS, beam_size=beam, max_len=p.gen_max_len)[0])
+    dt = time.perf_counter() - t0
+    return dict(value=round(images / dt, 3), unit="captions/s", cores=_blas_threads(), kind="port", host_cpus=os.cpu_count(),
+                sample="%s decode of %d images (max %d tokens%s), numpy oracle per image in fp32 (own CPU restatement, not TF1), %.1f s"
+                       % (kind, images, p.gen_max_len, ", beam %d x %d z samples" % (beam, p.gen_z_samples) if kind == "beam" else "", dt)), outs
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -315,7 +345,8 @@ def main():
         t = json.load(open(tj))
         # PMC bytes are per STEP (the launch count per step depends on VC_VGG_STREAMS: half-batch launches)
         roof["traffic"] = round(t["bytes_per_step"] * (max(2, args.steps // 4) if instrumented_pass else args.steps) / roof["launches"]) if "bytes_per_step" in t else t.get("bytes_per_launch")
-        roof["traffic_source"] = t.get("source")
+        # NOT measured by this process: PMC counters need rocprofv3 around the command.  The figure is replayed from the tracked file.
+        roof["traffic_source"] = "replayed from profiles/traffic_%s.json (rocprofv3 --pmc passes of this command, tools/collect_profiles.sh): %s" % (args.workload, t.get("source"))
         if roof.get("traffic") and tr.vgg is not None:
             # algorithmic bytes of one step's convolution calls (every call reads its input tensor and writes its
             # output tensor once, + the ReLU source of a data gradient, the pooled copy of a pooled forward, the 3x3 weights)
@@ -344,6 +375,8 @@ def main():
         out["data_parallel"] = dp_info
     if cpu_base is not None:
         out["cpu_baseline"] = cpu_base
+    if world == 1 and args.workload == "cfg1" and p.no_encoder:
+        out["greedy_decode"] = greedy_leg(args, lib, w, p, vocab, tr, with_cpu=(rank == 0 and not args.no_cpu_baseline))
     if world == 1 and args.workload == "cfg4" and args.scaling == "weak" and args.strong_n1 and not args.images_per_gpu and not use_graph:
         del tr
         torch.cuda.empty_cache()
@@ -414,7 +447,11 @@ def bench_generation(args, torch, dist, lib, w, p, world, rank):
     B = w["B"]
     feats = torch.from_numpy(np.maximum(rng.standard_normal((B, 4096), dtype=np.float32), 0)).cuda()
     cv = np.zeros((B, 90), np.float32)
-    run = lambda: gen.beam_search(feats, cv, None, synth.BOS, synth.EOS, beam_size=w["beam"], max_len=p.gen_max_len)
+    eps = rng.standard_normal((p.gen_z_samples, B, p.latent_size), dtype=np.float32)   # injected noise: the CPU leg decodes the SAME captions
+    cpu_base = cpu_ids = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # first, so that the GPU's timed region is the last thing the process does
+        cpu_base, cpu_ids = cpu_baseline_generate("beam", p, feats.cpu().numpy(), cv, eps, beam=w["beam"], images=8)
+    run = lambda: gen.beam_search(feats, cv, eps, synth.BOS, synth.EOS, beam_size=w["beam"], max_len=p.gen_max_len)
     for _ in range(args.warmup):
         run()
     eng.timer = KernelTimer()
@@ -441,11 +478,52 @@ def bench_generation(args, torch, dist, lib, w, p, world, rank):
                       "gen_z_samples": w["z"], "gen_max_len": p.gen_max_len, "vocab": VOCAB, "parallelism": "replicas%d" % world,
                       "mean_caption_len": round(float(np.mean([len(r[0][0]) for r in res])), 2)},
            "roofline": roof}
+    if cpu_base is not None:
+        # (random-init weights give near-uniform word distributions: a beam may legitimately differ where fp32 and the oracle's
+        # arithmetic order disagree in the last bit; the parity tests use peaked weights -- this is a report, not a gate)
+        cpu_base["beams_identical_to_gpu"] = "%d of %d images" % (sum([s for s, _ in res[b]] == cpu_ids[b] for b in range(len(cpu_ids))), len(cpu_ids))
+        out["cpu_baseline"] = cpu_base
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def greedy_leg(args, lib, w, p, vocab, tr, with_cpu):
+    """cfg1's decode leg ("+ greedy decode of 32 images, max 30 tokens"): the trained-in-place parameters of
+    the Trainer decode the batch's 32 images on the device (vae_model/decoder.py:145-201); reported beside the training line."""
+    import torch
+    from vae_captioning_amd import synth
+    from vae_captioning_amd.generate import CaptionGenerator
+    gen = CaptionGenerator(tr.cap)
+    B = w["B"]
+    rng = np.random.default_rng(args.seed + 77)
+    feats = np.maximum(rng.standard_normal((B, 4096), dtype=np.float32), 0)
+    fd = torch.from_numpy(feats).cuda()
+    run = lambda: gen.greedy(fd, None, None, synth.BOS, synth.EOS, max_len=p.gen_max_len)
+    for _ in range(3):
+        ids = run()
+    torch.cuda.synchronize()
+    reps = 20
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ids = run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    out = {"images": B, "max_len": p.gen_max_len, "ms_per_batch": round(1000 * dt, 3), "value": round(B / dt, 1), "unit": "captions/s generated (greedy)",
+           "mean_caption_len": round(float(np.mean([len(r) for r in ids])), 2)}
+    if with_cpu:
+        from oracle import decode as od
+        P = tr.state_dict()
+        t0 = time.perf_counter()
+        ref = [od.greedy(P, p, feats[b], None, None, synth.BOS, synth.EOS, max_len=p.gen_max_len) for b in range(B)]
+        dc = time.perf_counter() - t0
+        out["cpu_baseline"] = dict(value=round(B / dc, 3), unit="captions/s", cores=_blas_threads(), kind="port", host_cpus=os.cpu_count(),
+                                   sample="greedy decode of the same %d images with the same parameters, numpy oracle per image in fp32 "
+                                          "(own CPU restatement, not TF1), %.1f s" % (B, dc),
+                                   token_ids_identical_to_gpu="%d of %d images" % (sum(a == b for a, b in zip(ids, ref)), B))
+    return out
 
 
 def hbm_from_timer(timer):

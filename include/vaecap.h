@@ -23,7 +23,14 @@
 extern "C" {
 #endif
 
-#define VC_ABI_VERSION 2
+/* ABI history (binders gate on vc_abi_version(); a mismatch is a LAYOUT break, not just a symbol break):
+ *   3  the 3x3-convolution family (vc_conv3x3_wino_*, vc_conv3x3_wino4_*, vc_conv3x3_wino_wgrad_*, vc_conv1_fwd* / vc_conv1_wgrad*,
+ *      vc_maxpool2x2_bwd_bits_f32) takes and returns activations in the C4 layout [B][C/4][H][W][4] (v2: NHWC) and the pool routing
+ *      codes / ReLU mask bits follow it; the vc_conv3x3_patch_*, vc_conv3x3_pack_f32, *_packed_f32 and wgrad_patch_* entries of v2 are
+ *      gone.  A v2 binder would link and compute wrong numbers: it must refuse to run against a v3 library.  New in 3: the split-bf16
+ *      products (vc_gemm_bf16x3_*), vc_vgg_preprocess_u8.
+ *   2  round-3 surface (NHWC convolutions).  */
+#define VC_ABI_VERSION 3
 int vc_abi_version(void);
 const char* vc_last_error(void);
 /* 0 if a gfx950 device is usable from this process, else an error code. */

@@ -32,7 +32,7 @@ def test_every_prototype_maps_to_ctypes(built):
 
 
 def test_version_and_error_paths(built):
-    assert built.vc_abi_version() == 2
+    assert built.vc_abi_version() == 3
     assert built.vc_sumsq_blocks() > 0
     assert built.vc_gemm_workspace_bytes(1280, 256, 15000) > 0
     assert built.vc_gemm_workspace_bytes(25600, 10000, 512) == 0
