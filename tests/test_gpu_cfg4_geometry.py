@@ -324,3 +324,29 @@ def test_step_at_168_images_one_stream_cut_launches_equals_three_streams(lib):
         else:
             _maxerr(v1[n], v3[n], 1e-5, n)
     assert float(v1["cnn/conv1_1/weights"].abs().max()) > 0
+
+
+@pytest.mark.parametrize("shape", [(32, 56, 56, 256, 256), (8, 224, 224, 64, 64), (64, 14, 14, 512, 512)], ids=lambda s: "x".join(map(str, s)))
+def test_weight_gradient_at_bench_launch_size_matches_fp64_oracle(lib, shape):
+    """The F(3x3,2x2) weight gradient (vc_conv3x3_wino_wgrad_f32; utils/image_embeddings.py:36-212 under tf.gradients) against the fp64
+    numpy oracle -- not against another kernel of this library -- at launch sizes of the timed cfg4 step: conv3_2 at a 32-image half
+    batch (100 352 pixels summed per weight), the 224-wide conv1_2 shape at 8 images (401 408 pixels per weight: the largest reduction
+    length any VGG16 layer has at 64 images is 8x this, same kernel, same split structure) and conv5_x at the full 64 images (2x14 tile
+    family).  The oracle runs per image chunk on the host (chunks summed in fp64).  Tolerance 3e-6 sqrt(B H W) of the tensor maximum."""
+    B, H, W, Ci, Co = shape
+    rng = np.random.default_rng(H + Ci)
+    x = np.maximum(rng.random((B, H, W, Ci), dtype=np.float32) - 0.4, 0)
+    dy = rng.random((B, H, W, Co), dtype=np.float32) - 0.5
+    w0 = np.zeros((3, 3, Ci, Co), np.float64)
+    dw_ref, db_ref = np.zeros((3, 3, Ci, Co), np.float64), np.zeros(Co, np.float64)
+    step = max(1, (1 << 22) // (H * W * max(Ci, Co)))
+    for b0 in range(0, B, step):
+        _, dwc, dbc = OV.conv3x3_bwd(x[b0:b0 + step].astype(np.float64), w0, dy[b0:b0 + step].astype(np.float64), need_dx=False)
+        dw_ref += dwc
+        db_ref += dbc
+    ws = empty_bytes(lib.vc_conv3x3_wino_wgrad_workspace_bytes(B, H, W, Ci, Co))
+    dw, db = zeros(3, 3, Ci, Co), zeros(Co)
+    lib.vc_conv3x3_wino_wgrad_f32(stream(), B, H, W, Ci, Co, P(dev_c4(x)), P(dev_c4(dy)), P(dw), P(db), 0, P(ws), ws.numel() * 4)
+    tol = 3e-6 * np.sqrt(B * H * W)
+    assert_close(dw.cpu().numpy(), dw_ref, tol, msg="weight gradient %s" % (shape,))
+    assert_close(db.cpu().numpy(), db_ref, tol, msg="bias gradient %s" % (shape,))
