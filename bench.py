@@ -490,6 +490,20 @@ def bench_generation(args, torch, dist, lib, w, p, world, rank):
         dist.destroy_process_group()
 
 
+def cpu_baseline_greedy(P, p, feats, gpu_ids):
+    """cfg1's greedy leg on the host: the numpy oracle decodes the same images with the same parameters (per image, fp32)."""
+    from oracle import decode as od
+    from vae_captioning_amd import synth
+    B = feats.shape[0]
+    t0 = time.perf_counter()
+    ref = [od.greedy(P, p, feats[b], None, None, synth.BOS, synth.EOS, max_len=p.gen_max_len) for b in range(B)]
+    dc = time.perf_counter() - t0
+    return dict(value=round(B / dc, 3), unit="captions/s", cores=_blas_threads(), kind="port", host_cpus=os.cpu_count(),
+                sample="greedy decode of the same %d images with the same parameters, numpy oracle per image in fp32 "
+                       "(own CPU restatement, not TF1), %.1f s" % (B, dc),
+                token_ids_identical_to_gpu="%d of %d images" % (sum(a == b for a, b in zip(gpu_ids, ref)), B))
+
+
 def greedy_leg(args, lib, w, p, vocab, tr, with_cpu):
     """cfg1's decode leg ("+ greedy decode of 32 images, max 30 tokens"): the trained-in-place parameters of
     the Trainer decode the batch's 32 images on the device (vae_model/decoder.py:145-201); reported beside the training line."""
@@ -514,15 +528,7 @@ def greedy_leg(args, lib, w, p, vocab, tr, with_cpu):
     out = {"images": B, "max_len": p.gen_max_len, "ms_per_batch": round(1000 * dt, 3), "value": round(B / dt, 1), "unit": "captions/s generated (greedy)",
            "mean_caption_len": round(float(np.mean([len(r) for r in ids])), 2)}
     if with_cpu:
-        from oracle import decode as od
-        P = tr.state_dict()
-        t0 = time.perf_counter()
-        ref = [od.greedy(P, p, feats[b], None, None, synth.BOS, synth.EOS, max_len=p.gen_max_len) for b in range(B)]
-        dc = time.perf_counter() - t0
-        out["cpu_baseline"] = dict(value=round(B / dc, 3), unit="captions/s", cores=_blas_threads(), kind="port", host_cpus=os.cpu_count(),
-                                   sample="greedy decode of the same %d images with the same parameters, numpy oracle per image in fp32 "
-                                          "(own CPU restatement, not TF1), %.1f s" % (B, dc),
-                                   token_ids_identical_to_gpu="%d of %d images" % (sum(a == b for a, b in zip(ids, ref)), B))
+        out["cpu_baseline"] = cpu_baseline_greedy(tr.state_dict(), p, feats, ids)
     return out
 
 

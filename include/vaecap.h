@@ -57,6 +57,16 @@ int vc_trace_pop(void);
 size_t vc_gemm_workspace_bytes(int M, int N, int K);
 int vc_gemm_f32(void* stream, int ta, int tb, int M, int N, int K, const float* A, long lda, const float* B,
                 long ldb, float* C, long ldc, const float* bias, int flags, float* ws, size_t ws_bytes);
+/* The same product on the bf16 matrix pipe ("bf16x3"): the f32 operands are split into (hi, lo) bf16 pairs while they are staged
+ * into the LDS, three v_mfma_f32_32x32x16_bf16 products (hi.hi + hi.lo + lo.hi) accumulate in f32.  Same arguments, tile plan,
+ * workspace and summation structure as vc_gemm_f32; |error| <= ~1e-5 of sum |a.b| (tests/test_gpu_bf16x3.py) instead of ~1e-7.
+ * NOT the reference's arithmetic (tf.float32 matmul, main.py / vae_model/decoder.py:126-129): an opt-in mode, reported separately.
+ * vc_gemm_set_precision(1) makes every vc_gemm_f32 call of the process (and the GEMMs inside vc_lstm_seq_*) take this path;
+ * 0 (default) = f32 MFMA. */
+int vc_gemm_bf16x3_f32(void* stream, int ta, int tb, int M, int N, int K, const float* A, long lda, const float* B,
+                       long ldb, float* C, long ldc, const float* bias, int flags, float* ws, size_t ws_bytes);
+int vc_gemm_set_precision(int mode);
+int vc_gemm_get_precision(void);
 
 /* ------------------------------------------------------------------------------------
  * Embedding lookup and its gradient.   tf.nn.embedding_lookup, vae_model/encoder.py:31-36,

@@ -1,0 +1,148 @@
+"""-m gpu: the split-bf16 ("bf16x3") products -- vc_gemm_bf16x3_f32 and, through vc_gemm_set_precision(1), every GEMM of the step.
+
+NOT the reference's arithmetic (tf.float32 matmul): an opt-in mode reported on its own bench lines.  What it is held to:
+  * every storage-order / tile-plan / split-K / flag combination the f32 kernel is tested on, against the fp64 product, with the
+    tolerance the F(4x4,3x3) convolution path passes (6e-5 of the tensor maximum, flat) -- measured ~4e-6;
+  * the error model: |C - ref| <= 2^-16 * (|A| . |B|) element by element (three bf16 x bf16 products exact in f32, the dropped
+    lo.lo term and the two-term operand representation each ~2^-18 of |a b|, f32 accumulation on top);
+  * a whole training step in this mode against the fp64 oracle: loss / KL within the north-star 1e-3, gradients within 1e-3 of
+    their maximum."""
+import numpy as np
+import pytest
+import torch
+
+from .gpu_util import P, assert_close, dev, empty_bytes, host, stream, zeros
+
+pytestmark = pytest.mark.gpu
+TOL = 6e-5
+
+
+def _run(lib, ta, tb, M, N, K, A, B, bias=None, flags=0, C0=None, ldc=None):
+    ldc = ldc or N
+    C = dev(C0) if C0 is not None else zeros(M, ldc)
+    ws = empty_bytes(lib.vc_gemm_workspace_bytes(M, N, K))
+    lib.vc_gemm_bf16x3_f32(stream(), ta, tb, M, N, K, P(dev(A.T if ta else A)), M if ta else K, P(dev(B.T if tb else B)), K if tb else N,
+                           P(C), ldc, P(dev(bias)) if bias is not None else None, flags, P(ws), ws.numel() * 4)
+    return host(C)
+
+
+@pytest.mark.parametrize("ta", [0, 1])
+@pytest.mark.parametrize("tb", [0, 1])
+@pytest.mark.parametrize("shape", [(128, 128, 32), (256, 384, 64), (130, 70, 33), (64, 512, 1024), (37, 300, 700), (1000, 520, 96), (6, 40, 12), (512, 1000, 4096)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_bf16x3_gemm_matches_fp64(lib, ta, tb, shape):
+    M, N, K = shape
+    rng = np.random.default_rng(M * 7 + N * 3 + K + ta * 2 + tb)
+    A = rng.standard_normal((M, K), dtype=np.float32)
+    B = rng.standard_normal((K, N), dtype=np.float32)
+    bias = rng.standard_normal(N, dtype=np.float32)
+    ref = A.astype(np.float64) @ B.astype(np.float64) + bias
+    got = _run(lib, ta, tb, M, N, K, A, B, bias)
+    assert_close(got, ref, TOL, msg="bf16x3 gemm ta=%d tb=%d %s" % (ta, tb, shape))
+    # element-wise error model (asymmetric operands: a transposed or mis-mapped fragment fails this by orders of magnitude)
+    bound = 2.0 ** -16 * (np.abs(A).astype(np.float64) @ np.abs(B).astype(np.float64)) + 1e-6
+    assert (np.abs(got - ref) <= bound).all(), float((np.abs(got - ref) / bound).max())
+
+
+@pytest.mark.parametrize("ta,flags,shape", [(0, 0, (4224, 2052, 96)), (1, 3, (4100, 2052, 100)), (0, 1, (6880, 10000, 512)), (1, 2, (512, 10000, 6880)),
+                                            (0, 3, (1000, 2048, 2560)), (1, 0, (256, 2048, 6880)), (0, 0, (64, 4096, 6272))],
+                         ids=["unsplit-ragged-N", "KM-ragged-M-K", "logits-fwd", "logits-wgrad-splitK", "splitK-flags", "dWx-splitK", "skinny-fc"])
+def test_bf16x3_gemm_training_shapes(lib, ta, flags, shape):
+    M, N, K = shape
+    rng = np.random.default_rng(M + N + K + flags)
+    A = rng.standard_normal((M, K), dtype=np.float32)
+    B = rng.standard_normal((K, N), dtype=np.float32)
+    bias = rng.standard_normal(N, dtype=np.float32)
+    C0 = rng.standard_normal((M, N + 4), dtype=np.float32)
+    ref = C0.astype(np.float64).copy()
+    prod = A.astype(np.float64) @ B.astype(np.float64) + bias
+    if flags & 2:
+        prod = prod + C0[:, :N]
+    if flags & 1:
+        prod = np.maximum(prod, 0)
+    ref[:, :N] = prod
+    got = _run(lib, ta, 0, M, N, K, A, B, bias, flags, C0, ldc=N + 4)
+    assert_close(got, ref, TOL, msg="bf16x3 gemm ta=%d flags=%d %s (padding column untouched)" % (ta, flags, shape))
+
+
+def test_bf16x3_is_much_closer_than_plain_bf16_and_handles_wide_dynamic_range(lib):
+    """Operands spanning 2^-40 .. 2^40 per row (bf16 keeps f32's exponent range: no scaling needed) and the comparison that shows the
+    lo terms are really there: a single-bf16 product is ~2^-9 off, the split one ~2^-17."""
+    M, N, K = 256, 256, 512
+    rng = np.random.default_rng(3)
+    A = (rng.standard_normal((M, K)) * np.exp2(rng.integers(-40, 40, size=(M, 1)))).astype(np.float32)
+    B = (rng.standard_normal((K, N)) * np.exp2(rng.integers(-40, 40, size=(1, N)))).astype(np.float32)
+    ref = A.astype(np.float64) @ B.astype(np.float64)
+    got = _run(lib, 0, 0, M, N, K, A, B)
+    scale = np.abs(A).astype(np.float64) @ np.abs(B).astype(np.float64)
+    rel = np.abs(got - ref) / scale
+    assert rel.max() <= 2.0 ** -16, rel.max()
+    tb = lambda x: (torch.from_numpy(x).to(torch.bfloat16).to(torch.float64)).numpy()
+    plain = np.abs(tb(A) @ tb(B) - ref) / scale
+    assert np.median(rel) * 50 < np.median(plain)
+
+
+def test_precision_switch_routes_vc_gemm_f32_and_restores(lib):
+    M, N, K = 384, 256, 512
+    rng = np.random.default_rng(8)
+    A, B = rng.standard_normal((M, K), dtype=np.float32), rng.standard_normal((K, N), dtype=np.float32)
+    dA, dB = dev(A), dev(B)
+    ws = empty_bytes(lib.vc_gemm_workspace_bytes(M, N, K))
+    out = {}
+    try:
+        for mode in (0, 1):
+            lib.vc_gemm_set_precision(mode)
+            assert lib.vc_gemm_get_precision() == mode
+            C = zeros(M, N)
+            lib.vc_gemm_f32(stream(), 0, 0, M, N, K, P(dA), K, P(dB), N, P(C), N, None, 0, P(ws), ws.numel() * 4)
+            out[mode] = host(C).copy()
+    finally:
+        lib.vc_gemm_set_precision(0)
+    Cx = zeros(M, N)
+    lib.vc_gemm_bf16x3_f32(stream(), 0, 0, M, N, K, P(dA), K, P(dB), N, P(Cx), N, None, 0, P(ws), ws.numel() * 4)
+    assert np.array_equal(out[1], host(Cx)) and not np.array_equal(out[0], out[1])
+    ref = A.astype(np.float64) @ B.astype(np.float64)
+    assert np.abs(out[0] - ref).max() < np.abs(out[1] - ref).max() < TOL * np.abs(ref).max()
+    from vae_captioning_amd.abi import VaecapError
+    with pytest.raises(VaecapError):
+        lib.vc_gemm_set_precision(7)
+
+
+@pytest.mark.parametrize("prior,use_c_v", [("Normal", False), ("AG", True)])
+def test_training_step_in_bf16x3_mode_stays_within_the_north_star_tolerance(lib, prior, use_c_v):
+    """One whole caption-side step (vae_model/encoder.py:24-110, decoder.py:34-143, main.py:118-177) with every GEMM on the split-bf16
+    path, against the fp64 oracle on the same injected tensors: loss / KL within 1e-3 (north_star), gradients within 1e-3 of their
+    maximum -- the f32 engine test's bounds."""
+    from oracle import caption_model as cm
+    from vae_captioning_amd import spec, synth
+    from vae_captioning_amd.trainer import Trainer
+    from vae_captioning_amd.utils.parameters import Parameters
+    p = Parameters()
+    p.embed_size, p.encoder_hidden, p.decoder_hidden = 64, 128, 128
+    p.latent_size, p.gen_z_samples, p.cnn_feature_size = 20, 6, 256
+    p.num_captions, p.batch_size, p.prior, p.use_c_v = 5, 16, prior, use_c_v
+    V, B, T = 1000, 16, 12
+    rng = np.random.default_rng(0)
+    P0 = spec.init_caption_params(p, V, seed=1)
+    batch = synth.make_batch(rng, B, p.num_captions, T, V, variable_len=True, feature_size=p.cnn_feature_size, use_ci=spec.uses_ci(p))
+    noise = synth.make_noise(rng, B * p.num_captions, T, p)
+    f64 = lambda d: {k: (v.astype(np.float64) if v.dtype.kind == "f" else v) for k, v in d.items()}
+    n64 = f64(noise)
+    if prior == "AG":
+        from oracle import decode
+        n64["c_means"] = decode.init_clusters(90, p.latent_size).astype(np.float64)
+    ref = cm.forward_backward(f64(P0), f64(batch), n64, p, global_step=0)
+    try:
+        lib.vc_gemm_set_precision(1)
+        tr = Trainer(p, V, lib=lib)
+        tr.load_state_dict(P0)
+        tr.set_batch(batch, noise)
+        tr.train_step()
+        kld, rec, lb, ann = tr.losses()
+        G = tr.cap.grads_dict()
+    finally:
+        lib.vc_gemm_set_precision(0)
+    assert abs(rec - float(ref.rec_loss)) < 1e-3 and abs(kld - float(np.mean(ref.kld))) < 1e-3
+    for name, g in ref.grads.items():
+        err = np.abs(G[name] - g).max()
+        assert err <= 1e-3 * (np.abs(g).max() + 1e-12), (name, err)

@@ -45,6 +45,27 @@ def gemm():
         print("gemm NN %6d x %6d x %6d: %8.3f ms  %6.1f TFLOP/s (best %.1f)" % (M, N, K, med, 2e-9 * M * N * K / med, 2e-9 * M * N * K / mn))
 
 
+def gemmx():
+    """f32 MFMA against split-bf16 (bf16x3) on the training products: logits forward / data gradient / weight gradient at cfg2
+    (27520 rows) and cfg4 (6880 rows), LSTM projections, fc1, square references."""
+    for (ta, tb, M, N, K) in [(0, 0, 27520, 10000, 512), (0, 1, 27520, 512, 10000), (1, 0, 512, 10000, 27520),
+                              (0, 0, 6880, 10000, 512), (0, 1, 6880, 512, 10000), (1, 0, 512, 10000, 6880),
+                              (0, 0, 28160, 2048, 256), (0, 1, 28160, 256, 2048), (1, 0, 256, 2048, 28160), (1, 0, 512, 2048, 28160),
+                              (0, 0, 64, 4096, 25088), (0, 1, 64, 25088, 4096), (1, 0, 25088, 4096, 64),
+                              (0, 0, 4096, 4096, 4096), (0, 0, 8192, 8192, 8192)]:
+        A = rnd(K, M) if ta else rnd(M, K)
+        B = rnd(N, K) if tb else rnd(K, N)
+        C = torch.empty(M, N, device="cuda")
+        ws = torch.empty(max(lib.vc_gemm_workspace_bytes(M, N, K), 16) // 4 + 4, device="cuda")
+        res = []
+        for fn in (lib.vc_gemm_f32, lib.vc_gemm_bf16x3_f32):
+            med, mn = timeit(lambda: fn(st(), ta, tb, M, N, K, P(A), M if ta else K, P(B), K if tb else N, P(C), N, None, 0, P(ws), ws.numel() * 4))
+            res.append(med)
+        fl = 2e-9 * M * N * K
+        print("gemm ta=%d tb=%d %6d x %6d x %6d: f32 %7.3f ms %6.1f TF | bf16x3 %7.3f ms %6.1f TF effective = %6.1f TF on the bf16 pipe (%.3f of 2500)  x%.2f"
+              % (ta, tb, M, N, K, res[0], fl / res[0], res[1], fl / res[1], 3 * fl / res[1], 3 * fl / res[1] / 2500, res[0] / res[1]), flush=True)
+
+
 def conv1():
     """conv1_1's own kernels (csrc/conv_first.hip) against the general 3x3 kernels on the zero-padded 4-channel form; both are
     HBM-bound on the [B,224,224,64] activation (822 MB at B = 64: ~0.14 ms at 6.3 TB/s)"""

@@ -69,7 +69,7 @@ class Lib(object):
             raw = getattr(self._cdll, name)
             raw.argtypes = [_CTYPES[t] for t, _ in args]
             raw.restype = _CTYPES[ret]
-            if ret == "int" and name not in ("vc_abi_version", "vc_sumsq_blocks", "vc_embedding_index_max_vocab", "vc_comm_available", "vc_trace_available", "vc_adam_blocks") and not name.endswith("_supported") and not name.endswith("_preferred"):  # value-returning ints
+            if ret == "int" and name not in ("vc_abi_version", "vc_sumsq_blocks", "vc_embedding_index_max_vocab", "vc_comm_available", "vc_trace_available", "vc_adam_blocks", "vc_gemm_get_precision") and not name.endswith("_supported") and not name.endswith("_preferred"):  # value-returning ints
                 def fn(*a, _raw=raw, _name=name):
                     rc = _raw(*a)
                     if rc != 0:

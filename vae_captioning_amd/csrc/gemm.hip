@@ -4,6 +4,7 @@
 //  utils/image_embeddings.py:223,234) and every backward GEMM tf.gradients derives from them.
 #include <type_traits>
 #include "gemm_core.h"
+#include "gemm_bf16x3_core.h"
 #include "vaecap.h"
 #ifdef VC_MICROBENCH
 #include "vaecap_microbench.h"
@@ -28,7 +29,8 @@ struct GemmArgs {
     long ws_rows;
 };
 
-template <class CFG, int AM, int BMD, bool VEC, int ABL = 0>
+// PREC 0: f32 MFMA (v_mfma_f32_32x32x2_f32); 1: split-bf16, three v_mfma_f32_32x32x16_bf16 per k-step (gemm_bf16x3_core.h)
+template <class CFG, int AM, int BMD, bool VEC, int ABL = 0, int PREC = 0>
 __global__ __launch_bounds__(CFG::NT) void gemm_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int id = g.tile0 + xcd_remap(blockIdx.x, g.ntiles);
@@ -46,7 +48,8 @@ __global__ __launch_bounds__(CFG::NT) void gemm_kernel(GemmArgs g) {
     if (ABL == 8) mfma_mainloop_db<CFG, AM, BMD>(acc, la, lb, m0, n0, kb, ke, smem);
     else
 #endif
-    mfma_mainloop<CFG, AM, BMD, decltype(la), decltype(lb), ABL>(acc, la, lb, m0, n0, kb, ke, smem);
+    if (PREC == 1) mfma_mainloop_bf16x3<CFG, AM, BMD>(acc, la, lb, m0, n0, kb, ke, smem);
+    else mfma_mainloop<CFG, AM, BMD, decltype(la), decltype(lb), ABL>(acc, la, lb, m0, n0, kb, ke, smem);
     const bool split = g.splits > 1;
     float* out = split ? g.ws + ((long)blockIdx.y * g.ws_rows - g.ws_row0) * g.N : g.C;
     const long ldo = split ? g.N : g.ldc;
@@ -232,19 +235,24 @@ static GemmPlan plan_gemm(int M, int N, int K) {
     return p;
 }
 
-template <class CFG, int AM, int BMD, bool VEC>
+template <class CFG, int AM, int BMD, bool VEC, int PREC>
 static void launch_gemm(hipStream_t st, const GemmArgs& g) {
     dim3 grid(g.ntiles, g.splits);
-    hipLaunchKernelGGL((gemm_kernel<CFG, AM, BMD, VEC>), grid, dim3(CFG::NT), CFG::SMEM_BYTES, st, g);
+    hipLaunchKernelGGL((gemm_kernel<CFG, AM, BMD, VEC, 0, PREC>), grid, dim3(CFG::NT), CFG::SMEM_BYTES, st, g);
 }
 
-template <class CFG, bool VEC>
-static void dispatch_modes(hipStream_t st, const GemmArgs& g, int ta, int tb) {
+template <class CFG, bool VEC, int PREC>
+static void dispatch_modes_p(hipStream_t st, const GemmArgs& g, int ta, int tb) {
     // ta: A stored [K,M] (row-contiguous) -> KM.  tb == 0: B stored [K,N] -> KM; tb: B stored [N,K] -> MK.
-    if (!ta && !tb) launch_gemm<CFG, MODE_MK, MODE_KM, VEC>(st, g);
-    else if (!ta && tb) launch_gemm<CFG, MODE_MK, MODE_MK, VEC>(st, g);
-    else if (ta && !tb) launch_gemm<CFG, MODE_KM, MODE_KM, VEC>(st, g);
-    else launch_gemm<CFG, MODE_KM, MODE_MK, VEC>(st, g);
+    if (!ta && !tb) launch_gemm<CFG, MODE_MK, MODE_KM, VEC, PREC>(st, g);
+    else if (!ta && tb) launch_gemm<CFG, MODE_MK, MODE_MK, VEC, PREC>(st, g);
+    else if (ta && !tb) launch_gemm<CFG, MODE_KM, MODE_KM, VEC, PREC>(st, g);
+    else launch_gemm<CFG, MODE_KM, MODE_MK, VEC, PREC>(st, g);
+}
+template <class CFG, bool VEC>
+static void dispatch_modes(hipStream_t st, const GemmArgs& g, int ta, int tb, int prec = 0) {
+    if (prec == 1) dispatch_modes_p<CFG, VEC, 1>(st, g, ta, tb);
+    else dispatch_modes_p<CFG, VEC, 0>(st, g, ta, tb);
 }
 
 using Cfg128 = TileCfg<2, 2, 2, 2>;
@@ -311,17 +319,51 @@ extern "C" size_t vc_gemm_workspace_bytes(int M, int N, int K) {
     return 0;
 }
 
+namespace vc {
+static int g_gemm_precision = 0;  // process-wide: what vc_gemm_f32 computes with (vc_gemm_set_precision)
+}
+
+extern "C" int vc_gemm_set_precision(int mode) {
+    VC_CHECK_ARG(mode == 0 || mode == 1, "0 = f32 MFMA, 1 = split-bf16 (bf16x3)");
+    vc::g_gemm_precision = mode;
+    return 0;
+}
+extern "C" int vc_gemm_get_precision(void) { return vc::g_gemm_precision; }
+
+static int gemm_impl(int prec, const char* fn, void* stream, int ta, int tb, int M, int N, int K, const float* A, long lda, const float* B,
+                     long ldb, float* C, long ldc, const float* bias, int flags, float* ws, size_t ws_bytes);
+
 extern "C" int vc_gemm_f32(void* stream, int ta, int tb, int M, int N, int K, const float* A, long lda, const float* B,
                            long ldb, float* C, long ldc, const float* bias, int flags, float* ws, size_t ws_bytes) {
+    return gemm_impl(vc::g_gemm_precision, __func__, stream, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, ws, ws_bytes);
+}
+extern "C" int vc_gemm_bf16x3_f32(void* stream, int ta, int tb, int M, int N, int K, const float* A, long lda, const float* B,
+                                  long ldb, float* C, long ldc, const float* bias, int flags, float* ws, size_t ws_bytes) {
+    return gemm_impl(1, __func__, stream, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, ws, ws_bytes);
+}
+
+// (argument / launch checks of the shared body report the ENTRY's name)
+#define VC_GEMM_ARG(cond, what)                                               \
+    do {                                                                      \
+        if (!(cond)) return vc::fail(vc::VC_EINVAL, "%s: invalid argument: " what, fn); \
+    } while (0)
+#define VC_GEMM_LAUNCHED()                                                    \
+    do {                                                                      \
+        int s__ = vc::launch_status(fn);                                      \
+        if (s__) return s__;                                                  \
+    } while (0)
+
+static int gemm_impl(int prec, const char* fn, void* stream, int ta, int tb, int M, int N, int K, const float* A, long lda, const float* B,
+                     long ldb, float* C, long ldc, const float* bias, int flags, float* ws, size_t ws_bytes) {
     using namespace vc;
-    VC_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "negative dimension");
+    VC_GEMM_ARG(M >= 0 && N >= 0 && K >= 0, "negative dimension");
     if (M == 0 || N == 0) return 0;
-    VC_CHECK_ARG(A && B && C, "null operand");
-    VC_CHECK_ARG(lda >= (ta ? M : K) && ldb >= (tb ? K : N) && ldc >= N, "leading dimension too small");
+    VC_GEMM_ARG(A && B && C, "null operand");
+    VC_GEMM_ARG(lda >= (ta ? M : K) && ldb >= (tb ? K : N) && ldc >= N, "leading dimension too small");
     hipStream_t st = (hipStream_t)stream;
     GemmPlan p = plan_gemm(M, N, K);
     if (p.splits > 1 && (!ws || ws_bytes < (size_t)p.splits * M * N * sizeof(float)))
-        return fail(VC_EWORKSPACE, "%s: workspace too small (need vc_gemm_workspace_bytes)", __func__);
+        return fail(VC_EWORKSPACE, "%s: workspace too small (need vc_gemm_workspace_bytes)", fn);
     GemmArgs g;
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.ws = ws;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc;
@@ -336,16 +378,16 @@ extern "C" int vc_gemm_f32(void* stream, int ta, int tb, int M, int N, int K, co
     const bool tail = p.tail_splits > 1 && ws && ws_bytes >= (size_t)p.tail_splits * (M - tail_row0) * N * sizeof(float);
     if (tail) g.ntiles = p.main_m * p.tiles_n;  // whole rounds; the remaining tile rows follow as a K-split launch
     if (p.skinny) {
-        if (vec) dispatch_modes<CfgSkinny, true>(st, g, ta, tb); else dispatch_modes<CfgSkinny, false>(st, g, ta, tb);
+        if (vec) dispatch_modes<CfgSkinny, true>(st, g, ta, tb, prec); else dispatch_modes<CfgSkinny, false>(st, g, ta, tb, prec);
     } else if (p.big) {
-        if (vec) dispatch_modes<Cfg128, true>(st, g, ta, tb); else dispatch_modes<Cfg128, false>(st, g, ta, tb);
+        if (vec) dispatch_modes<Cfg128, true>(st, g, ta, tb, prec); else dispatch_modes<Cfg128, false>(st, g, ta, tb, prec);
     } else {
-        if (vec) dispatch_modes<Cfg64, true>(st, g, ta, tb); else dispatch_modes<Cfg64, false>(st, g, ta, tb);
+        if (vec) dispatch_modes<Cfg64, true>(st, g, ta, tb, prec); else dispatch_modes<Cfg64, false>(st, g, ta, tb, prec);
     }
-    VC_LAUNCH_CHECK();
+    VC_GEMM_LAUNCHED();
     if (p.splits > 1) {
         launch_splitk_reduce(st, ws, p.splits, (long)M * N, N, C, ldc, bias, flags);
-        VC_LAUNCH_CHECK();
+        VC_GEMM_LAUNCHED();
     }
     if (tail) {
         GemmArgs t = g;
@@ -353,10 +395,10 @@ extern "C" int vc_gemm_f32(void* stream, int ta, int tb, int M, int N, int K, co
         t.ntiles = (p.tiles_m - p.main_m) * p.tiles_n;
         t.kchunk = p.tail_kchunk; t.splits = p.tail_splits;
         t.ws_row0 = tail_row0; t.ws_rows = M - tail_row0;
-        if (vec) dispatch_modes<Cfg128, true>(st, t, ta, tb); else dispatch_modes<Cfg128, false>(st, t, ta, tb);
-        VC_LAUNCH_CHECK();
+        if (vec) dispatch_modes<Cfg128, true>(st, t, ta, tb, prec); else dispatch_modes<Cfg128, false>(st, t, ta, tb, prec);
+        VC_GEMM_LAUNCHED();
         launch_splitk_reduce(st, ws, t.splits, t.ws_rows * N, N, C + tail_row0 * ldc, ldc, bias, flags);
-        VC_LAUNCH_CHECK();
+        VC_GEMM_LAUNCHED();
     }
     return 0;
 }
