@@ -30,12 +30,26 @@ struct GemmArgs {
 };
 
 // PREC 0: f32 MFMA (v_mfma_f32_32x32x2_f32); 1: split-bf16, three v_mfma_f32_32x32x16_bf16 per k-step (gemm_bf16x3_core.h)
-template <class CFG, int AM, int BMD, bool VEC, int ABL = 0, int PREC = 0>
-__global__ __launch_bounds__(CFG::NT) void gemm_kernel(GemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int id = g.tile0 + xcd_remap(blockIdx.x, g.ntiles);
-    const int m0 = (id / g.tiles_n) * CFG::BM;
-    const int n0 = (id % g.tiles_n) * CFG::BN;
+template <class CFG, int AM, int BMD, bool VEC, int ABL, int PREC>
+__device__ __forceinline__ void gemm_body(const GemmArgs& g, float* smem) {
+    int id = xcd_remap(blockIdx.x, g.ntiles);
+    int tm_, tn_;
+    if (PREC == 1) {
+        // Grouped order: the ~96 workgroups an XCD holds at a time cover GM tile rows x ~12 tile columns instead of one row x all
+        // columns, so BOTH operand panels of the window stay in its 4 MB L2 (at 16x the f32 MFMA rate this kernel is bound by what
+        // it stages, and a [K, 10000] B operand streamed once per tile row was half of that).  Same tiles, same arithmetic.
+        constexpr int GM = 8;
+        const int tiles_m = g.ntiles / g.tiles_n, per = GM * g.tiles_n;
+        const int grp = id / per, r = id - grp * per;
+        const int gm = min(GM, tiles_m - grp * GM);
+        tm_ = grp * GM + r % gm;
+        tn_ = r / gm;
+    } else {
+        tm_ = id / g.tiles_n;
+        tn_ = id % g.tiles_n;
+    }
+    const int m0 = (tm_ + g.tile0 / g.tiles_n) * CFG::BM;
+    const int n0 = tn_ * CFG::BN;
     const int kb = blockIdx.y * g.kchunk;
     const int ke = min(g.K, kb + g.kchunk);
     f32x16 acc[CFG::TM][CFG::TN];
@@ -48,7 +62,10 @@ __global__ __launch_bounds__(CFG::NT) void gemm_kernel(GemmArgs g) {
     if (ABL == 8) mfma_mainloop_db<CFG, AM, BMD>(acc, la, lb, m0, n0, kb, ke, smem);
     else
 #endif
-    if (PREC == 1) mfma_mainloop_bf16x3<CFG, AM, BMD>(acc, la, lb, m0, n0, kb, ke, smem);
+    if (PREC == 1) {
+        if (VEC && g.K >= 32) mfma_mainloop_bf16x3<CFG, AM, BMD, true>(acc, la, lb, m0, n0, kb, ke, smem);
+        else mfma_mainloop_bf16x3<CFG, AM, BMD, false>(acc, la, lb, m0, n0, kb, ke, smem);
+    }
     else mfma_mainloop<CFG, AM, BMD, decltype(la), decltype(lb), ABL>(acc, la, lb, m0, n0, kb, ke, smem);
     const bool split = g.splits > 1;
     float* out = split ? g.ws + ((long)blockIdx.y * g.ws_rows - g.ws_row0) * g.N : g.C;
@@ -88,6 +105,22 @@ __global__ __launch_bounds__(CFG::NT) void gemm_kernel(GemmArgs g) {
             if (col + 3 < g.N) p[3] = v.w;
         }
     });
+}
+
+template <class CFG, int AM, int BMD, bool VEC, int ABL = 0>
+__global__ __launch_bounds__(CFG::NT) void gemm_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    gemm_body<CFG, AM, BMD, VEC, ABL, 0>(g, smem);
+}
+// the split-bf16 form of the same kernel (own symbol: its register budget is set for THREE workgroups per CU -- the loop waits on
+// one K-tile of global loads per iteration, and a third resident workgroup covers that latency)
+#ifndef VC_BX_WAVES
+#define VC_BX_WAVES 3
+#endif
+template <class CFG, int AM, int BMD, bool VEC>
+__global__ __launch_bounds__(CFG::NT, CFG::NT == 512 ? 2 : VC_BX_WAVES) void gemm_bx_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    gemm_body<CFG, AM, BMD, VEC, 0, 1>(g, smem);
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, long MN, int N,
@@ -238,7 +271,16 @@ static GemmPlan plan_gemm(int M, int N, int K) {
 template <class CFG, int AM, int BMD, bool VEC, int PREC>
 static void launch_gemm(hipStream_t st, const GemmArgs& g) {
     dim3 grid(g.ntiles, g.splits);
-    hipLaunchKernelGGL((gemm_kernel<CFG, AM, BMD, VEC, 0, PREC>), grid, dim3(CFG::NT), CFG::SMEM_BYTES, st, g);
+    if (PREC == 1) {
+        if (CFG::SMEM_BYTES > 65536) {   // the 256 x 256 tile: 72 KB of dynamic LDS
+            static bool done = false;
+            if (!done) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bx_kernel<CFG, AM, BMD, VEC>), hipFuncAttributeMaxDynamicSharedMemorySize, CFG::SMEM_BYTES);
+                done = true;
+            }
+        }
+        hipLaunchKernelGGL((gemm_bx_kernel<CFG, AM, BMD, VEC>), grid, dim3(CFG::NT), CFG::SMEM_BYTES, st, g);
+    } else hipLaunchKernelGGL((gemm_kernel<CFG, AM, BMD, VEC>), grid, dim3(CFG::NT), CFG::SMEM_BYTES, st, g);
 }
 
 template <class CFG, bool VEC, int PREC>
@@ -258,6 +300,38 @@ static void dispatch_modes(hipStream_t st, const GemmArgs& g, int ta, int tb, in
 using Cfg128 = TileCfg<2, 2, 2, 2>;
 using Cfg64 = TileCfg<2, 2, 1, 1>;
 using CfgSkinny = TileCfg<1, 4, 2, 1>;  // 64 x 128: four waves side by side, each 64 rows x 32 columns
+using CfgBx256 = TileCfg<2, 4, 4, 2>;   // split-bf16 only: 256 x 256, eight waves of 128 x 64 (half the staged bytes per MAC of 128 x 128)
+
+// Split-bf16 plan for large products: 256 x 256 tiles, ONE workgroup per CU.  At 16x the f32 MFMA rate the kernel is bound by
+// the bytes it stages (measured: the 128 x 128 form saturates at ~7-8 TB/s of L2 -> LDS traffic, 16 MACs per byte), so the tile
+// is as large as the accumulator file allows (32 MACs per byte).  K is split only to fill the last round of 256 workgroups.
+struct BxPlan {
+    bool use;
+    int tiles_m, tiles_n, splits, kchunk;
+};
+static BxPlan plan_bx256(int M, int N, int K) {
+    BxPlan p;
+    p.use = false;
+    static const char* force = getenv("VC_BX_TILE");   // experiments: 128 / 256
+    if (force && atoi(force) == 128) return p;
+    if (M < 192 || N < 192) return p;
+    p.tiles_m = cdiv(M, 256); p.tiles_n = cdiv(N, 256);
+    const long t = (long)p.tiles_m * p.tiles_n;
+    int best = 1;
+    double beff = 0;
+    const int maxs = K / 1024 < 1 ? 1 : (K / 1024 > 16 ? 16 : K / 1024);
+    for (int s = 1; s <= maxs; ++s) {
+        const long w = t * s;
+        const double eff = (double)w / (double)(cdiv(w, 256) * 256L) - 0.02 * (s - 1);   // (a split costs a workspace round trip)
+        if (eff > beff + 1e-9) { beff = eff; best = s; }
+    }
+    if (t * best < 200 && !(force && atoi(force) == 256)) return p;   // under one round: the 128 x 128 plan spreads the work better
+    p.splits = best;
+    p.kchunk = cdiv(cdiv(K, best), 32) * 32;
+    p.splits = cdiv(K, p.kchunk);
+    p.use = true;
+    return p;
+}
 
 // Split-K partial products only (no reduce, no bias): ws[s][M][N] = op(A) op(B) over the s-th K range, 64 x 64 tiles.
 // For consumers that sum the partials themselves (the LSTM gate kernels).  Returns the number of splits written
@@ -314,6 +388,17 @@ size_t gemm_partials_bytes(int M, int N, int K, int max_splits) {
 
 extern "C" size_t vc_gemm_workspace_bytes(int M, int N, int K) {
     vc::GemmPlan p = vc::plan_gemm(M, N, K);
+    size_t bx = 0;   // the split-bf16 plan may split K differently: the query covers both precisions
+    {
+        const vc::BxPlan b = vc::plan_bx256(M, N, K);
+        if (b.use && b.splits > 1) bx = (size_t)b.splits * M * N * sizeof(float);
+    }
+    if (bx) {
+        size_t f = 0;
+        if (p.splits > 1) f = (size_t)p.splits * M * N * sizeof(float);
+        else if (p.tail_splits > 1) f = (size_t)p.tail_splits * (M - (long)p.main_m * 128) * N * sizeof(float);
+        return f > bx ? f : bx;
+    }
     if (p.splits > 1) return (size_t)p.splits * M * N * sizeof(float);
     if (p.tail_splits > 1) return (size_t)p.tail_splits * (M - (long)p.main_m * 128) * N * sizeof(float);
     return 0;
@@ -361,6 +446,30 @@ static int gemm_impl(int prec, const char* fn, void* stream, int ta, int tb, int
     VC_GEMM_ARG(A && B && C, "null operand");
     VC_GEMM_ARG(lda >= (ta ? M : K) && ldb >= (tb ? K : N) && ldc >= N, "leading dimension too small");
     hipStream_t st = (hipStream_t)stream;
+    auto al = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+    const bool vec = al(A) && al(B) && (lda % 4 == 0) && (ldb % 4 == 0) && ((ta ? M : K) % 4 == 0) &&
+                     ((tb ? K : N) % 4 == 0);
+    if (prec == 1) {
+        const BxPlan b = plan_bx256(M, N, K);
+        if (b.use) {
+            if (b.splits > 1 && (!ws || ws_bytes < (size_t)b.splits * M * N * sizeof(float)))
+                return fail(VC_EWORKSPACE, "%s: workspace too small (need vc_gemm_workspace_bytes)", fn);
+            GemmArgs g;
+            g.A = A; g.B = B; g.C = C; g.bias = bias; g.ws = ws;
+            g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+            g.M = M; g.N = N; g.K = K;
+            g.tiles_n = b.tiles_n; g.ntiles = b.tiles_m * b.tiles_n;
+            g.kchunk = b.kchunk; g.splits = b.splits; g.flags = flags;
+            g.tile0 = 0; g.ws_row0 = 0; g.ws_rows = M;
+            if (vec) dispatch_modes_p<CfgBx256, true, 1>(st, g, ta, tb); else dispatch_modes_p<CfgBx256, false, 1>(st, g, ta, tb);
+            VC_GEMM_LAUNCHED();
+            if (b.splits > 1) {
+                launch_splitk_reduce(st, ws, b.splits, (long)M * N, N, C, ldc, bias, flags);
+                VC_GEMM_LAUNCHED();
+            }
+            return 0;
+        }
+    }
     GemmPlan p = plan_gemm(M, N, K);
     if (p.splits > 1 && (!ws || ws_bytes < (size_t)p.splits * M * N * sizeof(float)))
         return fail(VC_EWORKSPACE, "%s: workspace too small (need vc_gemm_workspace_bytes)", fn);
@@ -371,9 +480,6 @@ static int gemm_impl(int prec, const char* fn, void* stream, int ta, int tb, int
     g.tiles_n = p.tiles_n; g.ntiles = p.tiles_m * p.tiles_n;
     g.kchunk = p.kchunk; g.splits = p.splits; g.flags = flags;
     g.tile0 = 0; g.ws_row0 = 0; g.ws_rows = M;
-    auto al = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
-    const bool vec = al(A) && al(B) && (lda % 4 == 0) && (ldb % 4 == 0) && ((ta ? M : K) % 4 == 0) &&
-                     ((tb ? K : N) % 4 == 0);
     const long tail_row0 = (long)p.main_m * 128;
     const bool tail = p.tail_splits > 1 && ws && ws_bytes >= (size_t)p.tail_splits * (M - tail_row0) * N * sizeof(float);
     if (tail) g.ntiles = p.main_m * p.tiles_n;  // whole rounds; the remaining tile rows follow as a K-split launch
