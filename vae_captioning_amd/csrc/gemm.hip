@@ -63,8 +63,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, float* smem) {
     else
 #endif
     if (PREC == 1) {
-        if (VEC && g.K >= 32) mfma_mainloop_bf16x3<CFG, AM, BMD, true>(acc, la, lb, m0, n0, kb, ke, smem);
-        else mfma_mainloop_bf16x3<CFG, AM, BMD, false>(acc, la, lb, m0, n0, kb, ke, smem);
+        constexpr bool DB = CFG::NT == 512;   // the one-workgroup-per-CU tile: two LDS images
+        if (VEC && g.K >= 32) mfma_mainloop_bf16x3<CFG, AM, BMD, true, DB>(acc, la, lb, m0, n0, kb, ke, smem);
+        else mfma_mainloop_bf16x3<CFG, AM, BMD, false, DB>(acc, la, lb, m0, n0, kb, ke, smem);
     }
     else mfma_mainloop<CFG, AM, BMD, decltype(la), decltype(lb), ABL>(acc, la, lb, m0, n0, kb, ke, smem);
     const bool split = g.splits > 1;
@@ -272,14 +273,16 @@ template <class CFG, int AM, int BMD, bool VEC, int PREC>
 static void launch_gemm(hipStream_t st, const GemmArgs& g) {
     dim3 grid(g.ntiles, g.splits);
     if (PREC == 1) {
-        if (CFG::SMEM_BYTES > 65536) {   // the 256 x 256 tile: 72 KB of dynamic LDS
+        constexpr int LDS = CFG::NT == 512 ? 2 * (CFG::A_FLOATS + CFG::B_FLOATS) * 4 : CFG::SMEM_BYTES;   // 256 x 256: two images, 144 KB
+        static_assert(LDS >= CFG::SMEM_BYTES && LDS <= 160 * 1024, "LDS budget");
+        if (LDS > 65536) {
             static bool done = false;
             if (!done) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bx_kernel<CFG, AM, BMD, VEC>), hipFuncAttributeMaxDynamicSharedMemorySize, CFG::SMEM_BYTES);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bx_kernel<CFG, AM, BMD, VEC>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
                 done = true;
             }
         }
-        hipLaunchKernelGGL((gemm_bx_kernel<CFG, AM, BMD, VEC>), grid, dim3(CFG::NT), CFG::SMEM_BYTES, st, g);
+        hipLaunchKernelGGL((gemm_bx_kernel<CFG, AM, BMD, VEC>), grid, dim3(CFG::NT), LDS, st, g);
     } else hipLaunchKernelGGL((gemm_kernel<CFG, AM, BMD, VEC>), grid, dim3(CFG::NT), CFG::SMEM_BYTES, st, g);
 }
 

@@ -114,7 +114,10 @@ struct BxStageKM {
     static __device__ __forceinline__ int rq(int tid) { return ((tid & 63) >> 3) + 8 * (tid >> 6); }
 };
 
-template <class CFG, int AMODE, int BMODE, bool VEC, class ALoader, class BLoader>
+// DB: two LDS images (2 x CFG::SMEM_BYTES): the next K-tile is written while slower waves still read the current one -- ONE barrier
+// per K-tile, and a wave's split + write phase overlaps the other waves' MFMAs (the 256 x 256 tile runs one workgroup per CU: with
+// a single image all eight waves leave the matrix pipe idle together).
+template <class CFG, int AMODE, int BMODE, bool VEC, bool DB, class ALoader, class BLoader>
 __device__ __forceinline__ void mfma_mainloop_bf16x3(f32x16 (&acc)[CFG::TM][CFG::TN], ALoader A, BLoader B,
                                                      int m0, int n0, int k_begin, int k_end, float* smem) {
     constexpr int TM = CFG::TM, TN = CFG::TN, BM = CFG::BM, BN = CFG::BN, NT = CFG::NT;
@@ -129,6 +132,7 @@ __device__ __forceinline__ void mfma_mainloop_bf16x3(f32x16 (&acc)[CFG::TM][CFG:
     static_assert(NVA <= MAXNV && NVB <= MAXNV, "too many slots per thread");
     char* As = reinterpret_cast<char*>(smem);
     char* Bs = reinterpret_cast<char*>(smem + CFG::A_FLOATS);
+    constexpr int BUF_BYTES = (CFG::A_FLOATS + CFG::B_FLOATS) * 4;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / CFG::WN, wn = wave % CFG::WN;
@@ -220,25 +224,28 @@ __device__ __forceinline__ void mfma_mainloop_bf16x3(f32x16 (&acc)[CFG::TM][CFG:
             wr(p + 3 * BX_PITCH);
         }
     };
-    auto put_both = [&](bool masked) {
-        put(As, ra, okA, masked, std::integral_constant<bool, AMODE == MODE_MK>(), MA(), KA(), hasA);
-        put(Bs, rb, okB, masked, std::integral_constant<bool, BMODE == MODE_MK>(), MB(), KB(), hasB);
+    auto put_both = [&](bool masked, int buf) {
+        put(As + buf * BUF_BYTES, ra, okA, masked, std::integral_constant<bool, AMODE == MODE_MK>(), MA(), KA(), hasA);
+        put(Bs + buf * BUF_BYTES, rb, okB, masked, std::integral_constant<bool, BMODE == MODE_MK>(), MB(), KB(), hasB);
     };
     // Loads at the TOP of an iteration, their split + LDS write at its BOTTOM: no loaded value crosses the loop's back edge (hipcc
     // otherwise copies components of the first staged register at the back edge, behind an s_waitcnt on a load it has just issued).
     if (k_begin >= k_end) return;
     gload(k_begin);
-    if (!VEC || all_ok) put_both(false); else put_both(true);
+    if (!VEC || all_ok) put_both(false, 0); else put_both(true, 0);
     if (!(BX_ABL & 8)) __syncthreads();
+    int cur = 0;
     for (int k0 = k_begin; k0 < k_end; k0 += 32) {
         const bool more = k0 + 32 < k_end;
         if (!(BX_ABL & 1) && more) gload(k0 + 32);
+        const char* Ac = As + cur * BUF_BYTES;
+        const char* Bc = Bs + cur * BUF_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) {
-                const char* p = As + ((wm * TM + tm) * 32 + li) * BX_PITCH + (kk * 2 + lh) * 16;
+                const char* p = Ac + ((wm * TM + tm) * 32 + li) * BX_PITCH + (kk * 2 + lh) * 16;
                 if (BX_ABL & 16) {
                     const u32x4 c = {(unsigned)(tm + kk), (unsigned)lane, 0x3f803f80u, (unsigned)k0};
                     ah[tm] = __builtin_bit_cast(bf16x8, c); al[tm] = __builtin_bit_cast(bf16x8, c + 1u);
@@ -249,7 +256,7 @@ __device__ __forceinline__ void mfma_mainloop_bf16x3(f32x16 (&acc)[CFG::TM][CFG:
             }
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) {
-                const char* p = Bs + ((wn * TN + tn) * 32 + li) * BX_PITCH + (kk * 2 + lh) * 16;
+                const char* p = Bc + ((wn * TN + tn) * 32 + li) * BX_PITCH + (kk * 2 + lh) * 16;
                 if (BX_ABL & 16) {
                     const u32x4 c = {(unsigned)(tn + kk), (unsigned)lane, 0x3f803f80u, (unsigned)k0};
                     bh[tn] = __builtin_bit_cast(bf16x8, c); bl[tn] = __builtin_bit_cast(bf16x8, c + 2u);
@@ -283,9 +290,10 @@ __device__ __forceinline__ void mfma_mainloop_bf16x3(f32x16 (&acc)[CFG::TM][CFG:
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
         }
         if (more) {
-            if (!(BX_ABL & 8)) __syncthreads();   // every wave has read this K-tile's fragments
-            if (!VEC || all_ok) put_both(false); else put_both(true);
-            if (!(BX_ABL & 8)) __syncthreads();   // the next K-tile is visible
+            if (!DB && !(BX_ABL & 8)) __syncthreads();   // every wave has read this K-tile's fragments
+            if (DB) cur ^= 1;                             // (the other image was last read one barrier ago)
+            if (!VEC || all_ok) put_both(false, cur); else put_both(true, cur);
+            if (!(BX_ABL & 8)) __syncthreads();           // the next K-tile is visible
         }
     }
 }

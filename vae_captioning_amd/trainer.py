@@ -512,7 +512,7 @@ class Trainer(object):
     optimize_cnn, annealing])."""
 
     def __init__(self, p, vocab, device="cuda", lib=None, world=1, rank=0, group=None, seed=0, force_collectives=False, comm="auto",
-                 wgrad_stream=True):
+                 wgrad_stream=True, precision=None):
         """wgrad_stream: weight gradients of the caption side, its clip + optimiser and fc1 / fc2's optimiser run on a second
         stream (under the LSTM recurrences and the VGG16 backward pass); False = everything in program order on one stream --
         the same kernels on the same data either way, so the results are bit-identical.
@@ -521,6 +521,16 @@ class Trainer(object):
         (backend "nccl") or there is no process group at all (one forced rank), "torch" otherwise (the gloo test path).
         An existing dp.AbiComm may be passed instead."""
         self.p, self.lib = p, (lib or abi.load())
+        # precision: None = leave the library's process-wide GEMM mode alone (default f32: the reference's tf.float32 arithmetic);
+        # "f32" / "bf16x3" set it (vc_gemm_set_precision: every dense product of the step, including the ones inside vc_lstm_seq_*;
+        # "bf16x3" = split-bf16 operands, three bf16 MFMAs, f32 accumulate -- an opt-in mode with ~1e-5 relative product error,
+        # reported on its own bench lines, never the default).  VC_PRECISION overrides None.
+        precision = precision or os.environ.get("VC_PRECISION") or None
+        if precision is not None:
+            if precision not in ("f32", "bf16x3"):
+                raise ValueError("precision must be 'f32' or 'bf16x3', not %r" % (precision,))
+            self.lib.vc_gemm_set_precision(1 if precision == "bf16x3" else 0)
+        self.precision = "bf16x3" if self.lib.vc_gemm_get_precision() == 1 else "f32"
         self.collectives = world > 1 or force_collectives
         self.world, self.rank, self.group = world, rank, group
         self.dev = device
