@@ -95,6 +95,17 @@ def test_workgroup_orders_do_not_change_a_single_bit():
         assert got == ref, (env, [k for k in ref if got.get(k) != ref[k]])
 
 
+def test_chunk_width_one_keeps_conv1_1s_mask_bits_aligned_with_conv1_2s_data_gradient():
+    """conv1_1's forward (csrc/conv_first.hip) writes conv1_2's ReLU mask at (block pair, channel tile); the F(4x4,3x3) data gradient
+    used to index the mask by its chunk-remapped workgroup id, which equals that only while the chunk width covers both channel
+    tiles of the 64-channel layer.  VC_WINO4_TG=1 is the order where the two differ: a whole fine-tune step (conv1_1's weight gradient
+    flows through those bits) must stay bit-identical."""
+    code = STEP % (ROOT, os.path.join(ROOT, "tests"))
+    ref = _run(code, {})
+    got = _run(code, {"VC_WINO4_TG": "1"})
+    assert got == ref, (ref, got)
+
+
 def test_issue_point_of_the_logits_weight_gradient_does_not_change_the_step():
     code = STEP % (ROOT, os.path.join(ROOT, "tests"))
     ref = _run(code, {})

@@ -231,6 +231,7 @@ def lstm():
         res = {}
         for mode in modes:
             lib.vc_lstm_set_mode(mode)
+            lib.vc_gemm_set_precision(1 if os.environ.get("VC_PRECISION") == "bf16x3" else 0)
             t = {}
             for T in (2, 42):
                 X, W, b = rnd(T, N, E), rnd(E + H, 4 * H) * 0.05, rnd(4 * H) * 0.1

@@ -20,11 +20,6 @@ def family(name):
         k = re.search(r">,\s*(\d)\s*>\(", name)
         kinds = {"0": "fwd", "1": "dgrad", "2": "wgrad"}
         return "conv_kernel<%s>" % kinds.get(k.group(1) if k else "?", "?")
-    if "conv_patch_kernel" in name:  # conv_patch_kernel<TN, SCHEME, KIND, POOL>
-        k = re.search(r"conv_patch_kernel<\s*\d+,\s*\d+,\s*(\d)\s*(?:,\s*\w+\s*)*>", name)
-        return "conv_patch_kernel<%s>" % {"0": "fwd", "1": "dgrad"}.get(k.group(1) if k else "?", "?")
-    if "wgrad_patch_kernel" in name:
-        return "wgrad_patch_kernel<4x8 | 4x7 | 2x14>"
     if "conv_wino4_kernel" in name:  # conv_wino4_kernel<KIND, POOL> (round 3: Winograd F(4x4,3x3))
         k = re.search(r"conv_wino4_kernel<\s*(\d)", name)
         return "conv_wino4_kernel<%s>" % {"0": "fwd", "1": "dgrad"}.get(k.group(1) if k else "?", "?")
@@ -39,7 +34,7 @@ def family(name):
     return base
 
 
-CONV_FAMILY = ("conv_kernel", "conv1_", "conv_patch_kernel", "wgrad_patch", "conv_tail_reduce", "patch_tail_reduce", "wgrad_reduce", "wgrad_patch_reduce",
+CONV_FAMILY = ("conv_kernel", "conv1_", "conv_tail_reduce", "wgrad_reduce",
                "conv_wino_kernel", "conv_wino2_kernel", "conv_wino4_kernel", "wino_wgrad")
 
 

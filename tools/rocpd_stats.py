@@ -30,9 +30,9 @@ def main(path, top=40):
 # kernel families of the roofline report (substring match on the mangled kernel name)
 FAMILIES = [
     ("3x3 convolution (fwd + dgrad + wgrad, incl. K-split tails and split reduces)",
-     ["conv_kernel", "conv1_", "conv_patch_kernel", "wgrad_patch_kernel", "conv_tail_reduce", "patch_tail_reduce",
-      "wgrad_reduce_kernel", "wgrad_patch_reduce", "conv_wino_kernel", "conv_wino2_kernel", "conv_wino4_kernel", "wino_wgrad_kernel", "wino_wgrad_reduce"]),
-    ("GEMM (vc::gemm_kernel + split-K reduce)", ["gemm_kernel", "splitk_reduce"]),
+     ["conv_kernel", "conv1_", "conv_tail_reduce", "wgrad_reduce_kernel", "conv_wino_kernel", "conv_wino2_kernel", "conv_wino4_kernel",
+      "wino_wgrad_kernel", "wino_wgrad_reduce"]),
+    ("GEMM (vc::gemm_kernel / vc::gemm_bx_kernel + split-K reduce)", ["gemm_kernel", "gemm_bx_kernel", "splitk_reduce"]),
     ("LSTM recurrence (step / gate kernels)", ["lstm_"]),
     ("softmax cross-entropy", ["xent_"]),
     ("optimiser (Adam / SGD / Momentum)", ["adam_kernel", "sgd_kernel", "momentum_kernel"]),

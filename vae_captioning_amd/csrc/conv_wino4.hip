@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
     // load) or from the float activation (sixteen loads that overlap the first patch loads)
     unsigned mb0 = 0xffffffffu, mb1 = 0xffffffffu;
     if (KIND == W4_DGRAD && a.mask) {
-        const uint2 m = *reinterpret_cast<const uint2*>(a.mask + ((size_t)id * 256 + tid) * 2);
+        const uint2 m = *reinterpret_cast<const uint2*>(a.mask + ((size_t)(tm * a.tiles_n + nt) * 256 + tid) * 2);   // by (block pair, channel tile): independent of the workgroup order
         mb0 = m.x; mb1 = m.y;
     } else if (KIND == W4_DGRAD && a.aux) {
         mb0 = mb1 = 0u;
@@ -558,7 +558,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
                 if (rokx && ry0 + aa < g.H && !((W4_ABL & 64) && v.x != 12345.f)) *reinterpret_cast<float4*>(a.out + ((W4_ABL & 256) ? (po & 0x3fffcL) : po)) = v;
             }
     }
-    if (KIND == W4_FWD && a.mask) *reinterpret_cast<uint2*>(a.mask + ((size_t)id * 256 + tid) * 2) = make_uint2(ob0, ob1);
+    if (KIND == W4_FWD && a.mask) *reinterpret_cast<uint2*>(a.mask + ((size_t)(tm * a.tiles_n + nt) * 256 + tid) * 2) = make_uint2(ob0, ob1);
     if (POOL) {   // a 4 x 4 tile is 2 x 2 pooling windows: register math, no LDS, no separate pooling pass
         const int HP = g.H >> 1, WP = g.W >> 1;
 #pragma unroll

@@ -367,7 +367,7 @@ struct NoStripHook {
 };
 // g(tm, strip, LD): optional hook called by every lane after tile row-block tm of its wave has been written to the wave's LDS
 // strip (32 rows x TN*32 columns, row pitch LD floats) and streamed out through f -- lets a kernel derive a second output from
-// the whole 32-row block (conv_patch.hip: the fused 2x2 max-pool).
+// the whole 32-row block (e.g. a fused 2x2 max-pool).
 template <class CFG, class F, class G = NoStripHook>
 __device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[CFG::TM][CFG::TN], float* smem, F f, G g = G()) {
     constexpr int TM = CFG::TM, TN = CFG::TN;

@@ -953,6 +953,11 @@ class CaptionEngine(object):
 
     def losses(self):
         """(kld, rec_loss, lower_bound, annealing) as Python floats -- the fetches of main.py:241-244."""
+        if getattr(self, "_losses_deferred", False):
+            # data-parallel training forward: the reported scalars ride in the gradient all-reduce and are final only behind
+            # apply_gradients -- `out` still holds the PREVIOUS step's values.  Evaluate with forward(train=False) instead.
+            raise RuntimeError("losses of a data-parallel TRAINING forward are final only after apply_gradients() "
+                               "(they ride in the gradient all-reduce); use forward(train=False) / Trainer.eval_rec_loss() to evaluate")
         o = self.out.detach().cpu().numpy()
         self._release_retired()
         return float(o[1]), float(o[0]), float(o[2]), float(o[3])

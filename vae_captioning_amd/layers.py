@@ -12,11 +12,11 @@ def dense(inputs, units, name=None, params=None):
     if name == "imf_emb":
         if units != params.embed_size:
             raise ValueError("imf_emb has %d units in this model, not %d" % (params.embed_size, units))
-        session.stage(params, features=inputs)
+        session.stage(params, owner='imf_emb', features=inputs)
         return session.Staged("imf_emb", inputs)
     if name == "cv_emb":
         if units != params.embed_size:
             raise ValueError("cv_emb has %d units in this model, not %d" % (params.embed_size, units))
-        session.stage(params, c_v=inputs)
+        session.stage(params, owner='cv_emb', c_v=inputs)
         return session.Staged("cv_emb", inputs)
     raise ValueError("layers.dense(name=%r): only the graph builder's own two layers ('imf_emb', 'cv_emb') exist outside the modules" % name)

@@ -34,15 +34,19 @@ class Staged(object):
         self.name, self.source = name, source
 
 
-def stage(params, **arrays):
-    """Record the arrays a facade was constructed with.  None = not given: it also forgets what an EARLIER facade staged under that
-    name, so facades rebuilt with None arguments are back on the caller-uploads contract instead of a left-over array."""
+def stage(params, owner=None, **arrays):
+    """Record the arrays a facade was constructed with.  `owner` names the facade ("encoder", "decoder", "imf_emb", ...): a None
+    argument forgets only what THE SAME owner staged under that name earlier -- rebuilding one facade with None never erases what
+    another facade staged under a shared key (Encoder and Decoder both stage `lengths`; `c_v` comes from three places)."""
     st = params.__dict__.setdefault("_vc_staged", {})
+    who = params.__dict__.setdefault("_vc_staged_by", {})
     for k, v in arrays.items():
         if v is not None:
             st[k] = v
-        else:
-            st.pop(k, None)
+            who[k] = owner
+        elif k in st and who.get(k) == owner:
+            st.pop(k)
+            who.pop(k, None)
     return st
 
 

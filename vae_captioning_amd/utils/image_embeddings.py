@@ -24,7 +24,7 @@ class vgg16(object):
                 raise ValueError("vgg16(params=...): the session has no VGG16 (params.fine_tune is off)")
             engine = tr.vgg
             self._session = tr
-            session.stage(params, images=imgs)
+            session.stage(params, owner='vgg16', images=imgs)
         self.dropout_keep = dropout_keep
         self.trainable_fe = trainable_fe
         self.trainable_top = trainable_top

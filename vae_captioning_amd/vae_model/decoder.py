@@ -13,7 +13,7 @@ class Decoder(object):
         (vae_model/decoder.py:13-20).  Arrays given here are what the step runs on (session.bind)."""
         from .encoder import check_images_fv
         check_images_fv(images_fv)
-        session.stage(params, cap_dec=captions, lengths=lengths)
+        session.stage(params, owner='decoder', cap_dec=captions, lengths=lengths)
         self.images_fv = images_fv
         self.captions = captions
         self.lengths = lengths
@@ -33,7 +33,7 @@ class Decoder(object):
         eng = tr.cap
         if session.staged(self.params) and not eng.enc:   # --no_encoder: no q_net ran, this is the first stage of the step
             if self.c_i_ph is not None:
-                session.stage(self.params, c_v=self.c_i_ph)
+                session.stage(self.params, owner='decoder', c_v=self.c_i_ph)
             feats = session.bind(self.params)
             if tr.vgg is not None and tr.vgg.wd:
                 tr.vgg.reg_sumsq(eng.red.data_ptr() + 12)

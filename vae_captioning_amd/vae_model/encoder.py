@@ -22,7 +22,7 @@ class Encoder(object):
         self.params = params
         self.c_i = None      # cluster vectors mapped to the embedding space (set by the caller, main.py:113)
         self.c_i_ph = None   # raw cluster vectors [N, 90]
-        session.stage(params, cap_enc=captions, lengths=lengths)
+        session.stage(params, owner='encoder', cap_enc=captions, lengths=lengths)
 
     def q_net(self):
         """Returns (z [S, N, L] device tensor, tm_list, tl_list); tm/tl are the [N, 90, L] stacks of
@@ -31,7 +31,7 @@ class Encoder(object):
         eng = tr.cap
         if session.staged(self.params):   # arrays were given to the facades: they ARE the batch of this step
             if self.c_i_ph is not None:
-                session.stage(self.params, c_v=self.c_i_ph)
+                session.stage(self.params, owner='encoder', c_v=self.c_i_ph)
             feats = session.bind(self.params)
             if tr.vgg is not None and tr.vgg.wd:
                 tr.vgg.reg_sumsq(eng.red.data_ptr() + 12)
