@@ -257,7 +257,9 @@ def main():
     N = B * p.num_captions
     tr = Trainer(p, vocab, device="cuda", lib=lib, world=world, rank=rank, seed=args.seed, precision=args.precision)
     tr.load_state_dict({**spec.init_caption_params(p, vocab, seed=1), **(spec.init_vgg_params(seed=2) if p.fine_tune else {})})
-    mk = lambda: synth.make_batch(rng, B, p.num_captions, T_LEN, vocab, use_ci=spec.uses_ci(p), images=p.fine_tune, variable_len=args.variable_len)
+    # (--fresh-batch: host batches carry uint8 pixels like the reference's HDF5 file; the resident headline batch is the float32 feed)
+    mk = lambda: synth.make_batch(rng, B, p.num_captions, T_LEN, vocab, use_ci=spec.uses_ci(p), images=("u8" if args.fresh_batch else True) if p.fine_tune else False,
+                                  variable_len=args.variable_len)
     batch = mk()
     fresh = [batch] + [mk() for _ in range(max(0, args.fresh_batch - 1))] if args.fresh_batch else None
     tr.set_batch(batch)  # inputs resident in HBM before the timed region; noise is generated on device

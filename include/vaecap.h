@@ -276,6 +276,10 @@ int vc_conv3x3_wgrad_f32(void* stream, int B, int H, int W, int Cin, int Cout, c
 int vc_maxpool2x2_fwd_f32(void* stream, int B, int H, int W, int C, const float* x, float* y);
 int vc_maxpool2x2_bwd_f32(void* stream, int B, int H, int W, int C, const float* x, const float* dy, float* dx, int relu_grad);
 int vc_vgg_preprocess_f32(void* stream, const float* images, int B, int H, int W, float* out_nhwc4);
+/* The same from uint8 RGB pixels [B,H,W,3] -- what the reference's HDF5 file holds (preprocess.py:27-28) and feeds (utils/image_utils.py:8;
+ * the placeholder's float32 cast, utils/image_embeddings.py:31-34, is this kernel): a quarter of the host -> device bytes of the
+ * float form (9.6 MB instead of 38.5 MB per 64 images), bit-identical output.  B*H*W % 4 == 0. */
+int vc_vgg_preprocess_u8(void* stream, const void* images_u8, int B, int H, int W, float* out_nhwc4);
 int vc_pad_dim_f32(void* stream, const float* src, long outer, int c_src, int c_dst, int inner, float* dst);
 
 /* THE C4 ACTIVATION LAYOUT.  Every Winograd entry below (vc_conv3x3_wino_*, vc_conv3x3_wino4_*, vc_conv3x3_wino_wgrad_*) and conv1_1's

@@ -189,7 +189,7 @@ def test_data_class_builds_vocabulary_and_generators(coco):
     images, (ins, lab), lens, cv = next(iter(gen.next_batch(num_captions=5)))
     assert images.shape == (2, 224, 224, 3) and ins.shape[:2] == (2, 5)
     fd = feed_dict(images, (ins, lab), lens, cv, 5, True)
-    assert fd["images"].dtype == np.float32 and fd["images"].shape == (2, 224, 224, 3) and "c_v" not in fd
+    assert fd["images"].dtype == np.uint8 and fd["images"].shape == (2, 224, 224, 3) and "c_v" not in fd   # pixels stay uint8 (HDF5, preprocess.py:27-28); the device casts
     vg = data.get_valid_data(2, pretrained=False)
     assert len(list(vg.next_val_batch(get_image_ids=True))) == 2
     tg = data.get_test_data(2, pretrained=False)

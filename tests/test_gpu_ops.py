@@ -626,6 +626,10 @@ def test_maxpool_and_preprocess(lib):
     lib.vc_vgg_preprocess_f32(stream(), P(dev(img)), 2, 10, 6, P(o))
     ref = np.concatenate([img - OV.MEAN_RGB, np.zeros((2, 10, 6, 1), np.float32)], axis=3)
     np.testing.assert_array_equal(host(o), ref)
+    # the uint8 entry (the reference's HDF5 pixels, preprocess.py:27-28): bit-identical to the float32 feed of the same pixels
+    o8 = zeros(2, 10, 6, 4)
+    lib.vc_vgg_preprocess_u8(stream(), P(dev(img.astype(np.uint8))), 2, 10, 6, P(o8))
+    np.testing.assert_array_equal(host(o8), ref)
     w3 = rng.standard_normal((3, 3, 3, 64), dtype=np.float32)
     w4 = zeros(3, 3, 4, 64)
     lib.vc_pad_dim_f32(stream(), P(dev(w3)), 9, 3, 4, 64, P(w4))

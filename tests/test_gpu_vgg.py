@@ -352,3 +352,27 @@ def test_checkpoints_carry_cnn_variables_without_fine_tune_and_restore_into_fine
     tr4 = Trainer(p2, V, lib=lib)
     tr4.restore(ck2)
     np.testing.assert_array_equal(tr4.state_dict()["cnn/fc2/biases"], imagenet_weights(inet)["cnn/fc2/biases"])
+
+
+def test_uint8_images_train_bit_identically_to_the_float32_feed(lib):
+    """The reference's HDF5 file holds uint8 pixels (preprocess.py:27-28) and feeds them into a float32 placeholder
+    (utils/image_embeddings.py:31-34).  Trainer.set_batch ships a uint8 array as bytes (a quarter of the copy) and casts on the device
+    (vc_vgg_preprocess_u8): the step must be bit-identical to feeding the same pixels as float32."""
+    p = Parameters()
+    p.fine_tune, p.num_captions, p.gen_z_samples = True, 2, 4
+    V, B, T = 300, 2, 5
+    rng = np.random.default_rng(6)
+    P0 = {**spec.init_caption_params(p, V, seed=1), **spec.init_vgg_params(seed=3)}
+    batch = synth.make_batch(rng, B, p.num_captions, T, V, images="u8")
+    assert batch["images"].dtype == np.uint8
+    res = []
+    for cast in (False, True):
+        b = dict(batch, images=batch["images"].astype(np.float32)) if cast else batch
+        tr = Trainer(p, V, lib=lib, seed=5)
+        tr.load_state_dict(P0)
+        tr.set_batch(b)
+        assert tr.images.dtype == (torch.float32 if cast else torch.uint8)
+        tr.train_step()
+        torch.cuda.synchronize()
+        res.append((tr.losses(), tr.gall.clone()))
+    assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1])

@@ -553,6 +553,22 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const float* __restrict
         out[i] = make_float4(img[i * 3] - 123.68f, img[i * 3 + 1] - 116.779f, img[i * 3 + 2] - 103.939f, 0.f);
 }
 
+// the same from uint8 pixels (what the reference's HDF5 holds, preprocess.py:27-28; the feed's cast to float32 happens here): a thread
+// converts FOUR pixels = three 4-byte words in, four 16-byte vectors out (P % 4 == 0; bytes of a word are little-endian pixels)
+__global__ __launch_bounds__(256) void preprocess_u8_kernel(const uint32_t* __restrict__ img, long Q, float4* __restrict__ out) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < Q; i += (long)gridDim.x * 256) {
+        const uint32_t a = img[3 * i], b = img[3 * i + 1], c = img[3 * i + 2];
+        const float r0 = (float)(a & 255u), g0 = (float)((a >> 8) & 255u), b0 = (float)((a >> 16) & 255u);
+        const float r1 = (float)(a >> 24), g1 = (float)(b & 255u), b1 = (float)((b >> 8) & 255u);
+        const float r2 = (float)((b >> 16) & 255u), g2 = (float)(b >> 24), b2 = (float)(c & 255u);
+        const float r3 = (float)((c >> 8) & 255u), g3 = (float)((c >> 16) & 255u), b3 = (float)(c >> 24);
+        out[4 * i] = make_float4(r0 - 123.68f, g0 - 116.779f, b0 - 103.939f, 0.f);
+        out[4 * i + 1] = make_float4(r1 - 123.68f, g1 - 116.779f, b1 - 103.939f, 0.f);
+        out[4 * i + 2] = make_float4(r2 - 123.68f, g2 - 116.779f, b2 - 103.939f, 0.f);
+        out[4 * i + 3] = make_float4(r3 - 123.68f, g3 - 116.779f, b3 - 103.939f, 0.f);
+    }
+}
+
 // dst[o][c][i] = c < c_src ? src[o][c][i] : 0   (pad or truncate the middle dimension)
 __global__ __launch_bounds__(256) void pad_dim_kernel(const float* __restrict__ src, long outer, int c_src, int c_dst, int inner,
                                                       float* __restrict__ dst) {
@@ -673,6 +689,15 @@ extern "C" int vc_vgg_preprocess_f32(void* stream, const float* images, int B, i
     VC_CHECK_ARG(images && out_nhwc4 && B > 0 && H > 0 && W > 0, "bad argument");
     const long P = (long)B * H * W;
     hipLaunchKernelGGL(preprocess_kernel, dim3(grid_for(P)), dim3(256), 0, (hipStream_t)stream, images, P, (float4*)out_nhwc4);
+    VC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vc_vgg_preprocess_u8(void* stream, const void* images_u8, int B, int H, int W, float* out_nhwc4) {
+    VC_CHECK_ARG(images_u8 && out_nhwc4 && B > 0 && H > 0 && W > 0, "bad argument");
+    const long P = (long)B * H * W;
+    VC_CHECK_ARG(P % 4 == 0 && (((uintptr_t)images_u8) & 3) == 0 && (((uintptr_t)out_nhwc4) & 15) == 0, "B*H*W must be a multiple of 4; images 4-byte, output 16-byte aligned");
+    hipLaunchKernelGGL(preprocess_u8_kernel, dim3(grid_for(P / 4)), dim3(256), 0, (hipStream_t)stream, (const uint32_t*)images_u8, P / 4, (float4*)out_nhwc4);
     VC_LAUNCH_CHECK();
     return 0;
 }

@@ -494,7 +494,7 @@ class CaptionEngine(object):
         slot parity and the ordering events survive size changes."""
         arrs, offs, off = [], [], 0
         for name, a, dt in items:
-            a = np.ascontiguousarray(a, dtype=np.float32 if dt == torch.float32 else np.int32)
+            a = np.ascontiguousarray(a, dtype={torch.float32: np.float32, torch.uint8: np.uint8}.get(dt, np.int32))
             arrs.append(a)
             offs.append(off)
             off += (a.nbytes + 255) // 256 * 256

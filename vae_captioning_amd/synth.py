@@ -33,7 +33,9 @@ def make_batch(rng, B, nc, T, vocab, *, use_ci=False, images=False, variable_len
         cap_enc[n, :l] = seq[1:]
     out = dict(cap_dec=cap_dec, cap_enc=cap_enc, lengths=lens)
     if images:
-        out["images"] = rng.integers(0, 256, size=(B, 224, 224, 3), dtype=np.uint8).astype(np.float32)
+        out["images"] = rng.integers(0, 256, size=(B, 224, 224, 3), dtype=np.uint8)
+        if images != "u8":   # images="u8": the pixels as the reference's HDF5 holds them (preprocess.py:27-28); default: the float32 feed
+            out["images"] = out["images"].astype(np.float32)
     else:
         out["features"] = np.maximum(rng.standard_normal((B, feature_size), dtype=np.float32), 0)
     if use_ci:

@@ -238,7 +238,10 @@ class VggEngine(object):
         B, H, W = int(images.shape[0]), int(images.shape[1]), int(images.shape[2])
         self.B = B
         x = self._b("x0", (B, H, W, 4))   # NHWC4 == C4 with one channel quad
-        lib.vc_vgg_preprocess_f32(st, P(images), B, H, W, P(x))
+        if images.dtype == torch.uint8:
+            lib.vc_vgg_preprocess_u8(st, P(images), B, H, W, P(x))
+        else:
+            lib.vc_vgg_preprocess_f32(st, P(images), B, H, W, P(x))
         c1 = bool(self.use_conv1 and self.use_wino and lib.vc_conv1_supported(B, H, W))  # conv1_1 through csrc/conv_first.hip (unpadded weights)
         w4 = self._b("w1_4", (3, 3, 4, 64))
         if not c1:
@@ -303,8 +306,8 @@ class VggEngine(object):
                                 sh, nb, H, W, cie, co, P(x[b0:]), P(self.buf["vp_" + name]), P(S.param(bn)), P(y[b0:]), P(yp[b0:]) if pooled else None, 1))
                         continue
                     # NHWC implicit-GEMM kernels of csrc/conv.hip behind layout conversions: any shape (VC_CONV_WINO=0, odd image sizes)
-                    xn = self._to_nhwc("x_%d" % ch, x[b0:], nb, H, W, cie)
-                    yn = self._b("nhwc_y_%d" % ch, (nb, H, W, co))
+                    xn = self._to_nhwc("x_%s_%d" % (name, ch), x[b0:], nb, H, W, cie)   # (buffers keyed by layer: a shared name would be re-allocated at every shape change)
+                    yn = self._b("nhwc_y_%s_%d" % (name, ch), (nb, H, W, co))
                     self._timed("conv_fwd", fl, lambda: lib.vc_conv3x3_fwd_f32(
                         sh, nb, H, W, cie, co, P(xn), P(w), P(S.param(bn)), P(yn), 1, P(tws), tws.numel() * 4))
                     lib.vc_nhwc_to_c4_f32(sh, nb, H, W, co, P(yn), P(y[b0:]))
@@ -427,7 +430,7 @@ class VggEngine(object):
                 elif ci != 4 and self._wino_wgrad_ok(B, H, W, ci, co):   # Winograd F(3x3,2x2): both operands transformed in registers, K = the 2x2 tiles
                     self._timed("conv_wgrad", fl, lambda: lib.vc_conv3x3_wino_wgrad_f32(sw, B, H, W, ci, co, P(x), P(d), P(S.grad(wn)), P(S.grad(bn)), 0, P(self.ws), self.ws_bytes))
                 else:   # csrc/conv.hip on NHWC copies (conv1_1: zero-padded 4-channel weights)
-                    xn, dn_ = self._to_nhwc("wx", x, B, H, W, ci), self._to_nhwc("wd", d, B, H, W, co)
+                    xn, dn_ = self._to_nhwc("wx_" + wn, x, B, H, W, ci), self._to_nhwc("wd_" + wn, d, B, H, W, co)
                     self._timed("conv_wgrad", fl, lambda: lib.vc_conv3x3_wgrad_f32(sw, B, H, W, ci, co, P(xn), P(dn_), P(dw4 if ci == 4 else S.grad(wn)), P(S.grad(bn)), 0,
                                                                                    P(self.ws), self.ws_bytes))
                     if ci == 4:
@@ -462,9 +465,9 @@ class VggEngine(object):
                             self._timed("conv_dgrad", fl * nb / B, lambda: self._wino(name, "dgrad_f32")(
                                 sh, nb, H, W, ci, co, P(d[b0:]), P(self.buf["vpt_" + name]), None if prev_is_pool else P(x[b0:]), P(dx[b0:])))
                         else:   # csrc/conv.hip on NHWC copies
-                            dn_ = self._to_nhwc("d_%d" % ch, d[b0:], nb, H, W, co)
-                            xn = None if prev_is_pool else self._to_nhwc("x_%d" % ch, x[b0:], nb, H, W, ci)
-                            dxn = self._b("nhwc_dx_%d" % ch, (nb, H, W, ci))
+                            dn_ = self._to_nhwc("d_%s_%d" % (name, ch), d[b0:], nb, H, W, co)
+                            xn = None if prev_is_pool else self._to_nhwc("x_%s_%d" % (name, ch), x[b0:], nb, H, W, ci)
+                            dxn = self._b("nhwc_dx_%s_%d" % (name, ch), (nb, H, W, ci))
                             self._timed("conv_dgrad", fl * nb / B, lambda: lib.vc_conv3x3_dgrad_f32(
                                 sh, nb, H, W, ci, co, P(dn_), P(w), P(xn), P(dxn), P(tws), tws.numel() * 4))
                             lib.vc_nhwc_to_c4_f32(sh, nb, H, W, ci, P(dxn), P(dx[b0:]))
@@ -634,7 +637,12 @@ class Trainer(object):
         return comm
 
     def set_batch(self, batch, noise=None):
-        extra = [("images", np.asarray(batch["images"], np.float32), torch.float32)] if self.fine else []
+        extra = []
+        if self.fine:
+            img = np.asarray(batch["images"])
+            # uint8 pixels (what the reference's HDF5 holds, preprocess.py:27-28) travel as bytes -- 9.6 MB instead of 38.5 MB per 64
+            # images -- and are cast on the device (vc_vgg_preprocess_u8); anything else is fed as float32 like the placeholder's cast
+            extra = [("images", img, torch.uint8)] if img.dtype == np.uint8 else [("images", np.asarray(img, np.float32), torch.float32)]
         self.cap.set_batch(batch, noise, extra=extra)  # one pinned staging buffer, one asynchronous copy
         if self.fine:
             self.images = self.cap.buf["images"]

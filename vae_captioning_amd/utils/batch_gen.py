@@ -291,7 +291,8 @@ def feed_dict(images, captions, lengths, c_v, num_captions, fine_tune):
         ins, lab, lengths = ins[:, None, :], lab[:, None, :], np.asarray(lengths).reshape(-1, 1)
     cv = np.asarray(c_v, np.float32)[:, 1:] if c_v is not None and len(c_v) else None
     b = preprocess_captions(ins.astype(np.int32), lab.astype(np.int32), np.asarray(lengths, np.int32), cv)
-    b["images" if fine_tune else "features"] = np.asarray(images, np.float32)
+    # fine-tuning: uint8 pixels stay uint8 (the device casts them, Trainer.set_batch); precomputed features are float32
+    b["images" if fine_tune else "features"] = np.asarray(images) if (fine_tune and np.asarray(images).dtype == np.uint8) else np.asarray(images, np.float32)
     if fine_tune:
         b["features"] = np.zeros((len(images), 0), np.float32)
     return b
