@@ -148,7 +148,7 @@ def test_reference_call_sequence_with_arrays_as_arguments(lib, kw):
 def test_facade_arrays_refilled_in_place_and_direct_set_batch_between(lib):
     """session.bind uploads what the facades hold at EVERY step: (1) a caller that refills preallocated arrays in place trains on
     the new contents (object identity says nothing), (2) a direct Trainer.set_batch between two facade steps (a validation batch)
-    does not leave that batch resident for the next facade step, (3) facades rebuilt with None forget the earlier arrays."""
+    does not leave that batch resident for the next facade step, (3) a facade rebuilt with None forgets the arrays IT staged earlier (owner-scoped: never another facade's)."""
     from vae_captioning_amd import layers
     rng = np.random.default_rng(9)
     p1, p2 = _params(prior="Normal"), _params(prior="Normal")
@@ -186,8 +186,10 @@ def test_facade_arrays_refilled_in_place_and_direct_set_batch_between(lib):
         hold[k][...] = bs[0][k]         # ... and the facades' arrays go back to the first contents
     got.append(step())
     assert got == want, (got, want)
-    Encoder(None, None, None, p2)       # (3)
-    assert "cap_enc" not in session.staged(p2) and "lengths" not in session.staged(p2)
+    Encoder(None, None, None, p2)       # (3) a facade rebuilt with None forgets what IT staged -- not what the other facade staged
+    assert "cap_enc" not in session.staged(p2) and "lengths" in session.staged(p2) and "cap_dec" in session.staged(p2)
+    Decoder(None, None, None, p2, None)
+    assert "cap_dec" not in session.staged(p2) and "lengths" not in session.staged(p2)
 
 
 def test_facades_refuse_incomplete_or_embedded_inputs(lib):
