@@ -41,9 +41,17 @@ python bench.py --no-cpu-baseline --workload cfg2 --fresh-batch 4 > $OUT/${TAG}_
 python bench.py --no-cpu-baseline --workload cfg2 --vocab 11313 > $OUT/${TAG}_bench_cfg2_v11313.json 2>/dev/null
 python bench.py --no-cpu-baseline --workload cfg2 --variable-len > $OUT/${TAG}_bench_cfg2_varlen.json 2>/dev/null
 python bench.py --no-cpu-baseline --workload cfg2 --num-captions 1 > $OUT/${TAG}_bench_cfg2_nc1.json 2>/dev/null
-python bench.py --no-cpu-baseline --workload cfg1 > $OUT/${TAG}_bench_cfg1.json 2>/dev/null
+python bench.py --workload cfg1 --graph 1 > $OUT/${TAG}_bench_cfg1.json 2>/dev/null      # (with its CPU-baseline legs: training step + greedy decode of 32 images)
 python bench.py --no-cpu-baseline --workload cfg3 > $OUT/${TAG}_bench_cfg3.json 2>/dev/null
-python bench.py --no-cpu-baseline --workload cfg5 --steps 5 --warmup 1 > $OUT/${TAG}_bench_cfg5.json 2>/dev/null
+python bench.py --workload cfg5 --steps 5 --warmup 1 > $OUT/${TAG}_bench_cfg5.json 2>/dev/null   # (with the beam-search CPU-baseline leg, 8 images)
+# 6b. the split-bf16 (bf16x3) mode: every dense product on the bf16 matrix pipe, reported BESIDE the f32 lines above (never instead of them)
+for WL in cfg2 cfg3 cfg1; do python bench.py --no-cpu-baseline --workload $WL --precision bf16x3 > $OUT/${TAG}_bench_${WL}_bf16x3.json 2>/dev/null; done
+python bench.py --no-cpu-baseline --strong-n1 0 --precision bf16x3 > $OUT/${TAG}_bench_cfg4_bf16x3.json 2>/dev/null
+rm -rf /tmp/kt_bx
+(cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/kt_bx -- python $ROOT/bench.py --workload cfg2 --precision bf16x3 --no-cpu-baseline > $OUT/${TAG}_cfg2_bf16x3_kt.log 2>&1)
+python tools/rocpd_stats.py "$(find /tmp/kt_bx -name "*_results.db" | head -1)" 40 > $OUT/${TAG}_cfg2_bf16x3_kernel_stats.md
+python tools/microbench.py gemmx 2>/dev/null | grep "^gemm" > $OUT/${TAG}_gemm_bf16x3.txt
+if ls vae_captioning_amd/lib/libvaecap_bxabl*.so > /dev/null 2>&1; then bash tools/experiments/bx_ablate.sh 2>/dev/null | grep -E "^==|^gemm" > $OUT/${TAG}_gemm_bf16x3_ablation.txt; fi
 # 7. per-layer tables: F(2x2,3x3) forward / data gradient and the F(3x3,2x2) weight gradient; F(4x4,3x3) against F(2x2,3x3) per layer
 #    (forward, data gradient with the float mask, data gradient with mask bits); LSTM recurrence steps (default, two workgroups per CU)
 python tools/microbench.py winoab winow 2>/dev/null | grep -v amdgpu.ids > $OUT/${TAG}_wino_layers.txt
