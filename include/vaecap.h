@@ -362,6 +362,22 @@ size_t vc_conv3x3_wino_wgrad_workspace_bytes(int B, int H, int W, int Cin, int C
 int vc_conv3x3_wino_wgrad_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const float* dy, float* dw,
                               float* db, int accumulate, float* ws, size_t ws_bytes);
 
+/* DIRECT 3x3 convolution on the bf16 matrix pipe ("bf16x3"; csrc/conv_bx.hip): forward and data gradient of utils/image_embeddings.py:36-212
+ * with split-bf16 operands (a = a_hi + a_lo; hi.hi + hi.lo + lo.hi, f32 accumulate: the arithmetic of vc_gemm_bf16x3_f32) -- NOT the
+ * reference's tf.float32 conv2d: the opt-in mode of Trainer(precision="bf16x3"), reported separately.  Activations: the C4 layout, f32.
+ *   pack   w [3,3,Cin,Cout] HWIO -> wp (vc_conv3x3_bx_pack_bytes): the weights split once, in the LDS image order of the kernel;
+ *          transpose = 1: the data gradient's copy (rows = Cin, taps flipped).  Cin % 32 == 0, Cout % 32 == 0, produced channels % 64 == 0.
+ *   fwd    y = relu?(conv(x, w) + bias)          (bias may be NULL)
+ *   dgrad  dx = conv^T(dy, w) (.) (relu_src > 0)  (relu_src: the activation that fed the layer, layout of dx, or NULL)
+ * No fused pool / mask bits: callers use vc_maxpool2x2_fwd_f32 / vc_maxpool2x2_bwd_f32 on the C4 planes. */
+int vc_conv3x3_bx_supported(int B, int H, int W, int Cin, int Cout, int dgrad);
+size_t vc_conv3x3_bx_pack_bytes(int Cin, int Cout);
+int vc_conv3x3_bx_pack_f32(void* stream, int Cin, int Cout, const float* w, int transpose, void* wp);
+int vc_conv3x3_bx_fwd_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const void* wp, const float* bias,
+                          float* y, int relu);
+int vc_conv3x3_bx_dgrad_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* dy, const void* wpt, const float* relu_src,
+                            float* dx);
+
 /* conv1_1 (utils/image_embeddings.py:36-48: 3 -> 64 channels), csrc/conv_first.hip: the layer is HBM-bound (it writes / re-reads
  * the 64-channel activation, 822 MB at 64 images, for 0.6 % of the multiply-adds), so it has its own kernels: the forward makes
  * the 64 output channels the M dimension of the MFMA so that every lane stores 16-byte vectors of consecutive channels straight
