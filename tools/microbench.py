@@ -66,6 +66,37 @@ def gemmx():
               % (ta, tb, M, N, K, res[0], fl / res[0], res[1], fl / res[1], 3 * fl / res[1], 3 * fl / res[1] / 2500, res[0] / res[1]), flush=True)
 
 
+def convbx():
+    """the direct split-bf16 convolution (csrc/conv_bx.hip) against the f32 F(4x4,3x3) kernels, every VGG16 layer shape at a 32-image
+    half batch: forward (+ bias, ReLU) and data gradient (+ ReLU mask from the float activation)"""
+    B = int(os.environ.get("VC_CONVBX_B", "32"))
+    tf = td = tf4 = td4 = 0.0
+    for (name, H, ci, co, mult) in [("1_2", 224, 64, 64, 1), ("2_1", 112, 64, 128, 1), ("2_2", 112, 128, 128, 1), ("3_1", 56, 128, 256, 1), ("3_2", 56, 256, 256, 2),
+                                    ("4_1", 28, 256, 512, 1), ("4_2", 28, 512, 512, 2), ("5_2", 14, 512, 512, 3)]:
+        x = rnd(B, ci // 4, H, H, 4).clamp_(min=0)
+        w, bias = rnd(3, 3, ci, co) * (1.0 / (3 * ci ** 0.5)), rnd(co)
+        dy = rnd(B, co // 4, H, H, 4)
+        y, dx = torch.empty(B, co // 4, H, H, 4, device="cuda"), torch.empty(B, ci // 4, H, H, 4, device="cuda")
+        wp = torch.empty(lib.vc_conv3x3_bx_pack_bytes(ci, co) // 4, device="cuda")
+        wpt = torch.empty_like(wp)
+        lib.vc_conv3x3_bx_pack_f32(st(), ci, co, P(w), 0, P(wp))
+        lib.vc_conv3x3_bx_pack_f32(st(), ci, co, P(w), 1, P(wpt))
+        w4, w4t = torch.empty(36 * ci * co, device="cuda"), torch.empty(36 * ci * co, device="cuda")
+        lib.vc_conv3x3_wino4_pack_f32(st(), ci, co, P(w), 0, P(w4))
+        lib.vc_conv3x3_wino4_pack_f32(st(), ci, co, P(w), 1, P(w4t))
+        fl = 2e-9 * B * H * H * 9 * ci * co
+        r = {}
+        r["bx fwd"], _ = timeit(lambda: lib.vc_conv3x3_bx_fwd_f32(st(), B, H, H, ci, co, P(x), P(wp), P(bias), P(y), 1))
+        r["bx dgrad"], _ = timeit(lambda: lib.vc_conv3x3_bx_dgrad_f32(st(), B, H, H, ci, co, P(dy), P(wpt), P(x), P(dx)))
+        r["w4 fwd"], _ = timeit(lambda: lib.vc_conv3x3_wino4_fwd_f32(st(), B, H, H, ci, co, P(x), P(w4), P(bias), P(y), None, 1))
+        r["w4 dgrad"], _ = timeit(lambda: lib.vc_conv3x3_wino4_dgrad_f32(st(), B, H, H, ci, co, P(dy), P(w4t), P(x), P(dx)))
+        tf += mult * r["bx fwd"]; td += mult * r["bx dgrad"]; tf4 += mult * r["w4 fwd"]; td4 += mult * r["w4 dgrad"]
+        print("conv%s B=%d H=%3d %3d->%3d: bx fwd %6.3f ms %6.1f TF (%.3f of the bf16 pipe) dgrad %6.3f ms %6.1f TF | F(4x4,3x3) f32 fwd %6.3f dgrad %6.3f ms | x%.2f x%.2f"
+              % (name, B, H, ci, co, r["bx fwd"], fl / r["bx fwd"], 3 * fl / r["bx fwd"] / 2500, r["bx dgrad"], fl / r["bx dgrad"], r["w4 fwd"], r["w4 dgrad"],
+                 r["w4 fwd"] / r["bx fwd"], r["w4 dgrad"] / r["bx dgrad"]), flush=True)
+    print("sum over the twelve layers B=%d: bx fwd %.3f dgrad %.3f ms | F(4x4,3x3) fwd %.3f dgrad %.3f ms" % (B, tf, td, tf4, td4))
+
+
 def conv1():
     """conv1_1's own kernels (csrc/conv_first.hip) against the general 3x3 kernels on the zero-padded 4-channel form; both are
     HBM-bound on the [B,224,224,64] activation (822 MB at B = 64: ~0.14 ms at 6.3 TB/s)"""

@@ -32,6 +32,14 @@
 #include "conv_wino.h"
 #include "gemm_bf16x3_core.h"
 
+// CB_ABL (timing only, `make cbabl`; never shipped): 1 no weight loads after the first, 2 no patch loads / splits / writes after the
+// first, 4 no MFMAs, 8 no output stores, 16 no fragment reads, 32 no barriers
+#ifndef CB_ABL
+#define CB_ABL 0
+#endif
+#ifndef CB_KPRE   // 2: both k-steps' fragment reads of a tap ahead of its MFMAs (measured: slower); 1: per k-step
+#define CB_KPRE 1
+#endif
 namespace vc {
 
 constexpr int CB_NT = 512;
@@ -63,35 +71,48 @@ __global__ __launch_bounds__(CB_NT, 2) void conv_bx_kernel(ConvBxArgs a) {
     const int wc = wave % NWC, wp = wave / NWC;
     const int li = lane & 31, lh = lane >> 5;
     const int H = a.H, W = a.W, C = a.C, N = a.N;
-    const unsigned id = (unsigned)xcd_remap(blockIdx.x, a.ntiles);
-    const unsigned co_t = wino_div(id, a.m_ptiles), pt = id - co_t * a.ptiles;
-    const unsigned row_t = wino_div(pt, a.m_coltiles), col_t = pt - row_t * a.col_tiles;
-    const int pr0 = (int)row_t * a.TR, x0 = (int)col_t * a.RW;
     const unsigned plane_b = (unsigned)H * (unsigned)W * 16u;   // bytes of one channel-quad plane
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)((long)a.B * H * W * C * 4), 0x00020000);
+
+    // PERSISTENT workgroups: tile ids blockIdx.x, + gridDim.x, ... as ONE flat sequence of (tile, slab, tap) steps -- the patch of a
+    // tile's first slab is prefetched under the last taps of the previous tile exactly like the next slab's, and the epilogue's stores
+    // drain under the next tile's MFMAs (with one workgroup per CU a tile-per-launch kernel exposed both: conv1_2's tiles spent 24 of
+    // their 37 us outside the eighteen taps).  Channel tile slowest: the workgroups in flight share one tile of weights in L2.
+    struct Tile { int co_t, pr0, x0; };
+    auto decode = [&](int id) {
+        const unsigned co_t = wino_div((unsigned)id, a.m_ptiles), pt = (unsigned)id - co_t * a.ptiles;
+        const unsigned row_t = wino_div(pt, a.m_coltiles), col_t = pt - row_t * a.col_tiles;
+        return Tile{(int)co_t, (int)row_t * a.TR, (int)col_t * a.RW};
+    };
 
     // ---- staging slots of the patch: slot s = tid + 512 u -> (channel quad q = s / NPIX, patch pixel s % NPIX); consecutive lanes =
     // consecutive pixels of a patch row of ONE plane (16-byte pieces, contiguous in the C4 layout)
     const int nslots = a.NPIX * 8;
     unsigned pvoff[MAXP];
-    int plds[MAXP];
+    int plds[MAXP], pinfo[MAXP];   // pinfo = patch row << 12 | patch column << 4 | channel quad
 #pragma unroll
     for (int u = 0; u < MAXP; ++u) {
         const unsigned s = (unsigned)(tid + u * CB_NT);
-        pvoff[u] = WOOB;
-        plds[u] = -1;
+        plds[u] = -1; pinfo[u] = 0;
         if ((int)s < nslots) {
             const unsigned q = wino_div(s, a.m_npix), pix = s - q * a.NPIX;
             const unsigned py = wino_div(pix, a.m_pw), px = pix - py * a.PW;
-            const int pr = pr0 - 1 + (int)py, xx = x0 - 1 + (int)px;
             plds[u] = (int)pix * CB_PITCH + (int)q * 8;
-            if (pr >= 0 && xx >= 0 && xx < W) {
-                const unsigned b = wino_div((unsigned)pr, a.m_hp1), y = (unsigned)pr - b * (unsigned)(H + 1);
-                if ((int)b < a.B && (int)y < H)
-                    pvoff[u] = (((b * (unsigned)(C >> 2) + q) * (unsigned)H + y) * (unsigned)W + (unsigned)xx) * 16u;
-            }
+            pinfo[u] = (int)((py << 12) | (px << 4) | q);
         }
     }
+    auto set_patch = [&](const Tile& t) {   // global offsets of the thread's slots for tile t (WOOB: outside every image -> zeros)
+#pragma unroll
+        for (int u = 0; u < MAXP; ++u) {
+            pvoff[u] = WOOB;
+            const int pr = t.pr0 - 1 + (pinfo[u] >> 12), xx = t.x0 - 1 + ((pinfo[u] >> 4) & 255);
+            if (plds[u] >= 0 && pr >= 0 && xx >= 0 && xx < W) {
+                const unsigned b = wino_div((unsigned)pr, a.m_hp1), y = (unsigned)pr - b * (unsigned)(H + 1);
+                if ((int)b < a.B && (int)y < H)
+                    pvoff[u] = (((b * (unsigned)(C >> 2) + (unsigned)(pinfo[u] & 15)) * (unsigned)H + y) * (unsigned)W + (unsigned)xx) * 16u;
+            }
+        }
+    };
     float4 preg[MAXP];
     auto pload = [&](int slab) {
         const unsigned soff = (unsigned)(slab * 8) * plane_b;
@@ -109,19 +130,22 @@ __global__ __launch_bounds__(CB_NT, 2) void conv_bx_kernel(ConvBxArgs a) {
             *reinterpret_cast<u32x2*>(Ps + plds[u] + 64) = lo;
         }
     };
-    // ---- weights of one (slab, tap): a linear copy of WBYTES
-    const char* wtile = a.wp + (size_t)co_t * (size_t)(C / 32) * 9 * WBYTES;
-    u32x4 wreg[WSLOTS];
-    auto wload = [&](int step) {   // step = slab * 9 + tap
-        const char* src = wtile + (size_t)step * WBYTES;
+    // ---- weights of one (channel tile, slab, tap): a linear copy of WBYTES
+    const int nslab = C / 32, nsteps = nslab * 9;
+    // THREE register sets, set = tap % 3: the weights of step s are loaded at the top of step s - 3 and written to the LDS at the end
+    // of step s - 1 -- with one set the load issued at the top of a step was waited for at its end, one MFMA phase (~0.7 us) later:
+    // shorter than an L2 round trip under load (ablation: 16 % of the kernel).
+    u32x4 wreg[3][WSLOTS];
+    auto wload = [&](int set, int co_t, int step) {   // step = slab * 9 + tap
+        const char* src = a.wp + ((size_t)co_t * nsteps + step) * WBYTES;
 #pragma unroll
         for (int u = 0; u < WSLOTS; ++u)
-            if (tid + u * CB_NT < WPIECES) wreg[u] = *reinterpret_cast<const u32x4*>(src + (size_t)(tid + u * CB_NT) * 16);
+            if (tid + u * CB_NT < WPIECES) wreg[set][u] = *reinterpret_cast<const u32x4*>(src + (size_t)(tid + u * CB_NT) * 16);
     };
-    auto wput = [&](int buf) {
+    auto wput = [&](int set, int buf) {
 #pragma unroll
         for (int u = 0; u < WSLOTS; ++u)
-            if (tid + u * CB_NT < WPIECES) *reinterpret_cast<u32x4*>(Ws + buf * WBYTES + (tid + u * CB_NT) * 16) = wreg[u];
+            if (tid + u * CB_NT < WPIECES) *reinterpret_cast<u32x4*>(Ws + buf * WBYTES + (tid + u * CB_NT) * 16) = wreg[set][u];
     };
 
     // ---- fragment addresses: lane -> (row lr, column lc) of its run; idle lanes of a 28- / 14-wide run read lane 0's pixel
@@ -136,99 +160,166 @@ __global__ __launch_bounds__(CB_NT, 2) void conv_bx_kernel(ConvBxArgs a) {
     const int arow = (wc * 2) * 32 + li;   // + 32 tm
 
     f32x16 acc[2][2];
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
-
-    const int nslab = C / 32, nsteps = nslab * 9;
-    pload(0);
-    wload(0);
-    pput();
-    wput(0);
-    __syncthreads();
-    int buf = 0, step = 0;
-    for (int slab = 0; slab < nslab; ++slab) {
-#pragma unroll 1
-        for (int tap = 0; tap < 9; ++tap, ++step) {
-            const bool more = step + 1 < nsteps;
-            if (more) wload(step + 1);
-            if (tap == 6 && slab + 1 < nslab) pload(slab + 1);   // two taps ahead of the slab boundary
-            const int ty = tap / 3, tx = tap - ty * 3;
-            const char* Wc = Ws + buf * WBYTES + arow * CB_PITCH + lh * 16;
-            const char* Pc = Ps + (ty * a.PW + tx) * CB_PITCH + lh * 16;
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                bf16x8 ah[2], al[2], bh[2], bl[2];
-#pragma unroll
-                for (int tm = 0; tm < 2; ++tm) {
-                    const char* p = Wc + tm * 32 * CB_PITCH + kk * 32;
-                    ah[tm] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p));
-                    al[tm] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p + 64));
-                }
-#pragma unroll
-                for (int tn = 0; tn < 2; ++tn) {
-                    const char* p = Pc + prow[tn] * CB_PITCH + kk * 32;
-                    bh[tn] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p));
-                    bl[tn] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p + 64));
-                }
-#pragma unroll
-                for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-                    for (int tn = 0; tn < 2; ++tn)
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
-#pragma unroll
-                for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-                    for (int tn = 0; tn < 2; ++tn)
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
-#pragma unroll
-                for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-                    for (int tn = 0; tn < 2; ++tn)
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
-            }
-            if (more) {
-                wput(buf ^ 1);   // (last read one barrier ago)
-                if (tap == 8) {  // slab boundary: the patch image is single -- every wave must be done reading it
-                    __syncthreads();
-                    pput();
-                }
-                __syncthreads();
-                buf ^= 1;
-            }
-        }
-    }
-
-    // ---- epilogue: acc[tm][tn][4 q + e] = channel co0 + 32 tm + 8 q + 4 lh + e of pixel (run wp * 2 + tn, lane li)
-    const int co0 = (int)co_t * TN + wc * 64;
-#pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
-        const int pr = pr0 + (wp * 2 + tn) * a.RPT + (int)lr, xx = x0 + (int)lc;
-        const unsigned b = wino_div((unsigned)pr, a.m_hp1), y = (unsigned)pr - b * (unsigned)(H + 1);
-        if (!lane_live || (int)b >= a.B || (int)y >= H || xx >= W) continue;
-        const size_t pix = ((size_t)b * (size_t)(N >> 2) * H + y) * W + xx;   // + quad * H * W, in 16-byte elements
+    auto zero_acc = [&]() {
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int co = co0 + 32 * tm + 8 * q + 4 * lh;
-                float4 v = make_float4(acc[tm][tn][4 * q], acc[tm][tn][4 * q + 1], acc[tm][tn][4 * q + 2], acc[tm][tn][4 * q + 3]);
-                const size_t e = (pix + (size_t)(co >> 2) * H * W) * 4;
-                if (KIND == 0) {
-                    if (a.aux) {
-                        const float4 bb = *reinterpret_cast<const float4*>(a.aux + co);
-                        v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+    };
+    // epilogue of tile t: acc[tm][tn][4 q + e] = channel co0 + 32 tm + 8 q + 4 lh + e of pixel (run wp * 2 + tn, lane li)
+    auto store_tile = [&](const Tile& t) {
+        const int co0 = t.co_t * TN + wc * 64;
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const int pr = t.pr0 + (wp * 2 + tn) * a.RPT + (int)lr, xx = t.x0 + (int)lc;
+            const unsigned b = wino_div((unsigned)pr, a.m_hp1), y = (unsigned)pr - b * (unsigned)(H + 1);
+            if (!lane_live || (int)b >= a.B || (int)y >= H || xx >= W) continue;
+            const size_t pix = ((size_t)b * (size_t)(N >> 2) * H + y) * W + xx;   // + quad * H * W, in 16-byte elements
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int co = co0 + 32 * tm + 8 * q + 4 * lh;
+                    float4 v = make_float4(acc[tm][tn][4 * q], acc[tm][tn][4 * q + 1], acc[tm][tn][4 * q + 2], acc[tm][tn][4 * q + 3]);
+                    const size_t e = (pix + (size_t)(co >> 2) * H * W) * 4;
+                    if (KIND == 0) {
+                        if (a.aux) {
+                            const float4 bb = *reinterpret_cast<const float4*>(a.aux + co);
+                            v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+                        }
+                        if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    } else if (a.aux) {
+                        const float4 s = *reinterpret_cast<const float4*>(a.aux + e);
+                        v.x = s.x > 0.f ? v.x : 0.f; v.y = s.y > 0.f ? v.y : 0.f; v.z = s.z > 0.f ? v.z : 0.f; v.w = s.w > 0.f ? v.w : 0.f;
                     }
-                    if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                } else if (a.aux) {
-                    const float4 s = *reinterpret_cast<const float4*>(a.aux + e);
-                    v.x = s.x > 0.f ? v.x : 0.f; v.y = s.y > 0.f ? v.y : 0.f; v.z = s.z > 0.f ? v.z : 0.f; v.w = s.w > 0.f ? v.w : 0.f;
+                    *reinterpret_cast<float4*>(a.out + e) = v;
                 }
-                *reinterpret_cast<float4*>(a.out + e) = v;
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile >= a.ntiles) return;
+    Tile cur = decode(tile);
+    set_patch(cur);
+    zero_acc();
+    pload(0);
+    {
+        const int ntile0 = tile + (int)gridDim.x;   // (nsteps >= 9: the first three steps are this tile's)
+        (void)ntile0;
+        wload(0, cur.co_t, 0);
+        wload(1, cur.co_t, 1);
+        wload(2, cur.co_t, 2);
+    }
+    pput();
+    wput(0, 0);
+    __syncthreads();
+    int buf = 0;
+    for (;;) {
+        const int ntile = tile + (int)gridDim.x;
+        const bool has_next = ntile < a.ntiles;
+        Tile nxt = cur;
+        if (has_next) nxt = decode(ntile);
+        int step = 0;
+        for (int slab = 0; slab < nslab; ++slab) {
+#pragma unroll 1
+            for (int tap3 = 0; tap3 < 3; ++tap3) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j, ++step) {
+                    const int tap = 3 * tap3 + j;
+                    const bool last = step + 1 == nsteps;           // the tile's last step
+                    const bool more = !last || has_next;
+                    // set j held this step's weights: they went to the LDS at the end of the previous step -> reload it for step + 3
+                    // (ONE load site per register set: two sites that fill the same registers from different branches make hipcc copy the
+                    // loaded values where the branches meet -- behind an s_waitcnt vmcnt(0) right after the loads were issued)
+                    if (!(CB_ABL & 1)) {
+                        const int s3 = step + 3;
+                        const bool in_tile = s3 < nsteps;
+                        if (in_tile || has_next) wload(j, in_tile ? cur.co_t : nxt.co_t, in_tile ? s3 : s3 - nsteps);
+                    }
+                    if (tap == 5 && !(CB_ABL & 2)) {   // three taps ahead of the slab (or tile) boundary
+                        const bool tile_end = slab + 1 >= nslab;
+                        if (tile_end && has_next) set_patch(nxt);
+                        if (!tile_end || has_next) pload(tile_end ? 0 : slab + 1);
+                    }
+                    const int ty = tap3, tx = j;
+                    const char* Wc = Ws + buf * WBYTES + arow * CB_PITCH + lh * 16;
+                    const char* Pc = Ps + (ty * a.PW + tx) * CB_PITCH + lh * 16;
+                    // NWC == 2: all sixteen fragment reads of the tap first, then its 24 MFMAs -- the second k-step's reads land under the
+                    // first's MFMAs; NWC == 1 (ten patch slots per thread): one k-step at a time, the registers do not allow more
+                    constexpr int KPRE = (CB_KPRE == 2 && NWC == 2) ? 2 : 1;
+#pragma unroll
+                    for (int k0 = 0; k0 < 2; k0 += KPRE) {
+                        bf16x8 ah[KPRE][2], al[KPRE][2], bh[KPRE][2], bl[KPRE][2];
+#pragma unroll
+                        for (int kq = 0; kq < KPRE; ++kq) {
+                            const int kk = k0 + kq;
+#pragma unroll
+                            for (int tm = 0; tm < 2; ++tm) {
+                                const char* p = Wc + tm * 32 * CB_PITCH + kk * 32;
+                                if (CB_ABL & 16) {
+                                    const u32x4 c = {(unsigned)(tm + kk), (unsigned)lane, 0x3f803f80u, (unsigned)tap};
+                                    ah[kq][tm] = __builtin_bit_cast(bf16x8, c); al[kq][tm] = __builtin_bit_cast(bf16x8, c + 1u);
+                                    continue;
+                                }
+                                ah[kq][tm] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p));
+                                al[kq][tm] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p + 64));
+                            }
+#pragma unroll
+                            for (int tn = 0; tn < 2; ++tn) {
+                                const char* p = Pc + prow[tn] * CB_PITCH + kk * 32;
+                                if (CB_ABL & 16) {
+                                    const u32x4 c = {(unsigned)(tn + kk), (unsigned)lane, 0x3f803f80u, (unsigned)tap};
+                                    bh[kq][tn] = __builtin_bit_cast(bf16x8, c); bl[kq][tn] = __builtin_bit_cast(bf16x8, c + 2u);
+                                    continue;
+                                }
+                                bh[kq][tn] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p));
+                                bl[kq][tn] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p + 64));
+                            }
+                        }
+                        if (KPRE == 2) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int kq = 0; kq < KPRE; ++kq) {
+                            if (CB_ABL & 4) {
+#pragma unroll
+                                for (int t2 = 0; t2 < 2; ++t2) asm volatile("" ::"v"(ah[kq][t2]), "v"(al[kq][t2]), "v"(bh[kq][t2]), "v"(bl[kq][t2]));
+                                continue;
+                            }
+#pragma unroll
+                            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                                for (int tn = 0; tn < 2; ++tn)
+                                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[kq][tm], bh[kq][tn], acc[tm][tn], 0, 0, 0);
+#pragma unroll
+                            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                                for (int tn = 0; tn < 2; ++tn)
+                                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kq][tm], bl[kq][tn], acc[tm][tn], 0, 0, 0);
+#pragma unroll
+                            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                                for (int tn = 0; tn < 2; ++tn)
+                                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kq][tm], bh[kq][tn], acc[tm][tn], 0, 0, 0);
+                        }
+                    }
+                    if (more) {
+                        if (!(CB_ABL & 1)) wput((j + 1) % 3, buf ^ 1);   // the next step's weights (that image was last read one barrier ago)
+                        if (tap == 8 && !(CB_ABL & 2)) {  // slab / tile boundary: the patch image is single -- every wave must be done reading it
+                            if (!(CB_ABL & 32)) __syncthreads();
+                            pput();
+                        }
+                        if (!(CB_ABL & 32)) __syncthreads();
+                        buf ^= 1;
+                    }
+                }
             }
+        }
+        if (!(CB_ABL & 8) || !has_next) store_tile(cur);
+        if (!has_next) break;
+        zero_acc();
+        tile = ntile;
+        cur = nxt;
     }
 }
 
@@ -312,15 +403,24 @@ static int launch_conv_bx(hipStream_t st, int B, int H, int W, int C, int N, con
         a.m_rw = wino_magic(a.RW); a.m_pw = wino_magic(a.PW); a.m_hp1 = wino_magic(H + 1);
         a.m_coltiles = wino_magic(a.col_tiles); a.m_ptiles = wino_magic(a.ptiles); a.m_npix = wino_magic(a.NPIX);
         const int lds = 2 * 64 * p.nwc * CB_PITCH + a.NPIX * CB_PITCH;
+        // persistent grid: one workgroup per CU, every workgroup the same number of tiles (+- 1); VC_CONVBX_GRID overrides (experiments)
+        static const int grid_env = getenv("VC_CONVBX_GRID") ? atoi(getenv("VC_CONVBX_GRID")) : 0;
+        static const int cus = [] {
+            int dev = 0, n = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+            return n;
+        }();
+        int grid = grid_env > 0 ? grid_env : cus;
+        if (grid > a.ntiles) grid = a.ntiles;
         if (a.NPIX * 8 > (p.nwc == 1 ? 10 : 6) * CB_NT || lds > 160 * 1024) return fail(VC_EINVAL, "%s: patch does not fit", fn);
         if (p.nwc == 1) {
             static bool done = false;
             if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bx_kernel<KIND, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
-            hipLaunchKernelGGL((conv_bx_kernel<KIND, 1>), dim3(a.ntiles), dim3(CB_NT), lds, st, a);
+            hipLaunchKernelGGL((conv_bx_kernel<KIND, 1>), dim3(grid), dim3(CB_NT), lds, st, a);
         } else {
             static bool done = false;
             if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bx_kernel<KIND, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
-            hipLaunchKernelGGL((conv_bx_kernel<KIND, 2>), dim3(a.ntiles), dim3(CB_NT), lds, st, a);
+            hipLaunchKernelGGL((conv_bx_kernel<KIND, 2>), dim3(grid), dim3(CB_NT), lds, st, a);
         }
         const int rc = launch_status(fn);
         if (rc) return rc;
