@@ -42,8 +42,9 @@
 #endif
 namespace vc {
 
-constexpr int CB_NT = 512;
 constexpr int CB_PITCH = BX_PITCH;   // 144
+// patch staging slots (float4) per thread and slab, by (channel groups, waves)
+constexpr int cb_maxp(int nwc, int nw) { return nw == 8 ? (nwc == 1 ? 10 : 6) : (nwc == 1 ? 11 : 7); }
 
 struct ConvBxArgs {
     const float* x;      // [B][C/4][H][W][4]
@@ -58,13 +59,17 @@ struct ConvBxArgs {
     unsigned m_rw, m_pw, m_hp1, m_coltiles, m_ptiles, m_npix;   // wino_magic of RW, PW, H + 1, col_tiles, ptiles, NPIX
 };
 
-template <int KIND, int NWC>   // KIND 0: forward (bias, ReLU); 1: data gradient (ReLU mask from aux)
-__global__ __launch_bounds__(CB_NT, 2) void conv_bx_kernel(ConvBxArgs a) {
+// KIND 0: forward (bias, ReLU); 1: data gradient (ReLU mask from aux).  NW = 8 waves, one workgroup per CU; or 4 waves (half the pixel
+// tile), TWO workgroups per CU: twice the tiles for the small deep layers (conv5_x at 32 images: 120 eight-wave tiles for 256 CUs),
+// and two workgroups that are not barrier-locked to each other overlap one's staging with the other's MFMAs
+template <int KIND, int NWC, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void conv_bx_kernel(ConvBxArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NWP = 8 / NWC, TN = 64 * NWC, RUNS = 2 * NWP;
+    constexpr int CB_NT = NW * 64;
+    constexpr int NWP = NW / NWC, TN = 64 * NWC, RUNS = 2 * NWP;
     constexpr int WBYTES = TN * CB_PITCH;                  // one tap's weight image
     constexpr int WPIECES = WBYTES / 16, WSLOTS = (WPIECES + CB_NT - 1) / CB_NT;
-    constexpr int MAXP = NWC == 1 ? 10 : 6;                // patch slots (float4) per thread and slab
+    constexpr int MAXP = cb_maxp(NWC, NW);                 // patch slots (float4) per thread and slab
     char* Ws = smem;                                       // two weight images
     char* Ps = smem + 2 * WBYTES;                          // the patch image
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -360,11 +365,32 @@ __global__ __launch_bounds__(256) void conv_bx_pack_kernel(const float* __restri
 }
 
 struct ConvBxPlan {
-    int nwc, RW, RPT;
+    int nwc, nw, RW, RPT;
 };
+static bool plan_conv_bx_nw(int B, int H, int W, int C, int N, int nw, ConvBxPlan& p);
 static bool plan_conv_bx(int B, int H, int W, int C, int N, ConvBxPlan& p) {
+    static const int force = getenv("VC_CONVBX_WAVES") ? atoi(getenv("VC_CONVBX_WAVES")) : 0;   // experiments: 4 / 8
+    ConvBxPlan p8, p4;
+    const bool ok8 = plan_conv_bx_nw(B, H, W, C, N, 8, p8), ok4 = plan_conv_bx_nw(B, H, W, C, N, 4, p4);
+    if (!ok8 && !ok4) return false;
+    bool use4 = !ok8;
+    if (ok8 && ok4) {
+        if (force == 4) use4 = true;
+        else if (force == 8) use4 = false;
+        else {
+            // eight-wave tiles unless they leave CUs idle: under ~0.8 tiles per CU the four-wave form (twice the tiles, two per CU) wins
+            const long t8 = (long)cdiv(W, p8.RW) * cdiv((long)B * (H + 1), 2 * (8 / p8.nwc) * p8.RPT) * (N / (64 * p8.nwc));
+            use4 = t8 < 200;
+        }
+    }
+    p = use4 ? p4 : p8;
+    return true;
+}
+static bool plan_conv_bx_nw(int B, int H, int W, int C, int N, int nw, ConvBxPlan& p) {
     if (B < 1 || H < 2 || W < 2 || C % 32 || C < 32 || !(N == 64 || (N >= 128 && N % 128 == 0))) return false;
     p.nwc = N == 64 ? 1 : 2;
+    p.nw = nw;
+    const int CB_NT = nw * 64;
     // run shape: the candidate with the fewest idle lanes / columns
     const int cand[5][2] = {{32, 1}, {16, 2}, {8, 4}, {28, 1}, {14, 2}};
     double best = 0;
@@ -372,8 +398,8 @@ static bool plan_conv_bx(int B, int H, int W, int C, int N, ConvBxPlan& p) {
     for (int i = 0; i < 5; ++i) {
         const int rw = cand[i][0], rpt = cand[i][1];
         if (rw > W && !(rw == 32 && W >= 17)) continue;
-        const int runs = 2 * (8 / p.nwc);
-        if ((runs * rpt + 2) * (rw + 2) * 8 > (p.nwc == 1 ? 10 : 6) * CB_NT) continue;   // the patch must fit the staging slots
+        const int runs = 2 * (nw / p.nwc);
+        if ((runs * rpt + 2) * (rw + 2) * 8 > cb_maxp(p.nwc, nw) * CB_NT) continue;   // the patch must fit the staging slots
         const double eff = (double)W / (double)(cdiv(W, rw) * rw) * (double)(rw * rpt) / 32.0;
         if (eff > best + 1e-9) { best = eff; p.RW = rw; p.RPT = rpt; }
     }
@@ -393,7 +419,7 @@ static int launch_conv_bx(hipStream_t st, int B, int H, int W, int C, int N, con
         a.x = x + (size_t)b0 * H * W * C; a.wp = (const char*)wp; a.out = out + (size_t)b0 * H * W * N;
         a.aux = (KIND == 1 && aux) ? aux + (size_t)b0 * H * W * N : aux;
         a.B = nb; a.H = H; a.W = W; a.C = C; a.N = N; a.relu = relu;
-        const int runs = 2 * (8 / p.nwc);
+        const int runs = 2 * (p.nw / p.nwc), CB_NT = p.nw * 64;
         a.RW = p.RW; a.RPT = p.RPT; a.TR = runs * p.RPT;
         a.PW = p.RW + 2; a.NPIX = (a.TR + 2) * a.PW;
         a.col_tiles = cdiv(W, p.RW);
@@ -410,18 +436,17 @@ static int launch_conv_bx(hipStream_t st, int B, int H, int W, int C, int N, con
             if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
             return n;
         }();
-        int grid = grid_env > 0 ? grid_env : cus;
+        const int wgs_per_cu = (p.nw == 4 && 2 * lds <= 160 * 1024) ? 2 : 1;
+        int grid = grid_env > 0 ? grid_env : cus * wgs_per_cu;
         if (grid > a.ntiles) grid = a.ntiles;
-        if (a.NPIX * 8 > (p.nwc == 1 ? 10 : 6) * CB_NT || lds > 160 * 1024) return fail(VC_EINVAL, "%s: patch does not fit", fn);
-        if (p.nwc == 1) {
-            static bool done = false;
-            if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bx_kernel<KIND, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
-            hipLaunchKernelGGL((conv_bx_kernel<KIND, 1>), dim3(grid), dim3(CB_NT), lds, st, a);
-        } else {
-            static bool done = false;
-            if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bx_kernel<KIND, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
-            hipLaunchKernelGGL((conv_bx_kernel<KIND, 2>), dim3(grid), dim3(CB_NT), lds, st, a);
-        }
+        if (a.NPIX * 8 > cb_maxp(p.nwc, p.nw) * CB_NT || lds > 160 * 1024) return fail(VC_EINVAL, "%s: patch does not fit", fn);
+        auto go = [&](auto kern) {
+            static bool done = false;   // (the generic lambda is instantiated once per kernel type: one flag each)
+            if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(CB_NT), lds, st, a);
+        };
+        if (p.nw == 8) { if (p.nwc == 1) go(conv_bx_kernel<KIND, 1, 8>); else go(conv_bx_kernel<KIND, 2, 8>); }
+        else { if (p.nwc == 1) go(conv_bx_kernel<KIND, 1, 4>); else go(conv_bx_kernel<KIND, 2, 4>); }
         const int rc = launch_status(fn);
         if (rc) return rc;
     }
@@ -436,8 +461,8 @@ extern "C" int vc_conv3x3_bx_supported(int B, int H, int W, int Cin, int Cout, i
     ConvBxPlan p;
     const int C = dgrad ? Cout : Cin, N = dgrad ? Cin : Cout;   // contracted / produced channels of the launch
     if (!plan_conv_bx(B, H, W, C, N, p)) return 0;
-    const int runs = 2 * (8 / p.nwc), TR = runs * p.RPT, npix = (TR + 2) * (p.RW + 2);
-    if (npix * 8 > (p.nwc == 1 ? 10 : 6) * CB_NT) return 0;
+    const int runs = 2 * (p.nw / p.nwc), TR = runs * p.RPT, npix = (TR + 2) * (p.RW + 2);
+    if (npix * 8 > cb_maxp(p.nwc, p.nw) * p.nw * 64) return 0;
     if (2 * 64 * p.nwc * CB_PITCH + npix * CB_PITCH > 160 * 1024) return 0;
     return wino_images_per_launch(B, H, W, C, N) >= 1 ? 1 : 0;
 }
