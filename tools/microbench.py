@@ -258,7 +258,7 @@ def lstm():
     modes = [int(m) for m in os.environ.get("VC_LSTM_MODES", "3,1").split(",")]
     names = {3: "register-operand recurrence kernels", 2: "auto", 1: "gemm + gate kernels", 0: "round-1 fused step kernels"}
     H, E = 512, 256
-    for N in (160, 320, 640, 1280):
+    for N in [int(v) for v in os.environ.get("VC_LSTM_NS", "160,320,640,1280").split(",")]:
         res = {}
         for mode in modes:
             lib.vc_lstm_set_mode(mode)
