@@ -146,3 +146,21 @@ def test_training_step_in_bf16x3_mode_stays_within_the_north_star_tolerance(lib,
     for name, g in ref.grads.items():
         err = np.abs(G[name] - g).max()
         assert err <= 1e-3 * (np.abs(g).max() + 1e-12), (name, err)
+
+
+@pytest.mark.parametrize("dims", [(3, 320, 64, 512), (2, 1280, 32, 512), (4, 37, 32, 512), (3, 650, 48, 512), (3, 161, 16, 512)],
+                         ids=["cfg4-rows", "cfg2-rows-eight-wave-forward", "37-rows", "650-rows", "161-rows"])
+def test_lstm_recurrence_kernels_in_bf16x3_mode_match_the_fp64_oracle(lib, dims):
+    """The recurrence step kernels (utils/rnn_model.py:23-51 stepped at vae_model/encoder.py:46-55 / decoder.py:100-121) with
+    v_mfma_f32_16x16x32_bf16 on split operands -- Wh split by the pack kernels, the row operand split in registers -- and the
+    sequence's projection / weight-gradient GEMMs on the split-bf16 GEMM: whole sequences forward and backward against the fp64
+    oracle at four times the f32 kernels' tolerances (8e-5 on states and activations, 2e-4 on gradients; the error is the products'
+    ~1e-5 carried through T steps).  Rows: four-wave kernel (<= 400), eight-wave forward above, ragged blocks."""
+    from .test_gpu_ops import _lstm_seq_check
+    lib.vc_lstm_set_mode(3)
+    try:
+        lib.vc_gemm_set_precision(1)
+        _lstm_seq_check(lib, *dims, tol=4.0)
+    finally:
+        lib.vc_gemm_set_precision(0)
+        lib.vc_lstm_set_mode(2)

@@ -175,7 +175,7 @@ def test_lstm_sequence_modes_agree_with_oracle(lib, mode):
         lib.vc_lstm_set_mode(2)
 
 
-def _lstm_seq_check(lib, T, N, E, H):
+def _lstm_seq_check(lib, T, N, E, H, tol=1.0):
     X, W, b, lens = _lstm_case(T, N, E, H, seed=T * N)
     rng = np.random.default_rng(1)
     dhs = rng.standard_normal((T + 1, N, H), dtype=np.float32) * np.float32(0.1)
@@ -188,18 +188,18 @@ def _lstm_seq_check(lib, T, N, E, H):
     ws = empty_bytes(lib.vc_lstm_seq_workspace_bytes(T, N, E, H))
     tX, tW, tb, tl = dev(X), dev(W), dev(b), dev(lens)
     lib.vc_lstm_seq_fwd_f32(stream(), T, N, E, H, P(tX), P(tW), P(tb), P(tl), P(act), P(cs), P(hs), P(ws), ws.numel() * 4)
-    assert_close(host(hs), cache["hs"], 2e-5, msg="lstm hs")
-    assert_close(host(cs), cache["cs"], 2e-5, msg="lstm cs")
-    assert_close(host(act), cache["act"], 2e-5, msg="lstm gate activations")
+    assert_close(host(hs), cache["hs"], 2e-5 * tol, msg="lstm hs")
+    assert_close(host(cs), cache["cs"], 2e-5 * tol, msg="lstm cs")
+    assert_close(host(act), cache["act"], 2e-5 * tol, msg="lstm gate activations")
     dH, dC, dG = dev(dhs[T]).clone(), zeros(N, H), zeros(T, N, 4 * H)
     text = dev(dhs)
     # dH_run starts as the gradient w.r.t. the final state; dhs_ext[T] must then not be double counted
     text[T].zero_()
     lib.vc_lstm_seq_bwd_f32(stream(), T, N, E, H, P(tX), P(tW), P(tl), P(act), P(cs), P(hs), P(text), P(dH), P(dC), P(dG),
                             P(dX_), P(dW_), P(db_), P(ws), ws.numel() * 4)
-    assert_close(host(dX_), rdX, 5e-5, msg="lstm dX")
-    assert_close(host(dW_), rdW, 5e-5, msg="lstm dW")
-    assert_close(host(db_), rdb, 5e-5, msg="lstm db")
+    assert_close(host(dX_), rdX, 5e-5 * tol, msg="lstm dX")
+    assert_close(host(dW_), rdW, 5e-5 * tol, msg="lstm dW")
+    assert_close(host(db_), rdb, 5e-5 * tol, msg="lstm db")
 
 
 # ----------------------------------------------------------------------------- embedding

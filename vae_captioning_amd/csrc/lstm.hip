@@ -13,6 +13,7 @@
 // (row, unit) and the gate nonlinearity, cell update, length mask and state write are pure
 // per-lane register math -- no LDS round trip, no second kernel.
 #include "gemm_core.h"
+#include "gemm_bf16x3_core.h"
 #include "vaecap.h"
 
 namespace vc {
@@ -234,6 +235,32 @@ __device__ __forceinline__ float lcomp(const float4& v, int e) { return e == 0 ?
 __device__ __forceinline__ int rec_kbase(int kq) { return ((kq & 1) << 6) | ((kq >> 1) << 5); }
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
+// ---- the split-bf16 ("bf16x3") form of the recurrence kernels (template flag BX; chosen by vc_gemm_set_precision(1) in the sequence
+// drivers).  The operand orders are the SAME: a lane's pair of 16-byte fragments (j = 2 m, 2 m + 1) holds EIGHT consecutive k of its
+// lane group -- exactly one v_mfma_f32_16x16x32_bf16 operand.  The row operand is split into (hi, lo) in registers right before its
+// MFMAs; the packed Wh holds, in the same two float4 slots, the eight hi halves and the eight lo halves (split by the pack kernel).
+// Three bf16 MFMAs of 16 cycles replace eight f32 MFMAs of 32: the matrix time of a step drops ~5x (it was 40 % of a 1280-row step,
+// profiles/r05_lstm_pmc.md); everything else -- streaming, LDS round trip, K-split reduction, gate math -- is unchanged.
+__device__ __forceinline__ void rec_split8(const float4& p, const float4& q, bf16x8& hi, bf16x8& lo) {
+    unsigned h[4], l[4];
+    split_pair(p.x, p.y, h[0], l[0]);
+    split_pair(p.z, p.w, h[1], l[1]);
+    split_pair(q.x, q.y, h[2], l[2]);
+    split_pair(q.z, q.w, h[3], l[3]);
+    hi = __builtin_bit_cast(bf16x8, u32x4{h[0], h[1], h[2], h[3]});
+    lo = __builtin_bit_cast(bf16x8, u32x4{l[0], l[1], l[2], l[3]});
+}
+__device__ __forceinline__ bf16x8 rec_bits(const float4& v) { return __builtin_bit_cast(bf16x8, v); }
+__device__ __forceinline__ f32x4 mfma16bx(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+// pack side: the pair (j & ~1, j | 1) of a lane's slots = eight values v[0..7]; slot j gets the hi halves (j even) or the lo halves
+__device__ __forceinline__ float4 rec_pack_pair(const float (&v)[8], int odd) {
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) split_pair(v[2 * i], v[2 * i + 1], h[i], l[i]);
+    const u32x4 o = odd ? u32x4{l[0], l[1], l[2], l[3]} : u32x4{h[0], h[1], h[2], h[3]};
+    return __builtin_bit_cast(float4, o);
+}
+
 // tools/probes/rec_trace.hip compiles this file with VC_REC_TRACE: wave 0.. of every workgroup stamps s_memtime at phase edges
 #ifdef VC_REC_TRACE
 __device__ unsigned long long* g_rec_trace = nullptr;  // [workgroups][4 waves][32 stamps]
@@ -252,12 +279,20 @@ constexpr int REC_LDS_BYTES = 4 * 2 * REC_TILE * 4;  // 4 waves x 2 tiles = 67 5
 
 // forward: out[(((ug*4 + w)*2 + ct)*8 + j)*64 + lane] = Wh[k .. k+3][col], k = 128 w + kbase(lane>>4) + 4 j,
 // col = gate*H + 8 ug + unit with (gate, unit) = ((16 ct + (lane&15)) >> 3, & 7)
-__global__ __launch_bounds__(256) void lstm_rec_pack_fwd_kernel(const float* __restrict__ Wh, int H, float4* __restrict__ out) {
+__global__ __launch_bounds__(256) void lstm_rec_pack_fwd_kernel(const float* __restrict__ Wh, int H, float4* __restrict__ out, int bx) {
     const int total = (H / 8) * 4 * 2 * 8 * 64;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
         const int lane = i & 63, j = (i >> 6) & 7, ct = (i >> 9) & 1, w = (i >> 10) & 3, ug = i >> 12;
         const int lc = ct * 16 + (lane & 15);
         const int col = (lc >> 3) * H + ug * 8 + (lc & 7);
+        if (bx) {
+            const float* s = Wh + (long)(128 * w + rec_kbase(lane >> 4) + 4 * (j & ~1)) * 4 * H + col;
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = s[(long)r * 4 * H];
+            out[i] = rec_pack_pair(v, j & 1);
+            continue;
+        }
         const int k = 128 * w + rec_kbase(lane >> 4) + 4 * j;
         const float* s = Wh + (long)k * 4 * H + col;
         out[i] = make_float4(s[0], s[4L * H], s[8L * H], s[12L * H]);
@@ -265,10 +300,18 @@ __global__ __launch_bounds__(256) void lstm_rec_pack_fwd_kernel(const float* __r
 }
 
 // backward: out[(((ug*4 + w)*4 + sb)*8 + j)*64 + lane] = Wh[16 ug + (lane&15)][k .. k+3], k = 512 w + 128 sb + kbase(lane>>4) + 4 j
-__global__ __launch_bounds__(256) void lstm_rec_pack_bwd_kernel(const float* __restrict__ Wh, int H, float4* __restrict__ out) {
+__global__ __launch_bounds__(256) void lstm_rec_pack_bwd_kernel(const float* __restrict__ Wh, int H, float4* __restrict__ out, int bx) {
     const int total = (H / 16) * 4 * 4 * 8 * 64;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
         const int lane = i & 63, j = (i >> 6) & 7, sb = (i >> 9) & 3, w = (i >> 11) & 3, ug = i >> 13;
+        if (bx) {
+            const float* s = Wh + (long)(ug * 16 + (lane & 15)) * 4 * H + 512 * w + 128 * sb + rec_kbase(lane >> 4) + 4 * (j & ~1);
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = s[r];
+            out[i] = rec_pack_pair(v, j & 1);
+            continue;
+        }
         const int k = 512 * w + 128 * sb + rec_kbase(lane >> 4) + 4 * j;
         out[i] = *reinterpret_cast<const float4*>(Wh + (long)(ug * 16 + (lane & 15)) * 4 * H + k);
     }
@@ -285,7 +328,7 @@ __device__ __forceinline__ int rec_rot(int i, int rot) {
 // The contraction of one pass: acc[i][ct] += A[row0 + 16 i .., wave K range] . B, units u = sb*RT + i in order.
 // A: buffer resource over the row-major operand (rows past its end read as zeros), `pitch` bytes per row, kofs = byte offset of the
 // wave's K range in a row.  B: NSB == 1: resident fragments bres; else streamed from bp (1 KB per (sb, j), lane-linear).
-template <int NSB, int CT, int RT>
+template <int NSB, int CT, int RT, bool BX = false>
 __device__ __forceinline__ void rec_contract(f32x4 (&acc)[RT][CT], const __amdgpu_buffer_rsrc_t ra, const unsigned pitch, const int row0,
                                              const unsigned kofs, const float4 (&bres)[CT][8], const float4* __restrict__ bp, float* As,
                                              const int lane, const int rot) {
@@ -339,6 +382,21 @@ __device__ __forceinline__ void rec_contract(f32x4 (&acc)[RT][CT], const __amdgp
             frags(u + 1);
         }
         if (nextb) bload(sb + 1);
+        if constexpr (BX) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                bf16x8 ah, al;
+                rec_split8(fr[u & 1][2 * m], fr[u & 1][2 * m + 1], ah, al);
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const bf16x8 bh = rec_bits(NSB > 1 ? bs[sb & 1][ct][2 * m] : bres[ct][2 * m]);
+                    const bf16x8 bl = rec_bits(NSB > 1 ? bs[sb & 1][ct][2 * m + 1] : bres[ct][2 * m + 1]);
+                    acc[i][ct] = mfma16bx(al, bh, acc[i][ct]);
+                    acc[i][ct] = mfma16bx(ah, bl, acc[i][ct]);
+                    acc[i][ct] = mfma16bx(ah, bh, acc[i][ct]);
+                }
+            }
+        } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j)
 #pragma unroll
@@ -348,9 +406,11 @@ __device__ __forceinline__ void rec_contract(f32x4 (&acc)[RT][CT], const __amdgp
                     const float bv = NSB > 1 ? lcomp(bs[sb & 1][ct][j], e) : lcomp(bres[ct][j], e);
                     acc[i][ct] = mfma16(lcomp(fr[u & 1][j], e), bv, acc[i][ct]);
                 }
+        }
         // One wave per SIMD: nothing else fills the matrix pipe while this wave issues its LDS / memory instructions, so they are
         // spread between the unit's MFMAs (CT MFMAs, then one of: 8 LDS writes, 8 LDS reads, 8 global loads, 8 CT B loads).
-        if (u + 1 < U) {
+        // (BX: twelve CT short MFMAs per unit instead of 32 CT -- the compiler's own interleave is kept.)
+        if (!BX && u + 1 < U) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 __builtin_amdgcn_sched_group_barrier(0x008, CT, 0);
@@ -369,7 +429,7 @@ __device__ __forceinline__ void rec_contract(f32x4 (&acc)[RT][CT], const __amdgp
                 }
             }
         }
-        if (nextb) {
+        if (!BX && nextb) {
 #pragma unroll
             for (int q = 0; q < 8 * CT; ++q) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -405,7 +465,7 @@ __device__ __forceinline__ float at(const float4& v, int e) { return e == 0 ? v.
 
 // Gate math of both kernels: one thread per (row, four consecutive units) item, every global operand of the item is loaded BEFORE
 // the contraction (none depends on it), so the step's tail is LDS reads, arithmetic and 16-byte stores only.
-template <int RT>
+template <int RT, bool BX = false>
 __global__ __launch_bounds__(256, 1) void lstm_rec_fwd_kernel(LstmFwdArgs a, const float4* __restrict__ whp, int rows_wg) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int RP = 36;
@@ -442,7 +502,7 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_fwd_kernel(LstmFwdArgs a, con
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) acc[i][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (row0 != rbeg) __syncthreads();  // the previous pass's gate math has read every wave's partials
-        rec_contract<1, 2, RT>(acc, rh, H * 4, row0, wave * 512, bres, nullptr, As, lane, rot);
+        rec_contract<1, 2, RT, BX>(acc, rh, H * 4, row0, wave * 512, bres, nullptr, As, lane, rot);
         rec_spill<2, RT, RP>(acc, As, lane, rot);
         REC_STAMP(28);
         __syncthreads();
@@ -478,7 +538,7 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_fwd_kernel(LstmFwdArgs a, con
     }
 }
 
-template <int RT>
+template <int RT, bool BX = false>
 __global__ __launch_bounds__(256, 1) void lstm_rec_bwd_kernel(LstmBwdArgs a, const float4* __restrict__ whp, int rows_wg) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int RP = 20;
@@ -556,7 +616,7 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_bwd_kernel(LstmBwdArgs a, con
 #pragma unroll
             for (int i = 0; i < RT; ++i) acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (row0 != rbeg) __syncthreads();
-            rec_contract<4, 1, RT>(acc, rg, K * 4, row0, wave * 2048, nob, bp, As, lane, rot);
+            rec_contract<4, 1, RT, BX>(acc, rg, K * 4, row0, wave * 2048, nob, bp, As, lane, rot);
             rec_spill<1, RT, RP>(acc, As, lane, rot);
             REC_STAMP(28);
             __syncthreads();
@@ -586,17 +646,26 @@ constexpr int R8_WAVE = 80 * 36;             // floats per wave: its partial hal
 constexpr int R8_LDS_BYTES = 8 * R8_WAVE * 4;
 
 // out[((((ug*8 + w)*4 + ct)*4 + j)*64 + lane] = Wh[k .. k+3][col], k = 64 w + 16 (lane>>4) + 4 j, col = ct*H + 16 ug + (lane&15)
-__global__ __launch_bounds__(256) void lstm_rec8_pack_kernel(const float* __restrict__ Wh, int H, float4* __restrict__ out) {
+__global__ __launch_bounds__(256) void lstm_rec8_pack_kernel(const float* __restrict__ Wh, int H, float4* __restrict__ out, int bx) {
     const int total = (H / 16) * 8 * 4 * 4 * 64;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
         const int lane = i & 63, j = (i >> 6) & 3, ct = (i >> 8) & 3, w = (i >> 10) & 7, ug = i >> 13;
         const int col = ct * H + ug * 16 + (lane & 15);
+        if (bx) {
+            const float* s = Wh + (long)(64 * w + 16 * (lane >> 4) + 4 * (j & ~1)) * 4 * H + col;
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = s[(long)r * 4 * H];
+            out[i] = rec_pack_pair(v, j & 1);
+            continue;
+        }
         const int k = 64 * w + 16 * (lane >> 4) + 4 * j;
         const float* s = Wh + (long)k * 4 * H + col;
         out[i] = make_float4(s[0], s[4L * H], s[8L * H], s[12L * H]);
     }
 }
 
+template <bool BX>
 __global__ __launch_bounds__(512, 1) void lstm_rec8_fwd_kernel(LstmFwdArgs a, const float4* __restrict__ whp, int rows_wg) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int RT = 5, H = 512, RP = 36;
@@ -666,13 +735,28 @@ __global__ __launch_bounds__(512, 1) void lstm_rec8_fwd_kernel(LstmFwdArgs a, co
                 if (u + 3 < RT) gload(u + 3);
                 frags(u + 1);
             }
+            if constexpr (BX) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    bf16x8 ah, al;
+                    rec_split8(fr[u & 1][2 * m], fr[u & 1][2 * m + 1], ah, al);
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) {
+                        const bf16x8 bh = rec_bits(bres[ct][2 * m]), bl = rec_bits(bres[ct][2 * m + 1]);
+                        acc[u][ct] = mfma16bx(al, bh, acc[u][ct]);
+                        acc[u][ct] = mfma16bx(ah, bl, acc[u][ct]);
+                        acc[u][ct] = mfma16bx(ah, bh, acc[u][ct]);
+                    }
+                }
+            } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
                     for (int ct = 0; ct < 4; ++ct) acc[u][ct] = mfma16(lcomp(fr[u & 1][j], e), lcomp(bres[ct][j], e), acc[u][ct]);
-            if (u + 1 < RT) {
+            }
+            if (!BX && u + 1 < RT) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
@@ -785,36 +869,49 @@ static int rec_row_groups(int N, int UG) {
     return rg < cap ? rg : cap;
 }
 
-static int rec_fwd(hipStream_t st, const LstmFwdArgs& a, const float* whp) {
-    static int once = rec_lds(lstm_rec_fwd_kernel<5>) | rec_lds(lstm_rec_fwd_kernel<3>);
+// bx: the split-bf16 kernels (whp must then come from the pack kernels called with bx = 1)
+static bool rec_bx() { static const int off = lstm_env("VC_LSTM_BX", 1); return off != 0 && vc_gemm_get_precision() == 1; }
+
+static int rec_fwd(hipStream_t st, const LstmFwdArgs& a, const float* whp, bool bx = false) {
+    static int once = rec_lds(lstm_rec_fwd_kernel<5>) | rec_lds(lstm_rec_fwd_kernel<3>) | rec_lds(lstm_rec_fwd_kernel<5, true>) | rec_lds(lstm_rec_fwd_kernel<3, true>);
     if (once) return once;
     const int RG = rec_row_groups(a.N, 64), rows = cdiv(a.N, RG);
-    if (rows > 48)
-        hipLaunchKernelGGL(lstm_rec_fwd_kernel<5>, dim3(64, RG), dim3(256), REC_LDS_BYTES, st, a, (const float4*)whp, rows);
-    else
-        hipLaunchKernelGGL(lstm_rec_fwd_kernel<3>, dim3(64, RG), dim3(256), REC_LDS_BYTES, st, a, (const float4*)whp, rows);
+    const dim3 g(64, RG);
+    if (rows > 48) {
+        if (bx) hipLaunchKernelGGL((lstm_rec_fwd_kernel<5, true>), g, dim3(256), REC_LDS_BYTES, st, a, (const float4*)whp, rows);
+        else hipLaunchKernelGGL(lstm_rec_fwd_kernel<5>, g, dim3(256), REC_LDS_BYTES, st, a, (const float4*)whp, rows);
+    } else {
+        if (bx) hipLaunchKernelGGL((lstm_rec_fwd_kernel<3, true>), g, dim3(256), REC_LDS_BYTES, st, a, (const float4*)whp, rows);
+        else hipLaunchKernelGGL(lstm_rec_fwd_kernel<3>, g, dim3(256), REC_LDS_BYTES, st, a, (const float4*)whp, rows);
+    }
     return launch_status("lstm rec fwd");
 }
 
-static int rec8_fwd(hipStream_t st, const LstmFwdArgs& a, const float* whp) {
+static int rec8_fwd(hipStream_t st, const LstmFwdArgs& a, const float* whp, bool bx = false) {
     static int once = [] {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_rec8_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, R8_LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_rec8_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, R8_LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_rec8_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, R8_LDS_BYTES);
         return e == hipSuccess ? 0 : fail((int)e, "%s: hipFuncSetAttribute failed", "lstm rec8 kernel");
     }();
     if (once) return once;
     const int RG = rec_row_groups(a.N, 32), rows = cdiv(a.N, RG);
-    hipLaunchKernelGGL(lstm_rec8_fwd_kernel, dim3(32, RG), dim3(512), R8_LDS_BYTES, st, a, (const float4*)whp, rows);
+    if (bx) hipLaunchKernelGGL(lstm_rec8_fwd_kernel<true>, dim3(32, RG), dim3(512), R8_LDS_BYTES, st, a, (const float4*)whp, rows);
+    else hipLaunchKernelGGL(lstm_rec8_fwd_kernel<false>, dim3(32, RG), dim3(512), R8_LDS_BYTES, st, a, (const float4*)whp, rows);
     return launch_status("lstm rec8 fwd");
 }
 
-static int rec_bwd(hipStream_t st, const LstmBwdArgs& a, const float* whp) {
-    static int once = rec_lds(lstm_rec_bwd_kernel<5>) | rec_lds(lstm_rec_bwd_kernel<3>);
+static int rec_bwd(hipStream_t st, const LstmBwdArgs& a, const float* whp, bool bx = false) {
+    static int once = rec_lds(lstm_rec_bwd_kernel<5>) | rec_lds(lstm_rec_bwd_kernel<3>) | rec_lds(lstm_rec_bwd_kernel<5, true>) | rec_lds(lstm_rec_bwd_kernel<3, true>);
     if (once) return once;
     const int RG = rec_row_groups(a.N, 32), rows = cdiv(a.N, RG);
-    if (rows > 48)
-        hipLaunchKernelGGL(lstm_rec_bwd_kernel<5>, dim3(32, RG), dim3(256), REC_LDS_BYTES, st, a, (const float4*)whp, rows);
-    else
-        hipLaunchKernelGGL(lstm_rec_bwd_kernel<3>, dim3(32, RG), dim3(256), REC_LDS_BYTES, st, a, (const float4*)whp, rows);
+    const dim3 g(32, RG);
+    if (rows > 48) {
+        if (bx) hipLaunchKernelGGL((lstm_rec_bwd_kernel<5, true>), g, dim3(256), REC_LDS_BYTES, st, a, (const float4*)whp, rows);
+        else hipLaunchKernelGGL(lstm_rec_bwd_kernel<5>, g, dim3(256), REC_LDS_BYTES, st, a, (const float4*)whp, rows);
+    } else {
+        if (bx) hipLaunchKernelGGL((lstm_rec_bwd_kernel<3, true>), g, dim3(256), REC_LDS_BYTES, st, a, (const float4*)whp, rows);
+        else hipLaunchKernelGGL(lstm_rec_bwd_kernel<3>, g, dim3(256), REC_LDS_BYTES, st, a, (const float4*)whp, rows);
+    }
     return launch_status("lstm rec bwd");
 }
 
@@ -874,8 +971,9 @@ extern "C" int vc_lstm_pack_wh_f32(void* stream, int H, const float* Wh, float* 
     using namespace vc;
     VC_CHECK_ARG(H == 512 && Wh && whp, "H == 512 required (vc_lstm_step_packed_supported)");
     VC_CHECK_ARG(aligned16(Wh) && aligned16(whp), "Wh / whp must be 16-byte aligned");
-    hipLaunchKernelGGL(lstm_rec_pack_fwd_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, Wh, H, (float4*)whp);
-    hipLaunchKernelGGL(lstm_rec8_pack_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, Wh, H, (float4*)(whp + (size_t)H * 4 * H));
+    // (single steps stay on the f32 kernels whatever the process-wide precision: a packed buffer outlives mode changes)
+    hipLaunchKernelGGL(lstm_rec_pack_fwd_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, Wh, H, (float4*)whp, 0);
+    hipLaunchKernelGGL(lstm_rec8_pack_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, Wh, H, (float4*)(whp + (size_t)H * 4 * H), 0);
     return launch_status(__func__);
 }
 
@@ -931,9 +1029,10 @@ extern "C" int vc_lstm_seq_fwd_f32(void* stream, int T, int N, int E, int H, con
     const int eg = (int)((NH + 255) / 256) < 2048 ? (int)((NH + 255) / 256) : 2048;
     const bool rec = (g_lstm_mode == 3 || g_lstm_mode == 2) && rec_ok(N, H) && ws && ws_bytes >= REC_PACK_BYTES;
     const bool rec8 = rec && rec8_rows(N);
+    const bool bx = rec && rec_bx();   // split-bf16 recurrence (vc_gemm_set_precision(1))
     if (rec) {  // Wh in the MFMA-operand layout of the step kernel, once per sequence (4 MB at H = 512)
-        if (rec8) hipLaunchKernelGGL(lstm_rec8_pack_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, Wh, H, (float4*)ws);
-        else hipLaunchKernelGGL(lstm_rec_pack_fwd_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, Wh, H, (float4*)ws);
+        if (rec8) hipLaunchKernelGGL(lstm_rec8_pack_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, Wh, H, (float4*)ws, bx ? 1 : 0);
+        else hipLaunchKernelGGL(lstm_rec_pack_fwd_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, Wh, H, (float4*)ws, bx ? 1 : 0);
         rc = launch_status(__func__);
         if (rc) return rc;
     }
@@ -941,7 +1040,7 @@ extern "C" int vc_lstm_seq_fwd_f32(void* stream, int T, int N, int E, int H, con
         float* g = act + (long)t * N * 4 * H;
         if (rec) {
             LstmFwdArgs a{hs + t * NH, cs + t * NH, Wh, g, lens_eff, cs + (t + 1) * NH, hs + (t + 1) * NH, N, H, t};
-            rc = rec8 ? rec8_fwd((hipStream_t)stream, a, ws) : rec_fwd((hipStream_t)stream, a, ws);
+            rc = rec8 ? rec8_fwd((hipStream_t)stream, a, ws, bx) : rec_fwd((hipStream_t)stream, a, ws, bx);
         } else if (g_lstm_mode) {
             int ns = 1;  // recurrent product as split-K partials in ws; the gate kernel sums them (no separate reduce launch)
             rc = gemm_partials_f32((hipStream_t)stream, 0, 0, N, 4 * H, H, hs + t * NH, H, Wh, 4 * H, ws, ws_bytes, 8, &ns);
@@ -1001,8 +1100,9 @@ extern "C" int vc_lstm_seq_bwd_data_f32(void* stream, int T, int N, int E, int H
     // split form: the recurrent product dG[t+1].Wh^T as split-K partials in ws, summed by the gate kernel
     const float* rec = ws;
     const bool recb = (g_lstm_mode == 3 || g_lstm_mode == 2) && rec_ok(N, H) && ws && ws_bytes >= REC_PACK_BYTES;
+    const bool bx = recb && rec_bx();
     if (recb) {  // Wh^T slices in operand order; ws is free again for the GEMMs below once the step loop has run
-        hipLaunchKernelGGL(lstm_rec_pack_bwd_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, Wh, H, (float4*)ws);
+        hipLaunchKernelGGL(lstm_rec_pack_bwd_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, Wh, H, (float4*)ws, bx ? 1 : 0);
         rc = launch_status(__func__);
         if (rc) return rc;
     }
@@ -1012,7 +1112,7 @@ extern "C" int vc_lstm_seq_bwd_data_f32(void* stream, int T, int N, int E, int H
         if (recb) {
             LstmBwdArgs a{first ? nullptr : dG + (t + 1) * NG, Wh, lens_eff, ext, dH_run, dC_run, act + t * NG, cs + t * NH, cs + (t + 1) * NH,
                           dG + t * NG, N, H, t, first};
-            rc = rec_bwd((hipStream_t)stream, a, ws);
+            rc = rec_bwd((hipStream_t)stream, a, ws, bx);
         } else if (g_lstm_mode) {
             int ns = 1;
             if (!first) {
