@@ -676,7 +676,8 @@ class CaptionEngine(object):
             mg, sg = self._b("mean_g", (Ng, L)), self._b("std_g", (Ng, L))
             mg.view(W, N * L).copy_(gv[:, :N * L])
             sg.view(W, N * L).copy_(gv[:, N * L:2 * N * L])
-            torch.sum(gv[:, 2 * N * L], dim=0, keepdim=True, out=self.red[1:2])
+            # global label count = the W gathered counts summed in rank order (a [W, 1] column sum with row pitch M)
+            self.colsum(gath[2 * N * L:], W, 1, self.red[1:2], ld=M)
             self._den_gathered = True
             # this rank's z_rnn rows = flat range [rank*N*S, (rank+1)*N*S) of the global [S, Ng, L] tensor
             lib.vc_latent_sample_mixed_f32(st, Ng, L, self.rank * N * Sm, N * Sm, P(mg), P(sg), P(self.buf["eps"]), P(z))
