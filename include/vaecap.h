@@ -378,6 +378,16 @@ int vc_conv3x3_bx_fwd_f32(void* stream, int B, int H, int W, int Cin, int Cout, 
 int vc_conv3x3_bx_dgrad_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* dy, const void* wpt, const float* relu_src,
                             float* dx);
 
+/* DIRECT 3x3 weight gradient on the bf16 matrix pipe (csrc/conv_wgrad_bx.hip; backward of tf.nn.conv2d w.r.t. the filter,
+ * utils/image_embeddings.py:36-212, in the split-bf16 arithmetic of vc_gemm_bf16x3_f32 -- the opt-in mode of Trainer(precision="bf16x3")).
+ * The contraction runs over the pixels; both operands are split in registers.  Same contract as vc_conv3x3_wino_wgrad_f32 (db != NULL also
+ * returns the bias gradient -- summed in f32 --, accumulate adds to dw / db, the workspace is REQUIRED, results bit-reproducible).
+ * x, dy: C4 layout, f32; dw: HWIO.  Shapes: Cin % 64 == 0, Cout % 64 == 0, any H, W >= 1; ask vc_conv3x3_bx_wgrad_supported. */
+int vc_conv3x3_bx_wgrad_supported(int B, int H, int W, int Cin, int Cout);
+size_t vc_conv3x3_bx_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+int vc_conv3x3_bx_wgrad_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const float* dy, float* dw,
+                            float* db, int accumulate, float* ws, size_t ws_bytes);
+
 /* conv1_1 (utils/image_embeddings.py:36-48: 3 -> 64 channels), csrc/conv_first.hip: the layer is HBM-bound (it writes / re-reads
  * the 64-channel activation, 822 MB at 64 images, for 0.6 % of the multiply-adds), so it has its own kernels: the forward makes
  * the 64 output channels the M dimension of the MFMA so that every lane stores 16-byte vectors of consecutive channels straight

@@ -250,6 +250,26 @@ def winow():
     print("sum over the twelve layers B=%d wgrad %8.3f ms" % (B, tot))
 
 
+def wgbx():
+    """direct split-bf16 weight gradient (conv_wgrad_bx.hip) beside the f32 Winograd F(3x3,2x2) kernel, VGG16 layer shapes at VC_WG_B images
+    (default 64; algorithmic TFLOP/s); the last line sums the twelve layers.  Ablation builds: VC_LIB=.../libvaecap_wbablN.so"""
+    B = int(os.environ.get("VC_WG_B", "64"))
+    tot = [0.0, 0.0]
+    for (name, H, ci, co) in [("1_2", 224, 64, 64), ("2_1", 112, 64, 128), ("2_2", 112, 128, 128), ("3_1", 56, 128, 256), ("3_2", 56, 256, 256),
+                              ("4_1", 28, 256, 512), ("4_2", 28, 512, 512), ("5_2", 14, 512, 512)]:
+        x, dy, bias = rnd(B, H, H, ci), rnd(B, H, H, co), rnd(co)
+        dw = torch.empty(3, 3, ci, co, device="cuda")
+        ws = torch.empty(max(lib.vc_conv3x3_wino_wgrad_workspace_bytes(B, H, H, ci, co), lib.vc_conv3x3_bx_wgrad_workspace_bytes(B, H, H, ci, co)) // 4 + 4, device="cuda")
+        fl = 2e-9 * B * H * H * 9 * ci * co
+        mult = {"1_2": 1, "2_1": 1, "2_2": 1, "3_1": 1, "3_2": 2, "4_1": 1, "4_2": 2, "5_2": 3}[name]
+        mb, _ = timeit(lambda: lib.vc_conv3x3_bx_wgrad_f32(st(), B, H, H, ci, co, P(x), P(dy), P(dw), P(bias), 0, P(ws), ws.numel() * 4), reps=5)
+        mw, _ = timeit(lambda: lib.vc_conv3x3_wino_wgrad_f32(st(), B, H, H, ci, co, P(x), P(dy), P(dw), P(bias), 0, P(ws), ws.numel() * 4), reps=5)
+        tot[0] += mb * mult
+        tot[1] += mw * mult
+        print("conv%s wgrad B=%d H=%3d %3d->%3d: split-bf16 direct %8.3f ms %6.1f TFLOP/s | f32 Winograd %8.3f ms %6.1f TFLOP/s" % (name, B, H, ci, co, mb, fl / mb, mw, fl / mw), flush=True)
+    print("sum over the twelve layers B=%d wgrad: split-bf16 direct %8.3f ms | f32 Winograd %8.3f ms" % (B, tot[0], tot[1]))
+
+
 def lstm():
     """marginal cost of one recurrence step = (sequence of T=42) - (sequence of T=2), / 40: the input projection and the
     weight-gradient GEMMs of the sequence drivers scale with T too, so they are timed separately with mode 1 and N fixed ... no:
