@@ -113,45 +113,82 @@ __global__ __launch_bounds__(256, 1) void wgrad_bx_kernel(WgBxArgs a) {
     // lane (li, lh): x channel cw * 32 + li = quad cw * 8 + li / 4, component li % 4; pixels 8 lh + i of patch row 4 kh + R
     const int xb = (cw * 8 + (li >> 2)) * XPL + (li & 3) + ((4 * kh) * 18 + 8 * lh) * 4;
     const int yb = XPF + (li >> 2) * YPL + (li & 3) + ((4 * kh) * 16 + 8 * lh) * 4;   // + ng * 8 * YPL + (lr * 16 + k) * 4
-    float rx[10], ry[16];
     unsigned ph[5], pl[5];
     u32x4 xh[3], xl[3], xnh[3], xnl[3];
     u32x4 dyh[3][2], dyl[3][2];
-    f32x2 dbs[2] = {{0.f, 0.f}, {0.f, 0.f}};
-    auto rdx = [&](int img, int i, int row) {
-        if (WB_ABL & 2) { rx[i] = (float)(i + row); return; }
-        rx[i] = smem[img + xb + (row * 18 + i) * 4];
+    float dbs[2] = {0.f, 0.f};
+    // A PAIR of adjacent pixels is the unit of operand preparation: one ds_read2_b32, then the split (p, q) -> packed (hi, lo) in four
+    // STAGES, each behind a different MFMA (a dependent chain of six VALU instructions behind one MFMA outlasts it):
+    //   0: hi = bf16(p, q)   1: widen hi   2: r = (p, q) - float(hi)   3: lo = bf16(r)  (+ the pair's share of db)
+    // -- scalar subtractions on purpose: a v_pk_add_f32 beside MFMAs costs ~13 cycles beyond its issue slot (MI355X_MICROARCH.md,
+    // "price of one filler"); the file is compiled with -fno-slp-vectorize so that hipcc does not re-pack them.
+    // rawx / rawy / tmp* are indexed by compile-time constants: registers that live from a pair's read to its last stage.
+    float rawx[4][5][2], tmpx[4][5][2], rawy[7][8][2], tmpy[7][8][2];
+    auto st_hi = [&](float p, float q) -> unsigned {
+        if (WB_ABL & 1) return __float_as_uint(p);
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{p, q}, bf16x2));
     };
-    auto rdy = [&](int img, int idx, int lr) {
-        const int ng = idx >> 3, k = idx & 7;
-        if (WB_ABL & 2) { ry[idx] = (float)(idx + lr); return; }
-        ry[idx] = smem[img + yb + ng * 8 * YPL + (lr * 16 + k) * 4];
+    auto st_lo = [&](float p, float q) -> unsigned {
+        if (WB_ABL & 1) return __float_as_uint(q);
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{p, q}, bf16x2));
     };
-    auto spl = [&](float p, float q, unsigned& h, unsigned& l) {
-        if (WB_ABL & 1) { h = __float_as_uint(p); l = __float_as_uint(q); return; }
-        split_pair(p, q, h, l);
+    // x pair m of patch row `row` (task id t: distinct temporaries per row in flight); sg = -1: read, 0..3: stages
+    auto xpair = [&](int t, int img, int row, int m, int sg) {
+        if (sg == -1) {
+            if (WB_ABL & 2) { rawx[t][m][0] = (float)(m + row); rawx[t][m][1] = (float)(m - row); return; }
+            rawx[t][m][0] = smem[img + xb + (row * 18 + 2 * m) * 4];
+            rawx[t][m][1] = smem[img + xb + (row * 18 + 2 * m + 1) * 4];
+        } else if (sg == 0) ph[m] = st_hi(rawx[t][m][0], rawx[t][m][1]);
+        else if (sg == 1) {
+            if (!(WB_ABL & 1)) { tmpx[t][m][0] = __uint_as_float(ph[m] << 16); tmpx[t][m][1] = __uint_as_float(ph[m] & 0xffff0000u); }
+        } else if (sg == 2) {
+            if (!(WB_ABL & 1)) { tmpx[t][m][0] = rawx[t][m][0] - tmpx[t][m][0]; tmpx[t][m][1] = rawx[t][m][1] - tmpx[t][m][1]; }
+            else { tmpx[t][m][0] = rawx[t][m][1]; tmpx[t][m][1] = rawx[t][m][1]; }
+        } else pl[m] = st_lo(tmpx[t][m][0], tmpx[t][m][1]);
     };
-    auto spx = [&](int m) { spl(rx[2 * m], rx[2 * m + 1], ph[m], pl[m]); };
-    auto mkx = [&](int which) {   // the three kx operands of the next chunk from the five packed pairs
-        if (which == 0) {
-            xnh[0] = u32x4{ph[0], ph[1], ph[2], ph[3]};
-            xnh[2] = u32x4{ph[1], ph[2], ph[3], ph[4]};
-            xnh[1] = u32x4{__builtin_amdgcn_alignbit(ph[1], ph[0], 16), __builtin_amdgcn_alignbit(ph[2], ph[1], 16),
-                           __builtin_amdgcn_alignbit(ph[3], ph[2], 16), __builtin_amdgcn_alignbit(ph[4], ph[3], 16)};
+    auto mkx = [&](int k) {   // the three kx operands of the next chunk from the five packed pairs, in six parts
+        if (k == 0) { xnh[1][0] = __builtin_amdgcn_alignbit(ph[1], ph[0], 16); xnh[1][1] = __builtin_amdgcn_alignbit(ph[2], ph[1], 16); }
+        else if (k == 1) { xnh[1][2] = __builtin_amdgcn_alignbit(ph[3], ph[2], 16); xnh[1][3] = __builtin_amdgcn_alignbit(ph[4], ph[3], 16); }
+        else if (k == 2) { xnl[1][0] = __builtin_amdgcn_alignbit(pl[1], pl[0], 16); xnl[1][1] = __builtin_amdgcn_alignbit(pl[2], pl[1], 16); }
+        else if (k == 3) { xnl[1][2] = __builtin_amdgcn_alignbit(pl[3], pl[2], 16); xnl[1][3] = __builtin_amdgcn_alignbit(pl[4], pl[3], 16); }
+        else if (k == 4) { xnh[0] = u32x4{ph[0], ph[1], ph[2], ph[3]}; xnh[2] = u32x4{ph[1], ph[2], ph[3], ph[4]}; }
+        else { xnl[0] = u32x4{pl[0], pl[1], pl[2], pl[3]}; xnl[2] = u32x4{pl[1], pl[2], pl[3], pl[4]}; }
+    };
+    // dy pair p (channel group p / 4, pair p % 4) of patch row lr (relative to 4 kh) into register slot `slot`; task id t
+    auto ypair = [&](int t, int img, int lr, int p, int sg, int slot, bool centre) {
+        const int ng = p >> 2, m = p & 3;
+        if (sg == -1) {
+            if (WB_ABL & 2) { rawy[t][p][0] = (float)(p + lr); rawy[t][p][1] = (float)(p - lr); return; }
+            rawy[t][p][0] = smem[img + yb + ng * 8 * YPL + (lr * 16 + 2 * m) * 4];
+            rawy[t][p][1] = smem[img + yb + ng * 8 * YPL + (lr * 16 + 2 * m + 1) * 4];
+        } else if (sg == 0) dyh[slot][ng][m] = st_hi(rawy[t][p][0], rawy[t][p][1]);
+        else if (sg == 1) {
+            if (!(WB_ABL & 1)) { tmpy[t][p][0] = __uint_as_float(dyh[slot][ng][m] << 16); tmpy[t][p][1] = __uint_as_float(dyh[slot][ng][m] & 0xffff0000u); }
+        } else if (sg == 2) {
+            if (!(WB_ABL & 1)) { tmpy[t][p][0] = rawy[t][p][0] - tmpy[t][p][0]; tmpy[t][p][1] = rawy[t][p][1] - tmpy[t][p][1]; }
+            else { tmpy[t][p][0] = rawy[t][p][1]; tmpy[t][p][1] = rawy[t][p][1]; }
         } else {
-            xnl[0] = u32x4{pl[0], pl[1], pl[2], pl[3]};
-            xnl[2] = u32x4{pl[1], pl[2], pl[3], pl[4]};
-            xnl[1] = u32x4{__builtin_amdgcn_alignbit(pl[1], pl[0], 16), __builtin_amdgcn_alignbit(pl[2], pl[1], 16),
-                           __builtin_amdgcn_alignbit(pl[3], pl[2], 16), __builtin_amdgcn_alignbit(pl[4], pl[3], 16)};
+            dyl[slot][ng][m] = st_lo(tmpy[t][p][0], tmpy[t][p][1]);
+            if (centre) dbs[ng] += rawy[t][p][0] + rawy[t][p][1];   // db: every real dy row is the centre row of exactly one wave
         }
     };
-    auto spy = [&](int idx, int slot, bool centre) {   // pair idx % 4 of channel group idx / 4 into dy register slot `slot`
-        const int ng = idx >> 2, m = idx & 3;
-        unsigned h, l;
-        spl(ry[ng * 8 + 2 * m], ry[ng * 8 + 2 * m + 1], h, l);
-        dyh[slot][ng][m] = h;
-        dyl[slot][ng][m] = l;
-        if (centre) dbs[ng] += f32x2{ry[ng * 8 + 2 * m], ry[ng * 8 + 2 * m + 1]};   // db: every real dy row is the centre row of exactly one wave
+    // a row's pairs p0 .. p0 + np - 1 as a pipeline: pair p starts (stage 0) at interval S + II (p - p0), its read three intervals earlier
+    auto xrow = [&](int N, int S, int II, int t, int img, int row) {
+#pragma unroll
+        for (int m = 0; m < 5; ++m) {
+            const int d = N - (S + II * m);
+            if (d == -3) xpair(t, img, row, m, -1);
+            else if (d >= 0 && d < 4) xpair(t, img, row, m, d);
+        }
+    };
+    auto yrow = [&](int N, int S, int II, int p0, int np, int t, int img, int lr, int slot, bool centre) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int d = N - (S + II * (p - p0));
+            if (p < p0 || p >= p0 + np) continue;
+            if (d == -3) ypair(t, img, lr, p, -1, slot, centre);
+            else if (d >= 0 && d < 4) ypair(t, img, lr, p, d, slot, centre);
+        }
     };
 
     f32x16 acc[2][9];
@@ -183,63 +220,62 @@ __global__ __launch_bounds__(256, 1) void wgrad_bx_kernel(WgBxArgs a) {
     for (int i = 0; i < 7; ++i) st[i] = gload(i);
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 10; ++i) rdx(cur, i, 0);
+    for (int sg = -1; sg < 4; ++sg)
 #pragma unroll
-    for (int m = 0; m < 5; ++m) spx(m);
-    mkx(0); mkx(1);
+        for (int m = 0; m < 5; ++m) xpair(0, cur, 0, m, sg);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) mkx(k);
 #pragma unroll
     for (int t = 0; t < 3; ++t) { xh[t] = xnh[t]; xl[t] = xnl[t]; }
 #pragma unroll
-    for (int lr = 0; lr < 2; ++lr) {
+    for (int sg = -1; sg < 4; ++sg) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) rdy(cur, i, lr);
+        for (int i = 0; i < 8; ++i) ypair(0, cur, 0, i, sg, 0, false);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) spy(i, lr, lr == 1);
+        for (int i = 0; i < 4; ++i) ypair(1, cur, 1, i, sg, 1, true);   // pairs 4..7 of row 1: intervals 3..15 of the block (below)
     }
     WSB();
 
-    // ---- the operations placed behind MFMA n (0..53) of chunk J (0..3) of a block -------------------------------------------------
-    // chunk J multiplies x row J (xh / xl) with dy rows lr = J (ky 2), J + 1 (ky 1), J + 2 (ky 0) in register slots lr % 3, ky 2 first:
-    // its slot is free for row J + 3 from MFMA 18 on.  Chunk 3 prepares the next block's x row 0 and dy rows 0, 1 from the other
-    // image (behind the barrier), chunk 0 its own dy row 2 (for its last eighteen MFMAs) and row 3.
+    // ---- the operations placed behind MFMA N = 54 J + n (0..215) of a block ------------------------------------------------------
+    // chunk J multiplies x row J (xh / xl) with dy rows lr = J (ky 2), J + 1 (ky 1), J + 2 (ky 0) in register slots lr % 3, ky 2 first,
+    // so a dy row may be (re)written into its slot from interval 54 (lr - 3) + 18 on and must be complete by 54 (lr - 2) + 36:
+    //   row   slot   written during        from
+    //   1'    1      [3, 16) pairs 4..7    this image (the row's pairs 0..3 were split at the end of the previous block)
+    //   2     2      [4, 36)               this image
+    //   3     0      [37, 83)              this image
+    //   4     1      [84, 130)             this image
+    //   5     2      [132, 178)            this image
+    //   0'    0      [181, 213)            the other image (complete behind the barrier at 162): the NEXT block's row 0
+    //   1'    1      [199, 215) pairs 0..3 the other image
+    // x row J + 1 (five pairs + the kx operands) is prepared inside chunk J, the next block's row 0 inside chunk 3.  At most ~5
+    // instructions land behind one MFMA (what a 32-cycle MFMA hides for a single wave, MI355X_MICROARCH.md).
+    // Staging of the next block into the other image (free since the previous barrier): three batches of 16-byte slots, each loaded
+    // ~60 MFMAs (~2000 cycles) before it is written; the addresses of the block after next are formed behind batch C's loads.
     auto ops = [&](int J, int n, int blk_next2, bool live_next2) {
-        if (J == 0) {
-            if (n < 8) { rdy(cur, 2 * n, 2); rdy(cur, 2 * n + 1, 2); }
-            else if (n < 13) { rdx(cur, 2 * (n - 8), 1); rdx(cur, 2 * (n - 8) + 1, 1); }
-            if (n >= 10 && n < 18) spy(n - 10, 2, true);
-            if (n >= 19 && n < 24) spx(n - 19);
-            if (n == 24) mkx(0);
-            if (n == 25) mkx(1);
-            if (n >= 20 && n < 28) { rdy(cur, 2 * (n - 20), 3); rdy(cur, 2 * (n - 20) + 1, 3); }
-            if (n >= 30 && n < 38) spy(n - 30, 0, true);
-            if (!(WB_ABL & 4)) {
-                if (n >= 38 && n < 45) lstore(nxt, n - 38, st[n - 38]);
-                if (n >= 45 && n < 51) st[n - 45] = gload(7 + n - 45);
-            }
-        } else if (J == 1 || J == 2) {
-            if (n < 5) { rdx(cur, 2 * n, J + 1); rdx(cur, 2 * n + 1, J + 1); }
-            else if (n < 13) { rdy(cur, 2 * (n - 5), J + 3); rdy(cur, 2 * (n - 5) + 1, J + 3); }
-            if (n >= 18 && n < 23) spx(n - 18);
-            if (n == 23) mkx(0);
-            if (n == 24) mkx(1);
-            if (n >= 26 && n < 34) spy(n - 26, J % 3, J == 1);
-            if (!(WB_ABL & 4)) {
-                if (n >= 36 && n < 42) lstore(nxt, (J == 1 ? 7 : 13) + n - 36, st[n - 36]);
-                if (J == 1 && n >= 42 && n < 48) st[n - 42] = gload(13 + n - 42);
-            }
-        } else {
-            if (n < 5) { rdx(nxt, 2 * n, 0); rdx(nxt, 2 * n + 1, 0); }
-            else if (n < 13) { rdy(nxt, 2 * (n - 5), 0); rdy(nxt, 2 * (n - 5) + 1, 0); }
-            if (n >= 18 && n < 23) spx(n - 18);
-            if (n == 23) mkx(0);
-            if (n == 24) mkx(1);
-            if (n >= 26 && n < 34) spy(n - 26, 0, false);
-            if (n >= 34 && n < 42) { rdy(nxt, 2 * (n - 34), 1); rdy(nxt, 2 * (n - 34) + 1, 1); }
-            if (n >= 44 && n < 52) spy(n - 44, 1, true);
-            if (!(WB_ABL & 4)) {
-                if (n >= 36 && n < 40) set_family(n - 36, blk_next2, live_next2);
-                if (n >= 42 && n < 49) st[n - 42] = gload(n - 42);
-            }
+        const int N = 54 * J + n;
+        yrow(N, 3, 3, 4, 4, 1, cur, 1, 1, true);
+        yrow(N, 4, 4, 0, 8, 2, cur, 2, 2, true);
+        yrow(N, 37, 6, 0, 8, 3, cur, 3, 0, true);
+        yrow(N, 84, 6, 0, 8, 4, cur, 4, 1, true);
+        yrow(N, 132, 6, 0, 8, 5, cur, 5, 2, false);
+        yrow(N, 181, 4, 0, 8, 6, nxt, 0, 0, false);
+        yrow(N, 199, 4, 0, 4, 0, nxt, 1, 1, true);
+        xrow(N, 17, 4, 1, cur, 1);
+        if (N >= 38 && N < 44) mkx(N - 38);
+        xrow(N, 57, 4, 2, cur, 2);
+        if (N >= 78 && N < 84) mkx(N - 78);
+        xrow(N, 111, 4, 3, cur, 3);
+        if (N >= 132 && N < 138) mkx(N - 132);
+        xrow(N, 165, 4, 0, nxt, 0);
+        if (N >= 186 && N < 192) mkx(N - 186);
+        if (!(WB_ABL & 4)) {
+            if (N >= 30 && N < 37) lstore(nxt, N - 30, st[N - 30]);              // batch A (slots 0..6), loaded at 192.. of the previous block
+            if (N >= 40 && N < 46) st[N - 40] = gload(7 + N - 40);              // batch B (7..12)
+            if (N >= 100 && N < 106) lstore(nxt, 7 + N - 100, st[N - 100]);
+            if (N >= 106 && N < 112) st[N - 106] = gload(13 + N - 106);         // batch C (13..18)
+            if (N >= 140 && N < 148 && !(N & 1)) set_family((N - 140) >> 1, blk_next2, live_next2);
+            if (N >= 155 && N < 161) lstore(nxt, 13 + N - 155, st[N - 155]);
+            if (N >= 192 && N < 199) st[N - 192] = gload(N - 192);              // batch A of the block after next
         }
     };
     // eighteen accumulators are 288 registers against 256 AGPRs: left to itself the register allocator moves whole accumulators between
@@ -274,9 +310,9 @@ __global__ __launch_bounds__(256, 1) void wgrad_bx_kernel(WgBxArgs a) {
     for (int ci = 0; ci < nch; ++ci) {
         chunk(0, 0, false);
         chunk(1, 0, false);
-        chunk(2, 0, false);
+        chunk(2, blk0 + ci + 2, ci + 2 < nch);
         __syncthreads();   // the other image is complete; this one is behind every wave
-        chunk(3, blk0 + ci + 2, ci + 2 < nch);
+        chunk(3, 0, false);
         const int t = cur; cur = nxt; nxt = t;
     }
 #undef WSB
@@ -295,7 +331,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_bx_kernel(WgBxArgs a) {
     if (cb == 0 && cw == 0) {
 #pragma unroll
         for (int ng = 0; ng < 2; ++ng) {
-            float v = dbs[ng][0] + dbs[ng][1];
+            float v = dbs[ng];
             v += __shfl_xor(v, 32, 64);
             if (lh == 0) a.ws[(long)a.nsplit * 2 * 9 * C * N + z * N + n0 + 32 * ng + li] = v;
         }
