@@ -255,8 +255,11 @@ def wgbx():
     (default 64; algorithmic TFLOP/s); the last line sums the twelve layers.  Ablation builds: VC_LIB=.../libvaecap_wbablN.so"""
     B = int(os.environ.get("VC_WG_B", "64"))
     tot = [0.0, 0.0]
+    only = os.environ.get("VC_WG_ONLY")   # e.g. 3_2: one layer (counter passes)
     for (name, H, ci, co) in [("1_2", 224, 64, 64), ("2_1", 112, 64, 128), ("2_2", 112, 128, 128), ("3_1", 56, 128, 256), ("3_2", 56, 256, 256),
                               ("4_1", 28, 256, 512), ("4_2", 28, 512, 512), ("5_2", 14, 512, 512)]:
+        if only and name != only:
+            continue
         x, dy, bias = rnd(B, H, H, ci), rnd(B, H, H, co), rnd(co)
         dw = torch.empty(3, 3, ci, co, device="cuda")
         ws = torch.empty(max(lib.vc_conv3x3_wino_wgrad_workspace_bytes(B, H, H, ci, co), lib.vc_conv3x3_bx_wgrad_workspace_bytes(B, H, H, ci, co)) // 4 + 4, device="cuda")

@@ -32,7 +32,7 @@
 #include "gemm_bf16x3_core.h"
 
 // `make wbabl`: WB_ABL = bit mask that REMOVES parts (results wrong; timing only): 1 split arithmetic, 2 LDS operand reads,
-// 4 staging (global loads + LDS writes), 8 MFMAs
+// 4 staging (global loads + LDS writes), 8 MFMAs, 16 everything between the MFMAs (operands frozen after the first chunk)
 #ifndef WB_ABL
 #define WB_ABL 0
 #endif
@@ -233,6 +233,12 @@ __global__ __launch_bounds__(256, 1) void wgrad_bx_kernel(WgBxArgs a) {
         for (int i = 0; i < 8; ++i) ypair(0, cur, 0, i, sg, 0, false);
 #pragma unroll
         for (int i = 0; i < 4; ++i) ypair(1, cur, 1, i, sg, 1, true);   // pairs 4..7 of row 1: intervals 3..15 of the block (below)
+        if (WB_ABL & 16) {
+#pragma unroll
+            for (int i = 4; i < 8; ++i) ypair(1, cur, 1, i, sg, 1, true);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ypair(2, cur, 2, i, sg, 2, true);
+        }
     }
     WSB();
 
@@ -253,6 +259,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_bx_kernel(WgBxArgs a) {
     // ~60 MFMAs (~2000 cycles) before it is written; the addresses of the block after next are formed behind batch C's loads.
     auto ops = [&](int J, int n, int blk_next2, bool live_next2) {
         const int N = 54 * J + n;
+        if (WB_ABL & 16) return;   // MFMAs only, on the operands of the first chunk (real data: the matrix pipe's power draw, and clock, depend on it)
         yrow(N, 3, 3, 4, 4, 1, cur, 1, 1, true);
         yrow(N, 4, 4, 0, 8, 2, cur, 2, 2, true);
         yrow(N, 37, 6, 0, 8, 3, cur, 3, 0, true);
@@ -303,8 +310,10 @@ __global__ __launch_bounds__(256, 1) void wgrad_bx_kernel(WgBxArgs a) {
                         WSB();
                     }
         }
+        if (!(WB_ABL & 16)) {
 #pragma unroll
-        for (int t = 0; t < 3; ++t) { xh[t] = xnh[t]; xl[t] = xnl[t]; }
+            for (int t = 0; t < 3; ++t) { xh[t] = xnh[t]; xl[t] = xnl[t]; }
+        }
     };
 
     for (int ci = 0; ci < nch; ++ci) {

@@ -191,6 +191,12 @@ class VggEngine(object):
     def _wino_wgrad_ok(self, B, H, W, ci, co):
         return self.use_wino and ci % 64 == 0 and co % 64 == 0 and bool(self.lib.vc_conv3x3_wino_wgrad_supported(B, H, W, ci, co))
 
+    def _bx_wgrad_ok(self, B, H, W, ci, co):
+        """split-bf16 mode (vc_gemm_set_precision(1)): the direct weight gradient on the bf16 matrix pipe (csrc/conv_wgrad_bx.hip) replaces
+        the f32 Winograd F(3x3,2x2) kernel (VC_WGRAD_BX=0: A/B runs)"""
+        return (self.use_wino and ci % 64 == 0 and co % 64 == 0 and self.lib.vc_gemm_get_precision() == 1 and os.environ.get("VC_WGRAD_BX", "1") != "0"
+                and bool(self.lib.vc_conv3x3_bx_wgrad_supported(B, H, W, ci, co)))
+
     def colsum(self, x, rows, cols, out):
         self._need_ws(self.lib.vc_colsum_workspace_bytes(rows, cols))
         self.lib.vc_colsum_f32(_stream(), P(x), rows, cols, cols, P(out), 0, P(self.ws), self.ws_bytes)
@@ -394,7 +400,8 @@ class VggEngine(object):
         dw4 = self._b("dw1_4", (3, 3, 4, 64))
         self._need_ws(max(lib.vc_conv1_wgrad_workspace_bytes(),
                           max(max(lib.vc_conv3x3_wgrad_workspace_bytes(B, a[2], a[3], a[4], a[5]),
-                                  lib.vc_conv3x3_wino_wgrad_workspace_bytes(B, a[2], a[3], a[4], a[5]) if self._wino_wgrad_ok(B, a[2], a[3], a[4], a[5]) else 0)
+                                  lib.vc_conv3x3_wino_wgrad_workspace_bytes(B, a[2], a[3], a[4], a[5]) if self._wino_wgrad_ok(B, a[2], a[3], a[4], a[5]) else 0,
+                                  lib.vc_conv3x3_bx_wgrad_workspace_bytes(B, a[2], a[3], a[4], a[5]) if self._bx_wgrad_ok(B, a[2], a[3], a[4], a[5]) else 0)
                               for a in self.acts if a[0] != "P")))
         main = torch.cuda.current_stream()
         side, side2 = self.side, self.side2
@@ -427,6 +434,8 @@ class VggEngine(object):
                 sw = _stream()
                 if ci == 4 and self.use_conv1 and self.use_wino and lib.vc_conv1_supported(B, H, W):
                     self._timed("conv_wgrad", fl, lambda: lib.vc_conv1_wgrad_f32(sw, B, H, W, P(x), P(d), P(S.grad(wn)), P(S.grad(bn)), 0, P(self.ws), self.ws_bytes))
+                elif ci != 4 and self._bx_wgrad_ok(B, H, W, ci, co):   # split-bf16 mode: direct, K = the pixels, operands split in registers
+                    self._timed("conv_wgrad", fl, lambda: lib.vc_conv3x3_bx_wgrad_f32(sw, B, H, W, ci, co, P(x), P(d), P(S.grad(wn)), P(S.grad(bn)), 0, P(self.ws), self.ws_bytes))
                 elif ci != 4 and self._wino_wgrad_ok(B, H, W, ci, co):   # Winograd F(3x3,2x2): both operands transformed in registers, K = the 2x2 tiles
                     self._timed("conv_wgrad", fl, lambda: lib.vc_conv3x3_wino_wgrad_f32(sw, B, H, W, ci, co, P(x), P(d), P(S.grad(wn)), P(S.grad(bn)), 0, P(self.ws), self.ws_bytes))
                 else:   # csrc/conv.hip on NHWC copies (conv1_1: zero-padded 4-channel weights)
