@@ -378,6 +378,18 @@ int vc_conv3x3_bx_fwd_f32(void* stream, int B, int H, int W, int Cin, int Cout, 
 int vc_conv3x3_bx_dgrad_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* dy, const void* wpt, const float* relu_src,
                             float* dx);
 
+/* The same two operations with the activation operand split IN REGISTERS (csrc/conv_bx2.hip): four waves of 512 registers, the weights of a
+ * k-step (16 contraction channels x 9 taps x 64 produced channels) resident, one barrier per k-step.  Same contracts as vc_conv3x3_bx_*;
+ * its own packed weight format (pack: contraction channels % 16 == 0, produced channels % 64 == 0).  What Trainer(precision="bf16x3")
+ * runs when VC_CONV_BX2 is on. */
+int vc_conv3x3_bx2_supported(int B, int H, int W, int Cin, int Cout, int dgrad);
+size_t vc_conv3x3_bx2_pack_bytes(int Cin, int Cout);
+int vc_conv3x3_bx2_pack_f32(void* stream, int Cin, int Cout, const float* w, int transpose, void* wp);
+int vc_conv3x3_bx2_fwd_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const void* wp, const float* bias,
+                           float* y, int relu);
+int vc_conv3x3_bx2_dgrad_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* dy, const void* wpt, const float* relu_src,
+                             float* dx);
+
 /* DIRECT 3x3 weight gradient on the bf16 matrix pipe (csrc/conv_wgrad_bx.hip; backward of tf.nn.conv2d w.r.t. the filter,
  * utils/image_embeddings.py:36-212, in the split-bf16 arithmetic of vc_gemm_bf16x3_f32 -- the opt-in mode of Trainer(precision="bf16x3")).
  * The contraction runs over the pixels; both operands are split in registers.  Same contract as vc_conv3x3_wino_wgrad_f32 (db != NULL also
