@@ -52,6 +52,26 @@ rm -rf /tmp/kt_bx
 python tools/rocpd_stats.py "$(find /tmp/kt_bx -name "*_results.db" | head -1)" 40 > $OUT/${TAG}_cfg2_bf16x3_kernel_stats.md
 python tools/microbench.py gemmx 2>/dev/null | grep "^gemm" > $OUT/${TAG}_gemm_bf16x3.txt
 if ls vae_captioning_amd/lib/libvaecap_bxabl*.so > /dev/null 2>&1; then bash tools/experiments/bx_ablate.sh 2>/dev/null | grep -E "^==|^gemm" > $OUT/${TAG}_gemm_bf16x3_ablation.txt; fi
+# 6c. the convolution kernels of the split-bf16 mode: the direct weight gradient (adopted) per layer, its stages removed one by one
+#     (make wbabl), its counters on conv3_2 (full / MFMAs on constants / MFMAs on frozen real operands: the clock is the finding); the two
+#     direct forward / data-gradient kernels (not adopted) per layer; the cfg4 step in this mode kernel by kernel
+python tools/microbench.py wgbx 2>/dev/null | grep -E "^conv|^sum" > $OUT/${TAG}_wgrad_bx_layers.txt
+if ls vae_captioning_amd/lib/libvaecap_wbabl*.so > /dev/null 2>&1; then
+  (for n in 1 2 4 7 16; do echo "== WB_ABL=$n (1 split arithmetic, 2 LDS operand reads (and with them the split), 4 staging, 7 all three, 16 all of it with the operands of the first chunk kept: real data)"
+     VC_LIB=$ROOT/vae_captioning_amd/lib/libvaecap_wbabl$n.so python tools/microbench.py wgbx 2>/dev/null | grep -E "^conv|^sum" | sed -e "s/ | f32.*//"; done) > $OUT/${TAG}_wgrad_bx_ablation.txt
+  (export VC_WG_ONLY=3_2
+   echo "## shipped kernel"; bash tools/kernel_pmc.sh ${TAG}_wgbx_full wgrad_bx_kernel python $ROOT/tools/microbench.py wgbx
+   echo; echo "## WB_ABL=7: MFMAs only, operands = constants"; VC_LIB=$ROOT/vae_captioning_amd/lib/libvaecap_wbabl7.so bash tools/kernel_pmc.sh ${TAG}_wgbx_abl7 wgrad_bx_kernel python $ROOT/tools/microbench.py wgbx
+   echo; echo "## WB_ABL=16: MFMAs only, operands = the first chunk's (real data)"; VC_LIB=$ROOT/vae_captioning_amd/lib/libvaecap_wbabl16.so bash tools/kernel_pmc.sh ${TAG}_wgbx_abl16 wgrad_bx_kernel python $ROOT/tools/microbench.py wgbx) > $OUT/${TAG}_wgrad_bx_pmc.md 2>/dev/null
+fi
+(python tools/microbench.py convbx 2>/dev/null | grep -E "^conv|^sum"; echo "== conv_bx2"; python tools/microbench.py convbx2 2>/dev/null | grep -E "^conv|^sum") > $OUT/${TAG}_convbx_layers.txt
+if ls vae_captioning_amd/lib/libvaecap_c2abl*.so > /dev/null 2>&1; then
+  (for n in 1 2 4 8 16; do echo "== C2_ABL=$n (1 split arithmetic, 2 window reads, 4 staging, 8 weight-fragment reads, 16 everything between the MFMAs, operands frozen: real data)"
+     VC_LIB=$ROOT/vae_captioning_amd/lib/libvaecap_c2abl$n.so python tools/microbench.py convbx2 2>/dev/null | grep -E "^conv|^sum" | sed -e "s/ | F(4x4.*//"; done) > $OUT/${TAG}_convbx2_ablation.txt
+fi
+rm -rf /tmp/kt_c4bx
+(cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/kt_c4bx -- python $ROOT/bench.py --precision bf16x3 --no-cpu-baseline --strong-n1 0 > $OUT/${TAG}_cfg4_bf16x3_kt.log 2>&1)
+python tools/rocpd_stats.py "$(find /tmp/kt_c4bx -name "*_results.db" | head -1)" 40 > $OUT/${TAG}_cfg4_bf16x3_kernel_stats.md
 # 7. per-layer tables: F(2x2,3x3) forward / data gradient and the F(3x3,2x2) weight gradient; F(4x4,3x3) against F(2x2,3x3) per layer
 #    (forward, data gradient with the float mask, data gradient with mask bits); LSTM recurrence steps (default, two workgroups per CU)
 python tools/microbench.py winoab winow 2>/dev/null | grep -v amdgpu.ids > $OUT/${TAG}_wino_layers.txt
