@@ -24,8 +24,8 @@
 // Image rows are stacked with ONE zero row between images (global row g = b (H + 1) + y): a block of eight rows may span two
 // images, and the 14- and 28-row layers lose 1 / (H + 1) of their rows instead of an eighth.  Columns come in sixteens (a 14-,
 // 28- or 56-wide layer carries 12.5 % dead k).
-// K is split over the blocks (workgroups = channel tiles x splits >= 256); every wave writes its raw sums to the workspace,
-// wgrad_bx_reduce_kernel adds the 2 x nsplit partials in fixed order (deterministic) and forms db from the raw f32 dy sums.
+// K is split over the blocks (workgroups = channel tiles x splits >= 256); the two row halves of a workgroup are added in the LDS, its raw
+// sums go to the workspace, wgrad_bx_reduce_kernel adds the nsplit partials in fixed order (deterministic) and forms db from the raw f32 dy sums.
 #include <stdlib.h>
 #include <type_traits>
 #include "conv_wino.h"
@@ -46,7 +46,7 @@ constexpr int WB_LDS_BYTES = 2 * WB_BUF * 4;   // 156 672
 struct WgBxArgs {
     const float* x;      // [B][C/4][H][W][4]
     const float* dy;     // [B][N/4][H][W][4]
-    float* ws;           // [2 nsplit][9][C][N] raw sums, then [2 nsplit][N] dy sums
+    float* ws;           // [nsplit][9][C][N] raw sums, then [2 nsplit][N] dy sums
     int B, H, W, C, N;
     int bx_n, nblocks, grows;   // blocks per block row; blocks; stacked rows B (H + 1) - 1
     unsigned m_bx_n, one_bx_n, m_h1;   // wino_magic of bx_n (one_bx_n = ~0u when bx_n == 1) and of H + 1
@@ -327,27 +327,50 @@ __global__ __launch_bounds__(256, 1) void wgrad_bx_kernel(WgBxArgs a) {
 #undef WSB
     asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
 
-    // ---- raw sums of this (split, row half): acc[ng][tap][r] = S[tap][c0 + 8 (r >> 2) + 4 lh + (r & 3)][n0 + 32 ng + li] ------------
+    // ---- the two row halves meet in the LDS (waves kh = 1 write their accumulators, waves kh = 0 add them: half the workspace traffic
+    // and half the reduce kernel's reads), then the raw sums of this split go out:
+    //   acc[ng][tap][r] = S[tap][c0 + 8 (r >> 2) + 4 lh + (r & 3)][n0 + 32 ng + li]
+    __syncthreads();   // every wave is behind its last LDS read
+    float4* xch = reinterpret_cast<float4*>(smem) + (size_t)cw * (2 * 9 * 4 * 64) + lane;   // [cw][ng][tap][register quad][lane] float4: 147 456 bytes
+    if (kh == 1) {
+#pragma unroll
+        for (int ng = 0; ng < 2; ++ng)
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    xch[((ng * 9 + t) * 4 + q) * 64] = make_float4(acc[ng][t][4 * q], acc[ng][t][4 * q + 1], acc[ng][t][4 * q + 2], acc[ng][t][4 * q + 3]);
+    }
+    __syncthreads();
     const int c0 = cb * 64 + cw * 32, n0 = nb * 64;
-    const long z = (long)split * 2 + kh;
-    float* o = a.ws + z * 9 * (long)C * N + n0 + li;
+    if (kh == 0) {
+        float* o = a.ws + (long)split * 9 * (long)C * N + n0 + li;
 #pragma unroll
-    for (int ng = 0; ng < 2; ++ng)
+        for (int ng = 0; ng < 2; ++ng)
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
+            for (int t = 0; t < 9; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[((long)t * C + c0 + 8 * (r >> 2) + 4 * lh + (r & 3)) * N + 32 * ng] = acc[ng][t][r];
-    if (cb == 0 && cw == 0) {
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = xch[((ng * 9 + t) * 4 + q) * 64];
+                    float* oq = o + ((long)t * C + c0 + 8 * q + 4 * lh) * N + 32 * ng;
+                    oq[0] = acc[ng][t][4 * q] + v.x;
+                    oq[N] = acc[ng][t][4 * q + 1] + v.y;
+                    oq[2 * (long)N] = acc[ng][t][4 * q + 2] + v.z;
+                    oq[3 * (long)N] = acc[ng][t][4 * q + 3] + v.w;
+                }
+    }
+    if (cb == 0 && cw == 0) {   // dy sums: one row of N per (split, row half)
+        const long z = (long)split * 2 + kh;
 #pragma unroll
         for (int ng = 0; ng < 2; ++ng) {
             float v = dbs[ng];
             v += __shfl_xor(v, 32, 64);
-            if (lh == 0) a.ws[(long)a.nsplit * 2 * 9 * C * N + z * N + n0 + 32 * ng + li] = v;
+            if (lh == 0) a.ws[(long)a.nsplit * 9 * C * N + z * N + n0 + 32 * ng + li] = v;
         }
     }
 }
 
-// dw (+)= sum of the 2 nsplit partials (fixed order); db likewise.  One float4 of [9][C][N] per thread.
+// dw (+)= sum of the nsplit partials (fixed order); db = sum of the 2 nsplit dy-sum rows.  One float4 of [9][C][N] per thread.
 __global__ __launch_bounds__(256) void wgrad_bx_reduce_kernel(const float* __restrict__ ws, int nz, long n4, int N, float* __restrict__ dw,
                                                               float* __restrict__ db, int accumulate) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -366,7 +389,7 @@ __global__ __launch_bounds__(256) void wgrad_bx_reduce_kernel(const float* __res
         if (j < N) {
             const float* bw = ws + (long)nz * n4 * 4;
             float v = 0.f;
-            for (int z = 0; z < nz; ++z) v += bw[(long)z * N + j];
+            for (int z = 0; z < 2 * nz; ++z) v += bw[(long)z * N + j];
             db[j] = accumulate ? db[j] + v : v;
         }
     }
@@ -399,7 +422,7 @@ static WgBxPlan plan_wgrad_bx(int B, int H, int W, int C, int N) {
 }
 
 static size_t wgrad_bx_ws(const WgBxPlan& p, int C, int N) {
-    return p.ok ? ((size_t)p.nsplit * 2 * 9 * C * N + (size_t)p.nsplit * 2 * N) * sizeof(float) : 0;
+    return p.ok ? ((size_t)p.nsplit * 9 * C * N + (size_t)p.nsplit * 2 * N) * sizeof(float) : 0;
 }
 
 static size_t wgrad_bx_ws_call(int B, int H, int W, int Cin, int Cout) {
@@ -455,7 +478,7 @@ extern "C" int vc_conv3x3_bx_wgrad_f32(void* stream, int B, int H, int W, int Ci
         if (rc) return rc;
         const long n4 = 9L * Cin * Cout / 4;
         const long nthreads = n4 + (db ? Cout : 0);
-        hipLaunchKernelGGL(wgrad_bx_reduce_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ws, 2 * p.nsplit, n4, Cout, dw,
+        hipLaunchKernelGGL(wgrad_bx_reduce_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ws, p.nsplit, n4, Cout, dw,
                            db, (accumulate || b0 > 0) ? 1 : 0);
         rc = launch_status(__func__);
         if (rc) return rc;
