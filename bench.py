@@ -560,7 +560,7 @@ def _cdiv(a, b):
     return (a + b - 1) // b
 
 
-def wino_executed_ratio(images, wino4=True):
+def wino_executed_ratio(images, wino4=True, with_wgrad=True):
     """Executed MFMA FLOPs / algorithmic FLOPs of one cfg4 step's 3x3 convolution calls when the Winograd kernels run (default):
     F(2x2,3x3) / F(3x3,2x2) multiply 16 times per 2x2 tile and channel pair where the direct form multiplies 36 times, F(4x4,3x3) 36
     times per 4x4 tile where the direct form multiplies 144 times; tile blocks that stick out of the image add padding work.  Forward /
@@ -577,8 +577,8 @@ def wino_executed_ratio(images, wino4=True):
         th = tw = H // 2
         fl = 2.0 * images * H * H * 9 * ci * co
         if ci == 3:
-            alg += 2 * fl
-            ex += 2 * fl
+            alg += (2 if with_wgrad else 1) * fl
+            ex += (2 if with_wgrad else 1) * fl
         else:
             best = 0.0   # forward / data gradient: the block shape with the fewest empty slots
             for tbw in range(1, min(16, tw) + 1):
@@ -589,8 +589,8 @@ def wino_executed_ratio(images, wino4=True):
             effw = max(tw * th / (_cdiv(tw, bw) * _cdiv(th, bh) * float(bh * bw)) for bh, bw in ((4, 8), (4, 7), (2, 14)))
             eff4 = H * H / (_cdiv(H, 4) ** 2 * 16.0) if _cdiv(images * _cdiv(H, 4) ** 2, 16) < images * _cdiv(H, 16) ** 2 else H * H / (_cdiv(H, 16) ** 2 * 256.0)   # linear tiles (csrc/conv_wino4.hip plan_wino4) / square blocks
             fd = (36.0 / 144.0) / eff4 if (wino4 and prefers4(images, H, H, ci, co)) else (16.0 / 36.0) / best
-            alg += 3 * fl
-            ex += 2 * fl * fd + fl * (16.0 / 36.0) / effw
+            alg += (3 if with_wgrad else 2) * fl
+            ex += 2 * fl * fd + (fl * (16.0 / 36.0) / effw if with_wgrad else 0.0)
         if name in spec.VGG_POOL_AFTER:
             H //= 2
     return ex / alg
@@ -610,8 +610,12 @@ def roofline_from_timer(timer, fine_tune, images=0, precision="f32"):
                                             the peak -- the Winograd kernels do the algorithm's work with 2.25x fewer multiplications (fp32)
     Both are recomputable from the tracked rocprofv3 summary of the same command (profiles/*_kernel_stats.md ends with the family's
     summed and union dispatch time, tools/rocpd_stats.py)."""
-    tags = ["conv_fwd", "conv_dgrad", "conv_wgrad"] if fine_tune else ["logits_gemm"]
+    # split-bf16 mode with VGG16 fine-tuning: the weight gradients run on the bf16 pipe (csrc/conv_wgrad_bx.hip) -- the f32 family is the
+    # F(4x4,3x3) forward / data gradient alone, the weight gradient is priced separately below ("wgrad_bf16_pipe")
+    bxw = bool(fine_tune) and precision == "bf16x3" and os.environ.get("VC_WGRAD_BX", "1") != "0" and os.environ.get("VC_CONV_WINO", "1") != "0"
+    tags = (["conv_fwd", "conv_dgrad"] if bxw else ["conv_fwd", "conv_dgrad", "conv_wgrad"]) if fine_tune else ["logits_gemm"]
     sm = timer.summary(family=tags)
+    wg = timer.summary(family=["conv_wgrad"]) if bxw else None
     fl = sum(sm[t]["flops"] for t in tags)
     sec = sm["__union__"]
     ser = sum(sm[t]["seconds"] for t in tags)
@@ -620,7 +624,7 @@ def roofline_from_timer(timer, fine_tune, images=0, precision="f32"):
     per = {t: dict(launches=sm[t]["launches"], avg_us=round(1e6 * sm[t]["seconds"] / sm[t]["launches"], 2),
                    tflops=round(sm[t]["flops"] / sm[t]["seconds"] / 1e12, 2)) for t in tags}
     wino = fine_tune and os.environ.get("VC_CONV_WINO", "1") != "0"
-    ratio = wino_executed_ratio(images) if (wino and images) else 1.0
+    ratio = wino_executed_ratio(images, with_wgrad=not bxw) if (wino and images) else 1.0
     if not fine_tune and precision == "bf16x3":
         # the logits product on the bf16 matrix pipe: three bf16 MFMAs per algorithmic MAC, priced against the dense bf16 peak
         return {"bound": "mfma", "kernel": "vc::gemm_bx_kernel<256x256,MK,KM> (logits; split-bf16: hi.hi + hi.lo + lo.hi)",
@@ -638,7 +642,20 @@ def roofline_from_timer(timer, fine_tune, images=0, precision="f32"):
     else:
         kern = "vc::conv_kernel<fwd|dgrad|wgrad> (NHWC implicit GEMM behind layout conversions: the checker path)"
     ex = ach * ratio
-    return {"bound": "mfma", "kernel": kern,
+    extra = {}
+    if bxw:
+        kern = ("vc::conv_wino4_kernel (Winograd F(4x4,3x3) forward / data gradient of conv1_2 ... conv5_3, f32; + vc::conv1_fwd_kernel) -- the weight "
+                "gradients of this mode run on the bf16 pipe: wgrad_bf16_pipe")
+        w = wg["conv_wgrad"]
+        extra["wgrad_bf16_pipe"] = {
+            "kernel": "vc::wgrad_bx_kernel (direct, split-bf16: three bf16 MFMAs per algorithmic MAC; + vc::conv1_wgrad_kernel for conv1_1, f32)",
+            "achieved": round(3 * w["flops"] / w["seconds"] / 1e12, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(3 * w["flops"] / w["seconds"] / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4), "effective_tflops": round(w["flops"] / w["seconds"] / 1e12, 2),
+            "launches": w["launches"], "avg_launch_us": round(1e6 * w["seconds"] / w["launches"], 2),
+            "note": "3 x algorithmic FLOPs of the weight-gradient calls / the SUM of their HIP-event durations (they run beside the data-gradient "
+                    "chains on another stream: a call's duration includes what it loses to them); DESIGN.md section 4d: on real data the bf16 "
+                    "pipe is power-limited to ~0.5 of this peak"}
+    return {**extra, "bound": "mfma", "kernel": kern,
             # achieved / frac: the FLOPs the MFMAs EXECUTE per second against the dense fp32 MFMA peak (a fraction of the roofline, < 1)
             "achieved": round(ex, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ex / PEAK_F32_MFMA_TFLOPS, 4),
             "frac_serial": round(fl * ratio / ser / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
