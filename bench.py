@@ -104,7 +104,7 @@ def cpu_baseline(workload, w, seed):
     rng = np.random.default_rng(seed)
     # cfg1 at its own batch (32); cfg2 / cfg3 on a reduced batch and step count; cfg4 measured at 8 images
     # (and, separately, extrapolated linearly to the 512-image global batch -- marked as extrapolated)
-    Bc, warm, nsteps = {"cfg1": (32, 1, 5), "cfg2": (32, 1, 4), "cfg3": (16, 1, 4), "cfg4": (8, 0, 2)}[workload]
+    Bc, warm, nsteps = {"cfg1": (32, 1, 5), "cfg2": (32, 1, 4), "cfg3": (16, 1, 4), "cfg4": (8, 1, 2)}[workload]   # (one warm-up step: the first one pays for page faults and BLAS thread start-up)
     P = spec.init_caption_params(p, VOCAB, seed=1)
     batch = synth.make_batch(rng, Bc, p.num_captions, T_LEN, VOCAB, use_ci=spec.uses_ci(p), images=p.fine_tune)
     noise = synth.make_noise(rng, Bc * p.num_captions, T_LEN, p)
