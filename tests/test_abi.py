@@ -116,6 +116,34 @@ def test_bench_executed_ratio_of_the_winograd_kernels():
             ex2 += 2 * fl * fd2[H] + fl * (16.0 / 36.0) / effw[H]
     assert abs(r - ex / alg) < 1e-9 and abs(r2 - ex2 / alg) < 1e-9
     assert 0.31 < r < 0.34 and 0.46 < r2 < 0.49
+    # split-bf16 mode: the weight gradients leave the f32 family (csrc/conv_wgrad_bx.hip prices them on the bf16 pipe) -- forward / data
+    # gradient alone: 0.25 everywhere but the 14 x 14 layers, conv1_1's forward direct
+    r3 = bench.wino_executed_ratio(64, with_wgrad=False)
+    alg3 = sum((1 if ci == 3 else 2) * H * H * 9.0 * ci * co for H, ci, co in layers)
+    ex3 = sum((1.0 if ci == 3 else 2 * fd[H]) * H * H * 9.0 * ci * co for H, ci, co in layers)
+    assert abs(r3 - ex3 / alg3) < 1e-9 and 0.25 < r3 < 0.27
+
+
+def test_plans_of_the_split_bf16_convolution_kernels(built):
+    """host-side plan functions of csrc/conv_wgrad_bx.hip and csrc/conv_bx2.hip (no device needed): which shapes they take and what the
+    weight gradient's workspace is -- [K splits][9][Cin][Cout] raw sums + two rows of dy sums per split, channel tiles x splits = one
+    workgroup per CU (256), blocks of eight stacked rows x sixteen columns"""
+    lib = built
+    for (B, H, ci, co) in [(64, 224, 64, 64), (64, 112, 128, 128), (64, 56, 256, 256), (32, 28, 512, 512), (64, 14, 512, 512), (1, 1, 64, 64)]:
+        assert lib.vc_conv3x3_bx_wgrad_supported(B, H, H, ci, co) == 1
+        tiles = (ci // 64) * (co // 64)
+        nblocks = -(-H // 16) * -(-(B * (H + 1) - 1) // 8)
+        ns = min(-(-256 // tiles), nblocks)
+        cps = -(-nblocks // ns)
+        nsplit = -(-nblocks // cps)
+        assert lib.vc_conv3x3_bx_wgrad_workspace_bytes(B, H, H, ci, co) == (nsplit * 9 * ci * co + 2 * nsplit * co) * 4
+        assert tiles * nsplit <= 256 or nblocks < 256
+    assert lib.vc_conv3x3_bx_wgrad_supported(8, 8, 8, 32, 64) == 0 and lib.vc_conv3x3_bx_wgrad_supported(8, 8, 8, 64, 32) == 0
+    assert lib.vc_conv3x3_bx_wgrad_supported(8, 0, 8, 64, 64) == 0 and lib.vc_conv3x3_bx_wgrad_workspace_bytes(8, 8, 8, 32, 64) == 0
+    assert lib.vc_conv3x3_bx2_supported(32, 56, 56, 256, 256, 0) == 1 and lib.vc_conv3x3_bx2_supported(32, 56, 56, 256, 256, 1) == 1
+    assert lib.vc_conv3x3_bx2_supported(32, 56, 56, 16, 64, 0) == 1 and lib.vc_conv3x3_bx2_supported(32, 56, 56, 16, 64, 1) == 0   # produced channels % 64
+    assert lib.vc_conv3x3_bx2_supported(32, 56, 56, 24, 64, 0) == 0
+    assert lib.vc_conv3x3_bx2_pack_bytes(256, 512) == 9 * 256 * 512 * 4 and lib.vc_conv3x3_bx2_pack_bytes(8, 64) == 0
 
 
 def test_bench_algorithmic_bytes_of_the_convolution_calls():
