@@ -328,7 +328,9 @@ __device__ __forceinline__ int rec_rot(int i, int rot) {
 // The contraction of one pass: acc[i][ct] += A[row0 + 16 i .., wave K range] . B, units u = sb*RT + i in order.
 // A: buffer resource over the row-major operand (rows past its end read as zeros), `pitch` bytes per row, kofs = byte offset of the
 // wave's K range in a row.  B: NSB == 1: resident fragments bres; else streamed from bp (1 KB per (sb, j), lane-linear).
-template <int NSB, int CT, int RT, bool BX = false>
+// CTS != 0: column tile ct of the streamed B operand lives CTS float4 behind tile 0 (two 16-unit slices of the backward pack, which is
+// laid out per slice), else the tiles of a sub-block are consecutive.
+template <int NSB, int CT, int RT, bool BX = false, int CTS = 0>
 __device__ __forceinline__ void rec_contract(f32x4 (&acc)[RT][CT], const __amdgpu_buffer_rsrc_t ra, const unsigned pitch, const int row0,
                                              const unsigned kofs, const float4 (&bres)[CT][8], const float4* __restrict__ bp, float* As,
                                              const int lane, const int rot) {
@@ -358,7 +360,7 @@ __device__ __forceinline__ void rec_contract(f32x4 (&acc)[RT][CT], const __amdgp
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) bs[sb & 1][ct][j] = bp[((sb * CT + ct) * 8 + j) * 64];
+                for (int j = 0; j < 8; ++j) bs[sb & 1][ct][j] = CTS ? bp[(sb * 8 + j) * 64 + ct * CTS] : bp[((sb * CT + ct) * 8 + j) * 64];
         }
     };
     // software pipeline: global loads run TWO units ahead of the MFMAs, the LDS round trip one unit ahead
@@ -538,30 +540,33 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_fwd_kernel(LstmFwdArgs a, con
     }
 }
 
-template <int RT, bool BX = false>
+// CT = 2: 32 hidden units (two 16-unit column tiles) per workgroup -- half the column slices, so half the re-reads of dG[t+1] through the
+// L2 (profiles/r05_lstm_pmc.md: what bounds the step at 1280 rows), and twice the MFMAs per staged row tile.
+template <int RT, bool BX = false, int CT = 1>
 __global__ __launch_bounds__(256, 1) void lstm_rec_bwd_kernel(LstmBwdArgs a, const float4* __restrict__ whp, int rows_wg) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int RP = 20;
+    constexpr int RP = 16 * CT + 4, UW = 16 * CT, QW = 4 * CT;   // partial-tile row pitch; units and unit quads per workgroup
+    static_assert(16 * RT * RP <= 2 * REC_TILE, "a wave's partial tile lives in its two staging tiles");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ug = blockIdx.x, N = a.N, rot = ug % RT;
     constexpr int H = 512, K = 4 * H;
-    constexpr int ITEMS = 64 * RT, ITERS = (ITEMS + 255) / 256;  // item: (row of the pass, four consecutive units of the 16)
+    constexpr int ITEMS = 64 * RT * CT, ITERS = (ITEMS + 255) / 256;  // item: (row of the pass, four consecutive units of the 16 CT)
     const int rbeg = blockIdx.y * rows_wg, rend = min(N, rbeg + rows_wg);
     REC_STAMP(0);
     const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)a.dG_next, 0, a.first ? 0 : N * K * 4, 0x00020000);
-    const float4* bp = whp + (size_t)(ug * 4 + wave) * (4 * 8 * 64) + lane;
+    const float4* bp = whp + (size_t)(ug * CT * 4 + wave) * (4 * 8 * 64) + lane;   // (slice ug * CT; slice ug * CT + 1 lies 4 x 2048 float4 behind)
     float* As = smem + wave * (2 * REC_TILE);
-    const float4 nob[1][8] = {};
+    const float4 nob[CT][8] = {};
     struct Item {
         float4 ac[4], cc, cpv, dc, dh, ext;
         int len;
     };
     for (int row0 = rbeg; row0 < rend; row0 += 16 * RT) {
-        auto item_ok = [&](int it) { return tid + 256 * it < ITEMS && row0 + ((tid + 256 * it) >> 2) < rend; };
+        auto item_ok = [&](int it) { return tid + 256 * it < ITEMS && row0 + (tid + 256 * it) / QW < rend; };
         auto fetch = [&](int it, Item& m) {
-            const int p = tid + 256 * it, row = min(row0 + (p >> 2), N - 1);  // (clamped: threads without an item load a valid row)
-            const long si = (long)row * H + ug * 16 + 4 * (p & 3);
-            const float* ac = a.act + (long)row * 4 * H + ug * 16 + 4 * (p & 3);
+            const int p = tid + 256 * it, row = min(row0 + p / QW, N - 1);  // (clamped: threads without an item load a valid row)
+            const long si = (long)row * H + ug * UW + 4 * (p % QW);
+            const float* ac = a.act + (long)row * 4 * H + ug * UW + 4 * (p % QW);
 #pragma unroll
             for (int g = 0; g < 4; ++g) m.ac[g] = ld4(ac + g * H);
             m.cc = ld4(a.c_cur + si);
@@ -572,14 +577,14 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_bwd_kernel(LstmBwdArgs a, con
             m.len = a.lens[row];
         };
         auto finish = [&](int it, Item& m) {
-            const int p = tid + 256 * it, rr = p >> 2, row = row0 + rr;
-            const long si = (long)row * H + ug * 16 + 4 * (p & 3);
+            const int p = tid + 256 * it, rr = p / QW, row = row0 + rr;
+            const long si = (long)row * H + ug * UW + 4 * (p % QW);
             float4 dh = m.dh;
             if (!a.first && (a.t + 1 < m.len)) {  // step t+1 was active: its recurrent gradient replaces the carried one
                 float4 s = f4zero();
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {  // fixed order
-                    const float4 v = ld4(smem + w * (2 * REC_TILE) + rr * RP + 4 * (p & 3));
+                    const float4 v = ld4(smem + w * (2 * REC_TILE) + rr * RP + 4 * (p % QW));
                     s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
                 }
                 dh = s;
@@ -604,7 +609,7 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_bwd_kernel(LstmBwdArgs a, con
                 }
                 st4(a.dC_run + si, dcn);
             }
-            float* dgp = a.dG + (long)row * 4 * H + ug * 16 + 4 * (p & 3);
+            float* dgp = a.dG + (long)row * 4 * H + ug * UW + 4 * (p % QW);
 #pragma unroll
             for (int g = 0; g < 4; ++g) st4(dgp + g * H, dg[g]);
         };
@@ -612,12 +617,14 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_bwd_kernel(LstmBwdArgs a, con
         const bool ok0 = item_ok(0);
         fetch(0, m0);
         if (!a.first) {
-            f32x4 acc[RT][1];
+            f32x4 acc[RT][CT];
 #pragma unroll
-            for (int i = 0; i < RT; ++i) acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) acc[i][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (row0 != rbeg) __syncthreads();
-            rec_contract<4, 1, RT, BX>(acc, rg, K * 4, row0, wave * 2048, nob, bp, As, lane, rot);
-            rec_spill<1, RT, RP>(acc, As, lane, rot);
+            rec_contract<4, CT, RT, BX, CT == 1 ? 0 : 4 * 4 * 8 * 64>(acc, rg, K * 4, row0, wave * 2048, nob, bp, As, lane, rot);
+            rec_spill<CT, RT, RP>(acc, As, lane, rot);
             REC_STAMP(28);
             __syncthreads();
             REC_STAMP(29);
@@ -901,8 +908,24 @@ static int rec8_fwd(hipStream_t st, const LstmFwdArgs& a, const float* whp, bool
 }
 
 static int rec_bwd(hipStream_t st, const LstmBwdArgs& a, const float* whp, bool bx = false) {
-    static int once = rec_lds(lstm_rec_bwd_kernel<5>) | rec_lds(lstm_rec_bwd_kernel<3>) | rec_lds(lstm_rec_bwd_kernel<5, true>) | rec_lds(lstm_rec_bwd_kernel<3, true>);
+    static int once = rec_lds(lstm_rec_bwd_kernel<5>) | rec_lds(lstm_rec_bwd_kernel<3>) | rec_lds(lstm_rec_bwd_kernel<5, true>) | rec_lds(lstm_rec_bwd_kernel<3, true>) |
+                      rec_lds(lstm_rec_bwd_kernel<5, false, 2>) | rec_lds(lstm_rec_bwd_kernel<5, true, 2>) | rec_lds(lstm_rec_bwd_kernel<3, false, 2>) | rec_lds(lstm_rec_bwd_kernel<3, true, 2>);
     if (once) return once;
+    // many rows: 32 units per workgroup (16 column slices x 16 row groups at 1280 rows: ONE pass of five row tiles per workgroup instead
+    // of two, each dG[t+1] row read by 16 workgroups instead of 32); VC_LSTM_BWD_CT2_ROWS: from how many rows on (0: never)
+    static const int ct2_rows = lstm_env("VC_LSTM_BWD_CT2_ROWS", 600);
+    if (ct2_rows > 0 && a.N >= ct2_rows) {
+        const int RG = rec_row_groups(a.N, 16), rows = cdiv(a.N, RG);
+        const dim3 g(16, RG);
+        if (rows > 48) {
+            if (bx) hipLaunchKernelGGL((lstm_rec_bwd_kernel<5, true, 2>), g, dim3(256), REC_LDS_BYTES, st, a, (const float4*)whp, rows);
+            else hipLaunchKernelGGL((lstm_rec_bwd_kernel<5, false, 2>), g, dim3(256), REC_LDS_BYTES, st, a, (const float4*)whp, rows);
+        } else {
+            if (bx) hipLaunchKernelGGL((lstm_rec_bwd_kernel<3, true, 2>), g, dim3(256), REC_LDS_BYTES, st, a, (const float4*)whp, rows);
+            else hipLaunchKernelGGL((lstm_rec_bwd_kernel<3, false, 2>), g, dim3(256), REC_LDS_BYTES, st, a, (const float4*)whp, rows);
+        }
+        return launch_status("lstm rec bwd");
+    }
     const int RG = rec_row_groups(a.N, 32), rows = cdiv(a.N, RG);
     const dim3 g(32, RG);
     if (rows > 48) {
