@@ -66,9 +66,8 @@ def test_bx_wgrad_error_is_split_bf16_not_bf16(lib):
     assert rel.max() < 2e-5, rel.max()
 
 
-def test_bx_wgrad_splits_and_image_ranges(lib, monkeypatch):
-    """more K splits than the default (VC_WGBX_GRID is read once per process: the default plan here) and a call cut into image ranges
-    (VC_WINO_MAX_BYTES is read once too -- so this test drives the range loop through a large batch of a small layer instead)"""
+def test_bx_wgrad_many_images_of_a_small_layer(lib):
+    """forty images of a 6 x 10 layer: 35 blocks of stacked rows, most of them spanning two images, more K splits than blocks per split"""
     B, H, W, Ci, Co = 40, 6, 10, 64, 64
     rng = np.random.default_rng(9)
     x = np.maximum(rng.standard_normal((B, H, W, Ci), dtype=np.float32), 0)
@@ -77,6 +76,48 @@ def test_bx_wgrad_splits_and_image_ranges(lib, monkeypatch):
     dw, db = _run(lib, x, dy)
     assert_close(host(dw), dwref, _tol(B, H, W), msg="bx wgrad, 40 images")
     assert_close(host(db), dbref, 3e-6 * np.sqrt(B * H * W) + 1e-6, msg="bx wgrad, 40 images: bias gradient")
+
+
+def test_bx_wgrad_calls_over_the_launch_limit_are_cut_into_image_ranges(tmp_path):
+    """32-bit buffer offsets (< 2 GiB per launch): a call on more images runs as launches over image ranges that accumulate into dw / db.
+    VC_WINO_MAX_BYTES forces that on a small shape (a fresh process: the limit is read once); equal to the single launch up to the
+    summation order of the ranges, and to the f32 Winograd kernel's result on the same cut."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "run.py"
+    script.write_text(
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from vae_captioning_amd import abi\n"
+        "from vae_captioning_amd.abi import ptr as P\n"
+        "lib = abi.load(); st = torch.cuda.current_stream().cuda_stream\n"
+        "B, H, W, Ci, Co = 5, 8, 16, 64, 64\n"
+        "g = torch.Generator(device='cuda').manual_seed(1)\n"
+        "x = torch.rand(B, Ci // 4, H, W, 4, device='cuda', generator=g); dy = torch.rand(B, Co // 4, H, W, 4, device='cuda', generator=g) - 0.5\n"
+        "out = {}\n"
+        "for name in ('bx', 'wino'):\n"
+        "    dw = torch.zeros(3, 3, Ci, Co, device='cuda'); db = torch.zeros(Co, device='cuda')\n"
+        "    ws = torch.empty(getattr(lib, 'vc_conv3x3_%%s_wgrad_workspace_bytes' %% name)(B, H, W, Ci, Co) // 4 + 4, device='cuda')\n"
+        "    getattr(lib, 'vc_conv3x3_%%s_wgrad_f32' %% name)(st, B, H, W, Ci, Co, P(x), P(dy), P(dw), P(db), 0, P(ws), ws.numel() * 4)\n"
+        "    torch.cuda.synchronize()\n"
+        "    out['dw_' + name] = dw.cpu().numpy(); out['db_' + name] = db.cpu().numpy()\n"
+        "np.savez(sys.argv[1], **out)\n" % root)
+    out = {}
+    for tag, cap in (("one", None), ("cut", str(2 * 8 * 16 * 64 * 4))):   # cut: two images per launch -> ranges of 2, 2, 1
+        env = dict(os.environ)
+        env.pop("VC_WINO_MAX_BYTES", None)
+        if cap:
+            env["VC_WINO_MAX_BYTES"] = cap
+        f = str(tmp_path / (tag + ".npz"))
+        r = subprocess.run([sys.executable, str(script), f], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[tag] = np.load(f)
+    scale = np.abs(out["one"]["dw_wino"]).max()
+    assert np.abs(out["one"]["dw_bx"] - out["cut"]["dw_bx"]).max() <= 1e-5 * scale
+    assert np.abs(out["one"]["db_bx"] - out["cut"]["db_bx"]).max() <= 1e-5 * np.abs(out["one"]["db_bx"]).max()
+    assert np.abs(out["cut"]["dw_bx"] - out["cut"]["dw_wino"]).max() <= 5e-5 * scale
 
 
 def test_bx_wgrad_rejects_what_it_cannot_tile(lib):
