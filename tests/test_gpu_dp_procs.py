@@ -31,7 +31,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STEPS = 2
 
 
-def _spawn(case, q1_mode, outdir):
+def _spawn(case, q1_mode, outdir, extra_env=None):
     import socket
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -39,6 +39,7 @@ def _spawn(case, q1_mode, outdir):
     s.close()
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env.update(PYTHONPATH=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4")
+    env.update(extra_env or {})
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "dp_worker.py"), case, q1_mode, str(STEPS), str(outdir)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
@@ -109,6 +110,32 @@ def test_two_processes_train_like_one(lib, tmp_path, case, q1_mode):
     one, p = _single(lib, case)
     l2, l1 = ranks[0]["#losses"], one["#losses"]   # rows: steps; columns kld, rec_loss, lower_bound, annealing
     np.testing.assert_allclose(l2[:, :3], l1[:, :3], rtol=2e-4, atol=1e-6)
+    for k in ranks[0]:
+        if k.startswith("#") or k.endswith("#sum"):
+            continue
+        lr = p.cnn_lr if k.startswith("cnn/") else p.learning_rate
+        d = np.abs(ranks[0][k].astype(np.float64) - one[k]).max()
+        assert d <= 2.5 * lr * STEPS, (k, d)
+
+
+def test_two_processes_in_the_split_bf16_mode(lib, tmp_path, monkeypatch):
+    """the fine-tune case once more with VC_PRECISION=bf16x3 in both ranks: dense products, recurrences and the VGG16 weight gradients
+    (csrc/conv_wgrad_bx.hip, feeding the four asynchronous gradient buckets from the weight-gradient stream) on the bf16 pipe -- the
+    replicas stay bit-identical, two processes equal two threads bit for bit, and the result stays within Adam's sign noise of ONE
+    process on the global batch in the same mode"""
+    monkeypatch.setenv("VC_PRECISION", "bf16x3")
+    try:
+        ranks = _spawn("fine_tune", "global", tmp_path, {"VC_PRECISION": "bf16x3"})
+        for k in ranks[0]:
+            np.testing.assert_array_equal(ranks[0][k], ranks[1][k], err_msg="replicas differ: " + k)
+        emu = _threads(lib, "fine_tune", "global")
+        assert lib.vc_gemm_get_precision() == 1
+        for k in ranks[0]:
+            np.testing.assert_array_equal(ranks[0][k], emu[0][k], err_msg="two processes != two threads: " + k)
+        one, p = _single(lib, "fine_tune")
+    finally:
+        lib.vc_gemm_set_precision(0)
+    np.testing.assert_allclose(ranks[0]["#losses"][:, :3], one["#losses"][:, :3], rtol=5e-4, atol=1e-6)
     for k in ranks[0]:
         if k.startswith("#") or k.endswith("#sum"):
             continue
