@@ -390,18 +390,6 @@ int vc_conv3x3_bx2_fwd_f32(void* stream, int B, int H, int W, int Cin, int Cout,
 int vc_conv3x3_bx2_dgrad_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* dy, const void* wpt, const float* relu_src,
                              float* dx);
 
-/* PROTOTYPE, not used by the trainer (csrc/conv_wino4r.hip): Winograd F(4x4,3x3) forward / data gradient in f32 with one wave per SIMD,
- * accumulators for all 36 positions in registers and the input transform in registers -- the same arithmetic class as vc_conv3x3_wino4_*
- * (f32 MFMAs, f32 transforms), no fused pool / mask bits.  Its own packed weight format (pack: contraction channels % 8 == 0, produced
- * channels % 32 == 0); any H, W >= 1. */
-int vc_conv3x3_wino4r_supported(int B, int H, int W, int Cin, int Cout, int dgrad);
-size_t vc_conv3x3_wino4r_pack_bytes(int Cin, int Cout);
-int vc_conv3x3_wino4r_pack_f32(void* stream, int Cin, int Cout, const float* w, int transpose, float* wp);
-int vc_conv3x3_wino4r_fwd_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const float* wp, const float* bias,
-                              float* y, int relu);
-int vc_conv3x3_wino4r_dgrad_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* dy, const float* wpt, const float* relu_src,
-                                float* dx);
-
 /* DIRECT 3x3 weight gradient on the bf16 matrix pipe (csrc/conv_wgrad_bx.hip; backward of tf.nn.conv2d w.r.t. the filter,
  * utils/image_embeddings.py:36-212, in the split-bf16 arithmetic of vc_gemm_bf16x3_f32 -- the opt-in mode of Trainer(precision="bf16x3")).
  * The contraction runs over the pixels; both operands are split in registers.  Same contract as vc_conv3x3_wino_wgrad_f32 (db != NULL also
