@@ -367,7 +367,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1000 * dt / args.steps, 3),
         "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-        "dtype": "f32" if args.precision == "f32" else ("bf16x3 split operands, f32 accumulate (dense products; " + ("convolutions, " if p.fine_tune else "") + "recurrences and element-wise work in f32)"),
+        "dtype": "f32" if args.precision == "f32" else ("bf16x3 split operands, f32 accumulate (dense products, LSTM recurrence products" + (", VGG16 weight gradients; forward / data-gradient convolutions f32 Winograd" if p.fine_tune else "") + "; element-wise work in f32)"),
         "data": "synthetic",
         "config": {"workload": "%s: %s" % (args.workload, json.dumps(w, sort_keys=True)), "images_per_gpu": B, "precision": args.precision,
                    "captions_per_image": p.num_captions, "caption_rows_per_gpu": N, "global_caption_rows": N * world,
