@@ -24,13 +24,19 @@ extern "C" {
 #endif
 
 /* ABI history (binders gate on vc_abi_version(); a mismatch is a LAYOUT break, not just a symbol break):
+ *   4  precision and step-kernel choice are PER CALL: vc_gemm_f32 takes VC_GEMM_BF16X3 in `flags`; vc_lstm_seq_fwd_f32 / _bwd_f32 /
+ *      _bwd_data_f32 / _bwd_weights_f32 gained a trailing `int flags` (VC_LSTM_BF16X3, VC_LSTM_KERNELS(k)): a v3 binder would pass one
+ *      argument too few.  vc_gemm_set_precision / vc_lstm_set_mode remain as DEPRECATED process-wide defaults for calls that pass no
+ *      choice of their own (the product path never calls them: two trainers of different precision coexist in one process).  Gone: the
+ *      direct split-bf16 forward / data-gradient convolutions (vc_conv3x3_bx_* except the weight gradient, vc_conv3x3_bx2_*), which no
+ *      product path called.  New: the F(4x4,3x3) convolution with a pre-transformed input (vc_conv3x3_wino4v_*).
  *   3  the 3x3-convolution family (vc_conv3x3_wino_*, vc_conv3x3_wino4_*, vc_conv3x3_wino_wgrad_*, vc_conv1_fwd* / vc_conv1_wgrad*,
  *      vc_maxpool2x2_bwd_bits_f32) takes and returns activations in the C4 layout [B][C/4][H][W][4] (v2: NHWC) and the pool routing
  *      codes / ReLU mask bits follow it; the vc_conv3x3_patch_*, vc_conv3x3_pack_f32, *_packed_f32 and wgrad_patch_* entries of v2 are
  *      gone.  A v2 binder would link and compute wrong numbers: it must refuse to run against a v3 library.  New in 3: the split-bf16
  *      products (vc_gemm_bf16x3_*), vc_vgg_preprocess_u8.
  *   2  round-3 surface (NHWC convolutions).  */
-#define VC_ABI_VERSION 3
+#define VC_ABI_VERSION 4
 int vc_abi_version(void);
 const char* vc_last_error(void);
 /* 0 if a gfx950 device is usable from this process, else an error code. */
@@ -54,6 +60,7 @@ int vc_trace_pop(void);
  * ---------------------------------------------------------------------------------- */
 #define VC_GEMM_RELU 1
 #define VC_GEMM_ACCUMULATE 2
+#define VC_GEMM_BF16X3 4 /* this call on the bf16 matrix pipe with split operands (see vc_gemm_bf16x3_f32) */
 size_t vc_gemm_workspace_bytes(int M, int N, int K);
 int vc_gemm_f32(void* stream, int ta, int tb, int M, int N, int K, const float* A, long lda, const float* B,
                 long ldb, float* C, long ldc, const float* bias, int flags, float* ws, size_t ws_bytes);
@@ -61,8 +68,9 @@ int vc_gemm_f32(void* stream, int ta, int tb, int M, int N, int K, const float* 
  * into the LDS, three v_mfma_f32_32x32x16_bf16 products (hi.hi + hi.lo + lo.hi) accumulate in f32.  Same arguments, tile plan,
  * workspace and summation structure as vc_gemm_f32; |error| <= ~1e-5 of sum |a.b| (tests/test_gpu_bf16x3.py) instead of ~1e-7.
  * NOT the reference's arithmetic (tf.float32 matmul, main.py / vae_model/decoder.py:126-129): an opt-in mode, reported separately.
- * vc_gemm_set_precision(1) makes every vc_gemm_f32 call of the process (and the GEMMs inside vc_lstm_seq_*) take this path;
- * 0 (default) = f32 MFMA. */
+ * Per call: vc_gemm_f32 with VC_GEMM_BF16X3 in `flags` == this entry.  DEPRECATED: vc_gemm_set_precision(1) makes every vc_gemm_f32 /
+ * vc_lstm_seq_* call of the process that carries no flag of its own take this path (0, the default = f32 MFMA); process-wide state,
+ * not thread-safe, kept for ABI-3 callers only. */
 int vc_gemm_bf16x3_f32(void* stream, int ta, int tb, int M, int N, int K, const float* A, long lda, const float* B,
                        long ldb, float* C, long ldc, const float* bias, int flags, float* ws, size_t ws_bytes);
 int vc_gemm_set_precision(int mode);
@@ -111,12 +119,18 @@ int vc_lstm_step_fwd_f32(void* stream, int N, int H, int t, const float* h_prev,
 int vc_lstm_step_bwd_f32(void* stream, int N, int H, int t, int first, const float* dG_next, const float* Wh,
                          const int32_t* lens_eff, const float* dh_ext, float* dH_run, float* dC_run, const float* act,
                          const float* c_prev, const float* c_cur, float* dG);
-/* Sequence drivers, process-wide switch for A/B measurements (identical arithmetic up to fp32 summation order and, in the
+/* Sequence drivers: `flags` of the vc_lstm_seq_* calls = VC_LSTM_KERNELS(k) | VC_LSTM_BF16X3.
+ *   VC_LSTM_BF16X3   the call's products (input projection, recurrence, data / weight gradients) in the split-bf16 arithmetic of
+ *                    vc_gemm_bf16x3_f32 (an opt-in mode, NOT the reference's tf.float32 LSTMCell)
+ *   VC_LSTM_KERNELS(k), k = 0..3: which step kernels run (0 in the low bits = the default, auto); the numbering is vc_lstm_set_mode's.
+ * vc_lstm_set_mode is the DEPRECATED process-wide default for calls whose flags choose nothing (identical arithmetic up to fp32 summation order and, in the
  * recurrence kernels, sigmoid / tanh built from v_exp_f32 + v_rcp_f32, |error| < 3e-7):
  * 2 (default) = auto: the register-operand recurrence step kernels (one workgroup per CU, four waves split K, Wh slice packed
  * in MFMA-operand order, 16x16x4 tiles, gate math in the epilogue; above 400 rows the forward uses eight waves on 16-unit slices)
  * when H == 512, otherwise 1; 1 = recurrent GEMM via vc_gemm_f32 (split-K) + element-wise gate kernels; 3 = recurrence kernels wherever
  * supported; 0 = the round-1 fused step kernels. */
+#define VC_LSTM_BF16X3 0x10
+#define VC_LSTM_KERNELS(k) ((k) + 1)
 int vc_lstm_set_mode(int split);
 /* Single steps on the recurrence kernel for callers that advance one token at a time with fixed weights (generation: greedy /
  * sampling / beam search, vae_model/decoder.py:145-320): pack Wh [H,4H] once into whp (2 * H * 4H floats: the operand orders of
@@ -127,19 +141,19 @@ int vc_lstm_step_fwd_packed_f32(void* stream, int N, int H, int t, const float* 
                                 float* gact, const int32_t* lens_eff, float* c_out, float* h_out);
 size_t vc_lstm_seq_workspace_bytes(int T, int N, int E, int H);
 int vc_lstm_seq_fwd_f32(void* stream, int T, int N, int E, int H, const float* X, const float* W, const float* b,
-                        const int32_t* lens_eff, float* act, float* cs, float* hs, float* ws, size_t ws_bytes);
+                        const int32_t* lens_eff, float* act, float* cs, float* hs, float* ws, size_t ws_bytes, int flags);
 int vc_lstm_seq_bwd_f32(void* stream, int T, int N, int E, int H, const float* X, const float* W, const int32_t* lens_eff,
                         const float* act, const float* cs, const float* hs, const float* dhs_ext, float* dH_run,
-                        float* dC_run, float* dG, float* dX, float* dW, float* db, float* ws, size_t ws_bytes);
+                        float* dC_run, float* dG, float* dX, float* dW, float* db, float* ws, size_t ws_bytes, int flags);
 /* The backward pass in two calls (vc_lstm_seq_bwd_f32 = the first followed by the second on one stream): the recurrence with
  * dX = dG.Wx^T, which is all the gradient chain below the LSTM waits for, and the weight gradients dWx = X^T.dG, dWh = hs[0:T]^T.dG,
  * db = colsum(dG) from the dG the first call left -- tf.gradients has no consumer for them before the optimiser
  * (ops/optimizers.py:13-16), so a caller may enqueue the second call on another stream with its own workspace. */
 int vc_lstm_seq_bwd_data_f32(void* stream, int T, int N, int E, int H, const float* W, const int32_t* lens_eff, const float* act,
                              const float* cs, const float* dhs_ext, float* dH_run, float* dC_run, float* dG, float* dX, float* ws,
-                             size_t ws_bytes);
+                             size_t ws_bytes, int flags);
 int vc_lstm_seq_bwd_weights_f32(void* stream, int T, int N, int E, int H, const float* X, const float* hs, const float* dG, float* dW,
-                                float* db, float* ws, size_t ws_bytes);
+                                float* db, float* ws, size_t ws_bytes, int flags);
 
 /* ------------------------------------------------------------------------------------
  * Masked sparse softmax cross-entropy, main.py:152-158.  In place: `logits` [rows, V] (ld)
@@ -361,34 +375,6 @@ int vc_conv3x3_wino_wgrad_supported(int B, int H, int W, int Cin, int Cout);
 size_t vc_conv3x3_wino_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
 int vc_conv3x3_wino_wgrad_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const float* dy, float* dw,
                               float* db, int accumulate, float* ws, size_t ws_bytes);
-
-/* DIRECT 3x3 convolution on the bf16 matrix pipe ("bf16x3"; csrc/conv_bx.hip): forward and data gradient of utils/image_embeddings.py:36-212
- * with split-bf16 operands (a = a_hi + a_lo; hi.hi + hi.lo + lo.hi, f32 accumulate: the arithmetic of vc_gemm_bf16x3_f32) -- NOT the
- * reference's tf.float32 conv2d: the opt-in mode of Trainer(precision="bf16x3"), reported separately.  Activations: the C4 layout, f32.
- *   pack   w [3,3,Cin,Cout] HWIO -> wp (vc_conv3x3_bx_pack_bytes): the weights split once, in the LDS image order of the kernel;
- *          transpose = 1: the data gradient's copy (rows = Cin, taps flipped).  Cin % 32 == 0, Cout % 32 == 0, produced channels % 64 == 0.
- *   fwd    y = relu?(conv(x, w) + bias)          (bias may be NULL)
- *   dgrad  dx = conv^T(dy, w) (.) (relu_src > 0)  (relu_src: the activation that fed the layer, layout of dx, or NULL)
- * No fused pool / mask bits: callers use vc_maxpool2x2_fwd_f32 / vc_maxpool2x2_bwd_f32 on the C4 planes. */
-int vc_conv3x3_bx_supported(int B, int H, int W, int Cin, int Cout, int dgrad);
-size_t vc_conv3x3_bx_pack_bytes(int Cin, int Cout);
-int vc_conv3x3_bx_pack_f32(void* stream, int Cin, int Cout, const float* w, int transpose, void* wp);
-int vc_conv3x3_bx_fwd_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const void* wp, const float* bias,
-                          float* y, int relu);
-int vc_conv3x3_bx_dgrad_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* dy, const void* wpt, const float* relu_src,
-                            float* dx);
-
-/* The same two operations with the activation operand split IN REGISTERS (csrc/conv_bx2.hip): four waves of 512 registers, the weights of a
- * k-step (16 contraction channels x 9 taps x 64 produced channels) resident, one barrier per k-step.  Same contracts as vc_conv3x3_bx_*;
- * its own packed weight format (pack: contraction channels % 16 == 0, produced channels % 64 == 0).  What Trainer(precision="bf16x3")
- * runs when VC_CONV_BX2 is on. */
-int vc_conv3x3_bx2_supported(int B, int H, int W, int Cin, int Cout, int dgrad);
-size_t vc_conv3x3_bx2_pack_bytes(int Cin, int Cout);
-int vc_conv3x3_bx2_pack_f32(void* stream, int Cin, int Cout, const float* w, int transpose, void* wp);
-int vc_conv3x3_bx2_fwd_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const void* wp, const float* bias,
-                           float* y, int relu);
-int vc_conv3x3_bx2_dgrad_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* dy, const void* wpt, const float* relu_src,
-                             float* dx);
 
 /* DIRECT 3x3 weight gradient on the bf16 matrix pipe (csrc/conv_wgrad_bx.hip; backward of tf.nn.conv2d w.r.t. the filter,
  * utils/image_embeddings.py:36-212, in the split-bf16 arithmetic of vc_gemm_bf16x3_f32 -- the opt-in mode of Trainer(precision="bf16x3")).

@@ -32,7 +32,7 @@ def test_every_prototype_maps_to_ctypes(built):
 
 
 def test_version_and_error_paths(built):
-    assert built.vc_abi_version() == 3
+    assert built.vc_abi_version() == 4
     assert built.vc_sumsq_blocks() > 0
     assert built.vc_gemm_workspace_bytes(1280, 256, 15000) > 0
     assert built.vc_gemm_workspace_bytes(25600, 10000, 512) == 0
@@ -125,8 +125,8 @@ def test_bench_executed_ratio_of_the_winograd_kernels():
 
 
 def test_plans_of_the_split_bf16_convolution_kernels(built):
-    """host-side plan functions of csrc/conv_wgrad_bx.hip and csrc/conv_bx2.hip (no device needed): which shapes they take and what the
-    weight gradient's workspace is -- [K splits][9][Cin][Cout] raw sums + two rows of dy sums per split, channel tiles x splits = one
+    """host-side plan functions of csrc/conv_wgrad_bx.hip (no device needed): which shapes it takes and what its
+    workspace is -- [K splits][9][Cin][Cout] raw sums + two rows of dy sums per split, channel tiles x splits = one
     workgroup per CU (256), blocks of eight stacked rows x sixteen columns"""
     lib = built
     for (B, H, ci, co) in [(64, 224, 64, 64), (64, 112, 128, 128), (64, 56, 256, 256), (32, 28, 512, 512), (64, 14, 512, 512), (1, 1, 64, 64)]:
@@ -140,10 +140,6 @@ def test_plans_of_the_split_bf16_convolution_kernels(built):
         assert tiles * nsplit <= 256 or nblocks < 256
     assert lib.vc_conv3x3_bx_wgrad_supported(8, 8, 8, 32, 64) == 0 and lib.vc_conv3x3_bx_wgrad_supported(8, 8, 8, 64, 32) == 0
     assert lib.vc_conv3x3_bx_wgrad_supported(8, 0, 8, 64, 64) == 0 and lib.vc_conv3x3_bx_wgrad_workspace_bytes(8, 8, 8, 32, 64) == 0
-    assert lib.vc_conv3x3_bx2_supported(32, 56, 56, 256, 256, 0) == 1 and lib.vc_conv3x3_bx2_supported(32, 56, 56, 256, 256, 1) == 1
-    assert lib.vc_conv3x3_bx2_supported(32, 56, 56, 16, 64, 0) == 1 and lib.vc_conv3x3_bx2_supported(32, 56, 56, 16, 64, 1) == 0   # produced channels % 64
-    assert lib.vc_conv3x3_bx2_supported(32, 56, 56, 24, 64, 0) == 0
-    assert lib.vc_conv3x3_bx2_pack_bytes(256, 512) == 9 * 256 * 512 * 4 and lib.vc_conv3x3_bx2_pack_bytes(8, 64) == 0
 
 
 def test_bench_algorithmic_bytes_of_the_convolution_calls():

@@ -1,4 +1,5 @@
-"""-m gpu: the split-bf16 ("bf16x3") products -- vc_gemm_bf16x3_f32 and, through vc_gemm_set_precision(1), every GEMM of the step.
+"""-m gpu: the split-bf16 ("bf16x3") products -- vc_gemm_bf16x3_f32 == vc_gemm_f32 with VC_GEMM_BF16X3, VC_LSTM_BF16X3 on the
+sequence calls, Trainer(precision="bf16x3") on a whole step.  The mode is carried PER CALL (ABI 4): no test here restores anything.
 
 NOT the reference's arithmetic (tf.float32 matmul): an opt-in mode reported on its own bench lines.  What it is held to:
   * every storage-order / tile-plan / split-K / flag combination the f32 kernel is tested on, against the fp64 product, with the
@@ -82,30 +83,83 @@ def test_bf16x3_is_much_closer_than_plain_bf16_and_handles_wide_dynamic_range(li
     assert np.median(rel) * 50 < np.median(plain)
 
 
-def test_precision_switch_routes_vc_gemm_f32_and_restores(lib):
+def test_precision_is_a_flag_of_the_call_and_the_deprecated_global_is_only_a_default(lib):
     M, N, K = 384, 256, 512
     rng = np.random.default_rng(8)
     A, B = rng.standard_normal((M, K), dtype=np.float32), rng.standard_normal((K, N), dtype=np.float32)
     dA, dB = dev(A), dev(B)
     ws = empty_bytes(lib.vc_gemm_workspace_bytes(M, N, K))
-    out = {}
+
+    def run(fn, flags):
+        C = zeros(M, N)
+        fn(stream(), 0, 0, M, N, K, P(dA), K, P(dB), N, P(C), N, None, flags, P(ws), ws.numel() * 4)
+        return host(C).copy()
+    f32, flag, entry = run(lib.vc_gemm_f32, 0), run(lib.vc_gemm_f32, 4), run(lib.vc_gemm_bf16x3_f32, 0)   # 4 = VC_GEMM_BF16X3
+    assert np.array_equal(flag, entry) and not np.array_equal(f32, flag)
+    ref = A.astype(np.float64) @ B.astype(np.float64)
+    assert np.abs(f32 - ref).max() < np.abs(flag - ref).max() < TOL * np.abs(ref).max()
+    # the ABI-3 shim: a process-wide DEFAULT for calls that carry no flag (never used by the product path)
+    assert lib.vc_gemm_get_precision() == 0
+    lib.vc_gemm_set_precision(1)
     try:
-        for mode in (0, 1):
-            lib.vc_gemm_set_precision(mode)
-            assert lib.vc_gemm_get_precision() == mode
-            C = zeros(M, N)
-            lib.vc_gemm_f32(stream(), 0, 0, M, N, K, P(dA), K, P(dB), N, P(C), N, None, 0, P(ws), ws.numel() * 4)
-            out[mode] = host(C).copy()
+        assert lib.vc_gemm_get_precision() == 1 and np.array_equal(run(lib.vc_gemm_f32, 0), entry)
     finally:
         lib.vc_gemm_set_precision(0)
-    Cx = zeros(M, N)
-    lib.vc_gemm_bf16x3_f32(stream(), 0, 0, M, N, K, P(dA), K, P(dB), N, P(Cx), N, None, 0, P(ws), ws.numel() * 4)
-    assert np.array_equal(out[1], host(Cx)) and not np.array_equal(out[0], out[1])
-    ref = A.astype(np.float64) @ B.astype(np.float64)
-    assert np.abs(out[0] - ref).max() < np.abs(out[1] - ref).max() < TOL * np.abs(ref).max()
+    assert np.array_equal(run(lib.vc_gemm_f32, 0), f32)
     from vae_captioning_amd.abi import VaecapError
     with pytest.raises(VaecapError):
         lib.vc_gemm_set_precision(7)
+
+
+def _small_case(prior="Normal", use_c_v=False):
+    from vae_captioning_amd import spec, synth
+    from vae_captioning_amd.utils.parameters import Parameters
+    p = Parameters()
+    p.embed_size, p.encoder_hidden, p.decoder_hidden = 64, 128, 128
+    p.latent_size, p.gen_z_samples, p.cnn_feature_size = 20, 6, 256
+    p.num_captions, p.batch_size, p.prior, p.use_c_v = 5, 16, prior, use_c_v
+    V, B, T = 1000, 16, 12
+    rng = np.random.default_rng(0)
+    P0 = spec.init_caption_params(p, V, seed=1)
+    batch = synth.make_batch(rng, B, p.num_captions, T, V, variable_len=True, feature_size=p.cnn_feature_size, use_ci=spec.uses_ci(p))
+    noise = synth.make_noise(rng, B * p.num_captions, T, p)
+    return p, V, P0, batch, noise
+
+
+def test_two_trainers_of_different_precision_coexist_in_one_process(lib):
+    """Review item (round 5): precision was process-wide state.  Now an f32 and a bf16x3 Trainer are built side by side and stepped
+    ALTERNATELY for three steps; each must be bit-identical to the same trainer run alone in a fresh sequence -- i.e. nothing one does
+    reaches the other's arithmetic -- and the two must differ from each other."""
+    from vae_captioning_amd.trainer import Trainer
+    p, V, P0, batch, noise = _small_case()
+
+    def alone(prec):
+        tr = Trainer(p, V, lib=lib, precision=prec)
+        tr.load_state_dict(P0)
+        tr.set_batch(batch, noise)
+        out = []
+        for _ in range(3):
+            tr.train_step()
+            out.append(tr.losses())
+        return out, tr.state_dict()
+    ref = {prec: alone(prec) for prec in ("f32", "bf16x3")}
+    trs = {}
+    for prec in ("f32", "bf16x3"):
+        trs[prec] = Trainer(p, V, lib=lib, precision=prec)
+        trs[prec].load_state_dict(P0)
+        trs[prec].set_batch(batch, noise)
+    got = {"f32": [], "bf16x3": []}
+    for _ in range(3):
+        for prec in ("bf16x3", "f32"):
+            trs[prec].train_step()
+            got[prec].append(trs[prec].losses())
+    for prec in ("f32", "bf16x3"):
+        assert trs[prec].precision == prec and lib.vc_gemm_get_precision() == 0
+        assert got[prec] == ref[prec][0], (prec, got[prec], ref[prec][0])
+        sd = trs[prec].state_dict()
+        for k, v in ref[prec][1].items():
+            assert np.array_equal(sd[k], v), (prec, k)
+    assert got["f32"] != got["bf16x3"]
 
 
 @pytest.mark.parametrize("prior,use_c_v", [("Normal", False), ("AG", True)])
@@ -132,16 +186,12 @@ def test_training_step_in_bf16x3_mode_stays_within_the_north_star_tolerance(lib,
         from oracle import decode
         n64["c_means"] = decode.init_clusters(90, p.latent_size).astype(np.float64)
     ref = cm.forward_backward(f64(P0), f64(batch), n64, p, global_step=0)
-    try:
-        lib.vc_gemm_set_precision(1)
-        tr = Trainer(p, V, lib=lib)
-        tr.load_state_dict(P0)
-        tr.set_batch(batch, noise)
-        tr.train_step()
-        kld, rec, lb, ann = tr.losses()
-        G = tr.cap.grads_dict()
-    finally:
-        lib.vc_gemm_set_precision(0)
+    tr = Trainer(p, V, lib=lib, precision="bf16x3")
+    tr.load_state_dict(P0)
+    tr.set_batch(batch, noise)
+    tr.train_step()
+    kld, rec, lb, ann = tr.losses()
+    G = tr.cap.grads_dict()
     assert abs(rec - float(ref.rec_loss)) < 1e-3 and abs(kld - float(np.mean(ref.kld))) < 1e-3
     for name, g in ref.grads.items():
         err = np.abs(G[name] - g).max()
@@ -157,13 +207,7 @@ def test_lstm_recurrence_kernels_in_bf16x3_mode_match_the_fp64_oracle(lib, dims)
     oracle at four times the f32 kernels' tolerances (8e-5 on states and activations, 2e-4 on gradients; the error is the products'
     ~1e-5 carried through T steps).  Rows: four-wave kernel (<= 400), eight-wave forward above, ragged blocks."""
     from .test_gpu_ops import _lstm_seq_check
-    lib.vc_lstm_set_mode(3)
-    try:
-        lib.vc_gemm_set_precision(1)
-        _lstm_seq_check(lib, *dims, tol=4.0)
-    finally:
-        lib.vc_gemm_set_precision(0)
-        lib.vc_lstm_set_mode(2)
+    _lstm_seq_check(lib, *dims, tol=4.0, kernels=3, bf16x3=True)   # VC_LSTM_KERNELS(3) | VC_LSTM_BF16X3 on the calls themselves
 
 
 def test_fine_tune_step_in_bf16x3_mode_uses_the_direct_weight_gradient_and_matches_the_oracle(lib, monkeypatch):
@@ -192,22 +236,19 @@ def test_fine_tune_step_in_bf16x3_mode_uses_the_direct_weight_gradient_and_match
     PV64, PC64, b64, n64 = f64(PV), f64(PC), f64(batch), f64(noise)
     reg = float(ov.l2_reg_loss(PV, p.weight_decay))
     grads = {}
-    try:
-        for mode in ("1", "0"):
-            monkeypatch.setenv("VC_WGRAD_BX", mode)
-            tr = Trainer(p, V, lib=lib, precision="bf16x3")
-            tr.load_state_dict({**PC, **PV})
-            tr.set_batch(batch, noise)
-            tr.train_step()
-            torch.cuda.synchronize()
-            grads[mode] = {k: v.copy() for k, v in tr.vgg.grads_dict().items()}
-            if mode == "1":
-                fc2_dev = (tr.vgg.buf["fc2d"] if tr.vgg.keep < 1 else tr.vgg.buf["fc2"]).cpu().numpy().astype(np.float64)
-                b64["features"] = fc2_dev
-                out = cm.forward_backward(PC64, b64, n64, p, global_step=0, reg_loss=reg)
-                GV = ov.backward(PV64, device_cache(tr.vgg, PV64, p.cnn_dropout), out.dfeatures)
-    finally:
-        lib.vc_gemm_set_precision(0)
+    for mode in ("1", "0"):
+        monkeypatch.setenv("VC_WGRAD_BX", mode)
+        tr = Trainer(p, V, lib=lib, precision="bf16x3")
+        tr.load_state_dict({**PC, **PV})
+        tr.set_batch(batch, noise)
+        tr.train_step()
+        torch.cuda.synchronize()
+        grads[mode] = {k: v.copy() for k, v in tr.vgg.grads_dict().items()}
+        if mode == "1":
+            fc2_dev = (tr.vgg.buf["fc2d"] if tr.vgg.keep < 1 else tr.vgg.buf["fc2"]).cpu().numpy().astype(np.float64)
+            b64["features"] = fc2_dev
+            out = cm.forward_backward(PC64, b64, n64, p, global_step=0, reg_loss=reg)
+            GV = ov.backward(PV64, device_cache(tr.vgg, PV64, p.cnn_dropout), out.dfeatures)
     # what bounds the comparison is the gradient that ENTERS the VGG16: the caption side's BPTT in split-bf16 arithmetic carries ~9e-4
     # (cnn/fc2's gradient, which no convolution kernel touches, shows the same figure); the direct weight gradient must add nothing to it
     for n, ref in GV.items():

@@ -123,18 +123,15 @@ def test_two_processes_in_the_split_bf16_mode(lib, tmp_path, monkeypatch):
     (csrc/conv_wgrad_bx.hip, feeding the four asynchronous gradient buckets from the weight-gradient stream) on the bf16 pipe -- the
     replicas stay bit-identical, two processes equal two threads bit for bit, and the result stays within Adam's sign noise of ONE
     process on the global batch in the same mode"""
-    monkeypatch.setenv("VC_PRECISION", "bf16x3")
-    try:
-        ranks = _spawn("fine_tune", "global", tmp_path, {"VC_PRECISION": "bf16x3"})
-        for k in ranks[0]:
-            np.testing.assert_array_equal(ranks[0][k], ranks[1][k], err_msg="replicas differ: " + k)
-        emu = _threads(lib, "fine_tune", "global")
-        assert lib.vc_gemm_get_precision() == 1
-        for k in ranks[0]:
-            np.testing.assert_array_equal(ranks[0][k], emu[0][k], err_msg="two processes != two threads: " + k)
-        one, p = _single(lib, "fine_tune")
-    finally:
-        lib.vc_gemm_set_precision(0)
+    monkeypatch.setenv("VC_PRECISION", "bf16x3")   # (the default precision of every Trainer built below; per trainer, no library state)
+    ranks = _spawn("fine_tune", "global", tmp_path, {"VC_PRECISION": "bf16x3"})
+    for k in ranks[0]:
+        np.testing.assert_array_equal(ranks[0][k], ranks[1][k], err_msg="replicas differ: " + k)
+    emu = _threads(lib, "fine_tune", "global")
+    assert lib.vc_gemm_get_precision() == 0   # nobody touched the deprecated process-wide default
+    for k in ranks[0]:
+        np.testing.assert_array_equal(ranks[0][k], emu[0][k], err_msg="two processes != two threads: " + k)
+    one, p = _single(lib, "fine_tune")
     np.testing.assert_allclose(ranks[0]["#losses"][:, :3], one["#losses"][:, :3], rtol=5e-4, atol=1e-6)
     for k in ranks[0]:
         if k.startswith("#") or k.endswith("#sum"):

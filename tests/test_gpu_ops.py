@@ -146,11 +146,7 @@ def _lstm_case(T, N, E, H, seed, full_len=False):
                          ids=["small", "mid-128rows", "cfg2-shape", "cfg4-rows-ragged", "H1024"])
 def test_lstm_seq_fwd_bwd(lib, dims):
     T, N, E, H, full = dims
-    lib.vc_lstm_set_mode(2)  # auto: the recurrence kernels at H = 512 (forward up to 640 rows), the split form elsewhere
-    try:
-        _lstm_seq_check(lib, T, N, E, H)
-    finally:
-        lib.vc_lstm_set_mode(2)
+    _lstm_seq_check(lib, T, N, E, H)   # flags 0 = auto: the recurrence kernels at H = 512 (forward up to 640 rows), the split form elsewhere
 
 
 @pytest.mark.parametrize("dims", [(3, 320, 64, 512), (2, 1280, 32, 512), (4, 37, 32, 512), (3, 650, 48, 512), (2, 5, 16, 512), (3, 161, 16, 512)],
@@ -158,24 +154,27 @@ def test_lstm_seq_fwd_bwd(lib, dims):
 def test_lstm_recurrence_kernels(lib, dims):
     """mode 3: the register-operand recurrence kernels (16x16x4 MFMA, K split over four waves) forward AND backward, on whole and
     ragged row blocks, one and several passes per workgroup"""
-    lib.vc_lstm_set_mode(3)
-    try:
-        _lstm_seq_check(lib, *dims)
-    finally:
-        lib.vc_lstm_set_mode(2)
+    _lstm_seq_check(lib, *dims, kernels=3)
 
 
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_lstm_sequence_modes_agree_with_oracle(lib, mode):
     """every other driver mode (round-1 fused kernels, GEMM + gate kernels, auto) on the cfg4 row count at H = 512"""
-    lib.vc_lstm_set_mode(mode)
+    _lstm_seq_check(lib, 3, 320, 64, 512, kernels=mode)
+
+
+def test_lstm_deprecated_process_wide_mode_still_selects_for_calls_without_a_choice(lib):
+    """vc_lstm_set_mode (ABI <= 3) remains the default of calls whose flags choose nothing; a call's own VC_LSTM_KERNELS wins over it"""
+    lib.vc_lstm_set_mode(1)
     try:
-        _lstm_seq_check(lib, 3, 320, 64, 512)
+        _lstm_seq_check(lib, 2, 320, 32, 512)              # runs the GEMM + gate form
+        _lstm_seq_check(lib, 2, 320, 32, 512, kernels=3)   # the call's own choice
     finally:
         lib.vc_lstm_set_mode(2)
 
 
-def _lstm_seq_check(lib, T, N, E, H, tol=1.0):
+def _lstm_seq_check(lib, T, N, E, H, tol=1.0, kernels=None, bf16x3=False):
+    fl = (0 if kernels is None else kernels + 1) | (0x10 if bf16x3 else 0)   # VC_LSTM_KERNELS(k) | VC_LSTM_BF16X3
     X, W, b, lens = _lstm_case(T, N, E, H, seed=T * N)
     rng = np.random.default_rng(1)
     dhs = rng.standard_normal((T + 1, N, H), dtype=np.float32) * np.float32(0.1)
@@ -187,7 +186,7 @@ def _lstm_seq_check(lib, T, N, E, H, tol=1.0):
     act, cs, hs = zeros(T, N, 4 * H), zeros(T + 1, N, H), zeros(T + 1, N, H)
     ws = empty_bytes(lib.vc_lstm_seq_workspace_bytes(T, N, E, H))
     tX, tW, tb, tl = dev(X), dev(W), dev(b), dev(lens)
-    lib.vc_lstm_seq_fwd_f32(stream(), T, N, E, H, P(tX), P(tW), P(tb), P(tl), P(act), P(cs), P(hs), P(ws), ws.numel() * 4)
+    lib.vc_lstm_seq_fwd_f32(stream(), T, N, E, H, P(tX), P(tW), P(tb), P(tl), P(act), P(cs), P(hs), P(ws), ws.numel() * 4, fl)
     assert_close(host(hs), cache["hs"], 2e-5 * tol, msg="lstm hs")
     assert_close(host(cs), cache["cs"], 2e-5 * tol, msg="lstm cs")
     assert_close(host(act), cache["act"], 2e-5 * tol, msg="lstm gate activations")
@@ -196,7 +195,7 @@ def _lstm_seq_check(lib, T, N, E, H, tol=1.0):
     # dH_run starts as the gradient w.r.t. the final state; dhs_ext[T] must then not be double counted
     text[T].zero_()
     lib.vc_lstm_seq_bwd_f32(stream(), T, N, E, H, P(tX), P(tW), P(tl), P(act), P(cs), P(hs), P(text), P(dH), P(dC), P(dG),
-                            P(dX_), P(dW_), P(db_), P(ws), ws.numel() * 4)
+                            P(dX_), P(dW_), P(db_), P(ws), ws.numel() * 4, fl)
     assert_close(host(dX_), rdX, 5e-5 * tol, msg="lstm dX")
     assert_close(host(dW_), rdW, 5e-5 * tol, msg="lstm dW")
     assert_close(host(db_), rdb, 5e-5 * tol, msg="lstm db")

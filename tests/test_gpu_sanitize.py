@@ -25,7 +25,7 @@ from vae_captioning_amd.abi import VaecapError
 from vae_captioning_amd.trainer import Trainer
 from vae_captioning_amd.utils.parameters import Parameters
 lib = abi.load(%(lib)r)
-assert lib.vc_abi_version() == 3
+assert lib.vc_abi_version() == 4
 os.environ["VC_TRACE"] = "1"
 rng = np.random.default_rng(0)
 # 1. fine-tune step: every convolution planner / image-range loop / workspace computation, three streams

@@ -64,11 +64,6 @@ if ls vae_captioning_amd/lib/libvaecap_wbabl*.so > /dev/null 2>&1; then
    echo; echo "## WB_ABL=7: MFMAs only, operands = constants"; VC_LIB=$ROOT/vae_captioning_amd/lib/libvaecap_wbabl7.so bash tools/kernel_pmc.sh ${TAG}_wgbx_abl7 wgrad_bx_kernel python $ROOT/tools/microbench.py wgbx
    echo; echo "## WB_ABL=16: MFMAs only, operands = the first chunk's (real data)"; VC_LIB=$ROOT/vae_captioning_amd/lib/libvaecap_wbabl16.so bash tools/kernel_pmc.sh ${TAG}_wgbx_abl16 wgrad_bx_kernel python $ROOT/tools/microbench.py wgbx) > $OUT/${TAG}_wgrad_bx_pmc.md 2>/dev/null
 fi
-(python tools/microbench.py convbx 2>/dev/null | grep -E "^conv|^sum"; echo "== conv_bx2"; python tools/microbench.py convbx2 2>/dev/null | grep -E "^conv|^sum") > $OUT/${TAG}_convbx_layers.txt
-if ls vae_captioning_amd/lib/libvaecap_c2abl*.so > /dev/null 2>&1; then
-  (for n in 1 2 4 8 16; do echo "== C2_ABL=$n (1 split arithmetic, 2 window reads, 4 staging, 8 weight-fragment reads, 16 everything between the MFMAs, operands frozen: real data)"
-     VC_LIB=$ROOT/vae_captioning_amd/lib/libvaecap_c2abl$n.so python tools/microbench.py convbx2 2>/dev/null | grep -E "^conv|^sum" | sed -e "s/ | F(4x4.*//"; done) > $OUT/${TAG}_convbx2_ablation.txt
-fi
 rm -rf /tmp/kt_c4bx
 (cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/kt_c4bx -- python $ROOT/bench.py --precision bf16x3 --no-cpu-baseline --strong-n1 0 > $OUT/${TAG}_cfg4_bf16x3_kt.log 2>&1)
 python tools/rocpd_stats.py "$(find /tmp/kt_c4bx -name "*_results.db" | head -1)" 40 > $OUT/${TAG}_cfg4_bf16x3_kernel_stats.md

@@ -66,221 +66,6 @@ def gemmx():
               % (ta, tb, M, N, K, res[0], fl / res[0], res[1], fl / res[1], 3 * fl / res[1], 3 * fl / res[1] / 2500, res[0] / res[1]), flush=True)
 
 
-def convbx():
-    """the direct split-bf16 convolution (csrc/conv_bx.hip) against the f32 F(4x4,3x3) kernels, every VGG16 layer shape at a 32-image
-    half batch: forward (+ bias, ReLU) and data gradient (+ ReLU mask from the float activation)"""
-    B = int(os.environ.get("VC_CONVBX_B", "32"))
-    tf = td = tf4 = td4 = 0.0
-    for (name, H, ci, co, mult) in [("1_2", 224, 64, 64, 1), ("2_1", 112, 64, 128, 1), ("2_2", 112, 128, 128, 1), ("3_1", 56, 128, 256, 1), ("3_2", 56, 256, 256, 2),
-                                    ("4_1", 28, 256, 512, 1), ("4_2", 28, 512, 512, 2), ("5_2", 14, 512, 512, 3)]:
-        x = rnd(B, ci // 4, H, H, 4).clamp_(min=0)
-        w, bias = rnd(3, 3, ci, co) * (1.0 / (3 * ci ** 0.5)), rnd(co)
-        dy = rnd(B, co // 4, H, H, 4)
-        y, dx = torch.empty(B, co // 4, H, H, 4, device="cuda"), torch.empty(B, ci // 4, H, H, 4, device="cuda")
-        wp = torch.empty(lib.vc_conv3x3_bx_pack_bytes(ci, co) // 4, device="cuda")
-        wpt = torch.empty_like(wp)
-        lib.vc_conv3x3_bx_pack_f32(st(), ci, co, P(w), 0, P(wp))
-        lib.vc_conv3x3_bx_pack_f32(st(), ci, co, P(w), 1, P(wpt))
-        w4, w4t = torch.empty(36 * ci * co, device="cuda"), torch.empty(36 * ci * co, device="cuda")
-        lib.vc_conv3x3_wino4_pack_f32(st(), ci, co, P(w), 0, P(w4))
-        lib.vc_conv3x3_wino4_pack_f32(st(), ci, co, P(w), 1, P(w4t))
-        fl = 2e-9 * B * H * H * 9 * ci * co
-        r = {}
-        r["bx fwd"], _ = timeit(lambda: lib.vc_conv3x3_bx_fwd_f32(st(), B, H, H, ci, co, P(x), P(wp), P(bias), P(y), 1))
-        r["bx dgrad"], _ = timeit(lambda: lib.vc_conv3x3_bx_dgrad_f32(st(), B, H, H, ci, co, P(dy), P(wpt), P(x), P(dx)))
-        r["w4 fwd"], _ = timeit(lambda: lib.vc_conv3x3_wino4_fwd_f32(st(), B, H, H, ci, co, P(x), P(w4), P(bias), P(y), None, 1))
-        r["w4 dgrad"], _ = timeit(lambda: lib.vc_conv3x3_wino4_dgrad_f32(st(), B, H, H, ci, co, P(dy), P(w4t), P(x), P(dx)))
-        tf += mult * r["bx fwd"]; td += mult * r["bx dgrad"]; tf4 += mult * r["w4 fwd"]; td4 += mult * r["w4 dgrad"]
-        print("conv%s B=%d H=%3d %3d->%3d: bx fwd %6.3f ms %6.1f TF (%.3f of the bf16 pipe) dgrad %6.3f ms %6.1f TF | F(4x4,3x3) f32 fwd %6.3f dgrad %6.3f ms | x%.2f x%.2f"
-              % (name, B, H, ci, co, r["bx fwd"], fl / r["bx fwd"], 3 * fl / r["bx fwd"] / 2500, r["bx dgrad"], fl / r["bx dgrad"], r["w4 fwd"], r["w4 dgrad"],
-                 r["w4 fwd"] / r["bx fwd"], r["w4 dgrad"] / r["bx dgrad"]), flush=True)
-    print("sum over the twelve layers B=%d: bx fwd %.3f dgrad %.3f ms | F(4x4,3x3) fwd %.3f dgrad %.3f ms" % (B, tf, td, tf4, td4))
-
-
-def conv1():
-    """conv1_1's own kernels (csrc/conv_first.hip) against the general 3x3 kernels on the zero-padded 4-channel form; both are
-    HBM-bound on the [B,224,224,64] activation (822 MB at B = 64: ~0.14 ms at 6.3 TB/s)"""
-    B, H = 64, 224
-    x4 = rnd(B, H, H, 4)
-    w, bias = rnd(3, 3, 3, 64), rnd(64)
-    w4 = torch.zeros(3, 3, 4, 64, device="cuda")
-    w4[:, :, :3] = w
-    y, dy = torch.empty(B, H, H, 64, device="cuda"), rnd(B, H, H, 64)
-    dw, db, dw4 = torch.empty(3, 3, 3, 64, device="cuda"), torch.empty(64, device="cuda"), torch.empty(3, 3, 4, 64, device="cuda")
-    ws = torch.empty(max(lib.vc_conv1_wgrad_workspace_bytes(), lib.vc_conv3x3_wgrad_workspace_bytes(B, H, H, 4, 64)) // 4 + 4, device="cuda")
-    gb = 1e-9 * B * H * H * (64 + 4) * 4
-    for nm, fn in (("conv1 fwd", lambda: lib.vc_conv1_fwd_f32(st(), B, H, H, P(x4), P(w), P(bias), P(y), 1)),
-                   ("3x3 fwd (Cin 4)", lambda: lib.vc_conv3x3_fwd_f32(st(), B, H, H, 4, 64, P(x4), P(w4), P(bias), P(y), 1, None, 0)),
-                   ("conv1 wgrad", lambda: lib.vc_conv1_wgrad_f32(st(), B, H, H, P(x4), P(dy), P(dw), P(db), 0, P(ws), ws.numel() * 4)),
-                   ("3x3 wgrad (Cin 4)", lambda: lib.vc_conv3x3_wgrad_f32(st(), B, H, H, 4, 64, P(x4), P(dy), P(dw4), P(db), 0, P(ws), ws.numel() * 4))):
-        med, mn = timeit(fn, reps=10)
-        print("%-18s B=%d: %7.3f ms  %5.2f TB/s (activation once + input once)" % (nm, B, med, gb / med), flush=True)
-
-
-def gemmtrain():
-    """the tb = 0 products of a training step (cfg4: 6880 rows, cfg2: 27520 rows).  Round 2 measured a register-B variant on these
-    (B rows straight to registers as the operand of four interleaved MFMA tiles, 128 x 256 tiles, two workgroups per CU):
-    116.5 / 107.2 / 118.0 TFLOP/s against 119.6 / 119.4 / 124.9 of this kernel on 27520x10000x512 / 27520x2048x512 /
-    512x10000x27520 (only 8192^3 gained, 136.6 vs 133.3) -- per-tile prologue / epilogue with 16 K-tiles, not the main loop,
-    bounds these shapes, and three to four resident workgroups hide it better than two; not adopted."""
-    for (ta, M, N, K) in [(0, 6880, 10000, 512), (0, 27520, 10000, 512), (0, 6880, 2048, 512), (0, 27520, 2048, 512), (0, 6880, 2048, 256),
-                          (1, 512, 10000, 6880), (1, 512, 10000, 27520), (1, 512, 2048, 6880), (1, 512, 2048, 27520), (1, 256, 2048, 27520),
-                          (0, 64, 4096, 25088), (1, 25088, 4096, 64), (0, 64, 4096, 4096), (0, 8192, 8192, 8192)]:
-        A = rnd(K, M) if ta else rnd(M, K)
-        B = rnd(K, N)
-        C = torch.empty(M, N, device="cuda")
-        ws = torch.empty(max(lib.vc_gemm_workspace_bytes(M, N, K), 16) // 4 + 4, device="cuda")
-        med, mn = timeit(lambda: lib.vc_gemm_f32(st(), ta, 0, M, N, K, P(A), M if ta else K, P(B), N, P(C), N, None, 0, P(ws), ws.numel() * 4), reps=5)
-        print("gemm ta=%d tb=0 %6d x %6d x %6d: %8.3f ms  %6.1f TFLOP/s" % (ta, M, N, K, med, 2e-9 * M * N * K / med), flush=True)
-
-
-def gemmt():
-    """transposed-operand forms at conv-wgrad-like and dense-backward shapes"""
-    for (ta, tb, M, N, K) in [(0, 0, 8192, 8192, 8192), (0, 1, 8192, 8192, 8192), (1, 0, 8192, 8192, 8192), (1, 1, 8192, 8192, 8192), (0, 0, 2304, 256, 200704), (1, 0, 2304, 256, 200704), (0, 1, 200704, 256, 2304), (1, 0, 512, 10000, 25600), (0, 1, 25600, 512, 10000)]:
-        A = rnd(K, M) if ta else rnd(M, K)
-        B = rnd(N, K) if tb else rnd(K, N)
-        C = torch.empty(M, N, device="cuda")
-        ws = torch.empty(max(lib.vc_gemm_workspace_bytes(M, N, K), 16) // 4 + 4, device="cuda")
-        med, mn = timeit(lambda: lib.vc_gemm_f32(st(), ta, tb, M, N, K, P(A), M if ta else K, P(B), K if tb else N, P(C), N, None, 0, P(ws), ws.numel() * 4), reps=5)
-        print("gemm ta=%d tb=%d %6d x %6d x %6d: %8.3f ms  %6.1f TFLOP/s" % (ta, tb, M, N, K, med, 2e-9 * M * N * K / med))
-
-
-def ablate(shapes=((4096, 4096, 4096), (8192, 8192, 8192), (25600, 10000, 512), (200704, 256, 2304), (12544, 512, 4608))):
-    import ctypes
-    mb_path = os.path.join(os.path.dirname(abi.LIB_PATH), "libvaecap_microbench.so")  # make -C vae_captioning_amd/csrc microbench
-    mb = ctypes.CDLL(mb_path)
-    mb.vc_debug_gemm_ablate_f32.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
-    names = {0: "full", 8: "double-buffered", 2: "no lds-store/barrier", 7: "mfma only"}
-    for (M, N, K) in shapes:
-        M, N = M // 128 * 128, N // 128 * 128
-        A, B, C = rnd(M, K), rnd(K, N), torch.empty(M, N, device="cuda")
-        ref = None
-        for v, nm in names.items():
-            med, mn = timeit(lambda: mb.vc_debug_gemm_ablate_f32(st(), v, M, N, K, P(A), P(B), P(C)))
-            chk = ""
-            if v == 0:
-                ref = C.clone()
-            elif v == 8:
-                chk = " maxdiff vs full %.3g" % float((C - ref).abs().max())
-            print("ablate %dx%dx%d %d %-22s %8.3f ms  %6.1f TFLOP/s%s" % (M, N, K, v, nm, med, 2e-9 * M * N * K / med, chk))
-
-
-def conv():
-    B = 64
-    for (name, H, ci, co) in [("1_1", 224, 4, 64), ("1_2", 224, 64, 64), ("2_1", 112, 64, 128), ("2_2", 112, 128, 128), ("3_1", 56, 128, 256), ("3_2", 56, 256, 256), ("4_1", 28, 256, 512), ("4_2", 28, 512, 512), ("5_2", 14, 512, 512)]:
-        x, w, bias = rnd(B, H, H, ci), rnd(3, 3, ci, co), rnd(co)
-        y, dx, dw = torch.empty(B, H, H, co, device="cuda"), torch.empty(B, H, H, ci, device="cuda"), torch.empty(3, 3, ci, co, device="cuda")
-        dy = rnd(B, H, H, co)
-        ws = torch.empty(lib.vc_conv3x3_wgrad_workspace_bytes(B, H, H, ci, co) // 4 + 4, device="cuda")
-        tw = torch.empty(max(lib.vc_conv3x3_fwd_workspace_bytes(B, H, H, ci, co), lib.vc_conv3x3_dgrad_workspace_bytes(B, H, H, ci, co), 16) // 4 + 4, device="cuda")
-        tb = tw.numel() * 4 if os.environ.get("VC_NO_TAIL") != "1" else 0
-        fl = 2e-9 * B * H * H * 9 * ci * co
-        for nm, fn in (("fwd", lambda: lib.vc_conv3x3_fwd_f32(st(), B, H, H, ci, co, P(x), P(w), P(bias), P(y), 1, P(tw), tb)),
-                       ("dgrad", lambda: lib.vc_conv3x3_dgrad_f32(st(), B, H, H, ci, co, P(dy), P(w), P(x), P(dx), P(tw), tb)),
-                       ("dgr-nomask", lambda: lib.vc_conv3x3_dgrad_f32(st(), B, H, H, ci, co, P(dy), P(w), None, P(dx), P(tw), tb)),
-                       ("wgrad", lambda: lib.vc_conv3x3_wgrad_f32(st(), B, H, H, ci, co, P(x), P(dy), P(dw), P(bias), 0, P(ws), ws.numel() * 4)),
-                       ("wgrad-nobias", lambda: lib.vc_conv3x3_wgrad_f32(st(), B, H, H, ci, co, P(x), P(dy), P(dw), None, 0, P(ws), ws.numel() * 4))):
-            med, mn = timeit(fn, reps=5)
-            print("conv%s %-10s B=%d H=%3d %3d->%3d: %8.3f ms  %6.1f TFLOP/s" % (name, nm, B, H, ci, co, med, fl / med))
-
-
-def winoab():
-    """Winograd forward / data gradient only, VGG16 layer shapes at 64 and 32 images (round 3 A/B: profiles/r03_wino_fwd_dgrad_round2_kernel.txt keeps the round-2 32x32x2 kernel's
-    numbers from the same program); algorithmic TFLOP/s"""
-    tot = {}
-    for B in (64, 32):
-        for (name, H, ci, co) in [("1_2", 224, 64, 64), ("2_1", 112, 64, 128), ("2_2", 112, 128, 128), ("3_1", 56, 128, 256), ("3_2", 56, 256, 256),
-                                  ("4_1", 28, 256, 512), ("4_2", 28, 512, 512), ("5_2", 14, 512, 512)]:
-            x, w, bias = rnd(B, H, H, ci), rnd(3, 3, ci, co), rnd(co)
-            y, dx = torch.empty(B, H, H, co, device="cuda"), torch.empty(B, H, H, ci, device="cuda")
-            dy = rnd(B, H, H, co)
-            vp, vpt = torch.empty(16 * ci * co, device="cuda"), torch.empty(16 * ci * co, device="cuda")
-            lib.vc_conv3x3_wino_pack_f32(st(), ci, co, P(w), 0, P(vp))
-            lib.vc_conv3x3_wino_pack_f32(st(), ci, co, P(w), 1, P(vpt))
-            bits = torch.zeros(lib.vc_conv3x3_wino_mask_words(B, H, H, ci), dtype=torch.int32, device="cuda")
-            fl = 2e-9 * B * H * H * 9 * ci * co
-            for nm, fn in (("fwd", lambda: lib.vc_conv3x3_wino_fwd_f32(st(), B, H, H, ci, co, P(x), P(vp), P(bias), P(y), None, 1)),
-                           ("dgrad", lambda: lib.vc_conv3x3_wino_dgrad_f32(st(), B, H, H, ci, co, P(dy), P(vpt), P(x), P(dx))),
-                           ("dgrad-bits", lambda: lib.vc_conv3x3_wino_dgrad_bits_f32(st(), B, H, H, ci, co, P(dy), P(vpt), P(bits), P(dx)))):
-                med, mn = timeit(fn, reps=5)
-                tot[(B, nm)] = tot.get((B, nm), 0.0) + med * {"1_2": 1, "2_1": 1, "2_2": 1, "3_1": 1, "3_2": 2, "4_1": 1, "4_2": 2, "5_2": 3}[name]
-                print("conv%s %-10s B=%d H=%3d %3d->%3d: %8.3f ms  %6.1f TFLOP/s" % (name, nm, B, H, ci, co, med, fl / med), flush=True)
-    for k in sorted(tot):
-        print("sum over the twelve layers B=%d %-10s %8.3f ms" % (k[0], k[1], tot[k]))
-
-
-def winoq():
-    """quick form of winoab: conv3_2 / conv1_2 / conv4_2 / conv5_2 forward at 64 images (ablation builds: VC_LIB=.../libvaecap_ablN.so)"""
-    B = 64
-    for (name, H, ci, co) in [("3_2", 56, 256, 256), ("1_2", 224, 64, 64), ("4_2", 28, 512, 512), ("5_2", 14, 512, 512)]:
-        x, w, bias = rnd(B, H, H, ci), rnd(3, 3, ci, co), rnd(co)
-        y = torch.empty(B, H, H, co, device="cuda")
-        vp = torch.empty(16 * ci * co, device="cuda")
-        lib.vc_conv3x3_wino_pack_f32(st(), ci, co, P(w), 0, P(vp))
-        fl = 2e-9 * B * H * H * 9 * ci * co
-        med, mn = timeit(lambda: lib.vc_conv3x3_wino_fwd_f32(st(), B, H, H, ci, co, P(x), P(vp), P(bias), P(y), None, 1), reps=5)
-        print("%s conv%s fwd: %8.3f ms  %6.1f TFLOP/s" % (os.environ.get("VC_LIB", "default")[-12:], name, med, fl / med), flush=True)
-
-
-def winowq():
-    """quick form of winow: Winograd weight gradient only (ablation builds: VC_LIB=.../libvaecap_wgablN.so)"""
-    B = 64
-    for (name, H, ci, co) in [("1_2", 224, 64, 64), ("2_2", 112, 128, 128), ("3_2", 56, 256, 256), ("4_2", 28, 512, 512), ("5_2", 14, 512, 512)]:
-        x, dy, bias = rnd(B, H, H, ci), rnd(B, H, H, co), rnd(co)
-        dw = torch.empty(3, 3, ci, co, device="cuda")
-        ws = torch.empty(lib.vc_conv3x3_wino_wgrad_workspace_bytes(B, H, H, ci, co) // 4 + 4, device="cuda")
-        fl = 2e-9 * B * H * H * 9 * ci * co
-        med, mn = timeit(lambda: lib.vc_conv3x3_wino_wgrad_f32(st(), B, H, H, ci, co, P(x), P(dy), P(dw), P(bias), 0, P(ws), ws.numel() * 4), reps=5)
-        print("%s conv%s wgrad: %8.3f ms  %6.1f TFLOP/s" % (os.environ.get("VC_LIB", "default")[-14:], name, med, fl / med), flush=True)
-
-
-def winow():
-    """Winograd F(3x3,2x2) weight gradient, VGG16 layer shapes at 64 images (algorithmic TFLOP/s); the last line sums the twelve layers"""
-    B = 64
-    tot = 0.0
-    for (name, H, ci, co) in [("1_2", 224, 64, 64), ("2_1", 112, 64, 128), ("2_2", 112, 128, 128), ("3_1", 56, 128, 256), ("3_2", 56, 256, 256),
-                              ("4_1", 28, 256, 512), ("4_2", 28, 512, 512), ("5_2", 14, 512, 512)]:
-        x, dy, bias = rnd(B, H, H, ci), rnd(B, H, H, co), rnd(co)
-        dw = torch.empty(3, 3, ci, co, device="cuda")
-        ws = torch.empty(lib.vc_conv3x3_wino_wgrad_workspace_bytes(B, H, H, ci, co) // 4 + 4, device="cuda")
-        fl = 2e-9 * B * H * H * 9 * ci * co
-        med, mn = timeit(lambda: lib.vc_conv3x3_wino_wgrad_f32(st(), B, H, H, ci, co, P(x), P(dy), P(dw), P(bias), 0, P(ws), ws.numel() * 4), reps=5)
-        tot += med * {"1_2": 1, "2_1": 1, "2_2": 1, "3_1": 1, "3_2": 2, "4_1": 1, "4_2": 2, "5_2": 3}[name]
-        print("conv%s %-12s B=%d H=%3d %3d->%3d: %8.3f ms  %6.1f TFLOP/s" % (name, "wgrad-wino", B, H, ci, co, med, fl / med), flush=True)
-    print("sum over the twelve layers B=%d wgrad %8.3f ms" % (B, tot))
-
-
-def convbx2():
-    """the second direct split-bf16 convolution (csrc/conv_bx2.hip: operands split in registers) against the f32 F(4x4,3x3) kernels, every VGG16 layer shape at a 32-image
-    half batch: forward (+ bias, ReLU) and data gradient (+ ReLU mask from the float activation)"""
-    B = int(os.environ.get("VC_CONVBX_B", "32"))
-    tf = td = tf4 = td4 = 0.0
-    for (name, H, ci, co, mult) in [("1_2", 224, 64, 64, 1), ("2_1", 112, 64, 128, 1), ("2_2", 112, 128, 128, 1), ("3_1", 56, 128, 256, 1), ("3_2", 56, 256, 256, 2),
-                                    ("4_1", 28, 256, 512, 1), ("4_2", 28, 512, 512, 2), ("5_2", 14, 512, 512, 3)]:
-        x = rnd(B, ci // 4, H, H, 4).clamp_(min=0)
-        w, bias = rnd(3, 3, ci, co) * (1.0 / (3 * ci ** 0.5)), rnd(co)
-        dy = rnd(B, co // 4, H, H, 4)
-        y, dx = torch.empty(B, co // 4, H, H, 4, device="cuda"), torch.empty(B, ci // 4, H, H, 4, device="cuda")
-        wp = torch.empty(lib.vc_conv3x3_bx2_pack_bytes(ci, co) // 4, device="cuda")
-        wpt = torch.empty_like(wp)
-        lib.vc_conv3x3_bx2_pack_f32(st(), ci, co, P(w), 0, P(wp))
-        lib.vc_conv3x3_bx2_pack_f32(st(), ci, co, P(w), 1, P(wpt))
-        w4, w4t = torch.empty(36 * ci * co, device="cuda"), torch.empty(36 * ci * co, device="cuda")
-        lib.vc_conv3x3_wino4_pack_f32(st(), ci, co, P(w), 0, P(w4))
-        lib.vc_conv3x3_wino4_pack_f32(st(), ci, co, P(w), 1, P(w4t))
-        fl = 2e-9 * B * H * H * 9 * ci * co
-        r = {}
-        r["bx fwd"], _ = timeit(lambda: lib.vc_conv3x3_bx2_fwd_f32(st(), B, H, H, ci, co, P(x), P(wp), P(bias), P(y), 1))
-        r["bx dgrad"], _ = timeit(lambda: lib.vc_conv3x3_bx2_dgrad_f32(st(), B, H, H, ci, co, P(dy), P(wpt), P(x), P(dx)))
-        r["w4 fwd"], _ = timeit(lambda: lib.vc_conv3x3_wino4_fwd_f32(st(), B, H, H, ci, co, P(x), P(w4), P(bias), P(y), None, 1))
-        r["w4 dgrad"], _ = timeit(lambda: lib.vc_conv3x3_wino4_dgrad_f32(st(), B, H, H, ci, co, P(dy), P(w4t), P(x), P(dx)))
-        tf += mult * r["bx fwd"]; td += mult * r["bx dgrad"]; tf4 += mult * r["w4 fwd"]; td4 += mult * r["w4 dgrad"]
-        print("conv%s B=%d H=%3d %3d->%3d: bx fwd %6.3f ms %6.1f TF (%.3f of the bf16 pipe) dgrad %6.3f ms %6.1f TF | F(4x4,3x3) f32 fwd %6.3f dgrad %6.3f ms | x%.2f x%.2f"
-              % (name, B, H, ci, co, r["bx fwd"], fl / r["bx fwd"], 3 * fl / r["bx fwd"] / 2500, r["bx dgrad"], fl / r["bx dgrad"], r["w4 fwd"], r["w4 dgrad"],
-                 r["w4 fwd"] / r["bx fwd"], r["w4 dgrad"] / r["bx dgrad"]), flush=True)
-    print("sum over the twelve layers B=%d: bx fwd %.3f dgrad %.3f ms | F(4x4,3x3) fwd %.3f dgrad %.3f ms" % (B, tf, td, tf4, td4))
-
-
 def conv1():
     """conv1_1's own kernels (csrc/conv_first.hip) against the general 3x3 kernels on the zero-padded 4-channel form; both are
     HBM-bound on the [B,224,224,64] activation (822 MB at B = 64: ~0.14 ms at 6.3 TB/s)"""
@@ -468,24 +253,22 @@ def lstm():
     for N in [int(v) for v in os.environ.get("VC_LSTM_NS", "160,320,640,1280").split(",")]:
         res = {}
         for mode in modes:
-            lib.vc_lstm_set_mode(mode)
-            lib.vc_gemm_set_precision(1 if os.environ.get("VC_PRECISION") == "bf16x3" else 0)
+            fl = (mode + 1) | (0x10 if os.environ.get("VC_PRECISION") == "bf16x3" else 0)   # VC_LSTM_KERNELS(mode) | VC_LSTM_BF16X3
             t = {}
             for T in (2, 42):
                 X, W, b = rnd(T, N, E), rnd(E + H, 4 * H) * 0.05, rnd(4 * H) * 0.1
                 lens = torch.full((N,), T, dtype=torch.int32, device="cuda")
                 act, cs, hs = torch.empty(T, N, 4 * H, device="cuda"), torch.zeros(T + 1, N, H, device="cuda"), torch.zeros(T + 1, N, H, device="cuda")
                 ws = torch.empty(lib.vc_lstm_seq_workspace_bytes(T, N, E, H) // 4 + 4, device="cuda")
-                f, _ = timeit(lambda: lib.vc_lstm_seq_fwd_f32(st(), T, N, E, H, P(X), P(W), P(b), P(lens), P(act), P(cs), P(hs), P(ws), ws.numel() * 4), reps=5)
+                f, _ = timeit(lambda: lib.vc_lstm_seq_fwd_f32(st(), T, N, E, H, P(X), P(W), P(b), P(lens), P(act), P(cs), P(hs), P(ws), ws.numel() * 4, fl), reps=5)
                 dhs = rnd(T + 1, N, H) * 0.1
                 dH, dC, dG = torch.zeros(N, H, device="cuda"), torch.zeros(N, H, device="cuda"), torch.empty(T, N, 4 * H, device="cuda")
                 dX, dW, db = torch.empty(T, N, E, device="cuda"), torch.empty(E + H, 4 * H, device="cuda"), torch.empty(4 * H, device="cuda")
-                bw, _ = timeit(lambda: lib.vc_lstm_seq_bwd_f32(st(), T, N, E, H, P(X), P(W), P(lens), P(act), P(cs), P(hs), P(dhs), P(dH), P(dC), P(dG), P(dX), P(dW), P(db), P(ws), ws.numel() * 4), reps=5)
+                bw, _ = timeit(lambda: lib.vc_lstm_seq_bwd_f32(st(), T, N, E, H, P(X), P(W), P(lens), P(act), P(cs), P(hs), P(dhs), P(dH), P(dC), P(dG), P(dX), P(dW), P(db), P(ws), ws.numel() * 4, fl), reps=5)
                 t[T] = (f, bw)
             res[mode] = ((t[42][0] - t[2][0]) / 40 * 1e3, (t[42][1] - t[2][1]) / 40 * 1e3, t[42][0], t[42][1])
             print("lstm N=%4d mode %d (%s): T=42 sequence fwd %.3f ms bwd %.3f ms; marginal per step (incl. its share of the T-linear GEMMs) fwd %.1f us bwd %.1f us"
                   % (N, mode, names[mode], res[mode][2], res[mode][3], res[mode][0], res[mode][1]), flush=True)
-    lib.vc_lstm_set_mode(2)
 
 
 def mid():

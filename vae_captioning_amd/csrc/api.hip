@@ -22,7 +22,10 @@ extern "C" int vc_device_check(int device) {
     e = hipGetDeviceProperties(&p, device);
     if (e != hipSuccess) return vc::fail((int)e, "%s: hipGetDeviceProperties failed", __func__);
     if (strncmp(p.gcnArchName, "gfx950", 6) != 0)
-        return vc::fail(vc::VC_EINVAL, "%s: device is not gfx950 (MI355X): %s", __func__, (long)0) ;
+    {
+        snprintf(vc::last_error_buf(), 512, "%s: device %d is %s, not gfx950 (MI355X)", __func__, device, p.gcnArchName);
+        return vc::VC_EINVAL;
+    }
     return 0;
 }
 

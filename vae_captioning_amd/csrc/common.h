@@ -86,5 +86,6 @@ __device__ __forceinline__ float block_max(float v, float* sh) {
 int gemm_partials_f32(hipStream_t st, int ta, int tb, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
                       float* ws, size_t ws_bytes, int max_splits, int* splits_out);
 size_t gemm_partials_bytes(int M, int N, int K, int max_splits);
+int gemm_default_precision();   // the deprecated process-wide default of vc_gemm_set_precision (0 unless a caller set it)
 
 }  // namespace vc

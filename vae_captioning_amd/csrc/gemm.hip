@@ -275,12 +275,9 @@ static void launch_gemm(hipStream_t st, const GemmArgs& g) {
     if (PREC == 1) {
         constexpr int LDS = CFG::NT == 512 ? 2 * (CFG::A_FLOATS + CFG::B_FLOATS) * 4 : CFG::SMEM_BYTES;   // 256 x 256: two images, 144 KB
         static_assert(LDS >= CFG::SMEM_BYTES && LDS <= 160 * 1024, "LDS budget");
-        if (LDS > 65536) {
-            static bool done = false;
-            if (!done) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bx_kernel<CFG, AM, BMD, VEC>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-                done = true;
-            }
+        if (LDS > 65536) {   // set at every launch: a host-side attribute write, valid whichever device is current (cheap beside a 256 x 256-tile launch)
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bx_kernel<CFG, AM, BMD, VEC>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            if (e != hipSuccess) { fail((int)e, "%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed", "gemm_bx_kernel"); return; }
         }
         hipLaunchKernelGGL((gemm_bx_kernel<CFG, AM, BMD, VEC>), grid, dim3(CFG::NT), LDS, st, g);
     } else hipLaunchKernelGGL((gemm_kernel<CFG, AM, BMD, VEC>), grid, dim3(CFG::NT), CFG::SMEM_BYTES, st, g);
@@ -408,7 +405,10 @@ extern "C" size_t vc_gemm_workspace_bytes(int M, int N, int K) {
 }
 
 namespace vc {
-static int g_gemm_precision = 0;  // process-wide: what vc_gemm_f32 computes with (vc_gemm_set_precision)
+// DEPRECATED process-wide default (vc_gemm_set_precision): what a vc_gemm_f32 call WITHOUT the VC_GEMM_BF16X3 flag computes with.  The
+// product path never sets it: engine.CaptionEngine / trainer.VggEngine pass their precision with every call (ABI 4).
+static int g_gemm_precision = 0;
+int gemm_default_precision() { return g_gemm_precision; }
 }
 
 extern "C" int vc_gemm_set_precision(int mode) {
@@ -423,11 +423,11 @@ static int gemm_impl(int prec, const char* fn, void* stream, int ta, int tb, int
 
 extern "C" int vc_gemm_f32(void* stream, int ta, int tb, int M, int N, int K, const float* A, long lda, const float* B,
                            long ldb, float* C, long ldc, const float* bias, int flags, float* ws, size_t ws_bytes) {
-    return gemm_impl(vc::g_gemm_precision, __func__, stream, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, ws, ws_bytes);
+    return gemm_impl((flags & VC_GEMM_BF16X3) ? 1 : vc::g_gemm_precision, __func__, stream, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, flags & ~VC_GEMM_BF16X3, ws, ws_bytes);
 }
 extern "C" int vc_gemm_bf16x3_f32(void* stream, int ta, int tb, int M, int N, int K, const float* A, long lda, const float* B,
                                   long ldb, float* C, long ldc, const float* bias, int flags, float* ws, size_t ws_bytes) {
-    return gemm_impl(1, __func__, stream, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, ws, ws_bytes);
+    return gemm_impl(1, __func__, stream, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias, flags & ~VC_GEMM_BF16X3, ws, ws_bytes);
 }
 
 // (argument / launch checks of the shared body report the ENTRY's name)

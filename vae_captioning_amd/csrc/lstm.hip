@@ -844,7 +844,7 @@ __global__ __launch_bounds__(512, 1) void lstm_rec8_fwd_kernel(LstmFwdArgs a, co
 // (four-wave kernel alone: 31.9 / 58.9 at 640 / 1280), backward 18.4 / 25.1 / 42.5 / 80.3 against 24.3 / 33.7 / 50.9 / 88.7 us (the
 // step kernels alone, rocprofv3: 13.0 us forward and 11.8 us backward at N = 320, where round 2 started from a 13.4 us split-K
 // GEMM + 8.2 us gate kernel backward).
-static int g_lstm_mode = 2;
+static int g_lstm_mode = 2;   // DEPRECATED process-wide default (vc_lstm_set_mode): calls choose with VC_LSTM_KERNELS(k) in their flags (ABI 4)
 static bool rec_ok(int N, int H) { return H == 512 && (long)(N + 96) * 4 * H * 4 < 0x7fffffffL; }
 static int lstm_env(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 static bool rec8_rows(int N) { static const int thr = lstm_env("VC_LSTM_REC8_ROWS", 400); return N > thr; }  // forward: the eight-wave 16-unit kernel above (19.7 vs 17.1 us at 320 rows, 26.2 vs 31.9 at 640, 47.9 vs 58.9 at 1280)
@@ -877,7 +877,10 @@ static int rec_row_groups(int N, int UG) {
 }
 
 // bx: the split-bf16 kernels (whp must then come from the pack kernels called with bx = 1)
-static bool rec_bx() { static const int off = lstm_env("VC_LSTM_BX", 1); return off != 0 && vc_gemm_get_precision() == 1; }
+static bool rec_bx(int flags) { static const int off = lstm_env("VC_LSTM_BX", 1); return off != 0 && ((flags & VC_LSTM_BF16X3) || gemm_default_precision() == 1); }
+// which step kernels a sequence call runs: the call's own choice (VC_LSTM_KERNELS(k) in its flags), else the deprecated process-wide default
+static int seq_mode(int flags) { const int k = flags & 7; return (k >= 1 && k <= 4) ? k - 1 : g_lstm_mode; }
+static int seq_gemm_flags(int flags) { return (flags & VC_LSTM_BF16X3) ? VC_GEMM_BF16X3 : 0; }
 
 static int rec_fwd(hipStream_t st, const LstmFwdArgs& a, const float* whp, bool bx = false) {
     static int once = rec_lds(lstm_rec_fwd_kernel<5>) | rec_lds(lstm_rec_fwd_kernel<3>) | rec_lds(lstm_rec_fwd_kernel<5, true>) | rec_lds(lstm_rec_fwd_kernel<3, true>);
@@ -1040,19 +1043,20 @@ extern "C" size_t vc_lstm_seq_workspace_bytes(int T, int N, int E, int H) {
 // cs[0], hs[0] must hold the initial state (zeros for the reference's zero_state).
 extern "C" int vc_lstm_seq_fwd_f32(void* stream, int T, int N, int E, int H, const float* X, const float* W,
                                    const float* b, const int32_t* lens_eff, float* act, float* cs, float* hs, float* ws,
-                                   size_t ws_bytes) {
+                                   size_t ws_bytes, int flags) {
     using namespace vc;
+    const int mode = seq_mode(flags), gf = seq_gemm_flags(flags);
     VC_CHECK_ARG(T > 0 && N > 0 && E > 0 && H > 0 && H % 32 == 0, "bad dimensions (H % 32 == 0 required)");
     VC_CHECK_ARG(X && W && b && lens_eff && act && cs && hs, "null pointer");
     const float* Wx = W;
     const float* Wh = W + (long)E * 4 * H;
-    int rc = vc_gemm_f32(stream, 0, 0, T * N, 4 * H, E, X, E, Wx, 4 * H, act, 4 * H, b, 0, ws, ws_bytes);
+    int rc = vc_gemm_f32(stream, 0, 0, T * N, 4 * H, E, X, E, Wx, 4 * H, act, 4 * H, b, gf, ws, ws_bytes);
     if (rc) return rc;
     const long NH = (long)N * H;
     const int eg = (int)((NH + 255) / 256) < 2048 ? (int)((NH + 255) / 256) : 2048;
-    const bool rec = (g_lstm_mode == 3 || g_lstm_mode == 2) && rec_ok(N, H) && ws && ws_bytes >= REC_PACK_BYTES;
+    const bool rec = (mode == 3 || mode == 2) && rec_ok(N, H) && ws && ws_bytes >= REC_PACK_BYTES;
     const bool rec8 = rec && rec8_rows(N);
-    const bool bx = rec && rec_bx();   // split-bf16 recurrence (vc_gemm_set_precision(1))
+    const bool bx = rec && rec_bx(flags);   // split-bf16 recurrence (VC_LSTM_BF16X3)
     if (rec) {  // Wh in the MFMA-operand layout of the step kernel, once per sequence (4 MB at H = 512)
         if (rec8) hipLaunchKernelGGL(lstm_rec8_pack_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, Wh, H, (float4*)ws, bx ? 1 : 0);
         else hipLaunchKernelGGL(lstm_rec_pack_fwd_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, Wh, H, (float4*)ws, bx ? 1 : 0);
@@ -1064,7 +1068,7 @@ extern "C" int vc_lstm_seq_fwd_f32(void* stream, int T, int N, int E, int H, con
         if (rec) {
             LstmFwdArgs a{hs + t * NH, cs + t * NH, Wh, g, lens_eff, cs + (t + 1) * NH, hs + (t + 1) * NH, N, H, t};
             rc = rec8 ? rec8_fwd((hipStream_t)stream, a, ws, bx) : rec_fwd((hipStream_t)stream, a, ws, bx);
-        } else if (g_lstm_mode) {
+        } else if (mode) {
             int ns = 1;  // recurrent product as split-K partials in ws; the gate kernel sums them (no separate reduce launch)
             rc = gemm_partials_f32((hipStream_t)stream, 0, 0, N, 4 * H, H, hs + t * NH, H, Wh, 4 * H, ws, ws_bytes, 8, &ns);
             if (rc) return rc;
@@ -1089,12 +1093,13 @@ extern "C" int vc_lstm_seq_fwd_f32(void* stream, int T, int N, int E, int H, con
 //   vc_lstm_seq_bwd_weights_f32  dWx = X^T.dG, dWh = hs[0:T]^T.dG, db = colsum(dG), from the dG the first call left
 // vc_lstm_seq_bwd_f32 is the first followed by the second on one stream.
 extern "C" int vc_lstm_seq_bwd_weights_f32(void* stream, int T, int N, int E, int H, const float* X, const float* hs, const float* dG,
-                                           float* dW, float* db, float* ws, size_t ws_bytes) {
+                                           float* dW, float* db, float* ws, size_t ws_bytes, int flags) {
     VC_CHECK_ARG(T > 0 && N > 0 && E > 0 && H > 0 && H % 32 == 0, "bad dimensions (H % 32 == 0 required)");
     VC_CHECK_ARG(X && hs && dG && dW && db, "null pointer");
-    int rc = vc_gemm_f32(stream, 1, 0, E, 4 * H, T * N, X, E, dG, 4 * H, dW, 4 * H, nullptr, 0, ws, ws_bytes);
+    const int gf = vc::seq_gemm_flags(flags);
+    int rc = vc_gemm_f32(stream, 1, 0, E, 4 * H, T * N, X, E, dG, 4 * H, dW, 4 * H, nullptr, gf, ws, ws_bytes);
     if (rc) return rc;
-    rc = vc_gemm_f32(stream, 1, 0, H, 4 * H, T * N, hs, H, dG, 4 * H, dW + (long)E * 4 * H, 4 * H, nullptr, 0, ws, ws_bytes);
+    rc = vc_gemm_f32(stream, 1, 0, H, 4 * H, T * N, hs, H, dG, 4 * H, dW + (long)E * 4 * H, 4 * H, nullptr, gf, ws, ws_bytes);
     if (rc) return rc;
     return vc_colsum_f32(stream, dG, T * N, 4 * H, 4 * H, db, 0, ws, ws_bytes);
 }
@@ -1102,17 +1107,18 @@ extern "C" int vc_lstm_seq_bwd_weights_f32(void* stream, int T, int N, int E, in
 extern "C" int vc_lstm_seq_bwd_f32(void* stream, int T, int N, int E, int H, const float* X, const float* W,
                                    const int32_t* lens_eff, const float* act, const float* cs, const float* hs,
                                    const float* dhs_ext, float* dH_run, float* dC_run, float* dG, float* dX, float* dW,
-                                   float* db, float* ws, size_t ws_bytes) {
+                                   float* db, float* ws, size_t ws_bytes, int flags) {
     VC_CHECK_ARG(dW && db, "null pointer");
-    int rc = vc_lstm_seq_bwd_data_f32(stream, T, N, E, H, W, lens_eff, act, cs, dhs_ext, dH_run, dC_run, dG, dX, ws, ws_bytes);
+    int rc = vc_lstm_seq_bwd_data_f32(stream, T, N, E, H, W, lens_eff, act, cs, dhs_ext, dH_run, dC_run, dG, dX, ws, ws_bytes, flags);
     if (rc) return rc;
-    return vc_lstm_seq_bwd_weights_f32(stream, T, N, E, H, X, hs, dG, dW, db, ws, ws_bytes);
+    return vc_lstm_seq_bwd_weights_f32(stream, T, N, E, H, X, hs, dG, dW, db, ws, ws_bytes, flags);
 }
 
 extern "C" int vc_lstm_seq_bwd_data_f32(void* stream, int T, int N, int E, int H, const float* W, const int32_t* lens_eff,
                                         const float* act, const float* cs, const float* dhs_ext, float* dH_run, float* dC_run,
-                                        float* dG, float* dX, float* ws, size_t ws_bytes) {
+                                        float* dG, float* dX, float* ws, size_t ws_bytes, int flags) {
     using namespace vc;
+    const int mode = seq_mode(flags), gf = seq_gemm_flags(flags);
     VC_CHECK_ARG(T > 0 && N > 0 && E > 0 && H > 0 && H % 32 == 0, "bad dimensions (H % 32 == 0 required)");
     VC_CHECK_ARG(W && lens_eff && act && cs && dH_run && dC_run && dG && dX, "null pointer");
     const float* Wx = W;
@@ -1122,8 +1128,8 @@ extern "C" int vc_lstm_seq_bwd_data_f32(void* stream, int T, int N, int E, int H
     const int eg = (int)((NH + 255) / 256) < 2048 ? (int)((NH + 255) / 256) : 2048;
     // split form: the recurrent product dG[t+1].Wh^T as split-K partials in ws, summed by the gate kernel
     const float* rec = ws;
-    const bool recb = (g_lstm_mode == 3 || g_lstm_mode == 2) && rec_ok(N, H) && ws && ws_bytes >= REC_PACK_BYTES;
-    const bool bx = recb && rec_bx();
+    const bool recb = (mode == 3 || mode == 2) && rec_ok(N, H) && ws && ws_bytes >= REC_PACK_BYTES;
+    const bool bx = recb && rec_bx(flags);
     if (recb) {  // Wh^T slices in operand order; ws is free again for the GEMMs below once the step loop has run
         hipLaunchKernelGGL(lstm_rec_pack_bwd_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, Wh, H, (float4*)ws, bx ? 1 : 0);
         rc = launch_status(__func__);
@@ -1136,7 +1142,7 @@ extern "C" int vc_lstm_seq_bwd_data_f32(void* stream, int T, int N, int E, int H
             LstmBwdArgs a{first ? nullptr : dG + (t + 1) * NG, Wh, lens_eff, ext, dH_run, dC_run, act + t * NG, cs + t * NH, cs + (t + 1) * NH,
                           dG + t * NG, N, H, t, first};
             rc = rec_bwd((hipStream_t)stream, a, ws, bx);
-        } else if (g_lstm_mode) {
+        } else if (mode) {
             int ns = 1;
             if (!first) {
                 rc = gemm_partials_f32((hipStream_t)stream, 0, 1, N, H, 4 * H, dG + (t + 1) * NG, 4 * H, Wh, 4 * H, ws, ws_bytes, 16, &ns);
@@ -1151,5 +1157,5 @@ extern "C" int vc_lstm_seq_bwd_data_f32(void* stream, int T, int N, int E, int H
         }
         if (rc) return rc;
     }
-    return vc_gemm_f32(stream, 0, 1, T * N, E, 4 * H, dG, 4 * H, Wx, 4 * H, dX, E, nullptr, 0, ws, ws_bytes);
+    return vc_gemm_f32(stream, 0, 1, T * N, E, 4 * H, dG, 4 * H, Wx, 4 * H, dX, E, nullptr, gf, ws, ws_bytes);
 }

@@ -213,6 +213,11 @@ class CaptionEngine(object):
         self.inject = False
         self.seed = seed
         self.timer = None
+        # arithmetic of this engine's dense products and LSTM sequence calls: "f32" (the reference's tf.float32) or "bf16x3" (split-bf16
+        # operands, f32 accumulate: an opt-in mode).  Carried by EVERY call (VC_GEMM_BF16X3 / VC_LSTM_BF16X3, ABI 4): engines of different
+        # precision coexist in one process, and nothing another engine or caller does can change this one's arithmetic.
+        self.precision = "f32"
+        self.lstm_kernels = None   # None = the library's automatic choice; 0..3 = VC_LSTM_KERNELS(k) (A/B runs, tests)
         self.reg_scale = 0.0
         self.c_means = None
         if self.enc and p.prior == "AG":
@@ -333,9 +338,24 @@ class CaptionEngine(object):
         if self.wgrad_stream is not None:
             torch.cuda.current_stream().wait_stream(self.wgrad_stream)
 
+    def set_precision(self, precision):
+        if precision not in ("f32", "bf16x3"):
+            raise ValueError("precision must be 'f32' or 'bf16x3', not %r" % (precision,))
+        self.precision = precision
+
+    @property
+    def gemm_flags(self):
+        """VC_GEMM_BF16X3 when this engine computes in split-bf16 (include/vaecap.h)"""
+        return 4 if self.precision == "bf16x3" else 0
+
+    @property
+    def lstm_flags(self):
+        """VC_LSTM_BF16X3 | VC_LSTM_KERNELS(k) of this engine's vc_lstm_seq_* calls"""
+        return (0x10 if self.precision == "bf16x3" else 0) | (0 if self.lstm_kernels is None else int(self.lstm_kernels) + 1)
+
     def gemm(self, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias=None, flags=0):
         ws, nb = self._need_ws(self.lib.vc_gemm_workspace_bytes(M, N, K))
-        self.lib.vc_gemm_f32(_stream(), ta, tb, M, N, K, P(A), lda, P(B), ldb, P(C), ldc, P(bias), flags, ws, nb)
+        self.lib.vc_gemm_f32(_stream(), ta, tb, M, N, K, P(A), lda, P(B), ldb, P(C), ldc, P(bias), flags | self.gemm_flags, ws, nb)
 
     def _timed(self, tag, flops, fn):
         if self.timer is not None:
@@ -628,7 +648,7 @@ class CaptionEngine(object):
         ws, wsb = self._need_ws(lib.vc_lstm_seq_workspace_bytes(Te, N, E, He))
         # (cs_e[0] / hs_e[0] = the zero initial state: `_b` allocates zeros and nothing ever writes row 0)
         lib.vc_lstm_seq_fwd_f32(st, Te, N, E, He, P(Xe), P(S.param(spec.ENC_CELL + "kernel")), P(S.param(spec.ENC_CELL + "bias")),
-                                P(self.buf["lens_e"]), P(act_e), P(cs_e), P(hs_e), ws, wsb)
+                                P(self.buf["lens_e"]), P(act_e), P(cs_e), P(hs_e), ws, wsb, self.lstm_flags)
         hT = hs_e[Te]
         # [mean | std | non-PAD label count, 0, 0, 0]: one buffer, so that the data-parallel exchange of the global Q1 mix is ONE
         # all-gather (fw_encode_sample)
@@ -709,7 +729,7 @@ class CaptionEngine(object):
         ws, wsb = self._need_ws(lib.vc_lstm_seq_workspace_bytes(Td, N, E, Hd))
         # (cs_d[0] / hs_d[0]: zero initial state, as above)
         lib.vc_lstm_seq_fwd_f32(st, Td, N, E, Hd, P(Xd), P(S.param(spec.DEC_CELL + "kernel")), P(S.param(spec.DEC_CELL + "bias")),
-                                P(self.buf["lens_d"]), P(act_d), P(cs_d), P(hs_d), ws, wsb)
+                                P(self.buf["lens_d"]), P(act_d), P(cs_d), P(hs_d), ws, wsb, self.lstm_flags)
         # outputs of the word steps.  (The reference zeroes outputs past the caption length; those rows
         # have PAD labels, so neither the loss nor any gradient can see the difference.)
         outs = hs_d[self.n_init_d + 1:]
@@ -805,7 +825,7 @@ class CaptionEngine(object):
         dG, dXd = self._b("dG_d", (Td, N, 4 * Hd)), self._b("dXd", (Td, N, E))
         ws, wsb = self._need_ws(lib.vc_lstm_seq_workspace_bytes(Td, N, E, Hd))
         lib.vc_lstm_seq_bwd_data_f32(st, Td, N, E, Hd, P(S.param(spec.DEC_CELL + "kernel")), P(self.buf["lens_d"]), P(self.buf["act_d"]),
-                                     P(self.buf["cs_d"]), P(dhs), P(dH), P(dC), P(dG), P(dXd), ws, wsb)
+                                     P(self.buf["cs_d"]), P(dhs), P(dH), P(dC), P(dG), P(dXd), ws, wsb, self.lstm_flags)
         dxw = dXd[nid]
         if p.dec_keep_rate < 1:
             lib.vc_dropout_f32(st, P(dxw), P(self.buf["drop_in"]), p.dec_keep_rate, T * N * E, P(dxw))
@@ -813,7 +833,7 @@ class CaptionEngine(object):
         def dec_w(dG=dG, dxw=dxw):
             ws, wsb = self._need_ws(lib.vc_lstm_seq_workspace_bytes(Td, N, E, Hd))
             lib.vc_lstm_seq_bwd_weights_f32(_stream(), Td, N, E, Hd, P(self.buf["Xd"]), P(self.buf["hs_d"]), P(dG),
-                                            P(S.grad(spec.DEC_CELL + "kernel")), P(S.grad(spec.DEC_CELL + "bias")), ws, wsb)
+                                            P(S.grad(spec.DEC_CELL + "kernel")), P(S.grad(spec.DEC_CELL + "bias")), ws, wsb, self.lstm_flags)
             self._embedding_grad("decoder/net/dec_embeddings", "dec", dxw)
             lib.vc_sumsq_partial_f32(_stream(), P(dxw), T * N * E, self.part.data_ptr() + nb * 4)  # IndexedSlices.values (Q5)
         side(dec_w)
@@ -864,7 +884,7 @@ class CaptionEngine(object):
             dG, dXe = self._b("dG_e", (Te, N, 4 * He)), self._b("dXe", (Te, N, E))
             ws, wsb = self._need_ws(lib.vc_lstm_seq_workspace_bytes(Te, N, E, He))
             lib.vc_lstm_seq_bwd_data_f32(st, Te, N, E, He, P(S.param(spec.ENC_CELL + "kernel")), P(self.buf["lens_e"]), P(self.buf["act_e"]),
-                                         P(self.buf["cs_e"]), None, P(dhT), P(dC), P(dG), P(dXe), ws, wsb)
+                                         P(self.buf["cs_e"]), None, P(dhT), P(dC), P(dG), P(dXe), ws, wsb, self.lstm_flags)
             lib.vc_axpy_f32(st, 1.0, P(dXe[0]), N * E, P(d_imfv))
             if self.feed_cv:
                 lib.vc_axpy_f32(st, 1.0, P(dXe[1]), N * E, P(d_ci))
@@ -872,7 +892,7 @@ class CaptionEngine(object):
             def enc_w(dG=dG, dxe=dxe):
                 ws, wsb = self._need_ws(lib.vc_lstm_seq_workspace_bytes(Te, N, E, He))
                 lib.vc_lstm_seq_bwd_weights_f32(_stream(), Te, N, E, He, P(self.buf["Xe"]), P(self.buf["hs_e"]), P(dG),
-                                                P(S.grad(spec.ENC_CELL + "kernel")), P(S.grad(spec.ENC_CELL + "bias")), ws, wsb)
+                                                P(S.grad(spec.ENC_CELL + "kernel")), P(S.grad(spec.ENC_CELL + "bias")), ws, wsb, self.lstm_flags)
                 self._embedding_grad("encoder/enc_embeddings", "enc", dxe)
                 lib.vc_sumsq_partial_f32(_stream(), P(dxe), T * N * E, self.part.data_ptr() + 2 * nb * 4)
             side(enc_w)

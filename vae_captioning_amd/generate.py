@@ -100,7 +100,7 @@ class CaptionGenerator(object):
         lens = torch.full((B,), n_init, dtype=torch.int32, device=e.dev)
         e._need_ws(lib.vc_lstm_seq_workspace_bytes(n_init, B, E, Hd))
         lib.vc_lstm_seq_fwd_f32(st, n_init, B, E, Hd, P(X), P(S.param(spec.DEC_CELL + "kernel")), P(S.param(spec.DEC_CELL + "bias")),
-                                P(lens), P(act), P(cs), P(hs), P(e.ws), e.ws_bytes)
+                                P(lens), P(act), P(cs), P(hs), P(e.ws), e.ws_bytes, e.lstm_flags)
         return cs[n_init].clone(), hs[n_init].clone()
 
     # ------------------------------------------------------------------ one decoder step

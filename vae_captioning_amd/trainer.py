@@ -49,6 +49,7 @@ class VggEngine(object):
         self.seed, self.rank = seed, rank
         self.inject = False
         self.timer = None
+        self.precision = "f32"   # "bf16x3": fc1 / fc2 products and the weight gradients on the bf16 pipe (per call, like CaptionEngine.precision)
         # the weight gradient of layer l and the data-gradient chain (layer l, then l-1 ...) are independent:
         # wgrads run on a side stream so that the tail of one kernel (the last partial round of workgroups)
         # is filled by the other instead of idling the chip
@@ -127,7 +128,8 @@ class VggEngine(object):
 
     def gemm(self, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias=None, flags=0):
         self._need_ws(self.lib.vc_gemm_workspace_bytes(M, N, K))
-        self.lib.vc_gemm_f32(_stream(), ta, tb, M, N, K, P(A), lda, P(B), ldb, P(C), ldc, P(bias), flags, P(self.ws), self.ws_bytes)
+        self.lib.vc_gemm_f32(_stream(), ta, tb, M, N, K, P(A), lda, P(B), ldb, P(C), ldc, P(bias), flags | (4 if self.precision == "bf16x3" else 0),
+                             P(self.ws), self.ws_bytes)
 
     def _timed(self, tag, flops, fn):
         if self.timer is not None:
@@ -192,9 +194,9 @@ class VggEngine(object):
         return self.use_wino and ci % 64 == 0 and co % 64 == 0 and bool(self.lib.vc_conv3x3_wino_wgrad_supported(B, H, W, ci, co))
 
     def _bx_wgrad_ok(self, B, H, W, ci, co):
-        """split-bf16 mode (vc_gemm_set_precision(1)): the direct weight gradient on the bf16 matrix pipe (csrc/conv_wgrad_bx.hip) replaces
+        """split-bf16 mode (this engine's precision): the direct weight gradient on the bf16 matrix pipe (csrc/conv_wgrad_bx.hip) replaces
         the f32 Winograd F(3x3,2x2) kernel (VC_WGRAD_BX=0: A/B runs)"""
-        return (self.use_wino and ci % 64 == 0 and co % 64 == 0 and self.lib.vc_gemm_get_precision() == 1 and os.environ.get("VC_WGRAD_BX", "1") != "0"
+        return (self.use_wino and ci % 64 == 0 and co % 64 == 0 and self.precision == "bf16x3" and os.environ.get("VC_WGRAD_BX", "1") != "0"
                 and bool(self.lib.vc_conv3x3_bx_wgrad_supported(B, H, W, ci, co)))
 
     def colsum(self, x, rows, cols, out):
@@ -533,16 +535,14 @@ class Trainer(object):
         (backend "nccl") or there is no process group at all (one forced rank), "torch" otherwise (the gloo test path).
         An existing dp.AbiComm may be passed instead."""
         self.p, self.lib = p, (lib or abi.load())
-        # precision: None = leave the library's process-wide GEMM mode alone (default f32: the reference's tf.float32 arithmetic);
-        # "f32" / "bf16x3" set it (vc_gemm_set_precision: every dense product of the step, including the ones inside vc_lstm_seq_*;
-        # "bf16x3" = split-bf16 operands, three bf16 MFMAs, f32 accumulate -- an opt-in mode with ~1e-5 relative product error,
-        # reported on its own bench lines, never the default).  VC_PRECISION overrides None.
-        precision = precision or os.environ.get("VC_PRECISION") or None
-        if precision is not None:
-            if precision not in ("f32", "bf16x3"):
-                raise ValueError("precision must be 'f32' or 'bf16x3', not %r" % (precision,))
-            self.lib.vc_gemm_set_precision(1 if precision == "bf16x3" else 0)
-        self.precision = "bf16x3" if self.lib.vc_gemm_get_precision() == 1 else "f32"
+        # precision: "f32" (default: the reference's tf.float32 arithmetic) or "bf16x3" (split-bf16 operands, three bf16 MFMAs, f32
+        # accumulate: every dense product of the step, the LSTM recurrences and the VGG16 weight gradients -- an opt-in mode with ~1e-5
+        # relative product error, reported on its own bench lines, never the default).  None = VC_PRECISION, else "f32".  The mode
+        # belongs to THIS trainer: its engines pass it with every library call (ABI 4), no process-wide state is read or written.
+        precision = precision or os.environ.get("VC_PRECISION") or "f32"
+        if precision not in ("f32", "bf16x3"):
+            raise ValueError("precision must be 'f32' or 'bf16x3', not %r" % (precision,))
+        self.precision = precision
         self.collectives = world > 1 or force_collectives
         self.world, self.rank, self.group = world, rank, group
         self.dev = device
@@ -552,10 +552,12 @@ class Trainer(object):
         self.gall = torch.zeros(n_cap + n_vgg, dtype=torch.float32, device=device)  # THE all-reduce buffer
         self.cap = CaptionEngine(p, vocab, device, self.lib, grad_backing=self.gall[:n_cap], world=world, rank=rank, group=group, seed=seed,
                                  force_collectives=force_collectives)
+        self.cap.set_precision(self.precision)
         self.cap.enable_wgrad_stream(bool(wgrad_stream) and os.environ.get("VC_WGRAD_STREAM", "1") != "0")   # (VC_WGRAD_STREAM=0: A/B runs)
         self.vgg = None
         if self.fine:
             self.vgg = VggEngine(p, device, self.lib, grad_backing=self.gall[n_cap:], seed=seed, rank=rank)
+            self.vgg.precision = self.precision
             if self.vgg.wd:
                 self.cap.reg_scale = self.vgg.wd / 2.0  # l2_regularizer(wd)(w) = wd * sum(w^2)/2
         self.images = None
