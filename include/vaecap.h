@@ -367,6 +367,28 @@ int vc_conv3x3_wino4_dgrad_f32(void* stream, int B, int H, int W, int Cin, int C
                                const float* relu_src, float* dx);
 int vc_conv3x3_wino4_dgrad_bits_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* dy, const float* wpt,
                                     const uint32_t* mask_bits, float* dx);
+/* The F(4x4, 3x3) forward / data gradient with the input transformed ONCE per layer and pass (csrc/conv_wino4.hip, MODE 2): a first
+ * kernel writes V = B^T d B of every (4 x 4 tile, gathered channel) into the workspace `vws` in the B-operand order of the MFMAs
+ * (2.25 x the activation's bytes, HBM-bound), the main kernel then streams its B operands from V straight into registers -- no patch
+ * staging, no patch LDS traffic and no transform arithmetic beside the MFMAs, where the fused kernel re-transforms every patch for
+ * every 32-output-channel tile (16 x on the 512-channel layers).  Same packed weights (vc_conv3x3_wino4_pack_f32), same arithmetic in
+ * the same order -- outputs, ReLU mask bits, pooled outputs and routing codes are BIT-IDENTICAL to the vc_conv3x3_wino4_* entry of the
+ * same name, argument for argument + (vws, vws_bytes).  Shapes: those of vc_conv3x3_wino4_* whose launch puts the same tile in the same
+ * lane (the linear-tile layers -- VGG16's 56- and 28-wide -- and 13..16 x 13..16 images), one launch (< 2 GiB): ask
+ * vc_conv3x3_wino4v_supported.  vc_conv3x3_wino4v_workspace_bytes(B, H, W, C): C = the GATHERED channels (Cin forward, Cout data
+ * gradient).  utils/image_embeddings.py:96-212 (conv3_1 .. conv5_3) and tf.gradients of them. */
+int vc_conv3x3_wino4v_supported(int B, int H, int W, int Cin, int Cout, int dgrad);
+size_t vc_conv3x3_wino4v_workspace_bytes(int B, int H, int W, int C);
+int vc_conv3x3_wino4v_fwd_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const float* wp, const float* bias,
+                              float* y, float* ypool, int relu, float* vws, size_t vws_bytes);
+int vc_conv3x3_wino4v_fwd_pool_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const float* wp, const float* bias,
+                                   float* y, float* ypool, uint32_t* pool_bits, float* vws, size_t vws_bytes);
+int vc_conv3x3_wino4v_fwd_mask_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const float* wp, const float* bias,
+                                   float* y, int relu, uint32_t* mask_out, float* vws, size_t vws_bytes);
+int vc_conv3x3_wino4v_dgrad_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* dy, const float* wpt, const float* relu_src,
+                                float* dx, float* vws, size_t vws_bytes);
+int vc_conv3x3_wino4v_dgrad_bits_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* dy, const float* wpt,
+                                     const uint32_t* mask_bits, float* dx, float* vws, size_t vws_bytes);
 /* Winograd F(3x3, 2x2) weight gradient (csrc/conv_wino_wgrad.hip): both operands transformed in registers, the contraction runs over the
  * 2x2-pixel tiles; raw position sums per K split in the workspace, a reduce kernel sums the splits in fixed order and applies the
  * output transform.  Same contract as conv3x3_wgrad (db != NULL also returns the bias gradient, accumulate adds to dw / db); the

@@ -132,9 +132,19 @@ __device__ __forceinline__ void w4_hstep(int k, const float* d, float* o, float*
     }
 }
 
-template <int KIND, bool POOL, bool LT>
+// MODE 0: square blocks, 1: linear tile blocks, 2 (W4_VIN): linear tile blocks whose input arrives TRANSFORMED -- a.x = V, the
+// B^T d B of every (tile, input channel) in the B-operand order of the MFMAs, written once per layer and pass by wino4_xform_kernel
+// below.  The main loop then has no patch staging, no patch LDS traffic and no transform arithmetic: a lane's B operands of a phase are
+// five 16-byte loads straight into registers (1 KB contiguous per wave and load), everything else -- weights through the LDS, the 36
+// MFMAs, the epilogue with its bias / ReLU / mask bits / pool / routing codes -- is the code of MODE 1.  Why: on gfx950 the f32 MFMA
+// shares its issue port with the f32 VALU (HISTORY.md 4g) and the fused kernel's 2.3-3.9 VALU + 1.0-1.4 LDS instructions per MFMA are
+// what holds it at 46-57 % MFMA-busy; here the input transform is paid ONCE per input channel instead of once per 32-output-channel
+// tile (16 x on the 512-channel layers) and at HBM speed (V = 2.25 x the activation bytes, written + read once).
+enum { W4_SQUARE = 0, W4_LINEAR = 1, W4_VIN = 2 };
+template <int KIND, bool POOL, int MODE>
 __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
-    constexpr int NPS = LT ? 5 : 3;                                    // patch slots per thread and phase
+    constexpr bool LT = MODE != W4_SQUARE, VIN = MODE == W4_VIN;
+    constexpr int NPS = VIN ? 1 : LT ? 5 : 3;                          // patch slots per thread and phase
     constexpr int PBUF = LT ? W4L_PBUF : W4_PBUF, BLKF = LT ? W4L_BLKF : W4_BLKF, PLANE = LT ? W4L_PLANE : W4_PLANE;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const Wino4Geom& g = a.g;
@@ -148,7 +158,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
     const int C = g.C, N = g.N;
     const int nc0 = nt * 32 + hf * 16 + 4 * lg;   // the four output channels this lane FINISHES
 
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)((long)g.B * g.H * g.W * C * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, VIN ? (int)((long)g.nblocks * C * 2304) : (int)((long)g.B * g.H * g.W * C * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, (int)(36L * C * N * 4), 0x00020000);
 
     // patch slots: slot s = tid + 256 j; one float4 = the phase's four channels of a pixel.  Square blocks: s < 648 = (block s / 324, patch
@@ -158,7 +168,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
 #pragma unroll
     for (int j = 0; j < NPS; ++j) {
         const unsigned s = (unsigned)tid + 256u * j;
-        if constexpr (LT) {
+        if constexpr (VIN) {   // no patches: the wave's B operands come from V[block][phase][pq 9][g 4][tile 16][pp 4] (voff: the lane's 16 bytes of fragment 0)
+            voff[j] = (((unsigned)(tm * W4_NBLK + (wave >> 1)) * (unsigned)a.nphases * 9u + 4u * (unsigned)(wave & 1)) * 256u + (unsigned)lane * 4u) * 4u;
+            pst[j] = 0;
+        } else if constexpr (LT) {
             const unsigned blk = s >= 576u ? 1u : 0u, rem = s - blk * 576u;
             const unsigned tl = rem / 36u, pp = rem - tl * 36u, py = pp / 6u, px = pp - py * 6u;
             const unsigned T = ((unsigned)tm * W4_NBLK + blk) * 16u + tl;
@@ -282,7 +295,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
             d[0] = v.x; d[PLANE] = v.y; d[2 * PLANE] = v.z; d[3 * PLANE] = v.w;
         };
         auto wput = [&](const float4& v, int i, int wq) {   // weight piece i into weight buffer wq
-            const int dst = (i == 4 && !w4ok) ? (LT ? W4L_DUMP : W4_DUMP) + 4 * (tid & 3) : wq * W4_WBUF + (tid + 256 * i) * 4;
+            const int dst = (i == 4 && !w4ok) ? (VIN ? W4_POFF : LT ? W4L_DUMP : W4_DUMP) + 4 * (tid & 3) : wq * W4_WBUF + (tid + 256 * i) * 4;
             *reinterpret_cast<float4*>(&smem[dst]) = v;
         };
         auto keep = [&](const float4& v) { asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); };   // (ablation 1024: the loads stay, their LDS writes go)
@@ -311,6 +324,65 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
         };
 #define WSB() __builtin_amdgcn_sched_barrier(0)
 
+        // ---- MODE 2 (pre-transformed input): the same 36 MFMAs with their B operands in registers.  Vc / Vn: this / the next phase's five
+        // fragments (fragment f = positions 4 (4 HF + f) .. + 3, the weights' numbering); the loads of phase h + 1 are issued at gaps 0 .. 4 of
+        // phase h, AHEAD of the weight pieces (gaps 5 .. 9 -> LDS at 20 .. 24): vmcnt retires in order, so by the time the weights are
+        // written both sets have arrived and nothing waits at the top of the next phase.
+        if constexpr (VIN) {
+            float4 Va[5], Vb[5];
+            const unsigned vstep = 9u * 1024u;   // bytes of one phase of a block
+            auto vload = [&](float4 (&Vn)[5], int i, int hp) { Vn[i] = wbufload(rx, voff[0] + (unsigned)i * 1024u, (unsigned)hp * vstep); };
+            auto vphase = [&](auto qc, float4 (&Vc)[5], float4 (&Vn)[5], bool nxt, int h) {
+                constexpr int q = decltype(qc)::value;
+#pragma unroll
+                for (int m = 0; m < 36; ++m) {
+                    const int pos = m >> 1, gi = m & 1;
+                    {
+                        const int pp = 18 * HF + pos, f = (pp >> 2) - 4 * HF;
+                        const float4& fr = vf[(f + q) & 1][gi];
+                        const float av = (pp & 3) == 0 ? fr.x : (pp & 3) == 1 ? fr.y : (pp & 3) == 2 ? fr.z : fr.w;
+                        const float4& vb = Vc[f];
+                        const float bv = (pp & 3) == 0 ? vb.x : (pp & 3) == 1 ? vb.y : (pp & 3) == 2 ? vb.z : vb.w;
+                        acc[gi][pos] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[gi][pos], 0, 0, 0);
+                    }
+                    WSB();
+                    {
+                        constexpr int first = HF ? 0 : 1;
+                        if (m >= first && m <= first + 24 && ((m - first) & 7) == 0) {
+                            const int f = (m - first) / 8 + 1;
+                            rdfrag(f, (f + q) & 1, q);
+                        }
+                    }
+                    if (nxt && m == 33) rdfrag(0, (q ^ 1) & 1, q ^ 1);
+                    if (m < 5 && nxt) vload(Vn, m, h + 1);
+                    if (m >= 5 && m < 10 && nxt) wload(m - 5, m - 5, h + 1);
+                    if (m >= 20 && m < 25 && nxt) wstore(m - 20, m - 20, q ^ 1);
+                    if (m == 28 && nxt && !(W4_ABL & 16)) __syncthreads();
+                    WSB();
+                }
+            };
+            {   // prologue: phase 0's weights into the LDS, its B operands into registers
+                float4 pr[5];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) pr[i] = wbufload(rw, (i == 4 && !w4ok) ? WOOB : vsrc + (unsigned)i * 4096u, 0u);
+#pragma unroll
+                for (int i = 0; i < 5; ++i) vload(Va, i, 0);
+#pragma unroll
+                for (int i = 0; i < 5; ++i) wput(pr[i], i, 0);
+            }
+            __syncthreads();
+            rdfrag(0, 0, 0);
+            WSB();
+            using Q0 = std::integral_constant<int, 0>;
+            using Q1 = std::integral_constant<int, 1>;
+            int h = 0;
+            for (; h + 2 < a.nphases; h += 2) {
+                vphase(Q0{}, Va, Vb, true, h);
+                vphase(Q1{}, Vb, Va, true, h + 1);
+            }
+            vphase(Q0{}, Va, Vb, true, h);
+            vphase(Q1{}, Vb, Va, false, h + 1);
+        } else {
         // One phase (index h, parity q) = 36 MFMAs: the wave's eighteen positions x two channel groups, column by column of Hc (twelve
         // MFMAs per column).  Beside them the next phase's rows are read (patch buffer q ^ 1) and transformed into Hn (gaps 1 .. 24), the
         // next column is transformed vertically (one step per gap), the next phase's weights are staged into weight buffer q ^ 1 and the
@@ -421,6 +493,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
         }
         phase(Q0{}, HA, HB, false, true, h);
         phase(Q1{}, HB, HA, false, false, h + 1);
+        }   // (MODE 0 / 1 main loop)
 #undef WSB
 
         // ---- output transform A^T M A (6 x 6 -> 4 x 4): rows of A^T
@@ -621,6 +694,60 @@ __global__ __launch_bounds__(256) void wino4_pack_kernel(const float* __restrict
     }
 }
 
+
+// ---- MODE 2's input: V[block][phase][pq 9][g 4][tile 16][pp 4] = B^T d B of tile 16 block + tile, channel 4 phase + g, position 4 pq + pp
+// (p = 6 v + u, v horizontal) -- per (block, phase) exactly the image a wave's five fragment loads walk.  One wave = one (block, phase):
+// a lane = (g, tile) gathers its channel's 6 x 6 patch (36 4-byte loads; the four g lanes of a tile cover a pixel's 16 bytes, the six
+// columns a row's lines), runs the SAME twelve-operation 1-D transforms in the same order as the fused kernel (rows, then columns: the
+// results are bit-identical to what MODE 0 / 1 feed their MFMAs) and stores nine float4: 1 KB contiguous per wave and store.  HBM-bound:
+// reads the activation once (+ halos from the L2), writes 2.25 x its bytes.
+struct Wino4XArgs {
+    const float* x;
+    float* V;
+    int B, H, W, C, nph, nblocks, tw, tiles_img, ntiles_all;
+    unsigned m_tiles_img, m_tw;
+};
+__global__ __launch_bounds__(256) void wino4_xform_kernel(Wino4XArgs a) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lj = lane & 15, lg = lane >> 4;
+    const int blk = blockIdx.x * 4 + wave, ph = blockIdx.y;
+    if (blk >= a.nblocks) return;
+    const int T = blk * 16 + lj;
+    const bool live = T < a.ntiles_all;
+    const unsigned Tc = live ? (unsigned)T : 0u;
+    const unsigned b = wino_div(Tc, a.m_tiles_img), r2 = Tc - b * (unsigned)a.tiles_img;
+    const unsigned tyy = wino_div(r2, a.m_tw), txx = r2 - tyy * (unsigned)a.tw;
+    const int y0 = (int)(tyy * 4u) - 1, x0 = (int)(txx * 4u) - 1;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)((long)a.B * a.H * a.W * a.C * 4), 0x00020000);
+    const unsigned plane = (b * (unsigned)(a.C >> 2) + (unsigned)ph) * (unsigned)a.H;
+    float Hh[6][6];   // [row r][horizontal index v]
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        float d[6], t[3];
+        const int y = y0 + r;
+        const bool oky = live && (unsigned)y < (unsigned)a.H;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int x = x0 + j;
+            const unsigned off = (oky && (unsigned)x < (unsigned)a.W) ? (((plane + (unsigned)y) * (unsigned)a.W + (unsigned)x) * 4u + (unsigned)lg) * 4u : WOOB;
+            d[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, (int)off, 0, 0));
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) w4_hstep<0>(k, d, &Hh[r][0], t);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) w4_hstep<1>(k, d, &Hh[r][3], t);
+    }
+    float o[36];   // o[6 v + u]
+#pragma unroll
+    for (int v = 0; v < 6; ++v) {
+        float t[5];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) w4_bstep_v(k, Hh[0][v], Hh[1][v], Hh[2][v], Hh[3][v], Hh[4][v], Hh[5][v], &o[6 * v], t);
+    }
+    float4* dst = reinterpret_cast<float4*>(a.V) + ((size_t)blk * a.nph + ph) * 9 * 64 + lane;
+#pragma unroll
+    for (int pq = 0; pq < 9; ++pq) dst[pq * 64] = make_float4(o[4 * pq], o[4 * pq + 1], o[4 * pq + 2], o[4 * pq + 3]);
+}
+
 static bool plan_wino4(int B, int H, int W, int C, int N, Wino4Geom& g) {
     g.B = B; g.H = H; g.W = W; g.C = C; g.N = N;
     if (B <= 0 || H < 4 || W < 4 || C <= 0 || N <= 0 || C % 8 || N % 32) return false;   // (any H, W: stores and pooling windows past the image are masked)
@@ -652,18 +779,29 @@ static int wino4_attr() {
         setl(reinterpret_cast<const void*>(conv_wino4_kernel<W4_FWD, false, true>));
         setl(reinterpret_cast<const void*>(conv_wino4_kernel<W4_FWD, true, true>));
         setl(reinterpret_cast<const void*>(conv_wino4_kernel<W4_DGRAD, false, true>));
+        set(reinterpret_cast<const void*>(conv_wino4_kernel<W4_FWD, false, W4_VIN>));
+        set(reinterpret_cast<const void*>(conv_wino4_kernel<W4_FWD, true, W4_VIN>));
+        set(reinterpret_cast<const void*>(conv_wino4_kernel<W4_DGRAD, false, W4_VIN>));
         return e == hipSuccess ? 0 : fail((int)e, "%s: hipFuncSetAttribute failed", "conv wino4 kernel");
     }();
     return once;
 }
 
 // one launch over nb images; C = gathered channels, N = produced channels
+static bool plan_wino4v(int B, int H, int W, int C, int N, Wino4Geom& g);
 static int wino4_launch(hipStream_t st, int kind, int nb, int H, int W, int C, int N, const float* x, const float* wp, float* out, const float* aux,
-                        float* pool, unsigned* mask, int relu, unsigned* pbits = nullptr) {
+                        float* pool, unsigned* mask, int relu, unsigned* pbits = nullptr, float* vws = nullptr) {
     Wino4Args a;
-    if (!plan_wino4(nb, H, W, C, N, a.g)) return fail(VC_EINVAL, "%s: unsupported shape (vc_conv3x3_wino4_supported)", "conv wino4");
+    if (!(vws ? plan_wino4v(nb, H, W, C, N, a.g) : plan_wino4(nb, H, W, C, N, a.g))) return fail(VC_EINVAL, "%s: unsupported shape (vc_conv3x3_wino4_supported / vc_conv3x3_wino4v_supported)", "conv wino4");
     int rc = wino4_attr();
     if (rc) return rc;
+    if (vws) {   // MODE 2: transform the input once (x -> V), then run the main loop on V
+        Wino4XArgs xa{x, vws, nb, H, W, C, C / 4, a.g.nblocks, a.g.tw, a.g.tiles_img, a.g.ntiles_all, a.g.m_tiles_img, a.g.m_tw};
+        hipLaunchKernelGGL(wino4_xform_kernel, dim3(cdiv(a.g.nblocks, 4), C / 4), dim3(256), 0, st, xa);
+        rc = launch_status("conv wino4v transform");
+        if (rc) return rc;
+        x = vws;
+    }
     a.x = x; a.wp = wp; a.out = out; a.aux = aux; a.pool = pool; a.mask = mask; a.pbits = pbits; a.relu = relu;
     a.tiles_n = N / 32;
     a.nphases = C / 4;
@@ -677,7 +815,11 @@ static int wino4_launch(hipStream_t st, int kind, int nb, int H, int W, int C, i
     static const int tg_env = getenv("VC_WINO4_TG") ? atoi(getenv("VC_WINO4_TG")) : 4;
     a.tg = (tg_env > 0 && a.tiles_n % tg_env == 0) ? tg_env : a.tiles_n;
     a.per_chunk = cdiv(a.g.nblocks, W4_NBLK) * a.tg;
-    if (a.g.lt) {
+    if (vws) {
+        if (kind == W4_DGRAD) hipLaunchKernelGGL((conv_wino4_kernel<W4_DGRAD, false, W4_VIN>), dim3(a.ntiles), dim3(256), WINO4_LDS_BYTES, st, a);
+        else if (pool) hipLaunchKernelGGL((conv_wino4_kernel<W4_FWD, true, W4_VIN>), dim3(a.ntiles), dim3(256), WINO4_LDS_BYTES, st, a);
+        else hipLaunchKernelGGL((conv_wino4_kernel<W4_FWD, false, W4_VIN>), dim3(a.ntiles), dim3(256), WINO4_LDS_BYTES, st, a);
+    } else if (a.g.lt) {
         if (kind == W4_DGRAD) hipLaunchKernelGGL((conv_wino4_kernel<W4_DGRAD, false, true>), dim3(a.ntiles), dim3(256), WINO4L_LDS_BYTES, st, a);
         else if (pool) hipLaunchKernelGGL((conv_wino4_kernel<W4_FWD, true, true>), dim3(a.ntiles), dim3(256), WINO4L_LDS_BYTES, st, a);
         else hipLaunchKernelGGL((conv_wino4_kernel<W4_FWD, false, true>), dim3(a.ntiles), dim3(256), WINO4L_LDS_BYTES, st, a);
@@ -685,6 +827,16 @@ static int wino4_launch(hipStream_t st, int kind, int nb, int H, int W, int C, i
     else if (pool) hipLaunchKernelGGL((conv_wino4_kernel<W4_FWD, true, false>), dim3(a.ntiles), dim3(256), WINO4_LDS_BYTES, st, a);
     else hipLaunchKernelGGL((conv_wino4_kernel<W4_FWD, false, false>), dim3(a.ntiles), dim3(256), WINO4_LDS_BYTES, st, a);
     return launch_status("conv wino4");
+}
+
+// MODE 2's geometry: linear tile blocks, and only where the fused kernel's launch on the same shape puts the same tile in the same lane
+// (its linear blocks, or one 4 x 4-tile square per image): the ReLU mask bits of the two forms are then interchangeable.
+static bool plan_wino4v(int B, int H, int W, int C, int N, Wino4Geom& g) {
+    if (!plan_wino4(B, H, W, C, N, g)) return false;
+    if (!(g.lt || (g.tw == 4 && cdiv(H, 4) == 4))) return false;
+    g.lt = 1;
+    g.nblocks = cdiv(g.ntiles_all, 16);
+    return (long)g.nblocks * C * 2304 <= 0x7fffffffL;
 }
 
 }  // namespace vc
@@ -796,4 +948,67 @@ extern "C" int vc_conv3x3_wino4_dgrad_bits_f32(void* stream, int B, int H, int W
     VC_CHECK_ARG(wino_images_per_launch(B, H, W, Cin, Cout) >= B && vc_conv3x3_wino4_supported(B, H, W, Cin, Cout, 1),
                  "unsupported shape, or more images than one launch takes (vc_conv3x3_wino_single_launch_supported)");
     return wino4_launch((hipStream_t)stream, W4_DGRAD, B, H, W, Cout, Cin, dy, wpt, dx, nullptr, nullptr, const_cast<uint32_t*>(mask_bits), 0);
+}
+
+// ---- the same operations with the input transformed ONCE into a workspace (MODE 2 above): vc_conv3x3_wino4v_* = vc_conv3x3_wino4_* + (vws,
+// vws_bytes); same packed weights, same outputs, same mask bits / routing codes (the shapes it takes are the ones where the lanes coincide).
+extern "C" int vc_conv3x3_wino4v_supported(int B, int H, int W, int Cin, int Cout, int dgrad) {
+    vc::Wino4Geom g;
+    if (vc::wino_images_per_launch(B, H, W, Cin, Cout) < B) return 0;   // one launch only
+    return (dgrad ? vc::plan_wino4v(B, H, W, Cout, Cin, g) : vc::plan_wino4v(B, H, W, Cin, Cout, g)) ? 1 : 0;
+}
+extern "C" size_t vc_conv3x3_wino4v_workspace_bytes(int B, int H, int W, int C) {
+    vc::Wino4Geom g;
+    if (!vc::plan_wino4v(B, H, W, C, 32, g)) return 0;
+    return (size_t)g.nblocks * C * 2304;
+}
+#define VC_W4V_ARGS(C_)                                                                                                       \
+    VC_CHECK_ARG(vws && waligned16(vws) && vws_bytes >= vc_conv3x3_wino4v_workspace_bytes(B, H, W, C_) && vws_bytes > 0,      \
+                 "workspace missing or too small (vc_conv3x3_wino4v_workspace_bytes), or unsupported shape")
+extern "C" int vc_conv3x3_wino4v_fwd_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const float* wp, const float* bias,
+                                         float* y, float* ypool, int relu, float* vws, size_t vws_bytes) {
+    using namespace vc;
+    VC_CHECK_ARG(x && wp && y, "null pointer");
+    VC_CHECK_ARG(waligned16(x) && waligned16(wp) && waligned16(y) && waligned16(bias) && waligned16(ypool), "pointers must be 16-byte aligned");
+    VC_CHECK_ARG(!ypool || !((H | W) & 1), "the fused max-pool needs even H and W");
+    VC_CHECK_ARG(vc_conv3x3_wino4v_supported(B, H, W, Cin, Cout, 0), "unsupported shape (vc_conv3x3_wino4v_supported)");
+    VC_W4V_ARGS(Cin);
+    return wino4_launch((hipStream_t)stream, W4_FWD, B, H, W, Cin, Cout, x, wp, y, bias, ypool, nullptr, relu, nullptr, vws);
+}
+extern "C" int vc_conv3x3_wino4v_fwd_pool_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const float* wp, const float* bias,
+                                              float* y, float* ypool, uint32_t* pool_bits, float* vws, size_t vws_bytes) {
+    using namespace vc;
+    VC_CHECK_ARG(x && wp && y && ypool && pool_bits, "null pointer");
+    VC_CHECK_ARG(waligned16(x) && waligned16(wp) && waligned16(y) && waligned16(bias) && waligned16(ypool), "pointers must be 16-byte aligned");
+    VC_CHECK_ARG(!((H | W) & 1), "the fused max-pool needs even H and W");
+    VC_CHECK_ARG(vc_conv3x3_wino4v_supported(B, H, W, Cin, Cout, 0), "unsupported shape (vc_conv3x3_wino4v_supported)");
+    VC_W4V_ARGS(Cin);
+    return wino4_launch((hipStream_t)stream, W4_FWD, B, H, W, Cin, Cout, x, wp, y, bias, ypool, nullptr, 1, pool_bits, vws);
+}
+extern "C" int vc_conv3x3_wino4v_fwd_mask_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const float* wp, const float* bias,
+                                              float* y, int relu, uint32_t* mask_out, float* vws, size_t vws_bytes) {
+    using namespace vc;
+    VC_CHECK_ARG(x && wp && y && mask_out, "null pointer");
+    VC_CHECK_ARG(waligned16(x) && waligned16(wp) && waligned16(y) && waligned16(bias) && waligned16(mask_out), "pointers must be 16-byte aligned");
+    VC_CHECK_ARG(vc_conv3x3_wino4v_supported(B, H, W, Cin, Cout, 0), "unsupported shape (vc_conv3x3_wino4v_supported)");
+    VC_W4V_ARGS(Cin);
+    return wino4_launch((hipStream_t)stream, W4_FWD, B, H, W, Cin, Cout, x, wp, y, bias, nullptr, mask_out, relu, nullptr, vws);
+}
+extern "C" int vc_conv3x3_wino4v_dgrad_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* dy, const float* wpt, const float* relu_src,
+                                           float* dx, float* vws, size_t vws_bytes) {
+    using namespace vc;
+    VC_CHECK_ARG(dy && wpt && dx, "null pointer");
+    VC_CHECK_ARG(waligned16(dy) && waligned16(wpt) && waligned16(dx) && waligned16(relu_src), "pointers must be 16-byte aligned");
+    VC_CHECK_ARG(vc_conv3x3_wino4v_supported(B, H, W, Cin, Cout, 1), "unsupported shape (vc_conv3x3_wino4v_supported)");
+    VC_W4V_ARGS(Cout);
+    return wino4_launch((hipStream_t)stream, W4_DGRAD, B, H, W, Cout, Cin, dy, wpt, dx, relu_src, nullptr, nullptr, 0, nullptr, vws);
+}
+extern "C" int vc_conv3x3_wino4v_dgrad_bits_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* dy, const float* wpt,
+                                                const uint32_t* mask_bits, float* dx, float* vws, size_t vws_bytes) {
+    using namespace vc;
+    VC_CHECK_ARG(dy && wpt && dx && mask_bits, "null pointer");
+    VC_CHECK_ARG(waligned16(dy) && waligned16(wpt) && waligned16(dx) && waligned16(mask_bits), "pointers must be 16-byte aligned");
+    VC_CHECK_ARG(vc_conv3x3_wino4v_supported(B, H, W, Cin, Cout, 1), "unsupported shape (vc_conv3x3_wino4v_supported)");
+    VC_W4V_ARGS(Cout);
+    return wino4_launch((hipStream_t)stream, W4_DGRAD, B, H, W, Cout, Cin, dy, wpt, dx, nullptr, nullptr, const_cast<uint32_t*>(mask_bits), 0, nullptr, vws);
 }
