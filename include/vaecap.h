@@ -378,6 +378,7 @@ int vc_conv3x3_wino4_dgrad_bits_f32(void* stream, int B, int H, int W, int Cin, 
  * vc_conv3x3_wino4v_supported.  vc_conv3x3_wino4v_workspace_bytes(B, H, W, C): C = the GATHERED channels (Cin forward, Cout data
  * gradient).  utils/image_embeddings.py:96-212 (conv3_1 .. conv5_3) and tf.gradients of them. */
 int vc_conv3x3_wino4v_supported(int B, int H, int W, int Cin, int Cout, int dgrad);
+int vc_conv3x3_wino4v_preferred(int B, int H, int W, int Cin, int Cout, int dgrad); /* 1: faster than the fused form for this launch (measured rule) */
 size_t vc_conv3x3_wino4v_workspace_bytes(int B, int H, int W, int C);
 int vc_conv3x3_wino4v_fwd_f32(void* stream, int B, int H, int W, int Cin, int Cout, const float* x, const float* wp, const float* bias,
                               float* y, float* ypool, int relu, float* vws, size_t vws_bytes);

@@ -6,10 +6,10 @@ from vae_captioning_amd.trainer import Trainer
 from vae_captioning_amd.utils.parameters import Parameters
 
 
-def tiny_finetune_trainer():
+def tiny_finetune_trainer(images=2):
     p = Parameters()
     p.fine_tune, p.num_captions, p.gen_z_samples = True, 2, 4
-    V, B, T = 300, 2, 6
+    V, B, T = 300, images, 6
     rng = np.random.default_rng(11)
     batch = synth.make_batch(rng, B, p.num_captions, T, V, images=True, variable_len=True)
     tr = Trainer(p, V, seed=3)

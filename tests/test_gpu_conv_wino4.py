@@ -256,3 +256,85 @@ def test_conv1_forward_leaves_the_mask_bits_of_conv1_2s_data_gradient(lib, case)
     assert torch.equal(dxa, dxb) and float(dxa.abs().max()) > 0
     with pytest.raises(Exception):
         lib.vc_conv1_fwd_mask_f32(stream(), B, H + 8, W, P(x4), P(w), P(b), P(y2), P(bits))   # H % 16 != 0 is refused
+
+
+# ---- round 6: the same convolution on a once-transformed input (csrc/conv_wino4.hip MODE 2, vc_conv3x3_wino4v_*) -------------------------------
+# shapes whose launch puts a tile in the fused kernel's lane: linear-tile layers (28 / 56 wide, incl. ragged last blocks, an odd block
+# count, one image, tile counts that are no multiple of 16) and 13..16-pixel images (one square block per image); several channel tiles,
+# the shortest reduction
+V_CASES = [(2, 28, 28, 64, 128), (3, 28, 28, 32, 32), (3, 28, 28, 8, 64), (5, 14, 14, 96, 128), (3, 14, 14, 32, 64), (1, 56, 56, 64, 64),
+           (2, 16, 16, 32, 64), (2, 13, 15, 16, 32), (7, 28, 28, 256, 64)]
+
+
+@pytest.mark.parametrize("case", V_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_wino4v_is_bit_identical_to_the_fused_kernel_and_matches_the_oracle(lib, case):
+    """utils/image_embeddings.py:96-212 (the layers behind pool2) forward + tf.gradients' data gradient: the pre-transformed form runs the
+    same 1-D transforms in the same order and the same MFMA sequence as the fused kernel, so EVERYTHING it leaves -- activation, ReLU mask
+    bits, pooled activation, MaxPoolGrad routing codes, data gradient with the mask as bits and as floats -- must equal the fused
+    entry's output bit for bit; the forward is also held to the fp64 oracle (6e-5 flat, the F(4x4,3x3) bound)."""
+    B, H, W, Ci, Co = case
+    assert lib.vc_conv3x3_wino4v_supported(B, H, W, Ci, Co, 0) == 1
+    rng = np.random.default_rng(sum(case) + 1)
+    x = np.maximum(rng.standard_normal((B, H, W, Ci), dtype=np.float32), 0)
+    w = rng.standard_normal((3, 3, Ci, Co), dtype=np.float32) * np.float32(1 / np.sqrt(9 * Ci))
+    b = rng.standard_normal(Co, dtype=np.float32)
+    dy = rng.standard_normal((B, H, W, Co), dtype=np.float32)
+    tx, tw, tb, tdy = dev_c4(x), dev(w), dev(b), dev_c4(dy)
+    wp = _pack(lib, tw, 0)
+    nbytes = max(lib.vc_conv3x3_wino4v_workspace_bytes(B, H, W, Ci), lib.vc_conv3x3_wino4v_workspace_bytes(B, H, W, Co))
+    assert lib.vc_conv3x3_wino4v_workspace_bytes(B, H, W, Ci) == -(-(B * -(-H // 4) * -(-W // 4)) // 16) * Ci * 2304
+    vws = torch.full((nbytes // 4,), float("nan"), dtype=torch.float32, device="cuda")   # (stale NaNs: the transform must write every slot it reads)
+    mw = lib.vc_conv3x3_wino4_mask_words(B, H, W, Co)
+    y, mk = [zeros(B, H, W, Co) for _ in range(2)], [torch.zeros(mw, dtype=torch.int32, device="cuda") for _ in range(2)]
+    lib.vc_conv3x3_wino4_fwd_mask_f32(stream(), B, H, W, Ci, Co, P(tx), P(wp), P(tb), P(y[0]), 1, P(mk[0]))
+    lib.vc_conv3x3_wino4v_fwd_mask_f32(stream(), B, H, W, Ci, Co, P(tx), P(wp), P(tb), P(y[1]), 1, P(mk[1]), P(vws), nbytes)
+    assert torch.equal(y[0], y[1]) and torch.equal(mk[0], mk[1])
+    if B * H * W <= 20000:
+        pre = OV.conv3x3_fwd(x.astype(np.float64), w.astype(np.float64), b.astype(np.float64))
+        assert_close(host_c4(y[1], (B, H, W, Co)), np.maximum(pre, 0), 6e-5, msg="wino4v fwd (+bias, relu)")
+    lib.vc_conv3x3_wino4_fwd_f32(stream(), B, H, W, Ci, Co, P(tx), P(wp), None, P(y[0]), None, 0)
+    lib.vc_conv3x3_wino4v_fwd_f32(stream(), B, H, W, Ci, Co, P(tx), P(wp), None, P(y[1]), None, 0, P(vws), nbytes)
+    assert torch.equal(y[0], y[1])
+    if H % 2 == 0 and W % 2 == 0:
+        yp = [zeros(B, H // 2, W // 2, Co) for _ in range(2)]
+        pb = [torch.zeros(lib.vc_conv3x3_wino_pool_words(B, H, W, Co), dtype=torch.int32, device="cuda") for _ in range(2)]
+        lib.vc_conv3x3_wino4_fwd_pool_f32(stream(), B, H, W, Ci, Co, P(tx), P(wp), P(tb), P(y[0]), P(yp[0]), P(pb[0]))
+        lib.vc_conv3x3_wino4v_fwd_pool_f32(stream(), B, H, W, Ci, Co, P(tx), P(wp), P(tb), P(y[1]), P(yp[1]), P(pb[1]), P(vws), nbytes)
+        assert torch.equal(y[0], y[1]) and torch.equal(yp[0], yp[1]) and torch.equal(pb[0], pb[1])
+    if Ci % 32 == 0 and Co % 8 == 0 and lib.vc_conv3x3_wino4v_supported(B, H, W, Ci, Co, 1):
+        wpt = _pack(lib, tw, 1)
+        dx = [zeros(B, H, W, Ci) for _ in range(2)]
+        mi = torch.zeros(lib.vc_conv3x3_wino4_mask_words(B, H, W, Ci), dtype=torch.int32, device="cuda").random_(0, 2 ** 31 - 1)
+        vws.fill_(float("nan"))
+        lib.vc_conv3x3_wino4_dgrad_bits_f32(stream(), B, H, W, Ci, Co, P(tdy), P(wpt), P(mi), P(dx[0]))
+        lib.vc_conv3x3_wino4v_dgrad_bits_f32(stream(), B, H, W, Ci, Co, P(tdy), P(wpt), P(mi), P(dx[1]), P(vws), nbytes)
+        assert torch.equal(dx[0], dx[1])
+        lib.vc_conv3x3_wino4_dgrad_f32(stream(), B, H, W, Ci, Co, P(tdy), P(wpt), P(tx), P(dx[0]))
+        lib.vc_conv3x3_wino4v_dgrad_f32(stream(), B, H, W, Ci, Co, P(tdy), P(wpt), P(tx), P(dx[1]), P(vws), nbytes)
+        assert torch.equal(dx[0], dx[1])
+        if B * H * W <= 20000:
+            dxref = OV.conv3x3_bwd(x.astype(np.float64), w.astype(np.float64), dy.astype(np.float64))[0] * (x > 0)
+            assert_close(host_c4(dx[1], (B, H, W, Ci)), dxref, 6e-5, msg="wino4v dgrad (relu mask from the activation)")
+
+
+def test_wino4v_refuses_what_it_does_not_take(lib):
+    """square-block layers whose lanes differ from the linear order (224 / 112 wide, 32 wide), a workspace that is too small or missing"""
+    from vae_captioning_amd.abi import VaecapError
+    assert lib.vc_conv3x3_wino4v_supported(2, 224, 224, 64, 64, 0) == 0 and lib.vc_conv3x3_wino4v_supported(2, 32, 32, 32, 32, 0) == 0
+    assert lib.vc_conv3x3_wino4v_supported(2, 8, 8, 32, 32, 0) == 0          # two images per linear block, one per square block
+    assert lib.vc_conv3x3_wino4v_supported(2, 28, 28, 30, 32, 0) == 0         # channels
+    assert lib.vc_conv3x3_wino4v_workspace_bytes(2, 224, 224, 64) == 0
+    # the measured preference rule: the 28- and 14-wide layers with >= 256 gathered channels, not the 56-wide ones
+    assert lib.vc_conv3x3_wino4v_preferred(32, 28, 28, 512, 512, 0) == 1 and lib.vc_conv3x3_wino4v_preferred(32, 14, 14, 512, 512, 1) == 1
+    assert lib.vc_conv3x3_wino4v_preferred(32, 28, 28, 256, 512, 0) == 1 and lib.vc_conv3x3_wino4v_preferred(32, 56, 56, 256, 256, 0) == 0
+    assert lib.vc_conv3x3_wino4v_preferred(32, 28, 28, 128, 512, 0) == 0
+    B, H, W, Ci, Co = 1, 28, 28, 32, 32
+    x, wp, y = zeros(B, H, W, Ci), torch.zeros(36 * Ci * Co, device="cuda"), zeros(B, H, W, Co)
+    need = lib.vc_conv3x3_wino4v_workspace_bytes(B, H, W, Ci)
+    vws = torch.zeros(need // 4, device="cuda")
+    with pytest.raises(VaecapError):
+        lib.vc_conv3x3_wino4v_fwd_f32(stream(), B, H, W, Ci, Co, P(x), P(wp), None, P(y), None, 0, P(vws), need - 4)
+    with pytest.raises(VaecapError):
+        lib.vc_conv3x3_wino4v_fwd_f32(stream(), B, H, W, Ci, Co, P(x), P(wp), None, P(y), None, 0, None, need)
+    with pytest.raises(VaecapError):
+        lib.vc_conv3x3_wino4v_fwd_f32(stream(), 2, 32, 32, Ci, Co, P(x), P(wp), None, P(y), None, 0, P(vws), need)

@@ -3,6 +3,7 @@ computes: every A/B switch (read once per process, hence the subprocesses) must 
   VC_WINO4_TG     chunk width of the F(4x4,3x3) workgroup order (csrc/conv_wino4.hip wino4_launch; 0 = all channel tiles together)
   VC_WGRAD_XCD    XCD-contiguous (split, tile) ranges of the weight gradient (csrc/conv_wino_wgrad_kernel.h)
   VC_LOGITS_DW    where the logits layer's kernel gradient is issued (engine.backward)
+  VC_WINO4V       conv4_x / conv5_x on the once-transformed input (csrc/conv_wino4.hip MODE 2) or on the fused kernel (0)
   VC_ADAM_BLOCKS  workgroups of an Adam launch (changes the summation order of the regulariser's partial sums only: not compared)"""
 import hashlib
 import json
@@ -77,7 +78,7 @@ print("RESULT " + json.dumps(out, sort_keys=True))
 
 def _run(code, env_extra):
     env = dict(os.environ)
-    for k in ("VC_WINO4_TG", "VC_WGRAD_XCD", "VC_LOGITS_DW", "VC_ADAM_BLOCKS"):
+    for k in ("VC_WINO4_TG", "VC_WGRAD_XCD", "VC_LOGITS_DW", "VC_ADAM_BLOCKS", "VC_WINO4V"):
         env.pop(k, None)
     env.update(env_extra)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
@@ -110,4 +111,14 @@ def test_issue_point_of_the_logits_weight_gradient_does_not_change_the_step():
     code = STEP % (ROOT, os.path.join(ROOT, "tests"))
     ref = _run(code, {})
     got = _run(code, {"VC_LOGITS_DW": "now"})
+    assert got == ref, (ref, got)
+
+
+def test_fine_tune_step_on_the_pre_transformed_convolutions_equals_the_fused_kernels_bit_for_bit():
+    """round 6: with VC_WINO4V=1 (the default of the split-bf16 mode) conv4_1 .. conv5_3 forward and data gradient run
+    vc_conv3x3_wino4v_* (the input transformed once per layer and pass); VC_WINO4V=0 keeps the fused F(4x4,3x3) kernel.  Same transforms, same MFMA order, same mask bits and routing codes: two whole
+    fine-tune steps (losses, caption parameters, convolution parameters) must agree in every bit."""
+    code = (STEP % (ROOT, os.path.join(ROOT, "tests"))).replace("tiny_finetune_trainer()", "tiny_finetune_trainer(4)")   # two images per chain: conv4_x qualifies too
+    ref = _run(code, {"VC_WINO4V": "1"})
+    got = _run(code, {"VC_WINO4V": "0"})
     assert got == ref, (ref, got)

@@ -6,7 +6,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from vae_captioning_amd import abi
 from vae_captioning_amd.abi import ptr as P
 

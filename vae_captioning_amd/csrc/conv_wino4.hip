@@ -31,7 +31,7 @@
 #include "conv_wino.h"
 
 // `make wino4abl W4FLAGS=-DW4_ABL=n` builds this file with W4_ABL = a bit mask that REMOVES parts of the main loop (results are then wrong; timing only):
-// 1 transform arithmetic, 2 patch-row reads, 4 weight-fragment reads, 8 staging (global loads + LDS writes), 16 barriers, 32 the patch loads wrapped into a cache-resident 1 MB window (same pattern), 64 no output stores, 128 no exchange of the partial outputs (NOT a valid ablation: the compiler then drops the MFMAs of the unsent channel group), 256 the output stores wrapped into a cache-resident 1 MB window, 512 no global loads of the staging (its LDS writes stay), 1024 no LDS writes of the staging (its loads stay)
+// 1 transform arithmetic, 2 patch-row reads, 4 weight-fragment reads, 8 staging (global loads + LDS writes), 16 barriers, 32 the patch loads wrapped into a cache-resident 1 MB window (same pattern), 64 no output stores, 128 no exchange of the partial outputs (NOT a valid ablation: the compiler then drops the MFMAs of the unsent channel group), 256 the output stores wrapped into a cache-resident 1 MB window, 512 no global loads of the staging (its LDS writes stay), 1024 no LDS writes of the staging (its loads stay), 2048 (MODE 2) no loads of the transformed input
 #ifndef W4_ABL
 #define W4_ABL 0
 #endif
@@ -331,7 +331,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
         if constexpr (VIN) {
             float4 Va[5], Vb[5];
             const unsigned vstep = 9u * 1024u;   // bytes of one phase of a block
-            auto vload = [&](float4 (&Vn)[5], int i, int hp) { Vn[i] = wbufload(rx, voff[0] + (unsigned)i * 1024u, (unsigned)hp * vstep); };
+            auto vload = [&](float4 (&Vn)[5], int i, int hp) { if (!(W4_ABL & 2048)) Vn[i] = wbufload(rx, voff[0] + (unsigned)i * 1024u, (unsigned)((W4_ABL & 32) ? (hp & 1) : hp) * vstep); };
+            if (W4_ABL & 2048) {
+#pragma unroll
+                for (int i = 0; i < 5; ++i) Va[i] = Vb[i] = make_float4(1.f + lane, 2.f, 3.f, 0.5f * i);
+            }
             auto vphase = [&](auto qc, float4 (&Vc)[5], float4 (&Vn)[5], bool nxt, int h) {
                 constexpr int q = decltype(qc)::value;
 #pragma unroll
@@ -956,6 +960,14 @@ extern "C" int vc_conv3x3_wino4v_supported(int B, int H, int W, int Cin, int Cou
     vc::Wino4Geom g;
     if (vc::wino_images_per_launch(B, H, W, Cin, Cout) < B) return 0;   // one launch only
     return (dgrad ? vc::plan_wino4v(B, H, W, Cout, Cin, g) : vc::plan_wino4v(B, H, W, Cin, Cout, g)) ? 1 : 0;
+}
+// 1 where the pre-transformed form is the faster one for a launch over B images.  Measured per layer (tools/experiments/wino4v_try.py,
+// profiles/r06_wino4v_layers.txt; fused -> transform + main kernel): it wins where V (2.25 x the gathered activation, written and read
+// once) is small beside the MFMA work it unloads -- the 28- and 14-wide layers (conv4_x, conv5_x: x1.05-1.19) -- and loses on the 56-wide
+// ones (conv3_x: 0.73-0.89, V = 231-462 MB per half batch).  VC_WINO4V_MAX_PIXELS overrides the image-size bound (0 = never).
+extern "C" int vc_conv3x3_wino4v_preferred(int B, int H, int W, int Cin, int Cout, int dgrad) {
+    static const long maxpix = getenv("VC_WINO4V_MAX_PIXELS") ? atol(getenv("VC_WINO4V_MAX_PIXELS")) : 28 * 28;
+    return (long)H * W <= maxpix && (dgrad ? Cout : Cin) >= 256 && vc_conv3x3_wino4v_supported(B, H, W, Cin, Cout, dgrad) ? 1 : 0;
 }
 extern "C" size_t vc_conv3x3_wino4v_workspace_bytes(int B, int H, int W, int C) {
     vc::Wino4Geom g;

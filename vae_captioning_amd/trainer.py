@@ -62,6 +62,12 @@ class VggEngine(object):
         #                                              independent checker of tests/)
         self.use_conv1 = True
         self.use_wino = os.environ.get("VC_CONV_WINO", "1") != "0"
+        # conv4_x / conv5_x forward + data gradient on a once-transformed input (csrc/conv_wino4.hip MODE 2; bit-identical to the fused
+        # kernel).  Measured inside the cfg4 step (profiles/r06_wino4v_step.md): the main kernels shrink by 15-25 % but the 24 transform
+        # launches per step sit on the chains; f32 25.85-25.93 ms against 25.81-25.88 fused (nothing), split-bf16 mode 21.39 against
+        # 21.66 (its shorter weight-gradient stream leaves the chains critical).  Default: on in the split-bf16 mode only; VC_WINO4V=1 / 0 forces.
+        self._wino4v_env = os.environ.get("VC_WINO4V")
+        self.vws = {}   # conv chain -> workspace of the transformed input
         # Streams: 3 = two half-batch convolution chains + the weight gradients on a third stream (the tail of one launch is filled by
         # another stream's launch; the data-parallel gradient buckets are issued from the weight-gradient stream), 1 = serial
         nstreams = int(os.environ.get("VC_VGG_STREAMS", "3"))
@@ -185,10 +191,26 @@ class VggEngine(object):
         ok = self.lib.vc_conv3x3_wino4_supported if name in self.wino4 else self.lib.vc_conv3x3_wino_supported
         return self.use_wino and (("vpt_" if dgrad else "vp_") + name) in self.buf and bool(ok(nb, H, W, ci, co, dgrad))
 
-    def _wino(self, name, entry):
+    @property
+    def use_wino4v(self):
+        return self._wino4v_env != "0" if self._wino4v_env is not None else self.precision == "bf16x3"
+
+    def _wino(self, name, entry, geom=None, ch=0):
         """The Winograd entry `entry` ("fwd_f32", "dgrad_bits_f32", "mask_words" ...) of the family that holds layer `name` this
-        step: vc_conv3x3_wino4_* (F(4x4,3x3)) or vc_conv3x3_wino_* (F(2x2,3x3)) -- same arguments in both."""
-        return getattr(self.lib, ("vc_conv3x3_wino4_" if name in self.wino4 else "vc_conv3x3_wino_") + entry)
+        step: vc_conv3x3_wino4_* (F(4x4,3x3)) or vc_conv3x3_wino_* (F(2x2,3x3)) -- same arguments in both.
+        geom = (nb, H, W, Cin, Cout, dgrad) of a forward / data-gradient LAUNCH on conv chain `ch`: where the library prefers it
+        (vc_conv3x3_wino4v_preferred: conv4_x, conv5_x) the F(4x4,3x3) call runs on a once-transformed input -- the same entry with the
+        chain's transform workspace appended, bit-identical results, same mask bits (csrc/conv_wino4.hip MODE 2)."""
+        lib = self.lib
+        if geom is not None and name in self.wino4 and self.use_wino4v and bool(lib.vc_conv3x3_wino4v_preferred(*geom)):
+            nb, H, W, ci, co, dgrad = geom
+            need = lib.vc_conv3x3_wino4v_workspace_bytes(nb, H, W, co if dgrad else ci)
+            v = self.vws.get(ch)
+            if v is None or v.numel() * 4 < need:
+                v = self.vws[ch] = torch.empty(need // 4, dtype=torch.float32, device=self.dev)
+            fn = getattr(lib, "vc_conv3x3_wino4v_" + entry)
+            return lambda *a: fn(*a, P(v), v.numel() * 4)
+        return getattr(lib, ("vc_conv3x3_wino4_" if name in self.wino4 else "vc_conv3x3_wino_") + entry)
 
     def _wino_wgrad_ok(self, B, H, W, ci, co):
         return self.use_wino and ci % 64 == 0 and co % 64 == 0 and bool(self.lib.vc_conv3x3_wino_wgrad_supported(B, H, W, ci, co))
@@ -299,7 +321,7 @@ class VggEngine(object):
                             mk = self._b("mk_%s_%d" % (name, ch), (self._wino(name, "mask_words")(nb, H, W, co),), dtype=torch.int32)
                             self.mask_geom[name] = (nb, len(halves))   # the bits are per tile of THIS launch geometry
                             self.mask_family[name] = 4 if name in self.wino4 else 2
-                            self._timed("conv_fwd", fl, lambda: self._wino(name, "fwd_mask_f32")(
+                            self._timed("conv_fwd", fl, lambda: self._wino(name, "fwd_mask_f32", (nb, H, W, cie, co, 0), ch)(
                                 sh, nb, H, W, cie, co, P(x[b0:]), P(self.buf["vp_" + name]), P(S.param(bn)), P(y[b0:]), 1, P(mk)))
                         elif pooled and self.train:
                             # the 2x2 max-pool is register math in the epilogue; it also leaves MaxPoolGrad's routing codes (4 bits per pooled
@@ -307,10 +329,10 @@ class VggEngine(object):
                             pb = self._b("pb_" + name, (lib.vc_conv3x3_wino_pool_words(B, H, W, co),), dtype=torch.int32)
                             pool_bits = pb
                             w0 = b0 * (H // 2) * (W // 2) * (co // 8)
-                            self._timed("conv_fwd", fl, lambda: self._wino(name, "fwd_pool_f32")(
+                            self._timed("conv_fwd", fl, lambda: self._wino(name, "fwd_pool_f32", (nb, H, W, cie, co, 0), ch)(
                                 sh, nb, H, W, cie, co, P(x[b0:]), P(self.buf["vp_" + name]), P(S.param(bn)), P(y[b0:]), P(yp[b0:]), P(pb[w0:])))
                         else:
-                            self._timed("conv_fwd", fl, lambda: self._wino(name, "fwd_f32")(
+                            self._timed("conv_fwd", fl, lambda: self._wino(name, "fwd_f32", (nb, H, W, cie, co, 0), ch)(
                                 sh, nb, H, W, cie, co, P(x[b0:]), P(self.buf["vp_" + name]), P(S.param(bn)), P(y[b0:]), P(yp[b0:]) if pooled else None, 1))
                         continue
                     # NHWC implicit-GEMM kernels of csrc/conv.hip behind layout conversions: any shape (VC_CONV_WINO=0, odd image sizes)
@@ -470,10 +492,10 @@ class VggEngine(object):
                               and self.mask_family.get(self.acts[li - 1][0]) == (4 if name in self.wino4 else 2)   # (bits are in their family's lane order)
                               and lib.vc_conv3x3_wino_single_launch_supported(nb, H, W, ci, co)):
                             # ReluGrad from the bits the previous layer's forward left (one 8-byte load per lane instead of sixteen 16-byte ones)
-                            self._timed("conv_dgrad", fl * nb / B, lambda: self._wino(name, "dgrad_bits_f32")(
+                            self._timed("conv_dgrad", fl * nb / B, lambda: self._wino(name, "dgrad_bits_f32", (nb, H, W, ci, co, 1), ch)(
                                 sh, nb, H, W, ci, co, P(d[b0:]), P(self.buf["vpt_" + name]), P(self.buf["mk_%s_%d" % (self.acts[li - 1][0], ch)]), P(dx[b0:])))
                         elif self._wino_ok(name, nb, H, W, ci, co, 1):
-                            self._timed("conv_dgrad", fl * nb / B, lambda: self._wino(name, "dgrad_f32")(
+                            self._timed("conv_dgrad", fl * nb / B, lambda: self._wino(name, "dgrad_f32", (nb, H, W, ci, co, 1), ch)(
                                 sh, nb, H, W, ci, co, P(d[b0:]), P(self.buf["vpt_" + name]), None if prev_is_pool else P(x[b0:]), P(dx[b0:])))
                         else:   # csrc/conv.hip on NHWC copies
                             dn_ = self._to_nhwc("d_%s_%d" % (name, ch), d[b0:], nb, H, W, co)
