@@ -169,6 +169,10 @@ int vc_argmax_rows_f32(void* stream, const float* x, long rows, int cols, long l
 /* The first k entries of each row under a STABLE descending sort (ties -> lower index first): the
  * candidate expansion of beam search, vae_model/decoder.py:273-276. */
 int vc_topk_rows_f32(void* stream, const float* x, long rows, int cols, long ld, int k, float* out_val, int32_t* out_idx);
+/* vc_softmax_rows_f32 followed by vc_topk_rows_f32 (k <= 8) in ONE read of the logits and no [rows, V] probability buffer: out_p / out_idx
+ * [rows, k] equal the two-call sequence bit for bit (same expressions, same summation order, same tie rule).  One beam-search round,
+ * vae_model/decoder.py:248-276. */
+int vc_softmax_topk_rows_f32(void* stream, const float* logits, long rows, int V, long ld, int k, float* out_p, int32_t* out_idx);
 int vc_fill_f32(void* stream, float* x, long n, float value);
 /* tf.multinomial(logits / temperature, 1) (vae_model/decoder.py:137-138) by inverse CDF with injected
  * uniforms u[rows] in [0,1): out[r] = first index whose cumulative softmax exceeds u[r]. */
@@ -443,6 +447,10 @@ int vc_beam_update(void* stream, int B, int beam, int Lmax, int eos, double len_
                    const int32_t* top_i, int32_t* pcount, int32_t* ccount, double* p_score, double* p_logprob,
                    int32_t* p_len, const int32_t* sent_cur, int32_t* sent_next, double* c_score, double* c_logprob,
                    int32_t* c_len, int32_t* c_slot, int32_t* c_free, int32_t* c_sent, int32_t* parent, int32_t* tok);
+
+/* Stop-word bookkeeping of greedy / sampled decoding (vae_model/decoder.py:186-194), on device: done[b] |= (tok[b] == eos);
+ * pending[0] = number of rows that have not emitted eos yet (a float, like the other device scalars). */
+int vc_eos_track_i32(void* stream, const int32_t* tok, int B, int eos, int32_t* done, float* pending);
 
 /* ------------------------------------------------------------------------------------
  * Host-side helper (the only entry point that takes HOST pointers): CRC-32C (Castagnoli) of a byte

@@ -84,6 +84,57 @@ def test_topk_is_a_stable_descending_sort_prefix(lib, k, cols, ld):
         assert host(tv)[r].tolist() == [float(v) for _, v in ref]
 
 
+@pytest.mark.parametrize("k,V,ld", [(5, 10000, 10000), (8, 1000, 1004), (3, 257, 259), (1, 40, 40), (5, 6, 8), (5, 11313, 11316), (2, 12292, 12292)],
+                         ids=["k5-vocab", "k8-padded-pitch", "k3-unaligned-three-pass", "k1", "k5-of-6", "observed-vocab-three-pass", "beyond-the-register-form"])
+def test_fused_softmax_topk_equals_softmax_then_topk_bit_for_bit(lib, k, V, ld):
+    """round 6: one beam-search round reads its logits once (vc_softmax_topk_rows_f32) instead of writing [rows, V] probabilities
+    and reading them back (vae_model/decoder.py:248-276).  Rows with many EQUAL logits (ties -> lower index first), a constant row,
+    a row with one dominant word (p == 1.0 exactly, everything else underflows to equal zeros)."""
+    import torch
+    from .gpu_util import P, dev, host, stream
+    rng = np.random.default_rng(k * 7 + V)
+    R = 9
+    x = np.full((R, ld), 50.0, np.float32)   # (padding columns hold a LARGER value: they must never be read)
+    x[:, :V] = rng.standard_normal((R, V)).astype(np.float32) * 3
+    x[1, :V] = np.round(x[1, :V])            # ties
+    x[2, :V] = 0.25                          # constant row
+    x[3, :V] = -200.0
+    x[3, V // 2] = 100.0                     # one word takes everything
+    dx = dev(x)
+    probs = torch.empty((R, ld), dtype=torch.float32, device="cuda")
+    tv, ti = [torch.empty((R, k), dtype=torch.float32, device="cuda") for _ in range(2)], [torch.empty((R, k), dtype=torch.int32, device="cuda") for _ in range(2)]
+    lib.vc_softmax_rows_f32(stream(), P(dx), R, V, ld, P(probs), ld)
+    lib.vc_topk_rows_f32(stream(), P(probs), R, V, ld, k, P(tv[0]), P(ti[0]))
+    lib.vc_softmax_topk_rows_f32(stream(), P(dx), R, V, ld, k, P(tv[1]), P(ti[1]))
+    assert np.array_equal(host(ti[0]), host(ti[1])) and np.array_equal(host(tv[0]).view(np.uint32), host(tv[1]).view(np.uint32))
+    # and against the definition, in fp64 (values to 1e-6, the index set where the probabilities are distinct)
+    ref = np.exp(x[:, :V].astype(np.float64) - x[:, :V].max(1, keepdims=True))
+    ref /= ref.sum(1, keepdims=True)
+    for r in (0, 4, 5):
+        order = sorted(range(V), key=lambda i: -ref[r, i])[:k]
+        assert host(ti[1])[r].tolist() == order
+        np.testing.assert_allclose(host(tv[1])[r], ref[r, order], rtol=2e-6)
+    assert host(ti[1])[2].tolist() == list(range(k)) and host(ti[1])[3, 0] == V // 2 and host(tv[1])[3, 0] == 1.0
+
+
+@pytest.mark.parametrize("kw", [dict(prior="GMM"), dict(no_encoder=True)], ids=["gmm", "no-encoder"])
+def test_captured_rounds_generate_what_the_eager_loop_generates(lib, kw, monkeypatch):
+    """greedy and beam search replay hipGraphs of four decoder rounds; VC_DECODE_GRAPH=0 runs the same launches one by one.  Same
+    token ids, same beams, same scores (bitwise), also when the generator is called twice (cached greedy graph) and with a batch
+    size change in between."""
+    p, eng, gen, P64, feats, cv, eps, cm = setup(lib, 9, **kw)
+    c = cv if spec.uses_ci(p) else None
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("VC_DECODE_GRAPH", mode)
+        g = CaptionGenerator(eng)
+        out[mode] = (g.greedy(feats, c, eps, BOS, EOS, max_len=14), g.beam_search(feats, c, eps, BOS, EOS, beam_size=3, max_len=14),
+                     g.greedy(feats[:4], c[:4] if c is not None else None, eps[:, :4], BOS, EOS, max_len=14),
+                     g.greedy(feats, c, eps, BOS, EOS, max_len=14), g.beam_search(feats, c, eps, BOS, EOS, beam_size=3, max_len=14, check_every=0))
+    assert out["1"] == out["0"]
+    assert out["1"][0] == out["1"][3] and out["1"][1] == out["1"][4] and out["1"][2] == out["1"][0][:4]
+
+
 def test_multinomial_inverse_cdf_matches_numpy(lib):
     import torch
     from .gpu_util import P, dev, host, stream

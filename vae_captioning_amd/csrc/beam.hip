@@ -82,88 +82,142 @@ struct BeamArgs {
     int32_t *sent_next, *c_sent, *parent, *tok;
 };
 
-// The two heaps of a thread live in LDS (32 threads x 2 x 16 items x 32 B = 32 KB): as private arrays their run-time indexing went
-// through scratch memory, one L2 round trip per heap move (65 us per decoder step for 128 images x 5 beams; ~12 us now).
-constexpr int BEAM_THREADS = 32;
+// The two heaps of an image live in LDS (32 images x 2 x 16 items x 32 B = 32 KB): as private arrays their run-time indexing went
+// through scratch memory, one L2 round trip per heap move (65 us per decoder step for 128 images x 5 beams).
+// Round 6: the heap walk stays one thread per image (it IS sequential: heapq's sift order decides ties), but the token copies it
+// used to do itself -- a kept beam's sentence into the next round's buffer, a finished caption into its pool slot: up to
+// beam x (length - 1) dependent load / store pairs per thread, 41 us per round at 30 tokens -- are only RECORDED by the walk and carried
+// out afterwards by eight threads per image (a workgroup = 32 images = 256 threads, thread t of an image copies tokens t, t + 8, ...).
+// A finished caption is recorded PER POOL SLOT: a slot that was freed and taken again within the round keeps its last writer's record,
+// which is the caption the sequential code left there.
+constexpr int BEAM_IMAGES = 32;                 // images per workgroup
+constexpr int BEAM_THREADS = 8 * BEAM_IMAGES;   // 256
+constexpr int BEAM_SLOTS = BEAM_MAX + 1;        // pool slots of finished captions per image
+
 
 __global__ __launch_bounds__(BEAM_THREADS) void beam_update_kernel(BeamArgs a) {
-    __shared__ BeamItem heaps[2][BEAM_THREADS][BEAM_MAX];
-    const int b = blockIdx.x * BEAM_THREADS + threadIdx.x;
-    if (b >= a.B) return;
+    __shared__ BeamItem heaps[2][BEAM_IMAGES][BEAM_MAX];
+    __shared__ int part_n[BEAM_IMAGES];
+    __shared__ short crec_src[BEAM_IMAGES][BEAM_SLOTS], crec_len0[BEAM_IMAGES][BEAM_SLOTS];   // len0 < 0: no caption recorded for the slot this round
+    __shared__ int crec_tok[BEAM_IMAGES][BEAM_SLOTS];
     const int n = a.n, L = a.Lmax;
-    const int np = a.pcount[b];
-    for (int j = 0; j < n; ++j) {  // defaults for slots that stay empty: continue row b*n with token 0 (ignored)
-        a.parent[b * n + j] = b * n;
-        a.tok[b * n + j] = 0;
-    }
-    if (np == 0) return;  // every beam of this image has ended
-    BeamItem* part = heaps[0][threadIdx.x];
-    BeamItem* comp = heaps[1][threadIdx.x];
-    int hn = 0, cn = a.ccount[b];
-    for (int j = 0; j < cn; ++j) {
-        comp[j].score = a.c_score[b * n + j];
-        comp[j].logprob = a.c_logprob[b * n + j];
-        comp[j].len = a.c_len[b * n + j];
-        comp[j].slot = a.c_slot[b * n + j];
-        comp[j].parent = comp[j].tok = 0;
-    }
-    int freemask = a.c_free[b];
-    const int32_t* cur = a.sent_cur + (long)b * n * L;
-    for (int i = 0; i < np; ++i) {
-        const long row = (long)b * n + i;
-        const double lp0 = a.p_logprob[row];
-        const int len0 = a.p_len[row];
-        for (int j = 0; j < a.k; ++j) {
-            const float pw = a.tv[row * a.k + j];
-            if ((double)pw < 1e-12) continue;  // decoder.py:279: float32 p against the Python float 1e-12
-            BeamItem it;
-            it.tok = a.ti[row * a.k + j];
-            it.parent = i;
-            it.len = len0 + 1;
-            it.logprob = lp0 + (double)logf(pw);  // decoder.py:282: np.log of a float32 is a float32; the SUM is a float64
-            it.score = it.logprob;
-            it.slot = -1;
-            if (it.tok == a.eos) {
-                if (a.len_norm_f > 0) it.score = it.logprob / pow((double)it.len, a.len_norm_f);
-                // take a free pool slot, write the caption there, give it back if the heap does not keep it
-                int s = 0;
-                while (!((freemask >> s) & 1)) ++s;
-                freemask &= ~(1 << s);
-                it.slot = s;
-                int32_t* dst = a.c_sent + ((long)b * (n + 1) + s) * L;
-                for (int t = 0; t < len0; ++t) dst[t] = cur[i * L + t];
-                dst[len0] = it.tok;
-                const int freed = topn_push(comp, cn, n, it);
-                if (freed >= 0) freemask |= 1 << freed;
-            } else {
-                topn_push(part, hn, n, it);
+    if (threadIdx.x < BEAM_IMAGES) {   // ---- the walk: one thread per image
+        const int li = threadIdx.x, b = blockIdx.x * BEAM_IMAGES + li;
+        part_n[li] = 0;
+        for (int q = 0; q < BEAM_SLOTS; ++q) crec_len0[li][q] = -1;
+        if (b < a.B) {
+            const int np = a.pcount[b];
+            for (int j = 0; j < n; ++j) {  // defaults for slots that stay empty: continue row b*n with token 0 (ignored)
+                a.parent[b * n + j] = b * n;
+                a.tok[b * n + j] = 0;
+            }
+            if (np != 0) {  // (0: every beam of this image has ended)
+                BeamItem* part = heaps[0][li];
+                BeamItem* comp = heaps[1][li];
+                int hn = 0, cn = a.ccount[b];
+                for (int j = 0; j < cn; ++j) {
+                    comp[j].score = a.c_score[b * n + j];
+                    comp[j].logprob = a.c_logprob[b * n + j];
+                    comp[j].len = a.c_len[b * n + j];
+                    comp[j].slot = a.c_slot[b * n + j];
+                    comp[j].parent = comp[j].tok = 0;
+                }
+                int freemask = a.c_free[b];
+                for (int i = 0; i < np; ++i) {
+                    const long row = (long)b * n + i;
+                    const double lp0 = a.p_logprob[row];
+                    const int len0 = a.p_len[row];
+                    for (int j = 0; j < a.k; ++j) {
+                        const float pw = a.tv[row * a.k + j];
+                        if ((double)pw < 1e-12) continue;  // decoder.py:279: float32 p against the Python float 1e-12
+                        BeamItem it;
+                        it.tok = a.ti[row * a.k + j];
+                        it.parent = i;
+                        it.len = len0 + 1;
+                        it.logprob = lp0 + (double)logf(pw);  // decoder.py:282: np.log of a float32 is a float32; the SUM is a float64
+                        it.score = it.logprob;
+                        it.slot = -1;
+                        if (it.tok == a.eos) {
+                            if (a.len_norm_f > 0) it.score = it.logprob / pow((double)it.len, a.len_norm_f);
+                            // take a free pool slot, record the caption for it, give the slot back if the heap does not keep it
+                            int s = 0;
+                            while (!((freemask >> s) & 1)) ++s;
+                            freemask &= ~(1 << s);
+                            it.slot = s;
+                            crec_src[li][s] = (short)i; crec_len0[li][s] = (short)len0; crec_tok[li][s] = it.tok;
+                            const int freed = topn_push(comp, cn, n, it);
+                            if (freed >= 0) freemask |= 1 << freed;
+                        } else {
+                            topn_push(part, hn, n, it);
+                        }
+                    }
+                }
+                for (int j = 0; j < hn; ++j) {
+                    const long o = (long)b * n + j;
+                    a.p_score[o] = part[j].score;
+                    a.p_logprob[o] = part[j].logprob;
+                    a.p_len[o] = part[j].len;
+                    a.parent[o] = b * n + part[j].parent;
+                    a.tok[o] = part[j].tok;
+                }
+                a.pcount[b] = hn;
+                for (int j = 0; j < cn; ++j) {
+                    const long o = (long)b * n + j;
+                    a.c_score[o] = comp[j].score;
+                    a.c_logprob[o] = comp[j].logprob;
+                    a.c_len[o] = comp[j].len;
+                    a.c_slot[o] = comp[j].slot;
+                }
+                a.ccount[b] = cn;
+                a.c_free[b] = freemask;
+                part_n[li] = hn;
             }
         }
     }
+    __syncthreads();
+    // ---- the copies: eight threads per image
+    const int li = threadIdx.x >> 3, sub = threadIdx.x & 7, b = blockIdx.x * BEAM_IMAGES + li;
+    if (b >= a.B) return;
+    const int32_t* cur = a.sent_cur + (long)b * n * L;
+    for (int q = 0; q <= n; ++q) {   // finished captions, per pool slot
+        const int len0 = crec_len0[li][q], i = crec_src[li][q];
+        if (len0 < 0) continue;
+        int32_t* dst = a.c_sent + ((long)b * (n + 1) + q) * L;
+        for (int t = sub; t <= len0; t += 8) dst[t] = t < len0 ? cur[i * L + t] : crec_tok[li][q];
+    }
+    const int hn = part_n[li];
     int32_t* nxt = a.sent_next + (long)b * n * L;
+    const BeamItem* part = heaps[0][li];
     for (int j = 0; j < hn; ++j) {
-        const long o = (long)b * n + j;
-        a.p_score[o] = part[j].score;
-        a.p_logprob[o] = part[j].logprob;
-        a.p_len[o] = part[j].len;
-        for (int t = 0; t < part[j].len - 1; ++t) nxt[j * L + t] = cur[part[j].parent * L + t];
-        nxt[j * L + part[j].len - 1] = part[j].tok;
-        a.parent[o] = b * n + part[j].parent;
-        a.tok[o] = part[j].tok;
+        const int len = part[j].len, src = part[j].parent;
+        for (int t = sub; t < len; t += 8) nxt[j * L + t] = t < len - 1 ? cur[src * L + t] : part[j].tok;
     }
-    a.pcount[b] = hn;
-    for (int j = 0; j < cn; ++j) {
-        const long o = (long)b * n + j;
-        a.c_score[o] = comp[j].score;
-        a.c_logprob[o] = comp[j].logprob;
-        a.c_len[o] = comp[j].len;
-        a.c_slot[o] = comp[j].slot;
+}
+
+// greedy / sampled decoding (vae_model/decoder.py:186-194: the loop ends at the stop word): done[b] |= (tok[b] == eos); pending[0] = rows not done
+// yet.  One workgroup; lets a captured chunk of decoder steps report "has every image emitted <EOS>" in 4 bytes.
+__global__ __launch_bounds__(256) void eos_track_kernel(const int32_t* __restrict__ tok, int B, int eos, int32_t* __restrict__ done,
+                                                        float* __restrict__ pending) {
+    __shared__ float sh[4];
+    float open = 0.f;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        const int d = done[b] | (tok[b] == eos ? 1 : 0);
+        done[b] = d;
+        open += d ? 0.f : 1.f;
     }
-    a.ccount[b] = cn;
-    a.c_free[b] = freemask;
+    open = block_sum<256>(open, sh);
+    if (threadIdx.x == 0) pending[0] = open;
 }
 
 }  // namespace vc
+
+extern "C" int vc_eos_track_i32(void* stream, const int32_t* tok, int B, int eos, int32_t* done, float* pending) {
+    using namespace vc;
+    VC_CHECK_ARG(tok && done && pending && B > 0, "bad argument");
+    hipLaunchKernelGGL(eos_track_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, tok, B, eos, done, pending);
+    VC_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int vc_beam_update(void* stream, int B, int beam, int Lmax, int eos, double len_norm_f, const float* top_p,
                               const int32_t* top_i, int32_t* pcount, int32_t* ccount, double* p_score, double* p_logprob,
@@ -178,7 +232,7 @@ extern "C" int vc_beam_update(void* stream, int B, int beam, int Lmax, int eos, 
     a.tv = top_p; a.ti = top_i; a.pcount = pcount; a.ccount = ccount; a.p_len = p_len; a.c_len = c_len; a.c_slot = c_slot;
     a.c_free = c_free; a.p_score = p_score; a.p_logprob = p_logprob; a.c_score = c_score; a.c_logprob = c_logprob;
     a.sent_cur = sent_cur; a.sent_next = sent_next; a.c_sent = c_sent; a.parent = parent; a.tok = tok;
-    hipLaunchKernelGGL(beam_update_kernel, dim3(cdiv(B, BEAM_THREADS)), dim3(BEAM_THREADS), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(beam_update_kernel, dim3(cdiv(B, BEAM_IMAGES)), dim3(BEAM_THREADS), 0, (hipStream_t)stream, a);
     VC_LAUNCH_CHECK();
     return 0;
 }

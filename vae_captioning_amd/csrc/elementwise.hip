@@ -465,6 +465,104 @@ __global__ __launch_bounds__(256) void topk_rows_small_kernel(const float* __res
     }
 }
 
+// softmax + top-k of a row in ONE read of the logits (beam search, vae_model/decoder.py:248-276: probs = softmax(logits), then the
+// beam_size most probable words by a stable sort on -p).  The probabilities are formed by exactly the expressions of
+// softmax_rows_reg_kernel / softmax_rows_kernel (loss.hip: same maximum, same summation order, p = exp(l - max) * (1 / sum)) and offered
+// to the per-thread lists of topk_rows_small_kernel in the same column order, so (p, index) out equal vc_softmax_rows_f32 followed by
+// vc_topk_rows_f32 bit for bit -- without writing the [rows, V] probabilities (25.6 MB per round at 640 rows) and reading them back.
+template <bool REG>
+__global__ __launch_bounds__(256) void softmax_topk_rows_kernel(const float* __restrict__ x, int V, long ld, int k,
+                                                                float* __restrict__ out_val, int32_t* __restrict__ out_idx) {
+    __shared__ float sh[4];
+    __shared__ float lv[8][256];
+    __shared__ int li[8][256];
+    __shared__ float wv[4];
+    __shared__ int wi[4], wt[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float tv[8];
+    int ti[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { tv[j] = -INFINITY; ti[j] = 0x7fffffff; }
+    auto offer = [&](float v, int c) {
+        if (v > tv[7]) {
+            tv[7] = v; ti[7] = c;
+#pragma unroll
+            for (int j = 7; j > 0; --j)
+                if (tv[j] > tv[j - 1]) {
+                    const float a = tv[j]; tv[j] = tv[j - 1]; tv[j - 1] = a;
+                    const int b = ti[j]; ti[j] = ti[j - 1]; ti[j - 1] = b;
+                }
+        }
+    };
+    if (REG) {
+        const float4* p = reinterpret_cast<const float4*>(x + (long)blockIdx.x * ld);
+        const int Q = V >> 2;
+        float4 r[12];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            const int c = tid + 256 * i;
+            if (c < Q) {
+                r[i] = p[c];
+                mx = fmaxf(fmaxf(mx, fmaxf(r[i].x, r[i].y)), fmaxf(r[i].z, r[i].w));
+            }
+        }
+        mx = block_max<256>(mx, sh);
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            const int c = tid + 256 * i;
+            if (c < Q) {
+                r[i].x = __expf(r[i].x - mx); r[i].y = __expf(r[i].y - mx); r[i].z = __expf(r[i].z - mx); r[i].w = __expf(r[i].w - mx);
+                s += (r[i].x + r[i].y) + (r[i].z + r[i].w);
+            }
+        }
+        s = block_sum<256>(s, sh);
+        const float inv = 1.f / s;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            const int c = tid + 256 * i;
+            if (c < Q) { offer(r[i].x * inv, 4 * c); offer(r[i].y * inv, 4 * c + 1); offer(r[i].z * inv, 4 * c + 2); offer(r[i].w * inv, 4 * c + 3); }
+        }
+    } else {
+        const float* p = x + (long)blockIdx.x * ld;
+        float mx = -INFINITY;
+        for (int c = tid; c < V; c += 256) mx = fmaxf(mx, p[c]);
+        mx = block_max<256>(mx, sh);
+        float s = 0.f;
+        for (int c = tid; c < V; c += 256) s += __expf(p[c] - mx);
+        s = block_sum<256>(s, sh);
+        const float inv = 1.f / s;
+        for (int c = tid; c < V; c += 256) offer(__expf(p[c] - mx) * inv, c);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { lv[j][tid] = tv[j]; li[j][tid] = ti[j]; }
+    int head = 0;
+    for (int j = 0; j < k; ++j) {
+        float bv = head < 8 ? lv[head][tid] : -INFINITY;
+        int bi = head < 8 ? li[head][tid] : 0x7fffffff;
+        int bt = tid;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float v2 = __shfl_xor(bv, o, 64);
+            const int i2 = __shfl_xor(bi, o, 64), t2 = __shfl_xor(bt, o, 64);
+            if (v2 > bv || (v2 == bv && i2 < bi)) { bv = v2; bi = i2; bt = t2; }
+        }
+        if (lane == 0) { wv[wave] = bv; wi[wave] = bi; wt[wave] = bt; }
+        __syncthreads();
+        bv = wv[0]; bi = wi[0]; bt = wt[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (wv[w] > bv || (wv[w] == bv && wi[w] < bi)) { bv = wv[w]; bi = wi[w]; bt = wt[w]; }
+        if (tid == bt) ++head;
+        if (tid == 0) {
+            out_val[(long)blockIdx.x * k + j] = bv;
+            out_idx[(long)blockIdx.x * k + j] = bi;
+        }
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ x, long n, float v) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) x[i] = v;
 }
@@ -481,6 +579,18 @@ extern "C" int vc_topk_rows_f32(void* stream, const float* x, long rows, int col
         hipLaunchKernelGGL(topk_rows_small_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, cols, ld, k, out_val, out_idx);
     else
         hipLaunchKernelGGL(topk_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, cols, ld, k, out_val, out_idx);
+    VC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vc_softmax_topk_rows_f32(void* stream, const float* logits, long rows, int V, long ld, int k, float* out_p, int32_t* out_idx) {
+    VC_CHECK_ARG(logits && out_p && out_idx && rows >= 0 && V > 0 && ld >= V && k > 0 && k <= 8 && k <= V, "bad argument (k <= 8)");
+    if (rows == 0) return 0;
+    // (the register form under the conditions vc_softmax_rows_f32 takes it: the probabilities then round alike)
+    if ((V & 3) == 0 && V <= 12288 && (ld & 3) == 0 && (((uintptr_t)logits) & 15) == 0)
+        hipLaunchKernelGGL(softmax_topk_rows_kernel<true>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, logits, V, ld, k, out_p, out_idx);
+    else
+        hipLaunchKernelGGL(softmax_topk_rows_kernel<false>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, logits, V, ld, k, out_p, out_idx);
     VC_LAUNCH_CHECK();
     return 0;
 }

@@ -32,6 +32,7 @@ class CaptionGenerator(object):
         self._ones = {}
         self._whp = None        # decoder Wh in the recurrence kernel's operand order
         self._whp_fresh = False  # re-packed at the start of every init_state (the weights may have been trained in between)
+        self._graphs = {}        # captured decode rounds (hipGraphs), keyed by shapes + the addresses they bake
 
     def _b(self, name, shape, dtype=torch.float32):
         t = self.buf.get(name)
@@ -104,37 +105,79 @@ class CaptionGenerator(object):
         return cs[n_init].clone(), hs[n_init].clone()
 
     # ------------------------------------------------------------------ one decoder step
-    def step(self, tokens, c, h, want="probs"):
-        """Feed one token per row: returns (softmax probs [M, V], c', h')."""
+    def _round_bufs(self, tag, M):
+        """Persistent buffers of one decoder step over M rows (a captured round bakes their addresses)."""
+        p, e = self.p, self.e
+        E, Hd, V = p.embed_size, p.decoder_hidden, e.V
+        return {"x": self._b(tag + "x", (M, E)), "gact": self._b(tag + "gact", (M, 4 * Hd)), "c2": self._b(tag + "c2", (M, Hd)),
+                "h2": self._b(tag + "h2", (M, Hd)), "logits": self._b(tag + "logits", (M, V))}
+
+    def _pack_wh(self, M):
+        """decoder Wh in the recurrence step kernel's operand order, once per generation call (init_state clears _whp_fresh)"""
+        e, p, lib = self.e, self.p, self.lib
+        E, Hd = p.embed_size, p.decoder_hidden
+        if self._whp_fresh or not lib.vc_lstm_step_packed_supported(M, Hd):
+            return
+        if self._whp is None or self._whp.numel() != 2 * Hd * 4 * Hd:
+            self._whp = torch.empty(2 * Hd * 4 * Hd, dtype=torch.float32, device=e.dev)
+        lib.vc_lstm_pack_wh_f32(_stream(), Hd, e.store.param(spec.DEC_CELL + "kernel").data_ptr() + E * 4 * Hd * 4, P(self._whp))
+        self._whp_fresh = True
+
+    def step(self, tokens, c, h, want="probs", bufs=None, timed=True):
+        """Feed one token per row: returns (softmax probs [M, V], c', h').  bufs (from _round_bufs): write x / gate activations / new
+        state / logits into these persistent tensors instead of fresh ones (c, h must not alias bufs["c2"] / bufs["h2"])."""
         e, p, lib, st, S = self.e, self.p, self.lib, _stream(), self.e.store
         M = int(tokens.shape[0])
         E, Hd, V = p.embed_size, p.decoder_hidden, e.V
-        x = torch.empty((M, E), dtype=torch.float32, device=e.dev)
+        new = lambda k, shape: bufs[k] if bufs is not None else torch.empty(shape, dtype=torch.float32, device=e.dev)
+        x = new("x", (M, E))
         lib.vc_embedding_gather_f32(st, P(S.param("decoder/net/dec_embeddings")), P(tokens), M, E, V, P(x))
         W = S.param(spec.DEC_CELL + "kernel")
-        gact = torch.empty((M, 4 * Hd), dtype=torch.float32, device=e.dev)
+        gact = new("gact", (M, 4 * Hd))
         e.gemm(0, 0, M, 4 * Hd, E, x, E, W, 4 * Hd, gact, 4 * Hd, S.param(spec.DEC_CELL + "bias"))
-        c2, h2 = torch.empty_like(c), torch.empty_like(h)
+        c2, h2 = new("c2", (M, Hd)), new("h2", (M, Hd))
         ones = self._ones.get(M)
         if ones is None:
             ones = self._ones[M] = torch.ones((M,), dtype=torch.int32, device=e.dev)
         if lib.vc_lstm_step_packed_supported(M, Hd):  # the recurrence step kernel on Wh packed once per weight version
-            if not self._whp_fresh:
-                if self._whp is None or self._whp.numel() != 2 * Hd * 4 * Hd:
-                    self._whp = torch.empty(2 * Hd * 4 * Hd, dtype=torch.float32, device=e.dev)
-                lib.vc_lstm_pack_wh_f32(st, Hd, W.data_ptr() + E * 4 * Hd * 4, P(self._whp))
-                self._whp_fresh = True
+            self._pack_wh(M)
             lib.vc_lstm_step_fwd_packed_f32(st, M, Hd, 0, P(h), P(c), P(self._whp), P(gact), P(ones), P(c2), P(h2))
         else:
             lib.vc_lstm_step_fwd_f32(st, M, Hd, 0, P(h), P(c), W.data_ptr() + E * 4 * Hd * 4, P(gact), P(ones), P(c2), P(h2))
-        logits = torch.empty((M, V), dtype=torch.float32, device=e.dev)
-        e._timed("logits_gemm", 2.0 * M * V * Hd,
-                 lambda: e.gemm(0, 0, M, V, Hd, h2, Hd, S.param("decoder/rnn_logits/kernel"), e.Vp, logits, V, S.param("decoder/rnn_logits/bias")))
+        logits = new("logits", (M, V))
+        run = lambda: e.gemm(0, 0, M, V, Hd, h2, Hd, S.param("decoder/rnn_logits/kernel"), e.Vp, logits, V, S.param("decoder/rnn_logits/bias"))
+        if timed:
+            e._timed("logits_gemm", 2.0 * M * V * Hd, run)
+        else:   # (inside a hipGraph capture: no timer events)
+            run()
         if want == "logits":
             return logits, c2, h2
         probs = torch.empty_like(logits)
         lib.vc_softmax_rows_f32(st, P(logits), M, V, V, P(probs), V)
         return probs, c2, h2
+
+    # ------------------------------------------------------------------ captured rounds
+    def _graph_key(self, kind, *shape):
+        """A captured round is valid while every address it baked is: the parameter store, the packed Wh, the engine's workspace."""
+        e = self.e
+        return (kind,) + tuple(shape) + (e.store.p.data_ptr(), P(self._whp) if self._whp is not None else 0, P(e.ws) if e.ws is not None else 0, e.gemm_flags)
+
+    def _capture(self, key, fn):
+        """hipGraph of fn() (launches on the current stream only, no allocations, no host reads).  Returns None when graphs are off
+        (VC_DECODE_GRAPH=0: A/B runs)."""
+        import os
+        if os.environ.get("VC_DECODE_GRAPH", "1") == "0":
+            return None
+        g = self._graphs.get(key)
+        if g is None:
+            if len(self._graphs) > 16:
+                self._graphs.clear()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                fn()
+            self._graphs[key] = g
+        return g
 
     # ------------------------------------------------------------------ greedy (online_inference)
     def _trim(self, ids, eos):
@@ -149,20 +192,54 @@ class CaptionGenerator(object):
     def greedy(self, features, c_v=None, eps=None, bos=1, eos=2, max_len=None, check_every=4):
         """decoder.py:145-201 with sample_gen='greedy' for a batch of images: returns the list
         of generated token-id lists (each ends with <EOS> unless max_len was hit).  Tokens stay on the
-        device; the host only asks "has every image emitted <EOS>?" every `check_every` steps."""
+        device; the host only asks "has every image emitted <EOS>?" every `check_every` steps (4 bytes, vc_eos_track_i32).
+        Rounds run as hipGraph replays of `check_every` decoder steps each (embedding gather, input projection, LSTM step, logits,
+        argmax, stop-word tracking: six launches per step otherwise); VC_DECODE_GRAPH=0 keeps the eager loop -- same kernels, same ids."""
+        lib, e = self.lib, self.e
         max_len = max_len or self.p.gen_max_len
-        c, h = self.init_state(features, c_v, eps)
-        B = c.shape[0]
-        tok = torch.full((B,), bos, dtype=torch.int32, device=self.e.dev)
-        ids = torch.zeros((max_len, B), dtype=torch.int32, device=self.e.dev)
+        c0, h0 = self.init_state(features, c_v, eps)
+        B, V = c0.shape[0], e.V
+        dev = e.dev
+        K = int(check_every) if check_every and check_every % 2 == 0 else 4   # steps per captured chunk (even: the state ends where it started)
+        ids = torch.zeros((max_len, B), dtype=torch.int32, device=dev)
+        chunk = self._b("g_chunk", (K + 1, B), torch.int32)    # row 0: the token fed to the chunk's first step; rows 1..K: its outputs
+        done, pending = self._b("g_done", (B,), torch.int32), self._b("g_pending", (1,))
+        A, Bb = self._round_bufs("gA_", B), self._round_bufs("gB_", B)
+        chunk.zero_(); done.zero_()
+        chunk[0].fill_(bos)
+        Bb["c2"].copy_(c0); Bb["h2"].copy_(h0)    # state before step 0 lives in set B; step r reads set (B, A, B, ...) and writes the other
+
+        def one(r, timed):
+            src, dst = (Bb, A) if r % 2 == 0 else (A, Bb)
+            logits, _, _ = self.step(chunk[r], src["c2"], src["h2"], want="logits", bufs=dst, timed=timed)  # argmax(softmax**(1/t)/sum) == argmax(logits)
+            lib.vc_argmax_rows_f32(_stream(), P(logits), B, V, V, P(chunk[r + 1]))
+            lib.vc_eos_track_i32(_stream(), P(chunk[r + 1]), B, int(eos), P(done), P(pending))
+
+        # the first call of a shape runs one step eagerly (it sizes the workspace, whose address a captured chunk bakes; the chunk
+        # then repeats that step on unchanged inputs); every call re-packs Wh (the weights may have been trained since the last one)
+        self._pack_wh(B)
+        key = self._graph_key("greedy", B, K, int(eos), P(chunk), P(A["logits"]))
+        if key not in self._graphs:
+            one(0, True)
+            done.zero_()
+            key = self._graph_key("greedy", B, K, int(eos), P(chunk), P(A["logits"]))
+        graph = self._capture(key, lambda: [one(r, False) for r in range(K)])
         steps = 0
-        for it in range(max_len):
-            logits, c, h = self.step(tok, c, h, want="logits")  # argmax(softmax**(1/t)/sum) == argmax(logits)
-            tok = ids[it]
-            self.lib.vc_argmax_rows_f32(_stream(), P(logits), B, self.e.V, self.e.V, P(tok))
-            steps = it + 1
-            if check_every and steps % check_every == 0 and bool((ids[:steps] == eos).any(0).all().item()):
-                break
+        while steps < max_len:
+            k = min(K, max_len - steps)
+            if graph is not None and k == K:
+                graph.replay()
+            else:
+                for r in range(k):
+                    one(r, True)
+            ids[steps:steps + k].copy_(chunk[1:k + 1])
+            steps += k
+            if steps < max_len:
+                chunk[0].copy_(chunk[k])
+                if k % 2:   # (an odd remainder can only be the last chunk; kept for completeness)
+                    Bb["c2"].copy_(A["c2"]); Bb["h2"].copy_(A["h2"])
+                if check_every and pending.item() == 0:
+                    break
         return self._trim(ids[:steps], eos)
 
     def sample(self, features, c_v=None, eps=None, bos=1, eos=2, max_len=None, uniforms=None, check_every=4):
@@ -202,33 +279,82 @@ class CaptionGenerator(object):
         c, h = self.init_state(features, c_v, eps)
         B, Hd, V, n = c.shape[0], self.p.decoder_hidden, e.V, int(beam_size)
         dev = e.dev
-        tok = torch.full((B,), bos, dtype=torch.int32, device=dev)
-        _, c, h = self.step(tok, c, h, want="logits")  # :230-236 -- probabilities discarded, state kept
+        tok0 = self._b("bm_tok0", (B,), torch.int32)
+        tok0.fill_(bos)
+        _, c, h = self.step(tok0, c, h, want="logits", bufs=self._round_bufs("bm0_", B))  # :230-236 -- probabilities discarded, state kept
         M, L = B * n, max_len + 2
-        i32 = dict(dtype=torch.int32, device=dev)
-        f64 = dict(dtype=torch.float64, device=dev)
-        pcount, ccount = torch.ones(B, **i32), torch.zeros(B, **i32)      # partial = [Beam([bos], state b, 0.0, 0.0)]
-        p_score, p_logprob, p_len = torch.zeros(M, **f64), torch.zeros(M, **f64), torch.ones(M, **i32)
-        sent = [torch.full((M, L), bos, **i32), torch.zeros((M, L), **i32)]
-        c_score, c_logprob, c_len, c_slot = torch.zeros(M, **f64), torch.zeros(M, **f64), torch.zeros(M, **i32), torch.zeros(M, **i32)
-        c_free = torch.full((B,), (1 << (n + 1)) - 1, **i32)
-        c_sent = torch.zeros((B * (n + 1), L), **i32)
-        parent = torch.arange(B, **i32).repeat_interleave(n).contiguous()  # every row starts from its image's state
-        tok = torch.full((M,), bos, **i32)
-        tv, ti = torch.empty((M, n), dtype=torch.float32, device=dev), torch.empty((M, n), **i32)
-        cg, hg = torch.empty((M, Hd), device=dev), torch.empty((M, Hd), device=dev)
-        last = 0
-        for it in range(max_len - 1):
-            lib.vc_embedding_gather_f32(st, P(c), P(parent), M, Hd, c.shape[0], P(cg))
-            lib.vc_embedding_gather_f32(st, P(h), P(parent), M, Hd, h.shape[0], P(hg))
-            probs, c, h = self.step(tok, cg, hg)
-            lib.vc_topk_rows_f32(st, P(probs), M, V, V, n, P(tv), P(ti))
-            lib.vc_beam_update(st, B, n, L, int(eos), float(len_norm_f), P(tv), P(ti), P(pcount), P(ccount), P(p_score), P(p_logprob),
+        i32, f64 = torch.int32, torch.float64
+        # the bookkeeping of vae_model/decoder.py:238-247 as PERSISTENT device buffers (a captured chunk of rounds bakes their addresses
+        # and is replayed by later calls of the same shape), re-initialised per call: partial = [Beam([bos], state b, 0.0, 0.0)]
+        tag = "bm%d_%d_" % (n, L)
+        pcount, ccount = self._b(tag + "pcount", (B,), i32), self._b(tag + "ccount", (B,), i32)
+        p_score, p_logprob, p_len = self._b(tag + "p_score", (M,), f64), self._b(tag + "p_logprob", (M,), f64), self._b(tag + "p_len", (M,), i32)
+        sent = [self._b(tag + "sent0", (M, L), i32), self._b(tag + "sent1", (M, L), i32)]
+        c_score, c_logprob = self._b(tag + "c_score", (M,), f64), self._b(tag + "c_logprob", (M,), f64)
+        c_len, c_slot = self._b(tag + "c_len", (M,), i32), self._b(tag + "c_slot", (M,), i32)
+        c_free, c_sent = self._b(tag + "c_free", (B,), i32), self._b(tag + "c_sent", (B * (n + 1), L), i32)
+        parent, tok = self._b(tag + "parent", (M,), i32), self._b(tag + "tok", (M,), i32)
+        tv, ti = self._b(tag + "tv", (M, n)), self._b(tag + "ti", (M, n), i32)
+        first = self._b(tag + "first", (M,), i32)
+        pcount.fill_(1); ccount.zero_(); p_score.zero_(); p_logprob.zero_(); p_len.fill_(1)
+        sent[0].fill_(bos); sent[1].zero_()
+        c_score.zero_(); c_logprob.zero_(); c_len.zero_(); c_slot.zero_(); c_sent.zero_()
+        c_free.fill_((1 << (n + 1)) - 1)
+        tok.fill_(bos)
+        # every row starts from its image's state: the [B, Hd] state expanded to the M rows once, then parent = identity (what
+        # parent = arange(B).repeat_interleave(n) on the B-row state selects)
+        bufs = self._round_bufs("bm_", M)
+        torch.div(torch.arange(M, dtype=i32, device=dev), n, rounding_mode="floor", out=first)
+        lib.vc_embedding_gather_f32(st, P(c), P(first), M, Hd, B, P(bufs["c2"]))
+        lib.vc_embedding_gather_f32(st, P(h), P(first), M, Hd, B, P(bufs["h2"]))
+        torch.arange(M, dtype=i32, device=dev, out=parent)
+        cg, hg = self._b("bm_cg", (M, Hd)), self._b("bm_hg", (M, Hd))
+        alive = self._b("bm_alive", (1,))
+        fused = n <= 8   # softmax + top-k in one read of the logits (vc_softmax_topk_rows_f32: bit-identical to the two calls)
+
+        def one(it, timed):
+            s_ = _stream()
+            lib.vc_embedding_gather_f32(s_, P(bufs["c2"]), P(parent), M, Hd, M, P(cg))
+            lib.vc_embedding_gather_f32(s_, P(bufs["h2"]), P(parent), M, Hd, M, P(hg))
+            if fused:
+                logits, _, _ = self.step(tok, cg, hg, want="logits", bufs=bufs, timed=timed)
+                lib.vc_softmax_topk_rows_f32(s_, P(logits), M, V, V, n, P(tv), P(ti))
+            else:
+                probs, _, _ = self.step(tok, cg, hg, bufs=bufs, timed=timed)
+                lib.vc_topk_rows_f32(s_, P(probs), M, V, V, n, P(tv), P(ti))
+            lib.vc_beam_update(s_, B, n, L, int(eos), float(len_norm_f), P(tv), P(ti), P(pcount), P(ccount), P(p_score), P(p_logprob),
                                P(p_len), P(sent[it & 1]), P(sent[1 - (it & 1)]), P(c_score), P(c_logprob), P(c_len), P(c_slot),
                                P(c_free), P(c_sent), P(parent), P(tok))
-            last = 1 - (it & 1)
-            if check_every and (it + 1) % check_every == 0 and int(pcount.sum().item()) == 0:
-                break
+
+        # Rounds run as hipGraph replays of K rounds each (nine launches per round otherwise): every buffer above is persistent and the
+        # sentence buffers alternate with the round's parity, so a chunk that starts at an even round is the same graph every time.
+        # The FIRST call of a shape runs eagerly and captures the chunk at its end (a capture executes nothing); later calls replay
+        # it.  VC_DECODE_GRAPH=0 keeps the eager loop -- same kernels, same beams.
+        K = int(check_every) if check_every and check_every % 2 == 0 else 4
+
+        def chunk_fn():
+            for r in range(K):
+                one(r, False)
+            lib.vc_count_nonzero_i32(_stream(), P(pcount), B, P(alive))
+        key = self._graph_key("beam", B, n, L, K, int(eos), float(len_norm_f), P(pcount), P(bufs["logits"]))
+        graph = self._graphs.get(key) if fused else None
+        rounds = max_len - 1
+        last, it = 0, 0
+        while it < rounds:
+            if graph is not None and it % 2 == 0 and it + K <= rounds:
+                graph.replay()
+                it += K
+                last = 0
+                if check_every and alive.item() == 0:
+                    break
+            else:
+                one(it, True)
+                last = 1 - (it & 1)
+                it += 1
+                if check_every and it % check_every == 0:
+                    lib.vc_count_nonzero_i32(st, P(pcount), B, P(alive))
+                    if alive.item() == 0:
+                        break
         pc, cc = pcount.cpu().numpy(), ccount.cpu().numpy()
         ps, pl = p_score.cpu().numpy().reshape(B, n), p_len.cpu().numpy().reshape(B, n)
         cs, cl, csl = c_score.cpu().numpy().reshape(B, n), c_len.cpu().numpy().reshape(B, n), c_slot.cpu().numpy().reshape(B, n)
@@ -242,4 +368,6 @@ class CaptionGenerator(object):
                 beams = [Beam(psent[b, j, :pl[b, j]].tolist(), None, None, float(ps[b, j])) for j in range(pc[b])]
             beams.sort(reverse=True)  # TopN.extract(sort=True) on the heap array
             res.append([(bm.sentence, float(bm.score)) for bm in beams])
+        if graph is None and fused and rounds > K:
+            self._capture(key, chunk_fn)   # (the results are on the host: the capture touches no state)
         return res
