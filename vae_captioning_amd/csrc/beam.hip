@@ -25,46 +25,71 @@ struct BeamItem {
 
 __device__ __forceinline__ bool item_lt(const BeamItem& a, const BeamItem& b) { return a.score < b.score; }
 
-__device__ __forceinline__ void sift_down(BeamItem* heap, int startpos, int pos) {
-    const BeamItem newitem = heap[pos];
+// A TopN heap of one image in the LDS, stored field by field with the IMAGE as the fastest index ([position][image]): the 32 walking
+// threads of a workgroup step through their heaps side by side, and with one 32-byte item after another per image (512 bytes between
+// two images' items) every access of the 32 lanes fell on the same banks -- a 32-way conflict on each of the ~50 item moves of a push.
+constexpr int BEAM_IMAGES = 32;                 // images per workgroup
+struct HeapRef {
+    double* sc;     // [BEAM_MAX][BEAM_IMAGES] score, then logprob
+    double* lp;
+    int4* meta;     // [BEAM_MAX][BEAM_IMAGES] (parent, tok, len, slot)
+    __device__ __forceinline__ BeamItem get(int pos) const {
+        BeamItem it;
+        it.score = sc[pos * BEAM_IMAGES];
+        it.logprob = lp[pos * BEAM_IMAGES];
+        const int4 m = meta[pos * BEAM_IMAGES];
+        it.parent = m.x; it.tok = m.y; it.len = m.z; it.slot = m.w;
+        return it;
+    }
+    __device__ __forceinline__ void put(int pos, const BeamItem& it) const {
+        sc[pos * BEAM_IMAGES] = it.score;
+        lp[pos * BEAM_IMAGES] = it.logprob;
+        meta[pos * BEAM_IMAGES] = make_int4(it.parent, it.tok, it.len, it.slot);
+    }
+    __device__ __forceinline__ double score(int pos) const { return sc[pos * BEAM_IMAGES]; }
+};
+
+// CPython Lib/heapq.py _siftdown / _siftup, move for move (comparisons by score only)
+__device__ __forceinline__ void sift_down(const HeapRef& heap, int startpos, int pos) {
+    const BeamItem newitem = heap.get(pos);
     while (pos > startpos) {
         const int parentpos = (pos - 1) >> 1;
-        if (item_lt(newitem, heap[parentpos])) {
-            heap[pos] = heap[parentpos];
+        if (newitem.score < heap.score(parentpos)) {
+            heap.put(pos, heap.get(parentpos));
             pos = parentpos;
             continue;
         }
         break;
     }
-    heap[pos] = newitem;
+    heap.put(pos, newitem);
 }
 
-__device__ __forceinline__ void sift_up(BeamItem* heap, int n, int pos) {
+__device__ __forceinline__ void sift_up(const HeapRef& heap, int n, int pos) {
     const int startpos = pos;
-    const BeamItem newitem = heap[pos];
+    const BeamItem newitem = heap.get(pos);
     int childpos = 2 * pos + 1;
     while (childpos < n) {
         const int rightpos = childpos + 1;
-        if (rightpos < n && !item_lt(heap[childpos], heap[rightpos])) childpos = rightpos;
-        heap[pos] = heap[childpos];
+        if (rightpos < n && !(heap.score(childpos) < heap.score(rightpos))) childpos = rightpos;
+        heap.put(pos, heap.get(childpos));
         pos = childpos;
         childpos = 2 * pos + 1;
     }
-    heap[pos] = newitem;
+    heap.put(pos, newitem);
     sift_down(heap, startpos, pos);
 }
 
 // TopN.push: returns the slot field of the item that left the heap (the popped root, or the rejected newcomer), -1 if none
-__device__ __forceinline__ int topn_push(BeamItem* heap, int& count, int cap, const BeamItem& item) {
+__device__ __forceinline__ int topn_push(const HeapRef& heap, int& count, int cap, const BeamItem& item) {
     if (count < cap) {
-        heap[count] = item;
+        heap.put(count, item);
         ++count;
         sift_down(heap, 0, count - 1);
         return -1;
     }
-    if (count > 0 && item_lt(heap[0], item)) {
-        const int freed = heap[0].slot;
-        heap[0] = item;
+    if (count > 0 && heap.score(0) < item.score) {
+        const int freed = heap.get(0).slot;
+        heap.put(0, item);
         sift_up(heap, count, 0);
         return freed;
     }
@@ -82,25 +107,49 @@ struct BeamArgs {
     int32_t *sent_next, *c_sent, *parent, *tok;
 };
 
-// The two heaps of an image live in LDS (32 images x 2 x 16 items x 32 B = 32 KB): as private arrays their run-time indexing went
-// through scratch memory, one L2 round trip per heap move (65 us per decoder step for 128 images x 5 beams).
+// The two heaps of an image live in LDS (32 images x 2 x 16 items x 32 B = 32 KB, HeapRef above): as private arrays their run-time
+// indexing went through scratch memory, one L2 round trip per heap move (65 us per decoder step for 128 images x 5 beams).
 // Round 6: the heap walk stays one thread per image (it IS sequential: heapq's sift order decides ties), but the token copies it
 // used to do itself -- a kept beam's sentence into the next round's buffer, a finished caption into its pool slot: up to
 // beam x (length - 1) dependent load / store pairs per thread, 41 us per round at 30 tokens -- are only RECORDED by the walk and carried
 // out afterwards by eight threads per image (a workgroup = 32 images = 256 threads, thread t of an image copies tokens t, t + 8, ...).
 // A finished caption is recorded PER POOL SLOT: a slot that was freed and taken again within the round keeps its last writer's record,
 // which is the caption the sequential code left there.
-constexpr int BEAM_IMAGES = 32;                 // images per workgroup
 constexpr int BEAM_THREADS = 8 * BEAM_IMAGES;   // 256
 constexpr int BEAM_SLOTS = BEAM_MAX + 1;        // pool slots of finished captions per image
 
 
 __global__ __launch_bounds__(BEAM_THREADS) void beam_update_kernel(BeamArgs a) {
-    __shared__ BeamItem heaps[2][BEAM_IMAGES][BEAM_MAX];
+    __shared__ double h_sc[2][BEAM_MAX][BEAM_IMAGES], h_lp[2][BEAM_MAX][BEAM_IMAGES];
+    __shared__ int4 h_meta[2][BEAM_MAX][BEAM_IMAGES];
     __shared__ int part_n[BEAM_IMAGES];
     __shared__ short crec_src[BEAM_IMAGES][BEAM_SLOTS], crec_len0[BEAM_IMAGES][BEAM_SLOTS];   // len0 < 0: no caption recorded for the slot this round
     __shared__ int crec_tok[BEAM_IMAGES][BEAM_SLOTS];
+    // the round's candidates (top-k probabilities and words of every live beam) and the beams' running sums, fetched by all 256 threads
+    // (eight per image, coalesced) before the walk: read one by one inside it, each was a dependent global load -- 2 x beam x k round
+    // trips of ~0.5 us per image and round (25 of the kernel's 31 us at beam 5).  Up to beam x k = 64 candidates; beyond, the walk reads global memory.
+    constexpr int BEAM_PRE = 64;
+    __shared__ float pre_p[BEAM_IMAGES][BEAM_PRE];
+    __shared__ int pre_i[BEAM_IMAGES][BEAM_PRE];
+    __shared__ double pre_lp[BEAM_IMAGES][BEAM_MAX];
+    __shared__ int pre_len[BEAM_IMAGES][BEAM_MAX];
     const int n = a.n, L = a.Lmax;
+    const bool pre = n * a.k <= BEAM_PRE;
+    {
+        const int li = threadIdx.x >> 3, sub = threadIdx.x & 7, b = blockIdx.x * BEAM_IMAGES + li;
+        if (b < a.B) {
+            if (pre)
+                for (int q = sub; q < n * a.k; q += 8) {
+                    pre_p[li][q] = a.tv[(long)b * n * a.k + q];
+                    pre_i[li][q] = a.ti[(long)b * n * a.k + q];
+                }
+            for (int q = sub; q < n; q += 8) {
+                pre_lp[li][q] = a.p_logprob[(long)b * n + q];
+                pre_len[li][q] = a.p_len[(long)b * n + q];
+            }
+        }
+    }
+    __syncthreads();
     if (threadIdx.x < BEAM_IMAGES) {   // ---- the walk: one thread per image
         const int li = threadIdx.x, b = blockIdx.x * BEAM_IMAGES + li;
         part_n[li] = 0;
@@ -112,26 +161,28 @@ __global__ __launch_bounds__(BEAM_THREADS) void beam_update_kernel(BeamArgs a) {
                 a.tok[b * n + j] = 0;
             }
             if (np != 0) {  // (0: every beam of this image has ended)
-                BeamItem* part = heaps[0][li];
-                BeamItem* comp = heaps[1][li];
+                const HeapRef part{&h_sc[0][0][li], &h_lp[0][0][li], &h_meta[0][0][li]};
+                const HeapRef comp{&h_sc[1][0][li], &h_lp[1][0][li], &h_meta[1][0][li]};
                 int hn = 0, cn = a.ccount[b];
                 for (int j = 0; j < cn; ++j) {
-                    comp[j].score = a.c_score[b * n + j];
-                    comp[j].logprob = a.c_logprob[b * n + j];
-                    comp[j].len = a.c_len[b * n + j];
-                    comp[j].slot = a.c_slot[b * n + j];
-                    comp[j].parent = comp[j].tok = 0;
+                    BeamItem it;
+                    it.score = a.c_score[b * n + j];
+                    it.logprob = a.c_logprob[b * n + j];
+                    it.len = a.c_len[b * n + j];
+                    it.slot = a.c_slot[b * n + j];
+                    it.parent = it.tok = 0;
+                    comp.put(j, it);
                 }
                 int freemask = a.c_free[b];
                 for (int i = 0; i < np; ++i) {
                     const long row = (long)b * n + i;
-                    const double lp0 = a.p_logprob[row];
-                    const int len0 = a.p_len[row];
+                    const double lp0 = pre_lp[li][i];
+                    const int len0 = pre_len[li][i];
                     for (int j = 0; j < a.k; ++j) {
-                        const float pw = a.tv[row * a.k + j];
+                        const float pw = pre ? pre_p[li][i * a.k + j] : a.tv[row * a.k + j];
                         if ((double)pw < 1e-12) continue;  // decoder.py:279: float32 p against the Python float 1e-12
                         BeamItem it;
-                        it.tok = a.ti[row * a.k + j];
+                        it.tok = pre ? pre_i[li][i * a.k + j] : a.ti[row * a.k + j];
                         it.parent = i;
                         it.len = len0 + 1;
                         it.logprob = lp0 + (double)logf(pw);  // decoder.py:282: np.log of a float32 is a float32; the SUM is a float64
@@ -154,19 +205,21 @@ __global__ __launch_bounds__(BEAM_THREADS) void beam_update_kernel(BeamArgs a) {
                 }
                 for (int j = 0; j < hn; ++j) {
                     const long o = (long)b * n + j;
-                    a.p_score[o] = part[j].score;
-                    a.p_logprob[o] = part[j].logprob;
-                    a.p_len[o] = part[j].len;
-                    a.parent[o] = b * n + part[j].parent;
-                    a.tok[o] = part[j].tok;
+                    const BeamItem it = part.get(j);
+                    a.p_score[o] = it.score;
+                    a.p_logprob[o] = it.logprob;
+                    a.p_len[o] = it.len;
+                    a.parent[o] = b * n + it.parent;
+                    a.tok[o] = it.tok;
                 }
                 a.pcount[b] = hn;
                 for (int j = 0; j < cn; ++j) {
                     const long o = (long)b * n + j;
-                    a.c_score[o] = comp[j].score;
-                    a.c_logprob[o] = comp[j].logprob;
-                    a.c_len[o] = comp[j].len;
-                    a.c_slot[o] = comp[j].slot;
+                    const BeamItem it = comp.get(j);
+                    a.c_score[o] = it.score;
+                    a.c_logprob[o] = it.logprob;
+                    a.c_len[o] = it.len;
+                    a.c_slot[o] = it.slot;
                 }
                 a.ccount[b] = cn;
                 a.c_free[b] = freemask;
@@ -187,10 +240,10 @@ __global__ __launch_bounds__(BEAM_THREADS) void beam_update_kernel(BeamArgs a) {
     }
     const int hn = part_n[li];
     int32_t* nxt = a.sent_next + (long)b * n * L;
-    const BeamItem* part = heaps[0][li];
     for (int j = 0; j < hn; ++j) {
-        const int len = part[j].len, src = part[j].parent;
-        for (int t = sub; t < len; t += 8) nxt[j * L + t] = t < len - 1 ? cur[src * L + t] : part[j].tok;
+        const int4 m = h_meta[0][j][li];   // (parent, tok, len, slot) of the kept beam in heap-array position j
+        const int len = m.z, src = m.x;
+        for (int t = sub; t < len; t += 8) nxt[j * L + t] = t < len - 1 ? cur[src * L + t] : m.y;
     }
 }
 
