@@ -41,9 +41,10 @@ class KernelTimer(object):
     convolutions run on two streams), so busy time is the UNION of their [start, end] intervals:
     roofline.achieved = algorithmic FLOPs / union time."""
 
-    def __init__(self):
+    def __init__(self, all_gemms=False):
         self.recs = []
         self.base = None
+        self.all_gemms = all_gemms   # also bracket every CaptionEngine.gemm call (tag "gemm"), not only the tagged launches
 
     def run(self, tag, flops, fn):
         st = torch.cuda.current_stream()
@@ -353,9 +354,16 @@ class CaptionEngine(object):
         """VC_LSTM_BF16X3 | VC_LSTM_KERNELS(k) of this engine's vc_lstm_seq_* calls"""
         return (0x10 if self.precision == "bf16x3" else 0) | (0 if self.lstm_kernels is None else int(self.lstm_kernels) + 1)
 
-    def gemm(self, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias=None, flags=0):
+    def gemm(self, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias=None, flags=0, tag="gemm"):
+        """One dense product through vc_gemm_f32.  With a KernelTimer attached (bench.py) every call is bracketed by a HIP-event pair
+        under `tag` ("logits_gemm" for the [T N, H] x [H, V] product, "gemm" for every other one: heads, projections, weight and
+        data gradients) with its algorithmic FLOPs, on the stream it is launched on."""
         ws, nb = self._need_ws(self.lib.vc_gemm_workspace_bytes(M, N, K))
-        self.lib.vc_gemm_f32(_stream(), ta, tb, M, N, K, P(A), lda, P(B), ldb, P(C), ldc, P(bias), flags | self.gemm_flags, ws, nb)
+        run = lambda: self.lib.vc_gemm_f32(_stream(), ta, tb, M, N, K, P(A), lda, P(B), ldb, P(C), ldc, P(bias), flags | self.gemm_flags, ws, nb)
+        if self.timer is not None and tag is not None and (tag != "gemm" or self.timer.all_gemms):
+            self.timer.run(tag, 2.0 * M * N * K, run)
+        else:
+            run()
 
     def _timed(self, tag, flops, fn):
         if self.timer is not None:
@@ -740,8 +748,7 @@ class CaptionEngine(object):
         self.outs = outs
         Vp = _round(V, 4)  # row pitch of the logits: a multiple of 4 keeps the register cross-entropy kernel for V = 11313
         logits = self._b("logits", (T * N, Vp))
-        self._timed("logits_gemm", 2.0 * T * N * V * Hd,
-                    lambda: self.gemm(0, 0, T * N, Vp, Hd, outs, Hd, S.param("decoder/rnn_logits/kernel"), Vp, logits, Vp, S.param("decoder/rnn_logits/bias")))
+        self.gemm(0, 0, T * N, Vp, Hd, outs, Hd, S.param("decoder/rnn_logits/kernel"), Vp, logits, Vp, S.param("decoder/rnn_logits/bias"), tag="logits_gemm")
         return logits[:, :V]  # (a view: the padding columns are not part of x_logits)
 
     def fw_loss(self, train=True):
