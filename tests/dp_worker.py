@@ -67,11 +67,19 @@ def main():
     from vae_captioning_amd import abi, dp
     from vae_captioning_amd.trainer import Trainer
     world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    backend = os.environ.get("VC_DP_BACKEND", "gloo")
+    # gloo: both ranks on GPU 0 (the build box has one); nccl (= RCCL): one GPU per rank, collectives through libvaecap's vc_comm_* entries
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) if backend == "nccl" else 0)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     lib = abi.load()
     p, V, P0, batch, noise, B = problem(case)
     tr = Trainer(p, V, lib=lib, world=world, rank=rank, seed=3)
+    if backend == "nccl":   # the collectives must be the C ABI's own RCCL communicator over `world` ranks, not a fallback
+        import ctypes
+        w, r, ver = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        assert tr.comm is not None, "RCCL-backed process group, but the trainer did not bring up libvaecap's communicator"
+        lib.vc_comm_info(tr.comm.h, ctypes.byref(w), ctypes.byref(r), ctypes.byref(ver))
+        assert (w.value, r.value) == (world, rank), (w.value, r.value)
     tr.cap.q1_mode = q1_mode
     tr.load_state_dict(P0)
     losses = []

@@ -66,6 +66,19 @@ def gemmx():
               % (ta, tb, M, N, K, res[0], fl / res[0], res[1], fl / res[1], 3 * fl / res[1], 3 * fl / res[1] / 2500, res[0] / res[1]), flush=True)
 
 
+def gemmshape():
+    """one product, VC_SHAPE="ta,tb,M,N,K" (default: the AG / GMM heads of cfg3, [1280, 512] x [512, 27000], vae_model/encoder.py:90-107):
+    the launch tools/kernel_pmc.sh counts when it is asked about a single GEMM of a step"""
+    ta, tb, M, N, K = [int(v) for v in os.environ.get("VC_SHAPE", "0,0,1280,27000,512").split(",")]
+    A = rnd(K, M) if ta else rnd(M, K)
+    B = rnd(N, K) if tb else rnd(K, N)
+    C = torch.empty(M, N, device="cuda")
+    ws = torch.empty(max(lib.vc_gemm_workspace_bytes(M, N, K), 16) // 4 + 4, device="cuda")
+    fl = 4 if os.environ.get("VC_PRECISION") == "bf16x3" else 0
+    med, mn = timeit(lambda: lib.vc_gemm_f32(st(), ta, tb, M, N, K, P(A), M if ta else K, P(B), K if tb else N, P(C), N, None, fl, P(ws), ws.numel() * 4))
+    print("gemm ta=%d tb=%d %d x %d x %d: %.3f ms  %.1f TFLOP/s" % (ta, tb, M, N, K, med, 2e-9 * M * N * K / med))
+
+
 def conv1():
     """conv1_1's own kernels (csrc/conv_first.hip) against the general 3x3 kernels on the zero-padded 4-channel form; both are
     HBM-bound on the [B,224,224,64] activation (822 MB at B = 64: ~0.14 ms at 6.3 TB/s)"""

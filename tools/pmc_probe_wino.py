@@ -11,7 +11,8 @@ from vae_captioning_amd import abi  # noqa: E402
 from vae_captioning_amd.abi import ptr as P  # noqa: E402
 
 lib = abi.load()
-F4 = os.environ.get("FAMILY", "2") == "4"
+F4 = os.environ.get("FAMILY", "2") in ("4", "4v")
+F4V = os.environ.get("FAMILY", "2") == "4v"   # round 6: the pre-transformed form (vc_conv3x3_wino4v_*) where it takes the shape, the fused one elsewhere
 PRE = "vc_conv3x3_wino4_" if F4 else "vc_conv3x3_wino_"
 fn = lambda e: getattr(lib, PRE + e)
 st = lambda: torch.cuda.current_stream().cuda_stream
@@ -28,6 +29,13 @@ for (H, ci, co) in ((56, 256, 256), (224, 64, 64), (28, 512, 512), (14, 512, 512
     cases.append((H, ci, co, x, bias, y, vp, vpt))
 for _ in range(3):
     for i, (H, ci, co, x, bias, y, vp, vpt) in enumerate(cases):
+        if F4V and lib.vc_conv3x3_wino4v_supported(B, H, H, ci, co, 0):
+            nb = lib.vc_conv3x3_wino4v_workspace_bytes(B, H, H, max(ci, co))
+            vws = torch.empty(nb // 4, device="cuda")
+            lib.vc_conv3x3_wino4v_fwd_f32(st(), B, H, H, ci, co, P(x), P(vp), P(bias), P(y), None, 1, P(vws), nb)
+            if i == 0:
+                lib.vc_conv3x3_wino4v_dgrad_f32(st(), B, H, H, ci, co, P(y), P(vpt), P(x), P(x), P(vws), nb)
+            continue
         fn("fwd_f32")(st(), B, H, H, ci, co, P(x), P(vp), P(bias), P(y), None, 1)
         if i == 0:
             fn("dgrad_f32")(st(), B, H, H, ci, co, P(y), P(vpt), P(x), P(x))

@@ -6,9 +6,9 @@ TAG=${1:-r03}
 ROOT=$(pwd)
 export TMPDIR=/tmp GRAFT_REPO_ROOT=$ROOT
 mkdir -p $ROOT/gpurun_out
-for FAM in 2 4; do
+for FAM in ${FAMILIES:-2 4 4v}; do
 export FAMILY=$FAM
-SUF=$([ $FAM = 4 ] && echo 4 || echo "")
+SUF=$([ $FAM = 2 ] && echo "" || echo $FAM)
 rm -rf /tmp/sqw
 i=0
 for C in "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES"; do

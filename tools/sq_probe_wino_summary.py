@@ -13,7 +13,7 @@ dur = defaultdict(list)
 for f in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True)):
     rows = defaultdict(dict)
     for r in csv.DictReader(open(f)):
-        if "wino" not in r["Kernel_Name"] or "pack" in r["Kernel_Name"]:
+        if "wino" not in r["Kernel_Name"] or "pack" in r["Kernel_Name"] or "xform" in r["Kernel_Name"]:
             continue
         d = int(r["Dispatch_Id"])
         rows[d][r["Counter_Name"]] = float(r["Counter_Value"])
