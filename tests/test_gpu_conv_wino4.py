@@ -263,7 +263,7 @@ def test_conv1_forward_leaves_the_mask_bits_of_conv1_2s_data_gradient(lib, case)
 # count, one image, tile counts that are no multiple of 16) and 13..16-pixel images (one square block per image); several channel tiles,
 # the shortest reduction
 V_CASES = [(2, 28, 28, 64, 128), (3, 28, 28, 32, 32), (3, 28, 28, 8, 64), (5, 14, 14, 96, 128), (3, 14, 14, 32, 64), (1, 56, 56, 64, 64),
-           (2, 16, 16, 32, 64), (2, 13, 15, 16, 32), (7, 28, 28, 256, 64)]
+           (2, 16, 16, 32, 64), (2, 13, 15, 16, 32), (7, 28, 28, 256, 64), (2, 8, 8, 32, 32)]
 
 
 @pytest.mark.parametrize("case", V_CASES, ids=lambda c: "x".join(map(str, c)))
@@ -321,7 +321,8 @@ def test_wino4v_refuses_what_it_does_not_take(lib):
     """square-block layers whose lanes differ from the linear order (224 / 112 wide, 32 wide), a workspace that is too small or missing"""
     from vae_captioning_amd.abi import VaecapError
     assert lib.vc_conv3x3_wino4v_supported(2, 224, 224, 64, 64, 0) == 0 and lib.vc_conv3x3_wino4v_supported(2, 32, 32, 32, 32, 0) == 0
-    assert lib.vc_conv3x3_wino4v_supported(2, 8, 8, 32, 32, 0) == 0          # two images per linear block, one per square block
+    assert lib.vc_conv3x3_wino4v_supported(2, 8, 8, 32, 32, 0) == 1          # (two 8 x 8 images fill ONE linear block: the fused kernel takes linear blocks there too)
+    assert lib.vc_conv3x3_wino4v_supported(1, 8, 8, 32, 32, 0) == 0          # one image = one square block of the fused kernel, lanes (ty, tx) != the linear order at 2 tiles per row
     assert lib.vc_conv3x3_wino4v_supported(2, 28, 28, 30, 32, 0) == 0         # channels
     assert lib.vc_conv3x3_wino4v_workspace_bytes(2, 224, 224, 64) == 0
     # the measured preference rule: the 28- and 14-wide layers with >= 256 gathered channels, not the 56-wide ones
