@@ -12,7 +12,7 @@ export TMPDIR=/tmp
 python bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/${TAG}_bench_default.err
 # 2. kernel traces of the same command (cfg4) and of cfg2: per-kernel table + per-family sum / union of dispatch intervals; cfg4 also
 #    with ONE VGG stream (VC_VGG_STREAMS=1: nothing overlaps, the per-kernel durations are the kernels' own)
-for WL in cfg4 cfg2; do
+for WL in cfg4 cfg2 cfg3 cfg5; do   # (round 6: cfg3 and cfg5 too -- every BASELINE config's bench line follows from a tracked table)
   rm -rf /tmp/kt_$WL
   (cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/kt_$WL -- python $ROOT/bench.py --workload $WL --no-cpu-baseline --strong-n1 0 > $OUT/${TAG}_${WL}_kt.log 2>&1)
   DB=$(find /tmp/kt_$WL -name "*_results.db" | head -1)
@@ -74,5 +74,12 @@ python tools/microbench.py winoab winow 2>/dev/null | grep -v amdgpu.ids > $OUT/
  for v in fwd bits; do echo "== python tools/experiments/wino4_try.py 32 $v"; python tools/experiments/wino4_try.py 32 $v 2>&1 | grep "^conv\|^sum"; done) > $OUT/${TAG}_wino4_layers.txt
 (echo "== python tools/microbench.py lstm (VC_LSTM_MODES=3,1)"; python tools/microbench.py lstm 2>&1 | grep "^lstm"
  echo "== VC_LSTM_WGS_PER_CU=2 (two workgroups of the four-wave recurrence kernels per CU; measured, not adopted)"; VC_LSTM_WGS_PER_CU=2 VC_LSTM_MODES=3 python tools/microbench.py lstm 2>&1 | grep "^lstm") > $OUT/${TAG}_lstm_steps.txt
-# 8. SQ counters of the Winograd forward / data-gradient kernel per layer shape
+# 7b. round 6: F(4x4,3x3) on a once-transformed input (MODE 2, vc_conv3x3_wino4v_*) against the fused kernel per layer, and inside the step
+(for b in 32 64; do python tools/experiments/wino4v_try.py $b 2>&1 | grep "^conv\|^sum"; done) > $OUT/${TAG}_wino4v_layers_rerun.txt
+for v in 1 0; do VC_WINO4V=$v python bench.py --no-cpu-baseline --strong-n1 0 > $OUT/${TAG}_bench_wino4v$v.json 2>/dev/null; done
+VC_DECODE_GRAPH=0 python bench.py --no-cpu-baseline --workload cfg5 --steps 5 --warmup 1 > $OUT/${TAG}_bench_cfg5_eager.json 2>/dev/null
+# 8. SQ counters of the Winograd forward / data-gradient kernel per layer shape (fused and MODE 2)
 bash tools/sq_probe_wino.sh ${TAG} > /dev/null 2>&1
+# 9. round 6: counters of the AG heads GEMM (cfg3) and of one decode round's logits GEMM (cfg5)
+bash tools/kernel_pmc.sh ${TAG}_heads gemm_kernel python $ROOT/tools/microbench.py gemmshape > /dev/null 2>&1
+VC_SHAPE=0,0,640,10000,512 bash tools/kernel_pmc.sh ${TAG}_declogits gemm_kernel python $ROOT/tools/microbench.py gemmshape > /dev/null 2>&1
