@@ -350,3 +350,43 @@ def test_weight_gradient_at_bench_launch_size_matches_fp64_oracle(lib, shape):
     tol = 3e-6 * np.sqrt(B * H * W)
     assert_close(dw.cpu().numpy(), dw_ref, tol, msg="weight gradient %s" % (shape,))
     assert_close(db.cpu().numpy(), db_ref, tol, msg="bias gradient %s" % (shape,))
+
+
+@pytest.mark.parametrize("shape", [(32, 28, 28, 512, 512), (32, 14, 14, 512, 512), (32, 56, 56, 256, 256), (16, 112, 112, 128, 128), (8, 224, 224, 64, 64)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_forward_and_data_gradient_at_bench_launch_size_match_fp64_oracle(lib, shape):
+    """Round-5 review: forward and data gradient met the fp64 oracle only at B <= 2; at the launch sizes of the timed step they met
+    another kernel of this library.  Here: the F(4x4,3x3) forward (+ bias, ReLU) and data gradient (+ ReLU mask from the activation) of
+    utils/image_embeddings.py:36-212 against oracle.vgg in fp64 at the half-batch launch of conv4_2 / conv5_2 / conv3_2 (32 images: what
+    each chain of the cfg4 step launches), 16 images of conv2_2 and 8 of conv1_2 (same kernels, same blocks; the oracle's host time is what
+    bounds the image count), image chunk by image chunk on the host.  Where the once-transformed form takes the shape it is held to
+    the same oracle AND to bit-identity with the fused kernel.  Tolerance: 6e-5 of the tensor maximum, the F(4x4,3x3) bound."""
+    B, H, W, Ci, Co = shape
+    rng = np.random.default_rng(H * 3 + Ci)
+    x = np.maximum(rng.standard_normal((B, H, W, Ci), dtype=np.float32), 0)
+    w = rng.standard_normal((3, 3, Ci, Co), dtype=np.float32) * np.float32(np.sqrt(2.0 / (9 * Ci)))
+    b = rng.standard_normal(Co, dtype=np.float32) * np.float32(0.1)
+    dy = rng.standard_normal((B, H, W, Co), dtype=np.float32)
+    w64, b64 = w.astype(np.float64), b.astype(np.float64)
+    yref, dxref = np.empty((B, H, W, Co), np.float64), np.empty((B, H, W, Ci), np.float64)
+    step = max(1, (1 << 21) // (H * W * max(Ci, Co)))
+    for b0 in range(0, B, step):
+        xs = x[b0:b0 + step].astype(np.float64)
+        yref[b0:b0 + step] = np.maximum(OV.conv3x3_fwd(xs, w64, b64), 0)
+        dxref[b0:b0 + step] = OV.conv3x3_bwd(xs, w64, dy[b0:b0 + step].astype(np.float64))[0] * (xs > 0)
+    tx, tdy, tw, tb = dev_c4(x), dev_c4(dy), torch.from_numpy(w).cuda(), torch.from_numpy(b).cuda()
+    wp, wpt = torch.empty(36 * Ci * Co, device="cuda"), torch.empty(36 * Ci * Co, device="cuda")
+    lib.vc_conv3x3_wino4_pack_f32(stream(), Ci, Co, P(tw), 0, P(wp))
+    lib.vc_conv3x3_wino4_pack_f32(stream(), Ci, Co, P(tw), 1, P(wpt))
+    y, dx = zeros(B, H, W, Co), zeros(B, H, W, Ci)
+    lib.vc_conv3x3_wino4_fwd_f32(stream(), B, H, W, Ci, Co, P(tx), P(wp), P(tb), P(y), None, 1)
+    lib.vc_conv3x3_wino4_dgrad_f32(stream(), B, H, W, Ci, Co, P(tdy), P(wpt), P(tx), P(dx))
+    assert_close(host_c4(y, (B, H, W, Co)), yref, 6e-5, msg="F(4x4,3x3) forward %s" % (shape,))
+    assert_close(host_c4(dx, (B, H, W, Ci)), dxref, 6e-5, msg="F(4x4,3x3) data gradient %s" % (shape,))
+    if lib.vc_conv3x3_wino4v_supported(B, H, W, Ci, Co, 0) and lib.vc_conv3x3_wino4v_supported(B, H, W, Ci, Co, 1):
+        nb = max(lib.vc_conv3x3_wino4v_workspace_bytes(B, H, W, Ci), lib.vc_conv3x3_wino4v_workspace_bytes(B, H, W, Co))
+        vws = empty_bytes(nb)
+        y2, dx2 = zeros(B, H, W, Co), zeros(B, H, W, Ci)
+        lib.vc_conv3x3_wino4v_fwd_f32(stream(), B, H, W, Ci, Co, P(tx), P(wp), P(tb), P(y2), None, 1, P(vws), nb)
+        lib.vc_conv3x3_wino4v_dgrad_f32(stream(), B, H, W, Ci, Co, P(tdy), P(wpt), P(tx), P(dx2), P(vws), nb)
+        assert torch.equal(y, y2) and torch.equal(dx, dx2)

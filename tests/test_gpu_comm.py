@@ -137,3 +137,45 @@ def test_a_dead_communicator_aborts_the_step(lib):
     now = tr.state_dict()
     for k in after_one:
         np.testing.assert_array_equal(after_one[k], now[k], err_msg=k)
+
+
+def test_losses_of_a_data_parallel_training_forward_raise_until_the_gradients_are_applied(lib):
+    """With collectives on, the reported kld / rec_loss / lower_bound of a TRAINING forward ride in the tail of the gradient all-reduce:
+    between forward(train=True) and apply_gradients() `losses()` raises instead of returning the previous step's values; an evaluation
+    forward (train=False: scalars reduced on the spot, the reference's validate(), main.py:262-284) clears the state, and so does the
+    completed step."""
+    p = _small()
+    V, B, T = 203, 4, 6
+    rng = np.random.default_rng(17)
+    batch = synth.make_batch(rng, B, p.num_captions, T, V, variable_len=True, feature_size=p.cnn_feature_size)
+    noise = synth.make_noise(rng, B * p.num_captions, T, p)
+    tr = Trainer(p, V, lib=lib, force_collectives=True)
+    tr.load_state_dict(spec.init_caption_params(p, V, seed=18))
+    tr.set_batch(batch, noise)
+    tr.train_step()
+    done = tr.losses()                      # a completed step reports
+    tr.cap.forward(train=True)
+    with pytest.raises(RuntimeError, match="final only after apply_gradients"):
+        tr.cap.losses()
+    tr.cap.forward(train=False)             # abandoning the step for an evaluation pass is legal and readable
+    ev = tr.cap.losses()
+    assert np.isfinite(ev[1]) and ev[1] != done[1]
+    tr.train_step()                         # and a whole step afterwards reports again
+    assert np.isfinite(tr.losses()[1])
+
+
+def test_set_batch_under_a_captured_graph_names_shapes_and_dtypes(lib):
+    """a hipGraph bakes its input buffers: a later batch of another shape OR dtype is refused with both in the message (uint8 images
+    against float32 ones have identical shapes)"""
+    p = _small()
+    V, B, T = 203, 4, 6
+    rng = np.random.default_rng(19)
+    batch = synth.make_batch(rng, B, p.num_captions, T, V, feature_size=p.cnn_feature_size)
+    tr = Trainer(p, V, lib=lib)
+    tr.load_state_dict(spec.init_caption_params(p, V, seed=20))
+    tr.set_batch(batch)
+    tr.capture()
+    tr.train_step()
+    longer = synth.make_batch(rng, B, p.num_captions, T + 2, V, feature_size=p.cnn_feature_size)
+    with pytest.raises(ValueError, match=r"changed from \(.*\) \w+ to \(.*\) \w+"):
+        tr.set_batch(longer)

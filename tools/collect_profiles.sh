@@ -43,7 +43,7 @@ python bench.py --no-cpu-baseline --workload cfg2 --variable-len > $OUT/${TAG}_b
 python bench.py --no-cpu-baseline --workload cfg2 --num-captions 1 > $OUT/${TAG}_bench_cfg2_nc1.json 2>/dev/null
 python bench.py --workload cfg1 --graph 1 > $OUT/${TAG}_bench_cfg1.json 2>/dev/null      # (with its CPU-baseline legs: training step + greedy decode of 32 images)
 python bench.py --no-cpu-baseline --workload cfg3 > $OUT/${TAG}_bench_cfg3.json 2>/dev/null
-python bench.py --workload cfg5 --steps 5 --warmup 1 > $OUT/${TAG}_bench_cfg5.json 2>/dev/null   # (with the beam-search CPU-baseline leg, 8 images)
+python bench.py --workload cfg5 --steps 30 --warmup 4 > $OUT/${TAG}_bench_cfg5.json 2>/dev/null   # (with the beam-search CPU-baseline leg, 8 images)
 # 6b. the split-bf16 (bf16x3) mode: every dense product on the bf16 matrix pipe, reported BESIDE the f32 lines above (never instead of them)
 for WL in cfg2 cfg3 cfg1; do python bench.py --no-cpu-baseline --workload $WL --precision bf16x3 > $OUT/${TAG}_bench_${WL}_bf16x3.json 2>/dev/null; done
 python bench.py --no-cpu-baseline --strong-n1 0 --precision bf16x3 > $OUT/${TAG}_bench_cfg4_bf16x3.json 2>/dev/null
@@ -77,7 +77,7 @@ python tools/microbench.py winoab winow 2>/dev/null | grep -v amdgpu.ids > $OUT/
 # 7b. round 6: F(4x4,3x3) on a once-transformed input (MODE 2, vc_conv3x3_wino4v_*) against the fused kernel per layer, and inside the step
 (for b in 32 64; do python tools/experiments/wino4v_try.py $b 2>&1 | grep "^conv\|^sum"; done) > $OUT/${TAG}_wino4v_layers_rerun.txt
 for v in 1 0; do VC_WINO4V=$v python bench.py --no-cpu-baseline --strong-n1 0 > $OUT/${TAG}_bench_wino4v$v.json 2>/dev/null; done
-VC_DECODE_GRAPH=0 python bench.py --no-cpu-baseline --workload cfg5 --steps 5 --warmup 1 > $OUT/${TAG}_bench_cfg5_eager.json 2>/dev/null
+VC_DECODE_GRAPH=0 python bench.py --no-cpu-baseline --workload cfg5 --steps 30 --warmup 4 > $OUT/${TAG}_bench_cfg5_eager.json 2>/dev/null
 # 8. SQ counters of the Winograd forward / data-gradient kernel per layer shape (fused and MODE 2)
 bash tools/sq_probe_wino.sh ${TAG} > /dev/null 2>&1
 # 9. round 6: counters of the AG heads GEMM (cfg3) and of one decode round's logits GEMM (cfg5)

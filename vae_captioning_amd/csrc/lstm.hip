@@ -910,36 +910,49 @@ static int rec8_fwd(hipStream_t st, const LstmFwdArgs& a, const float* whp, bool
     return launch_status("lstm rec8 fwd");
 }
 
+// (the LDS attribute of a variant is set the first time THAT variant launches: a process that only ever runs one of the eight
+// instantiations touches one)
+template <class K>
+static int rec_lds_once(K kern, int& state) {
+    if (state < 0) state = rec_lds(kern);
+    return state;
+}
+#define REC_BWD_LAUNCH(RT, BX, CT, grid)                                                                                     \
+    do {                                                                                                                     \
+        static int st_ = -1;                                                                                                 \
+        const int rc_ = rec_lds_once(lstm_rec_bwd_kernel<RT, BX, CT>, st_);                                                  \
+        if (rc_) return rc_;                                                                                                 \
+        hipLaunchKernelGGL((lstm_rec_bwd_kernel<RT, BX, CT>), grid, dim3(256), REC_LDS_BYTES, st, a, (const float4*)whp, rows); \
+    } while (0)
+
 static int rec_bwd(hipStream_t st, const LstmBwdArgs& a, const float* whp, bool bx = false) {
-    static int once = rec_lds(lstm_rec_bwd_kernel<5>) | rec_lds(lstm_rec_bwd_kernel<3>) | rec_lds(lstm_rec_bwd_kernel<5, true>) | rec_lds(lstm_rec_bwd_kernel<3, true>) |
-                      rec_lds(lstm_rec_bwd_kernel<5, false, 2>) | rec_lds(lstm_rec_bwd_kernel<5, true, 2>) | rec_lds(lstm_rec_bwd_kernel<3, false, 2>) | rec_lds(lstm_rec_bwd_kernel<3, true, 2>);
-    if (once) return once;
     // many rows: 32 units per workgroup (16 column slices x 16 row groups at 1280 rows: ONE pass of five row tiles per workgroup instead
-    // of two, each dG[t+1] row read by 16 workgroups instead of 32); VC_LSTM_BWD_CT2_ROWS: from how many rows on (0: never)
+    // of two, each dG[t+1] row read by 16 workgroups instead of 32).  Measured (tools/microbench.py lstm, 1280 rows): split-bf16 54.8 ->
+    // 48.5 us per step, f32 81.4 -> 77.6; in the f32 steps it is small but repeatable (round 6, same box, VC_LSTM_BWD_CT2_F32=0 / 1:
+    // cfg2 13.566 / 13.544 -> 13.519 / 13.515 ms, cfg3 14.935 -> 14.842), so both precisions take it from 600 rows on.
+    // VC_LSTM_BWD_CT2_ROWS: from how many rows on (0: never); VC_LSTM_BWD_CT2_F32=0: split-bf16 only (A/B runs).
     static const int ct2_rows = lstm_env("VC_LSTM_BWD_CT2_ROWS", 600);
-    if (ct2_rows > 0 && a.N >= ct2_rows) {
+    static const int ct2_f32 = lstm_env("VC_LSTM_BWD_CT2_F32", 1);
+    if (ct2_rows > 0 && a.N >= ct2_rows && (bx || ct2_f32)) {
         const int RG = rec_row_groups(a.N, 16), rows = cdiv(a.N, RG);
         const dim3 g(16, RG);
         if (rows > 48) {
-            if (bx) hipLaunchKernelGGL((lstm_rec_bwd_kernel<5, true, 2>), g, dim3(256), REC_LDS_BYTES, st, a, (const float4*)whp, rows);
-            else hipLaunchKernelGGL((lstm_rec_bwd_kernel<5, false, 2>), g, dim3(256), REC_LDS_BYTES, st, a, (const float4*)whp, rows);
+            if (bx) REC_BWD_LAUNCH(5, true, 2, g); else REC_BWD_LAUNCH(5, false, 2, g);
         } else {
-            if (bx) hipLaunchKernelGGL((lstm_rec_bwd_kernel<3, true, 2>), g, dim3(256), REC_LDS_BYTES, st, a, (const float4*)whp, rows);
-            else hipLaunchKernelGGL((lstm_rec_bwd_kernel<3, false, 2>), g, dim3(256), REC_LDS_BYTES, st, a, (const float4*)whp, rows);
+            if (bx) REC_BWD_LAUNCH(3, true, 2, g); else REC_BWD_LAUNCH(3, false, 2, g);
         }
         return launch_status("lstm rec bwd");
     }
     const int RG = rec_row_groups(a.N, 32), rows = cdiv(a.N, RG);
     const dim3 g(32, RG);
     if (rows > 48) {
-        if (bx) hipLaunchKernelGGL((lstm_rec_bwd_kernel<5, true>), g, dim3(256), REC_LDS_BYTES, st, a, (const float4*)whp, rows);
-        else hipLaunchKernelGGL(lstm_rec_bwd_kernel<5>, g, dim3(256), REC_LDS_BYTES, st, a, (const float4*)whp, rows);
+        if (bx) REC_BWD_LAUNCH(5, true, 1, g); else REC_BWD_LAUNCH(5, false, 1, g);
     } else {
-        if (bx) hipLaunchKernelGGL((lstm_rec_bwd_kernel<3, true>), g, dim3(256), REC_LDS_BYTES, st, a, (const float4*)whp, rows);
-        else hipLaunchKernelGGL(lstm_rec_bwd_kernel<3>, g, dim3(256), REC_LDS_BYTES, st, a, (const float4*)whp, rows);
+        if (bx) REC_BWD_LAUNCH(3, true, 1, g); else REC_BWD_LAUNCH(3, false, 1, g);
     }
     return launch_status("lstm rec bwd");
 }
+#undef REC_BWD_LAUNCH
 
 using FwdCfg128 = TileCfg<4, 1, 1, 4>;  // 128 rows x (4 gates x 32 units), 256 threads
 using FwdCfg64 = TileCfg<2, 1, 1, 4>;   //  64 rows,                       128 threads

@@ -447,8 +447,8 @@ class CaptionEngine(object):
                 if dst is None or self._is_landing_view(dst):
                     dst = self.buf[name] = torch.empty_like(v)
                 if tuple(dst.shape) != tuple(v.shape) or dst.dtype != v.dtype:
-                    raise ValueError("set_batch under a captured hipGraph: %s changed from %s to %s (shapes are baked into the graph)"
-                                     % (name, tuple(dst.shape), tuple(v.shape)))
+                    raise ValueError("set_batch under a captured hipGraph: %s changed from %s %s to %s %s (shapes and dtypes are baked into the graph)"
+                                     % (name, tuple(dst.shape), str(dst.dtype).replace("torch.", ""), tuple(v.shape), str(v.dtype).replace("torch.", "")))
                 dst.copy_(v)
             if not host_index:
                 self._build_index(R, nsub, "fixed", _stream())
