@@ -671,8 +671,11 @@ def roofline_from_timer(timer, fine_tune, images=0, precision="f32"):
             "executed_over_algorithmic": round(ratio, 4),
             "family_flops": fl, "family_seconds_union": round(sec, 6), "family_seconds_serial": round(ser, 6),
             "traffic": None, "launches": n, "avg_launch_us": round(1e6 * sec / n, 2), "per_kernel": per,
-            "streams": int(os.environ.get("VC_VGG_STREAMS", "3")) if fine_tune else 1,
-            "note": "achieved = EXECUTED MFMA FLOPs of the family's calls in the timed region (Winograd, fp32: F(4x4,3x3) 36 multiplications per "
+            "streams": int(os.environ.get("VC_VGG_STREAMS", "3")) if fine_tune else 2,
+            "note": ("achieved = algorithmic FLOPs (2 M N K) of every vc_gemm_f32 call the step issues (tags logits_gemm + gemm; the products inside "
+                     "vc_lstm_seq_* are issued by the library and not bracketed) / union of the calls' HIP-event intervals, recorded on the stream each "
+                     "call is launched on (the weight-gradient products run on a second stream); frac = achieved / the dense f32 MFMA peak") if not fine_tune else
+                    "achieved = EXECUTED MFMA FLOPs of the family's calls in the timed region (Winograd, fp32: F(4x4,3x3) 36 multiplications per "
                     "4x4 tile and channel pair where the direct form has 144, F(2x2,3x3) / F(3x3,2x2) 16 per 2x2 tile where it has 36, + tile-block "
                     "padding; = algorithmic FLOPs x "
                     "executed_over_algorithmic) / union of the calls' HIP-event intervals (events recorded on the stream each call is "
