@@ -448,6 +448,12 @@ int vc_beam_update(void* stream, int B, int beam, int Lmax, int eos, double len_
                    int32_t* p_len, const int32_t* sent_cur, int32_t* sent_next, double* c_score, double* c_logprob,
                    int32_t* c_len, int32_t* c_slot, int32_t* c_free, int32_t* c_sent, int32_t* parent, int32_t* tok);
 
+/* One beam-search round's row moves in ONE launch (vae_model/decoder.py:254-262): cg[r] = c[parent[r]], hg[r] = h[parent[r]] ([rows, H]
+ * each) and, when xproj != NULL, gact[r] = xproj[tok[r]] ([vocab, G] -> [rows, G]: a word's LSTM input projection E.Wx + b looked up from a
+ * table built once per generation call instead of multiplied every round).  H, G multiples of 4, 16-byte aligned pointers. */
+int vc_beam_gather_f32(void* stream, const float* c, const float* h, const int32_t* parent, int rows, int H, float* cg, float* hg,
+                       const float* xproj, const int32_t* tok, int vocab, int G, float* gact);
+
 /* Stop-word bookkeeping of greedy / sampled decoding (vae_model/decoder.py:186-194), on device: done[b] |= (tok[b] == eos);
  * pending[0] = number of rows that have not emitted eos yet (a float, like the other device scalars). */
 int vc_eos_track_i32(void* stream, const int32_t* tok, int B, int eos, int32_t* done, float* pending);

@@ -465,6 +465,31 @@ __global__ __launch_bounds__(256) void topk_rows_small_kernel(const float* __res
     }
 }
 
+// One decoder round's three row moves in one launch (beam search, vae_model/decoder.py:254-262: every new beam continues the LSTM state
+// of its parent and feeds its last word): cg[r] = c[parent[r]], hg[r] = h[parent[r]] (H floats each) and, when xproj is given,
+// gact[r] = xproj[tok[r]] (G floats: the word's input projection E.Wx + b, looked up instead of multiplied).  16-byte accesses.
+__global__ __launch_bounds__(256) void beam_gather_kernel(const float4* __restrict__ c, const float4* __restrict__ h, const int32_t* __restrict__ parent,
+                                                          int rows, int H4, float4* __restrict__ cg, float4* __restrict__ hg,
+                                                          const float4* __restrict__ xproj, const int32_t* __restrict__ tok, int vocab, int G4,
+                                                          float4* __restrict__ gact) {
+    const long per = 2L * H4 + (xproj ? G4 : 0);
+    const long total = (long)rows * per;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int r = (int)(i / per);
+        const int e = (int)(i - (long)r * per);
+        if (e < 2 * H4) {
+            int pr = parent[r];
+            pr = pr < 0 ? 0 : (pr >= rows ? rows - 1 : pr);
+            if (e < H4) cg[(long)r * H4 + e] = c[(long)pr * H4 + e];
+            else hg[(long)r * H4 + e - H4] = h[(long)pr * H4 + e - H4];
+        } else {
+            int id = tok[r];
+            id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+            gact[(long)r * G4 + e - 2 * H4] = xproj[(long)id * G4 + e - 2 * H4];
+        }
+    }
+}
+
 // softmax + top-k of a row in ONE read of the logits (beam search, vae_model/decoder.py:248-276: probs = softmax(logits), then the
 // beam_size most probable words by a stable sort on -p).  The probabilities are formed by exactly the expressions of
 // softmax_rows_reg_kernel / softmax_rows_kernel (loss.hip: same maximum, same summation order, p = exp(l - max) * (1 / sum)) and offered
@@ -579,6 +604,19 @@ extern "C" int vc_topk_rows_f32(void* stream, const float* x, long rows, int col
         hipLaunchKernelGGL(topk_rows_small_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, cols, ld, k, out_val, out_idx);
     else
         hipLaunchKernelGGL(topk_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, cols, ld, k, out_val, out_idx);
+    VC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vc_beam_gather_f32(void* stream, const float* c, const float* h, const int32_t* parent, int rows, int H, float* cg, float* hg,
+                                  const float* xproj, const int32_t* tok, int vocab, int G, float* gact) {
+    VC_CHECK_ARG(c && h && parent && cg && hg && rows > 0 && H > 0 && H % 4 == 0, "bad argument (H % 4 == 0)");
+    VC_CHECK_ARG(!xproj || (tok && gact && vocab > 0 && G > 0 && G % 4 == 0), "xproj needs tok, gact, vocab and G % 4 == 0");
+    VC_CHECK_ARG(((((uintptr_t)c | (uintptr_t)h | (uintptr_t)cg | (uintptr_t)hg | (uintptr_t)xproj | (uintptr_t)gact)) & 15) == 0, "pointers must be 16-byte aligned");
+    const long total = (long)rows * (2L * (H / 4) + (xproj ? G / 4 : 0));
+    hipLaunchKernelGGL(beam_gather_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(c),
+                       reinterpret_cast<const float4*>(h), parent, rows, H / 4, reinterpret_cast<float4*>(cg), reinterpret_cast<float4*>(hg),
+                       reinterpret_cast<const float4*>(xproj), tok, vocab, G / 4, reinterpret_cast<float4*>(gact));
     VC_LAUNCH_CHECK();
     return 0;
 }

@@ -33,6 +33,8 @@ class CaptionGenerator(object):
         self._whp = None        # decoder Wh in the recurrence kernel's operand order
         self._whp_fresh = False  # re-packed at the start of every init_state (the weights may have been trained in between)
         self._graphs = {}        # captured decode rounds (hipGraphs), keyed by shapes + the addresses they bake
+        self._xproj = None       # [V, 4H] input projection of every word (beam search with many rows x rounds)
+        self._xproj_fresh = False
 
     def _b(self, name, shape, dtype=torch.float32):
         t = self.buf.get(name)
@@ -70,6 +72,7 @@ class CaptionGenerator(object):
         eps: [S, B, L] N(0,1) draws (generated on device when None)."""
         e, p, lib, st, S = self.e, self.p, self.lib, _stream(), self.e.store
         self._whp_fresh = False  # a new generation call: re-pack Wh on the first step (5 us)
+        self._xproj_fresh = False
         feats = self._dev(features, np.float32)
         B = feats.shape[0]
         E, Hd, L, Sm, F = p.embed_size, p.decoder_hidden, p.latent_size, p.gen_z_samples, p.cnn_feature_size
@@ -123,18 +126,34 @@ class CaptionGenerator(object):
         lib.vc_lstm_pack_wh_f32(_stream(), Hd, e.store.param(spec.DEC_CELL + "kernel").data_ptr() + E * 4 * Hd * 4, P(self._whp))
         self._whp_fresh = True
 
-    def step(self, tokens, c, h, want="probs", bufs=None, timed=True):
+    def _project_vocab(self):
+        """xproj [V, 4H] = dec_embeddings . Wx + b: the LSTM input projection of EVERY word, once per generation call (the weights may
+        have been trained since the last one).  A round then looks its rows up (vc_beam_gather_f32) instead of gathering embeddings and
+        multiplying: one product of V rows (0.1 ms at V = 10 000) against rows x rounds of them -- callers use it when rows x rounds >= V."""
+        e, p, S = self.e, self.p, self.e.store
+        E, Hd, V = p.embed_size, p.decoder_hidden, e.V
+        if not self._xproj_fresh:
+            if self._xproj is None or tuple(self._xproj.shape) != (V, 4 * Hd):
+                self._xproj = torch.empty((V, 4 * Hd), dtype=torch.float32, device=e.dev)
+            e.gemm(0, 0, V, 4 * Hd, E, S.param("decoder/net/dec_embeddings"), E, S.param(spec.DEC_CELL + "kernel"), 4 * Hd, self._xproj, 4 * Hd,
+                   S.param(spec.DEC_CELL + "bias"))
+            self._xproj_fresh = True
+        return self._xproj
+
+    def step(self, tokens, c, h, want="probs", bufs=None, timed=True, projected=False):
         """Feed one token per row: returns (softmax probs [M, V], c', h').  bufs (from _round_bufs): write x / gate activations / new
-        state / logits into these persistent tensors instead of fresh ones (c, h must not alias bufs["c2"] / bufs["h2"])."""
+        state / logits into these persistent tensors instead of fresh ones (c, h must not alias bufs["c2"] / bufs["h2"]).
+        projected: bufs["gact"] already holds the tokens' input projections (vc_beam_gather_f32 from _project_vocab's table)."""
         e, p, lib, st, S = self.e, self.p, self.lib, _stream(), self.e.store
         M = int(tokens.shape[0])
         E, Hd, V = p.embed_size, p.decoder_hidden, e.V
         new = lambda k, shape: bufs[k] if bufs is not None else torch.empty(shape, dtype=torch.float32, device=e.dev)
-        x = new("x", (M, E))
-        lib.vc_embedding_gather_f32(st, P(S.param("decoder/net/dec_embeddings")), P(tokens), M, E, V, P(x))
         W = S.param(spec.DEC_CELL + "kernel")
         gact = new("gact", (M, 4 * Hd))
-        e.gemm(0, 0, M, 4 * Hd, E, x, E, W, 4 * Hd, gact, 4 * Hd, S.param(spec.DEC_CELL + "bias"), tag="gemm" if timed else None)
+        if not projected:
+            x = new("x", (M, E))
+            lib.vc_embedding_gather_f32(st, P(S.param("decoder/net/dec_embeddings")), P(tokens), M, E, V, P(x))
+            e.gemm(0, 0, M, 4 * Hd, E, x, E, W, 4 * Hd, gact, 4 * Hd, S.param(spec.DEC_CELL + "bias"), tag="gemm" if timed else None)
         c2, h2 = new("c2", (M, Hd)), new("h2", (M, Hd))
         ones = self._ones.get(M)
         if ones is None:
@@ -154,6 +173,13 @@ class CaptionGenerator(object):
         return probs, c2, h2
 
     # ------------------------------------------------------------------ captured rounds
+    def _pinned_alive(self, n):
+        t = self.buf.get("bm_host_alive")
+        if t is None or t.numel() < n:
+            t = self.buf["bm_host_alive"] = torch.ones(max(n, 16), dtype=torch.float32).pin_memory()
+        t.fill_(1.0)
+        return t
+
     def _graph_key(self, kind, *shape):
         """A captured round is valid while every address it baked is: the parameter store, the packed Wh, the engine's workspace."""
         e = self.e
@@ -309,15 +335,20 @@ class CaptionGenerator(object):
         alive = self._b("bm_alive", (1,))
         fused = n <= 8   # softmax + top-k in one read of the logits (vc_softmax_topk_rows_f32: bit-identical to the two calls)
 
+        import os
+        rounds = max_len - 1
+        # the words' input projections from a table (rows x rounds of lookups against ONE product over the vocabulary)
+        xproj = self._project_vocab() if (M * rounds >= V and Hd % 4 == 0 and os.environ.get("VC_DECODE_XPROJ", "1") != "0") else None
+
         def one(it, timed):
             s_ = _stream()
-            lib.vc_embedding_gather_f32(s_, P(bufs["c2"]), P(parent), M, Hd, M, P(cg))
-            lib.vc_embedding_gather_f32(s_, P(bufs["h2"]), P(parent), M, Hd, M, P(hg))
+            # every new beam continues its parent's state and feeds its last word: three row moves, one launch
+            lib.vc_beam_gather_f32(s_, P(bufs["c2"]), P(bufs["h2"]), P(parent), M, Hd, P(cg), P(hg), P(xproj), P(tok), V, 4 * Hd, P(bufs["gact"]))
             if fused:
-                logits, _, _ = self.step(tok, cg, hg, want="logits", bufs=bufs, timed=timed)
+                logits, _, _ = self.step(tok, cg, hg, want="logits", bufs=bufs, timed=timed, projected=xproj is not None)
                 lib.vc_softmax_topk_rows_f32(s_, P(logits), M, V, V, n, P(tv), P(ti))
             else:
-                probs, _, _ = self.step(tok, cg, hg, bufs=bufs, timed=timed)
+                probs, _, _ = self.step(tok, cg, hg, bufs=bufs, timed=timed, projected=xproj is not None)
                 lib.vc_topk_rows_f32(s_, P(probs), M, V, V, n, P(tv), P(ti))
             lib.vc_beam_update(s_, B, n, L, int(eos), float(len_norm_f), P(tv), P(ti), P(pcount), P(ccount), P(p_score), P(p_logprob),
                                P(p_len), P(sent[it & 1]), P(sent[1 - (it & 1)]), P(c_score), P(c_logprob), P(c_len), P(c_slot),
@@ -333,17 +364,27 @@ class CaptionGenerator(object):
             for r in range(K):
                 one(r, False)
             lib.vc_count_nonzero_i32(_stream(), P(pcount), B, P(alive))
-        key = self._graph_key("beam", B, n, L, K, int(eos), float(len_norm_f), P(pcount), P(bufs["logits"]))
+        key = self._graph_key("beam", B, n, L, K, int(eos), float(len_norm_f), P(pcount), P(bufs["logits"]), P(xproj))
         graph = self._graphs.get(key) if fused else None
-        rounds = max_len - 1
+        # "is any beam alive" without idling the GPU: after every replayed chunk the 4-byte count is copied to pinned memory behind an
+        # event; the host looks at the count of the PREVIOUS chunk before it launches the next (rounds of an image whose beams have all
+        # ended are no-ops of vc_beam_update, so a chunk too many changes nothing)
+        host_alive = self._pinned_alive(rounds // K + 2)
+        pending = []
         last, it = 0, 0
         while it < rounds:
             if graph is not None and it % 2 == 0 and it + K <= rounds:
+                if check_every and len(pending) >= 2 and pending[-2][1].query() and float(host_alive[pending[-2][0]]) == 0.0:
+                    break
                 graph.replay()
                 it += K
                 last = 0
-                if check_every and alive.item() == 0:
-                    break
+                if check_every:
+                    slot = len(pending)
+                    host_alive[slot:slot + 1].copy_(alive, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    pending.append((slot, ev))
             else:
                 one(it, True)
                 last = 1 - (it & 1)
