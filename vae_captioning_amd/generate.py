@@ -393,17 +393,25 @@ class CaptionGenerator(object):
                     lib.vc_count_nonzero_i32(st, P(pcount), B, P(alive))
                     if alive.item() == 0:
                         break
-        pc, cc = pcount.cpu().numpy(), ccount.cpu().numpy()
-        ps, pl = p_score.cpu().numpy().reshape(B, n), p_len.cpu().numpy().reshape(B, n)
-        cs, cl, csl = c_score.cpu().numpy().reshape(B, n), c_len.cpu().numpy().reshape(B, n), c_slot.cpu().numpy().reshape(B, n)
-        psent = sent[last].cpu().numpy().reshape(B, n, L)
-        csent = c_sent.cpu().numpy().reshape(B, n + 1, L)
+        # results: TWO device-to-host copies (every int32 field in one buffer, the two float64 score arrays in another)
+        ints = torch.cat([pcount, ccount, p_len, c_len, c_slot, sent[last].reshape(-1), c_sent.reshape(-1)]).cpu().numpy()
+        dbls = torch.cat([p_score, c_score]).cpu().numpy()
+        o = 0
+        def take(cnt, shape):
+            nonlocal o
+            a = ints[o:o + cnt].reshape(shape)
+            o += cnt
+            return a
+        pc, cc = take(B, (B,)).tolist(), take(B, (B,)).tolist()
+        pl, cl, csl = take(M, (B, n)).tolist(), take(M, (B, n)).tolist(), take(M, (B, n)).tolist()
+        psent, csent = take(M * L, (B, n, L)), take(B * (n + 1) * L, (B, n + 1, L))
+        ps, cs = dbls[:M].reshape(B, n).tolist(), dbls[M:].reshape(B, n).tolist()
         res = []
         for b in range(B):
             if cc[b]:  # never mix complete and partial (:295-299)
-                beams = [Beam(csent[b, csl[b, j], :cl[b, j]].tolist(), None, None, float(cs[b, j])) for j in range(cc[b])]
+                beams = [Beam(csent[b, csl[b][j], :cl[b][j]].tolist(), None, None, cs[b][j]) for j in range(cc[b])]
             else:
-                beams = [Beam(psent[b, j, :pl[b, j]].tolist(), None, None, float(ps[b, j])) for j in range(pc[b])]
+                beams = [Beam(psent[b, j, :pl[b][j]].tolist(), None, None, ps[b][j]) for j in range(pc[b])]
             beams.sort(reverse=True)  # TopN.extract(sort=True) on the heap array
             res.append([(bm.sentence, float(bm.score)) for bm in beams])
         if graph is None and fused and rounds > K:
