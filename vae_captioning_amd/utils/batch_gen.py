@@ -104,16 +104,17 @@ class BatchGenerator(object):
 # (the HDF5 file's role) or from the image files themselves.
 # ------------------------------------------------------------------------------------------------
 def open_image_array(path):
-    """The `images (N, 224, 224, 3) uint8` array preprocess.py writes.  The reference keeps it in HDF5
-    (needs h5py, absent here); this build's preprocess.py writes the same array as .npy and memory-maps it."""
+    """The `images (N, 224, 224, 3) uint8` array preprocess.py writes.  The reference keeps it in HDF5 (preprocess.py:25-45) and reads it
+    with h5py (utils/batch_gen.py:35-41); without h5py (this image) the file is opened by `hdf5_min`, a reader of exactly the layout
+    that call writes (superblock 0, old-style root group, one contiguous data set); this build's own preprocess.py writes the same
+    array as .npy, which is memory-mapped."""
     if path.endswith(".npy"):
         return np.load(path, mmap_mode="r")
     try:
-        import h5py  # noqa: F401
+        import h5py
     except ImportError:
-        raise ImportError("%s: reading HDF5 needs h5py, which is not installed; run this build's preprocess.py "
-                          "(writes the same array as .npy) and pass that file as hdf5_file" % path)
-    import h5py
+        from . import hdf5_min
+        return hdf5_min.File(path)["images"]
     return h5py.File(path, "r")["images"]
 
 
