@@ -29,7 +29,12 @@ tf, tb = [], []
 for it in range(12):
     e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     e[0].record()
-    vgg.forward(tr.images, tr.cap.step)
+    if os.environ.get("VC_FWD_ONE_CHAIN") == "1":   # (experiment: the forward as ONE chain of full-batch launches, the backward on three streams)
+        keep, vgg._side = vgg._side, None
+        vgg.forward(tr.images, tr.cap.step)
+        vgg._side = keep
+    else:
+        vgg.forward(tr.images, tr.cap.step)
     e[1].record()
     vgg.backward(d)
     e[2].record()
