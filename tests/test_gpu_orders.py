@@ -4,7 +4,7 @@ computes: every A/B switch (read once per process, hence the subprocesses) must 
   VC_WGRAD_XCD    XCD-contiguous (split, tile) ranges of the weight gradient (csrc/conv_wino_wgrad_kernel.h)
   VC_LOGITS_DW    where the logits layer's kernel gradient is issued (engine.backward)
   VC_WINO4V       conv4_x / conv5_x on the once-transformed input (csrc/conv_wino4.hip MODE 2) or on the fused kernel (0)
-  VC_ADAM_BLOCKS  workgroups of an Adam launch (changes the summation order of the regulariser's partial sums only: not compared)"""
+"""
 import hashlib
 import json
 import os
@@ -78,7 +78,7 @@ print("RESULT " + json.dumps(out, sort_keys=True))
 
 def _run(code, env_extra):
     env = dict(os.environ)
-    for k in ("VC_WINO4_TG", "VC_WGRAD_XCD", "VC_LOGITS_DW", "VC_ADAM_BLOCKS", "VC_WINO4V"):
+    for k in ("VC_WINO4_TG", "VC_WGRAD_XCD", "VC_LOGITS_DW", "VC_WINO4V"):
         env.pop(k, None)
     env.update(env_extra)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)

@@ -72,8 +72,7 @@ python tools/rocpd_stats.py "$(find /tmp/kt_c4bx -name "*_results.db" | head -1)
 python tools/microbench.py winoab winow 2>/dev/null | grep -v amdgpu.ids > $OUT/${TAG}_wino_layers.txt
 (for v in fwd dgrad bits; do echo "== python tools/experiments/wino4_try.py 64 $v"; python tools/experiments/wino4_try.py 64 $v 2>&1 | grep "^conv\|^sum"; done
  for v in fwd bits; do echo "== python tools/experiments/wino4_try.py 32 $v"; python tools/experiments/wino4_try.py 32 $v 2>&1 | grep "^conv\|^sum"; done) > $OUT/${TAG}_wino4_layers.txt
-(echo "== python tools/microbench.py lstm (VC_LSTM_MODES=3,1)"; python tools/microbench.py lstm 2>&1 | grep "^lstm"
- echo "== VC_LSTM_WGS_PER_CU=2 (two workgroups of the four-wave recurrence kernels per CU; measured, not adopted)"; VC_LSTM_WGS_PER_CU=2 VC_LSTM_MODES=3 python tools/microbench.py lstm 2>&1 | grep "^lstm") > $OUT/${TAG}_lstm_steps.txt
+(echo "== python tools/microbench.py lstm (VC_LSTM_MODES=3,1)"; python tools/microbench.py lstm 2>&1 | grep "^lstm") > $OUT/${TAG}_lstm_steps.txt
 # 7b. round 6: F(4x4,3x3) on a once-transformed input (MODE 2, vc_conv3x3_wino4v_*) against the fused kernel per layer, and inside the step
 (for b in 32 64; do python tools/experiments/wino4v_try.py $b 2>&1 | grep "^conv\|^sum"; done) > $OUT/${TAG}_wino4v_layers_rerun.txt
 for v in 1 0; do VC_WINO4V=$v python bench.py --no-cpu-baseline --strong-n1 0 > $OUT/${TAG}_bench_wino4v$v.json 2>/dev/null; done

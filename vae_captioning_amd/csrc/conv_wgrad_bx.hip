@@ -412,7 +412,7 @@ static WgBxPlan plan_wgrad_bx(int B, int H, int W, int C, int N) {
     p.by_n = cdiv(p.grows, 8);
     p.nblocks = p.bx_n * p.by_n;
     p.ncb = C / 64; p.nnb = N / 64;
-    static const int target = getenv("VC_WGBX_GRID") ? atoi(getenv("VC_WGBX_GRID")) : 256;
+    const int target = 256;   // one workgroup per CU
     int ns = cdiv(target, p.ncb * p.nnb);
     if (ns > p.nblocks) ns = p.nblocks;
     p.cps = cdiv(p.nblocks, ns);

@@ -145,7 +145,7 @@ template <int KIND, bool POOL, int MODE>
 __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(Wino4Args a) {
     constexpr bool LT = MODE != W4_SQUARE, VIN = MODE == W4_VIN;
     constexpr int NPS = VIN ? 1 : LT ? 5 : 3;                          // patch slots per thread and phase
-    constexpr int PBUF = LT ? W4L_PBUF : W4_PBUF, BLKF = LT ? W4L_BLKF : W4_BLKF, PLANE = LT ? W4L_PLANE : W4_PLANE;
+    constexpr int PBUF = LT ? W4L_PBUF : W4_PBUF, PLANE = LT ? W4L_PLANE : W4_PLANE;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const Wino4Geom& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lj = lane & 15, lg = lane >> 4;
@@ -766,8 +766,7 @@ static bool plan_wino4(int B, int H, int W, int C, int N, Wino4Geom& g) {
     const int th = cdiv(H, 4);
     g.tw = cdiv(W, 4); g.tiles_img = th * g.tw; g.ntiles_all = B * g.tiles_img;
     g.m_tiles_img = wino_magic(g.tiles_img); g.m_tw = wino_magic(g.tw);
-    static const int lt_on = getenv("VC_WINO4_LINEAR") ? atoi(getenv("VC_WINO4_LINEAR")) : 1;   // (A/B runs)
-    g.lt = (lt_on && (long)B * g.tiles_img < 0x7ffffff0L && cdiv(g.ntiles_all, 16) < g.nblocks) ? 1 : 0;
+    g.lt = ((long)B * g.tiles_img < 0x7ffffff0L && cdiv(g.ntiles_all, 16) < g.nblocks) ? 1 : 0;
     if (g.lt) g.nblocks = cdiv(g.ntiles_all, 16);
     return true;
 }

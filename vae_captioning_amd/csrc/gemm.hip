@@ -312,8 +312,6 @@ struct BxPlan {
 static BxPlan plan_bx256(int M, int N, int K) {
     BxPlan p;
     p.use = false;
-    static const char* force = getenv("VC_BX_TILE");   // experiments: 128 / 256
-    if (force && atoi(force) == 128) return p;
     if (M < 192 || N < 192) return p;
     p.tiles_m = cdiv(M, 256); p.tiles_n = cdiv(N, 256);
     const long t = (long)p.tiles_m * p.tiles_n;
@@ -325,7 +323,7 @@ static BxPlan plan_bx256(int M, int N, int K) {
         const double eff = (double)w / (double)(cdiv(w, 256) * 256L) - 0.02 * (s - 1);   // (a split costs a workspace round trip)
         if (eff > beff + 1e-9) { beff = eff; best = s; }
     }
-    if (t * best < 200 && !(force && atoi(force) == 256)) return p;   // under one round: the 128 x 128 plan spreads the work better
+    if (t * best < 200) return p;   // under one round: the 128 x 128 plan spreads the work better
     p.splits = best;
     p.kchunk = cdiv(cdiv(K, best), 32) * 32;
     p.splits = cdiv(K, p.kchunk);

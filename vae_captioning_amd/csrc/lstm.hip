@@ -847,7 +847,7 @@ __global__ __launch_bounds__(512, 1) void lstm_rec8_fwd_kernel(LstmFwdArgs a, co
 static int g_lstm_mode = 2;   // DEPRECATED process-wide default (vc_lstm_set_mode): calls choose with VC_LSTM_KERNELS(k) in their flags (ABI 4)
 static bool rec_ok(int N, int H) { return H == 512 && (long)(N + 96) * 4 * H * 4 < 0x7fffffffL; }
 static int lstm_env(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
-static bool rec8_rows(int N) { static const int thr = lstm_env("VC_LSTM_REC8_ROWS", 400); return N > thr; }  // forward: the eight-wave 16-unit kernel above (19.7 vs 17.1 us at 320 rows, 26.2 vs 31.9 at 640, 47.9 vs 58.9 at 1280)
+static bool rec8_rows(int N) { return N > 400; }  // forward: the eight-wave 16-unit kernel above (19.7 vs 17.1 us at 320 rows, 26.2 vs 31.9 at 640, 47.9 vs 58.9 at 1280)
 constexpr size_t REC_PACK_BYTES = (size_t)512 * 2048 * sizeof(float);
 
 static int rec_cus() {
@@ -869,15 +869,14 @@ static int rec_lds(K kern) {  // 66 KB of dynamic LDS: above the 64 KB a kernel 
 
 // row groups: as many as keep one workgroup per CU (UG column slices x RG <= CUs), at least 16 rows each
 static int rec_row_groups(int N, int UG) {
-    static const int occ = lstm_env("VC_LSTM_WGS_PER_CU", 1);   // (experiment knob: workgroups of the four-wave kernels per CU)
-    int rg = occ * rec_cus() / UG;
+    int rg = rec_cus() / UG;   // (two workgroups per CU measured slower: HISTORY.md section R)
     if (rg < 1) rg = 1;
     const int cap = cdiv(N, 16);
     return rg < cap ? rg : cap;
 }
 
 // bx: the split-bf16 kernels (whp must then come from the pack kernels called with bx = 1)
-static bool rec_bx(int flags) { static const int off = lstm_env("VC_LSTM_BX", 1); return off != 0 && ((flags & VC_LSTM_BF16X3) || gemm_default_precision() == 1); }
+static bool rec_bx(int flags) { return (flags & VC_LSTM_BF16X3) || gemm_default_precision() == 1; }
 // which step kernels a sequence call runs: the call's own choice (VC_LSTM_KERNELS(k) in its flags), else the deprecated process-wide default
 static int seq_mode(int flags) { const int k = flags & 7; return (k >= 1 && k <= 4) ? k - 1 : g_lstm_mode; }
 static int seq_gemm_flags(int flags) { return (flags & VC_LSTM_BF16X3) ? VC_GEMM_BF16X3 : 0; }
@@ -928,12 +927,11 @@ static int rec_lds_once(K kern, int& state) {
 static int rec_bwd(hipStream_t st, const LstmBwdArgs& a, const float* whp, bool bx = false) {
     // many rows: 32 units per workgroup (16 column slices x 16 row groups at 1280 rows: ONE pass of five row tiles per workgroup instead
     // of two, each dG[t+1] row read by 16 workgroups instead of 32).  Measured (tools/microbench.py lstm, 1280 rows): split-bf16 54.8 ->
-    // 48.5 us per step, f32 81.4 -> 77.6; in the f32 steps it is small but repeatable (round 6, same box, VC_LSTM_BWD_CT2_F32=0 / 1:
+    // 48.5 us per step, f32 81.4 -> 77.6; in the f32 steps it is small but repeatable (round 6, same box, sixteen- / 32-unit form:
     // cfg2 13.566 / 13.544 -> 13.519 / 13.515 ms, cfg3 14.935 -> 14.842), so both precisions take it from 600 rows on.
-    // VC_LSTM_BWD_CT2_ROWS: from how many rows on (0: never); VC_LSTM_BWD_CT2_F32=0: split-bf16 only (A/B runs).
+    // VC_LSTM_BWD_CT2_ROWS: from how many rows on (0: never; A/B runs).
     static const int ct2_rows = lstm_env("VC_LSTM_BWD_CT2_ROWS", 600);
-    static const int ct2_f32 = lstm_env("VC_LSTM_BWD_CT2_F32", 1);
-    if (ct2_rows > 0 && a.N >= ct2_rows && (bx || ct2_f32)) {
+    if (ct2_rows > 0 && a.N >= ct2_rows) {
         const int RG = rec_row_groups(a.N, 16), rows = cdiv(a.N, RG);
         const dim3 g(16, RG);
         if (rows > 48) {

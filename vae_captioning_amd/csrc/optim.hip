@@ -19,11 +19,8 @@ static inline int grid_for(long work_items, int per_block = 256, int cap = 2048)
 
 constexpr int SUMSQ_BLOCKS = 512;
 
-// Workgroups of an Adam launch (grid-stride, all resident at once).  (VC_ADAM_BLOCKS: A/B runs)
-static inline int adam_grid(long n) {
-    static const int cap = getenv("VC_ADAM_BLOCKS") ? atoi(getenv("VC_ADAM_BLOCKS")) : 2048;
-    return grid_for(n / 4 + 1, 256, cap > 0 ? cap : 2048);
-}
+// Workgroups of an Adam launch (grid-stride, all resident at once; 256 / 512 / 1024 measured no better: HISTORY.md section R)
+static inline int adam_grid(long n) { return grid_for(n / 4 + 1, 256, 2048); }
 
 // partial[b] = sum over a fixed grid-stride slice of x^2: deterministic for a fixed n.
 __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ x, long n, float* __restrict__ partial) {
