@@ -175,6 +175,9 @@ def cpu_baseline_generate(kind, p, feats, cv, eps, beam=5, images=8):
 
 
 def main():
+    # multi-process GPU work: the host driver only supports dmabuf IPC (without this RCCL's peer mappings fail with
+    # "hipIpcGetMemHandle: invalid argument"); exported by the launch environment, defaulted here for bare invocations
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)

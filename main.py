@@ -14,6 +14,8 @@ batches with the same tensor contract (vae_captioning_amd/synth.py).
 """
 import json
 import os
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for multi-process GPU work (RCCL peer mappings)
 import pickle
 import sys
 
