@@ -282,3 +282,30 @@ def test_beam_update_matches_reference_topn_fixture(lib):
                 assert cc[b] == len(cheap), (n, it, b)
                 for j, bm in enumerate(cheap):
                     assert cst[b, csl[b, j], :cl[b, j]].tolist() == bm["sentence"] and cs[b, j] == bm["score"] and clp[b, j] == bm["logprob"]
+
+
+@pytest.mark.parametrize("beam,max_len,check_every", [(10, 9, 4), (1, 12, 4), (3, 3, 4), (3, 12, 3), (8, 7, 0), (2, 6, 2)],
+                         ids=["beam10-unfused-topk", "beam1", "two-rounds-no-graph", "odd-check-interval", "beam8-no-checks", "chunks-of-two"])
+def test_beam_search_edge_shapes_match_the_oracle_eager_and_replayed(lib, beam, max_len, check_every, monkeypatch):
+    """the round-6 decode paths at their edges: beam > 8 (separate softmax + k-pass top-k), beam 1, fewer rounds than a chunk (never
+    captured), a check interval that is not a chunk size, no host checks at all, chunks of two rounds -- each called TWICE (eager +
+    capture, then replay) and with VC_DECODE_XPROJ=0, always the fp64 oracle's beams (vae_model/decoder.py:203-320)."""
+    p, eng, gen, P64, feats, cv, eps, cm = setup(lib, 11, prior="GMM")
+    ref = [od.beam_search(P64, p, feats[b].astype(np.float64), cv[b].astype(np.float64), eps[:, b:b + 1].astype(np.float64), BOS, EOS,
+                          c_means=cm, beam_size=beam, max_len=max_len)[0] for b in range(feats.shape[0])]
+    for xproj in ("1", "0"):
+        monkeypatch.setenv("VC_DECODE_XPROJ", xproj)
+        g = CaptionGenerator(eng)
+        for call in range(2):
+            got = g.beam_search(feats, None, eps, BOS, EOS, beam_size=beam, max_len=max_len, check_every=check_every)
+            assert [[s for s, _ in got[b]] for b in range(len(got))] == ref, (xproj, call)
+
+
+@pytest.mark.parametrize("max_len,check_every", [(1, 4), (3, 4), (9, 0), (10, 2), (13, 3)])
+def test_greedy_edge_lengths_match_the_oracle(lib, max_len, check_every):
+    p, eng, gen, P64, feats, cv, eps, cm = setup(lib, 13, no_encoder=True)
+    for call in range(2):
+        got = gen.greedy(feats, None, None, BOS, EOS, max_len=max_len, check_every=check_every)
+        for b in range(feats.shape[0]):
+            ref = od.greedy(P64, p, feats[b].astype(np.float64), cv[b].astype(np.float64), None, BOS, EOS, c_means=cm, max_len=max_len)
+            assert got[b] == ref, (call, b, got[b], ref)
