@@ -11,6 +11,8 @@ tie order, score = logprob / len**0.7 for completed captions, `<BOS>` consumed t
 Per-image semantics of the z input are those of batch 1: row b of the z_rnn input is the S
 samples of image b (the Q1 reshape is the identity at N = 1).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -115,6 +117,13 @@ class CaptionGenerator(object):
         return {"x": self._b(tag + "x", (M, E)), "gact": self._b(tag + "gact", (M, 4 * Hd)), "c2": self._b(tag + "c2", (M, Hd)),
                 "h2": self._b(tag + "h2", (M, Hd)), "logits": self._b(tag + "logits", (M, V))}
 
+    def _ones_for(self, M):
+        """[M] int32 ones: the "every row is active" lengths of a single decoder step (persistent: captured chunks bake the address)"""
+        t = self._ones.get(M)
+        if t is None:
+            t = self._ones[M] = torch.ones((M,), dtype=torch.int32, device=self.e.dev)
+        return t
+
     def _pack_wh(self, M):
         """decoder Wh in the recurrence step kernel's operand order, once per generation call (init_state clears _whp_fresh)"""
         e, p, lib = self.e, self.p, self.lib
@@ -155,9 +164,7 @@ class CaptionGenerator(object):
             lib.vc_embedding_gather_f32(st, P(S.param("decoder/net/dec_embeddings")), P(tokens), M, E, V, P(x))
             e.gemm(0, 0, M, 4 * Hd, E, x, E, W, 4 * Hd, gact, 4 * Hd, S.param(spec.DEC_CELL + "bias"), tag="gemm" if timed else None)
         c2, h2 = new("c2", (M, Hd)), new("h2", (M, Hd))
-        ones = self._ones.get(M)
-        if ones is None:
-            ones = self._ones[M] = torch.ones((M,), dtype=torch.int32, device=e.dev)
+        ones = self._ones_for(M)
         if lib.vc_lstm_step_packed_supported(M, Hd):  # the recurrence step kernel on Wh packed once per weight version
             self._pack_wh(M)
             lib.vc_lstm_step_fwd_packed_f32(st, M, Hd, 0, P(h), P(c), P(self._whp), P(gact), P(ones), P(c2), P(h2))
@@ -180,15 +187,17 @@ class CaptionGenerator(object):
         t.fill_(1.0)
         return t
 
-    def _graph_key(self, kind, *shape):
-        """A captured round is valid while every address it baked is: the parameter store, the packed Wh, the engine's workspace."""
+    def _graph_key(self, kind, *shape, tensors=()):
+        """A captured chunk is valid while EVERY address it baked is: the parameter store, the packed Wh, the engine's workspace and
+        each persistent buffer of the round (`tensors`: a buffer re-allocated by a call of another shape gets a new address, and a
+        graph that still holds the old one must never be replayed)."""
         e = self.e
-        return (kind,) + tuple(shape) + (e.store.p.data_ptr(), P(self._whp) if self._whp is not None else 0, P(e.ws) if e.ws is not None else 0, e.gemm_flags)
+        return ((kind,) + tuple(shape) + (e.store.p.data_ptr(), P(self._whp) if self._whp is not None else 0, P(e.ws) if e.ws is not None else 0, e.gemm_flags)
+                + tuple(P(t) if t is not None else 0 for t in tensors))
 
     def _capture(self, key, fn):
         """hipGraph of fn() (launches on the current stream only, no allocations, no host reads).  Returns None when graphs are off
         (VC_DECODE_GRAPH=0: A/B runs)."""
-        import os
         if os.environ.get("VC_DECODE_GRAPH", "1") == "0":
             return None
         g = self._graphs.get(key)
@@ -241,11 +250,12 @@ class CaptionGenerator(object):
         # the first call of a shape runs one step eagerly (it sizes the workspace, whose address a captured chunk bakes; the chunk
         # then repeats that step on unchanged inputs); every call re-packs Wh (the weights may have been trained since the last one)
         self._pack_wh(B)
-        key = self._graph_key("greedy", B, K, int(eos), P(chunk), P(A["logits"]))
+        baked = [chunk, done, pending, self._ones_for(B)] + list(A.values()) + list(Bb.values())
+        key = self._graph_key("greedy", B, K, int(eos), tensors=baked)
         if key not in self._graphs:
             one(0, True)
             done.zero_()
-            key = self._graph_key("greedy", B, K, int(eos), P(chunk), P(A["logits"]))
+            key = self._graph_key("greedy", B, K, int(eos), tensors=baked)   # (the first step may have sized the workspace)
         graph = self._capture(key, lambda: [one(r, False) for r in range(K)])
         steps = 0
         while steps < max_len:
@@ -335,7 +345,6 @@ class CaptionGenerator(object):
         alive = self._b("bm_alive", (1,))
         fused = n <= 8   # softmax + top-k in one read of the logits (vc_softmax_topk_rows_f32: bit-identical to the two calls)
 
-        import os
         rounds = max_len - 1
         # the words' input projections from a table (rows x rounds of lookups against ONE product over the vocabulary)
         xproj = self._project_vocab() if (M * rounds >= V and Hd % 4 == 0 and os.environ.get("VC_DECODE_XPROJ", "1") != "0") else None
@@ -364,7 +373,9 @@ class CaptionGenerator(object):
             for r in range(K):
                 one(r, False)
             lib.vc_count_nonzero_i32(_stream(), P(pcount), B, P(alive))
-        key = self._graph_key("beam", B, n, L, K, int(eos), float(len_norm_f), P(pcount), P(bufs["logits"]), P(xproj))
+        key = self._graph_key("beam", B, n, L, K, int(eos), float(len_norm_f),
+                              tensors=[pcount, ccount, p_score, p_logprob, p_len, sent[0], sent[1], c_score, c_logprob, c_len, c_slot, c_free, c_sent,
+                                       parent, tok, tv, ti, cg, hg, alive, xproj, self._ones_for(M)] + list(bufs.values()))
         graph = self._graphs.get(key) if fused else None
         # "is any beam alive" without idling the GPU: after every replayed chunk the 4-byte count is copied to pinned memory behind an
         # event; the host looks at the count of the PREVIOUS chunk before it launches the next (rounds of an image whose beams have all
