@@ -60,11 +60,12 @@ class File(object):
         self.path = path
         self._fh = open(path, "rb")
         self._links = None
+        self.base = 0            # (absolute offsets until the superblock has told the base address)
         self._parse_superblock()
 
     # ---- plumbing
     def _read(self, off, n):
-        self._fh.seek(self.base + off if hasattr(self, "base") else off)
+        self._fh.seek(self.base + off)
         b = self._fh.read(n)
         if len(b) != n:
             raise Hdf5FormatError("%s: truncated file (wanted %d bytes at offset %d)" % (self.path, n, off))
