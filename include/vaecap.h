@@ -433,7 +433,7 @@ int vc_conv1_wgrad_f32(void* stream, int B, int H, int W, const float* x4, const
                        float* ws, size_t ws_bytes);
 
 /* ------------------------------------------------------------------------------------
- * Beam-search bookkeeping after one decoder step, on device, one thread per image: the loop body of
+ * Beam-search bookkeeping after one decoder step, on device, one wave per image: the loop body of
  * vae_model/decoder.py:254-293 with utils/top_n.py's TopN (heapq min-heap keyed by score; ties resolved by
  * heapq's sift order, reproduced exactly).  Rows are [B, beam]: row b*beam + i is the i-th live beam of
  * image b in heap-array order.
@@ -448,6 +448,15 @@ int vc_beam_update(void* stream, int B, int beam, int Lmax, int eos, double len_
                    const int32_t* top_i, int32_t* pcount, int32_t* ccount, double* p_score, double* p_logprob,
                    int32_t* p_len, const int32_t* sent_cur, int32_t* sent_next, double* c_score, double* c_logprob,
                    int32_t* c_len, int32_t* c_slot, int32_t* c_free, int32_t* c_sent, int32_t* parent, int32_t* tok);
+
+/* The state vc_beam_update starts from, in ONE launch (vae_model/decoder.py:238-247: partial = [Beam([bos], state, 0.0, 0.0)], complete
+ * empty): pcount = 1, ccount = 0, p_score = p_logprob = 0, p_len = 1, every sent_cur token = bos, sent_next / c_* / c_sent = 0,
+ * c_free = 2^(beam+1)-1, parent[r] = r, tok[r] = bos, and the images' LSTM state expanded to the beam rows:
+ * c_out[r] = c_in[r / beam], h_out[r] = h_in[r / beam] ([B, H] -> [B*beam, H]).  Same buffers and shapes as vc_beam_update. */
+int vc_beam_init(void* stream, int B, int beam, int Lmax, int bos, int H, const float* c_in, const float* h_in, float* c_out, float* h_out,
+                 int32_t* pcount, int32_t* ccount, double* p_score, double* p_logprob, int32_t* p_len, int32_t* sent_cur,
+                 int32_t* sent_next, double* c_score, double* c_logprob, int32_t* c_len, int32_t* c_slot, int32_t* c_free,
+                 int32_t* c_sent, int32_t* parent, int32_t* tok);
 
 /* One beam-search round's row moves in ONE launch (vae_model/decoder.py:254-262): cg[r] = c[parent[r]], hg[r] = h[parent[r]] ([rows, H]
  * each) and, when xproj != NULL, gact[r] = xproj[tok[r]] ([vocab, G] -> [rows, G]: a word's LSTM input projection E.Wx + b looked up from a

@@ -178,26 +178,40 @@ def test_sample_mode_generates_valid_tokens(lib):
     assert a == b and all(0 <= t < 40 for s in a for t in s) and all(1 <= len(s) <= 6 for s in a)
 
 
-@pytest.mark.parametrize("n", [1, 3, 5])
-def test_beam_update_replays_heapq_including_ties(lib, n):
+@pytest.mark.parametrize("n,rounds,L", [(1, 6, 12), (3, 6, 12), (5, 6, 12), (9, 6, 12), (16, 5, 12), (2, 70, 80)],
+                         ids=["beam1", "beam3", "beam5", "beam9-two-candidate-blocks", "beam16-four-candidate-blocks", "captions-longer-than-a-wave"])
+def test_beam_update_replays_heapq_including_ties(lib, n, rounds, L):
     """vc_beam_update vs the Python TopN / heapq bookkeeping of decoder.py:254-293 on synthetic top-k tables whose
     probabilities are quantised to a few values (many exact score ties, many <EOS> hits): heap ARRAY order, scores,
-    captions and the parent / token rows for the next step must be identical after every round."""
+    captions and the parent / token rows for the next step must be identical after every round.  The kernel works one wave per image
+    on blocks of 64 candidates (beam x beam of them) and copies tokens 64 at a time: beams 9 / 16 and captions of > 64 tokens cross
+    those limits.  The starting state comes from vc_beam_init (on buffers filled with garbage)."""
     import torch
     from vae_captioning_amd.utils.top_n import Beam, TopN
     from .gpu_util import P, dev, host, stream
     rng = np.random.default_rng(n)
-    B, rounds, L, eos, bos, lnf = 7, 6, 12, 2, 1, 0.7
+    B, eos, bos, lnf, H = 7, 2, 1, 0.7, 8
     M = B * n
     i32 = dict(dtype=torch.int32, device="cuda")
     f64 = dict(dtype=torch.float64, device="cuda")
-    pcount, ccount = torch.ones(B, **i32), torch.zeros(B, **i32)
-    p_score, p_logprob, p_len = torch.zeros(M, **f64), torch.zeros(M, **f64), torch.ones(M, **i32)
-    sent = [torch.full((M, L), bos, **i32), torch.zeros((M, L), **i32)]
-    c_score, c_logprob, c_len, c_slot = torch.zeros(M, **f64), torch.zeros(M, **f64), torch.zeros(M, **i32), torch.zeros(M, **i32)
-    c_free = torch.full((B,), (1 << (n + 1)) - 1, **i32)
-    c_sent = torch.zeros((B * (n + 1), L), **i32)
-    parent, tok = torch.zeros(M, **i32), torch.zeros(M, **i32)
+    junk_i = lambda *shape: torch.full(shape, -7, **i32)
+    junk_d = lambda *shape: torch.full(shape, 3.5, **f64)
+    pcount, ccount = junk_i(B), junk_i(B)
+    p_score, p_logprob, p_len = junk_d(M), junk_d(M), junk_i(M)
+    sent = [junk_i(M, L), junk_i(M, L)]
+    c_score, c_logprob, c_len, c_slot = junk_d(M), junk_d(M), junk_i(M), junk_i(M)
+    c_free = junk_i(B)
+    c_sent = junk_i(B * (n + 1), L)
+    parent, tok = junk_i(M), junk_i(M)
+    c_in, h_in = torch.randn(B, H, device="cuda"), torch.randn(B, H, device="cuda")
+    c_out, h_out = torch.zeros(M, H, device="cuda"), torch.zeros(M, H, device="cuda")
+    lib.vc_beam_init(stream(), B, n, L, bos, H, P(c_in), P(h_in), P(c_out), P(h_out), P(pcount), P(ccount), P(p_score), P(p_logprob), P(p_len),
+                     P(sent[0]), P(sent[1]), P(c_score), P(c_logprob), P(c_len), P(c_slot), P(c_free), P(c_sent), P(parent), P(tok))
+    assert torch.equal(c_out, c_in.repeat_interleave(n, 0)) and torch.equal(h_out, h_in.repeat_interleave(n, 0))
+    assert bool((pcount == 1).all()) and bool((ccount == 0).all()) and bool((c_free == (1 << (n + 1)) - 1).all())
+    assert bool((p_score == 0).all()) and bool((p_logprob == 0).all()) and bool((p_len == 1).all()) and bool((sent[0] == bos).all())
+    assert all(bool((t == 0).all()) for t in (sent[1], c_score, c_logprob, c_len, c_slot, c_sent))
+    assert torch.equal(parent, torch.arange(M, **i32)) and bool((tok == bos).all())
     partial = [TopN(n) for _ in range(B)]
     complete = [TopN(n) for _ in range(B)]
     for b in range(B):
@@ -299,6 +313,29 @@ def test_beam_search_edge_shapes_match_the_oracle_eager_and_replayed(lib, beam, 
         for call in range(2):
             got = g.beam_search(feats, None, eps, BOS, EOS, beam_size=beam, max_len=max_len, check_every=check_every)
             assert [[s for s, _ in got[b]] for b in range(len(got))] == ref, (xproj, call)
+
+
+@pytest.mark.parametrize("slices", [2, 3])
+def test_sliced_beam_search_on_streams_returns_the_single_slice_beams(lib, slices):
+    """A batch of >= 2 x 256 rows is decoded as two slices of images on two streams (generate.py beam_search).  Here the row
+    threshold is lowered so that six images run as 2 x 3 and 3 x 2: same beams and scores as one slice and as the fp64 oracle, on the
+    eager first call, on the replayed second, and after a call of another width in between (buffers and graphs are per slice shape)."""
+    p, eng, gen, P64, feats, cv, eps, cm = setup(lib, 13, prior="GMM")
+    ref = [od.beam_search(P64, p, feats[b].astype(np.float64), cv[b].astype(np.float64), eps[:, b:b + 1].astype(np.float64), BOS, EOS,
+                          c_means=cm, beam_size=4, max_len=12)[0] for b in range(feats.shape[0])]
+    one = CaptionGenerator(eng)
+    one.slices = 1
+    single = one.beam_search(feats, None, eps, BOS, EOS, beam_size=4, max_len=12)
+    g = CaptionGenerator(eng)
+    g.slices, g.slice_rows = slices, 1
+    for call in range(3):
+        got = g.beam_search(feats, None, eps, BOS, EOS, beam_size=4, max_len=12)
+        assert len(g._side) == slices - 1
+        assert [[s for s, _ in r] for r in got] == ref, call
+        assert [[s for s, _ in r] for r in got] == [[s for s, _ in r] for r in single]
+        np.testing.assert_allclose([sc for r in got for _, sc in r], [sc for r in single for _, sc in r], rtol=1e-5, atol=1e-6)
+        if call == 0:
+            g.beam_search(feats, None, eps, BOS, EOS, beam_size=2, max_len=12)
 
 
 @pytest.mark.parametrize("max_len,check_every", [(1, 4), (3, 4), (9, 0), (10, 2), (13, 3)])

@@ -63,6 +63,38 @@ def test_trainer_memorises_sixteen_captions_and_greedy_decoding_returns_them(lib
             assert [s_ for s_, _ in beams[b]] == sents, (b, beams[b], sents)
 
 
+def test_a_generator_used_before_training_decodes_with_the_trained_weights(lib):
+    """The generator keeps operands DERIVED from the parameters (decoder Wh in the step kernel's order, the vocabulary's input
+    projections) across calls, keyed by CaptionEngine.param_version.  Every way the parameters change must invalidate them: optimiser
+    steps (library kernels: torch's version counter does not move), load_state_dict and an in-place write through a view (it does)."""
+    p = _params(num_captions=1, batch_size=8, learning_rate=4e-3, prior="Normal")
+    V, B, T = 60, 8, 7
+    rng = np.random.default_rng(7)
+    batch = synth.make_batch(rng, B, 1, T, V, variable_len=True, feature_size=p.cnn_feature_size)
+    tr = Trainer(p, V, lib=lib, seed=5)
+    tr.load_state_dict(spec.init_caption_params(p, V, seed=3))
+    tr.set_batch(batch)
+    eps = rng.standard_normal((p.gen_z_samples, B, p.latent_size)).astype(np.float32)
+    old = CaptionGenerator(tr.cap)
+    decode_all = lambda g: (g.greedy(batch["features"], None, eps, synth.BOS, synth.EOS, max_len=T + 3),
+                            g.beam_search(batch["features"], None, eps, synth.BOS, synth.EOS, beam_size=3, max_len=T + 3))
+    before = decode_all(old)
+    v0 = tr.cap.param_version
+    assert decode_all(old) == before and tr.cap.param_version == v0      # (nothing changed: same version, cached operands reused)
+    for _ in range(40):
+        tr.train_step()
+    assert tr.cap.param_version != v0
+    after = decode_all(old)
+    assert after == decode_all(CaptionGenerator(tr.cap)) and after != before
+    v1 = tr.cap.param_version
+    tr.cap.store.param("decoder/net/dec_embeddings").mul_(-1.0)           # a write through a view
+    assert tr.cap.param_version != v1
+    flipped = decode_all(old)
+    assert flipped == decode_all(CaptionGenerator(tr.cap)) and flipped != after
+    tr.load_state_dict(spec.init_caption_params(p, V, seed=3))             # back to the start
+    assert decode_all(old) == before
+
+
 @pytest.mark.parametrize("name,lr,kw", [("normal", 5e-4, dict(prior="Normal")), ("ag_cv", 2e-4, dict(prior="AG", use_c_v=True))])
 def test_fifty_consecutive_steps_stay_on_the_oracles_trajectory(lib, name, lr, kw):
     """AG runs at lr = 2e-4: at 5e-4 its KL term (482 at the start, Q3's per-row sum) reaches its floor after ~40 steps, and from there

@@ -24,6 +24,10 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(20): run()
 torch.cuda.synchronize(); tot = (time.perf_counter() - t0) / 20
 print("per call %.3f ms; init_state %.3f ms (synchronised)" % (1e3 * tot, 1e3 * acc["init"] / acc["n"]))
+G.PHASE_TIMES = {}
+for _ in range(20): run()
+print("phases (ms per call, synchronised at each boundary):", {k: round(1e3 * v / 20, 3) for k, v in G.PHASE_TIMES.items() if k})
+G.PHASE_TIMES = None
 import cProfile, pstats
 gen.init_state = orig
 pr = cProfile.Profile(); pr.enable()

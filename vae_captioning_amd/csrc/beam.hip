@@ -1,6 +1,6 @@
 // Beam-search bookkeeping on device (vae_model/decoder.py:238-300 + utils/top_n.py:4-43).
 //
-// One thread per image replays, for its image, exactly what the reference's Python does after every
+// One wave per image replays, for its image, exactly what the reference's Python does after every
 // decoder step: walk the image's live beams in the order TopN.extract() returned them (the heap ARRAY order),
 // walk each beam's top-`beam_size` words in descending probability, skip p < 1e-12, and push the extended
 // caption into the image's `complete` (word == <EOS>, score = logprob / len**len_norm_f) or `partial`
@@ -23,34 +23,38 @@ struct BeamItem {
     int parent, tok, len, slot;
 };
 
-__device__ __forceinline__ bool item_lt(const BeamItem& a, const BeamItem& b) { return a.score < b.score; }
+// ---- a value that every lane of the wave holds alike, and arrays spread over the lanes (element p in lane p)
+__device__ __forceinline__ int lane_get(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ int lane_set(int old, int l, int x) { return (int)threadIdx.x == l ? x : old; }   // (x: the same in every lane)
+__device__ __forceinline__ double lane_get(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ double lane_set(double old, int l, double x) {
+    return (int)threadIdx.x == l ? x : old;
+}
 
-// A TopN heap of one image in the LDS, stored field by field with the IMAGE as the fastest index ([position][image]): the 32 walking
-// threads of a workgroup step through their heaps side by side, and with one 32-byte item after another per image (512 bytes between
-// two images' items) every access of the 32 lanes fell on the same banks -- a 32-way conflict on each of the ~50 item moves of a push.
-constexpr int BEAM_IMAGES = 32;                 // images per workgroup
-struct HeapRef {
-    double* sc;     // [BEAM_MAX][BEAM_IMAGES] score, then logprob
-    double* lp;
-    int4* meta;     // [BEAM_MAX][BEAM_IMAGES] (parent, tok, len, slot)
+// A TopN heap of one image IN REGISTERS: one wave works on one image, and heap position p is lane p of six registers.  The walk below
+// is sequential (heapq's sift order decides ties) and every lane runs it alike; `heap[pos]` with the wave-uniform pos is a
+// v_readlane / a one-lane select -- a few cycles -- where the LDS heaps of rounds 4-6 paid one ~120-cycle round trip per dependent access,
+// ~20 of them per push (1.2 us per candidate, 33-40 us per round at beam 5: the longest latency-bound kernel of a decode round).
+struct WaveHeap {
+    double sc, lp;
+    int par, tok, len, slot;
     __device__ __forceinline__ BeamItem get(int pos) const {
         BeamItem it;
-        it.score = sc[pos * BEAM_IMAGES];
-        it.logprob = lp[pos * BEAM_IMAGES];
-        const int4 m = meta[pos * BEAM_IMAGES];
-        it.parent = m.x; it.tok = m.y; it.len = m.z; it.slot = m.w;
+        it.score = lane_get(sc, pos); it.logprob = lane_get(lp, pos);
+        it.parent = lane_get(par, pos); it.tok = lane_get(tok, pos); it.len = lane_get(len, pos); it.slot = lane_get(slot, pos);
         return it;
     }
-    __device__ __forceinline__ void put(int pos, const BeamItem& it) const {
-        sc[pos * BEAM_IMAGES] = it.score;
-        lp[pos * BEAM_IMAGES] = it.logprob;
-        meta[pos * BEAM_IMAGES] = make_int4(it.parent, it.tok, it.len, it.slot);
+    __device__ __forceinline__ void put(int pos, const BeamItem& it) {
+        sc = lane_set(sc, pos, it.score); lp = lane_set(lp, pos, it.logprob);
+        par = lane_set(par, pos, it.parent); tok = lane_set(tok, pos, it.tok); len = lane_set(len, pos, it.len); slot = lane_set(slot, pos, it.slot);
     }
-    __device__ __forceinline__ double score(int pos) const { return sc[pos * BEAM_IMAGES]; }
+    __device__ __forceinline__ double score(int pos) const { return lane_get(sc, pos); }
 };
 
 // CPython Lib/heapq.py _siftdown / _siftup, move for move (comparisons by score only)
-__device__ __forceinline__ void sift_down(const HeapRef& heap, int startpos, int pos) {
+__device__ __forceinline__ void sift_down(WaveHeap& heap, int startpos, int pos) {
     const BeamItem newitem = heap.get(pos);
     while (pos > startpos) {
         const int parentpos = (pos - 1) >> 1;
@@ -64,7 +68,7 @@ __device__ __forceinline__ void sift_down(const HeapRef& heap, int startpos, int
     heap.put(pos, newitem);
 }
 
-__device__ __forceinline__ void sift_up(const HeapRef& heap, int n, int pos) {
+__device__ __forceinline__ void sift_up(WaveHeap& heap, int n, int pos) {
     const int startpos = pos;
     const BeamItem newitem = heap.get(pos);
     int childpos = 2 * pos + 1;
@@ -80,7 +84,7 @@ __device__ __forceinline__ void sift_up(const HeapRef& heap, int n, int pos) {
 }
 
 // TopN.push: returns the slot field of the item that left the heap (the popped root, or the rejected newcomer), -1 if none
-__device__ __forceinline__ int topn_push(const HeapRef& heap, int& count, int cap, const BeamItem& item) {
+__device__ __forceinline__ int topn_push(WaveHeap& heap, int& count, int cap, const BeamItem& item) {
     if (count < cap) {
         heap.put(count, item);
         ++count;
@@ -88,7 +92,7 @@ __device__ __forceinline__ int topn_push(const HeapRef& heap, int& count, int ca
         return -1;
     }
     if (count > 0 && heap.score(0) < item.score) {
-        const int freed = heap.get(0).slot;
+        const int freed = lane_get(heap.slot, 0);
         heap.put(0, item);
         sift_up(heap, count, 0);
         return freed;
@@ -107,143 +111,130 @@ struct BeamArgs {
     int32_t *sent_next, *c_sent, *parent, *tok;
 };
 
-// The two heaps of an image live in LDS (32 images x 2 x 16 items x 32 B = 32 KB, HeapRef above): as private arrays their run-time
-// indexing went through scratch memory, one L2 round trip per heap move (65 us per decoder step for 128 images x 5 beams).
-// Round 6: the heap walk stays one thread per image (it IS sequential: heapq's sift order decides ties), but the token copies it
-// used to do itself -- a kept beam's sentence into the next round's buffer, a finished caption into its pool slot: up to
-// beam x (length - 1) dependent load / store pairs per thread, 41 us per round at 30 tokens -- are only RECORDED by the walk and carried
-// out afterwards by eight threads per image (a workgroup = 32 images = 256 threads, thread t of an image copies tokens t, t + 8, ...).
-// A finished caption is recorded PER POOL SLOT: a slot that was freed and taken again within the round keeps its last writer's record,
-// which is the caption the sequential code left there.
-constexpr int BEAM_THREADS = 8 * BEAM_IMAGES;   // 256
-constexpr int BEAM_SLOTS = BEAM_MAX + 1;        // pool slots of finished captions per image
-
-
-__global__ __launch_bounds__(BEAM_THREADS) void beam_update_kernel(BeamArgs a) {
-    __shared__ double h_sc[2][BEAM_MAX][BEAM_IMAGES], h_lp[2][BEAM_MAX][BEAM_IMAGES];
-    __shared__ int4 h_meta[2][BEAM_MAX][BEAM_IMAGES];
-    __shared__ int part_n[BEAM_IMAGES];
-    __shared__ short crec_src[BEAM_IMAGES][BEAM_SLOTS], crec_len0[BEAM_IMAGES][BEAM_SLOTS];   // len0 < 0: no caption recorded for the slot this round
-    __shared__ int crec_tok[BEAM_IMAGES][BEAM_SLOTS];
-    // the round's candidates (top-k probabilities and words of every live beam) and the beams' running sums, fetched by all 256 threads
-    // (eight per image, coalesced) before the walk: read one by one inside it, each was a dependent global load -- 2 x beam x k round
-    // trips of ~0.5 us per image and round (25 of the kernel's 31 us at beam 5).  Up to beam x k = 64 candidates; beyond, the walk reads global memory.
-    constexpr int BEAM_PRE = 64;
-    __shared__ float pre_p[BEAM_IMAGES][BEAM_PRE];
-    __shared__ int pre_i[BEAM_IMAGES][BEAM_PRE];
-    __shared__ double pre_lp[BEAM_IMAGES][BEAM_MAX];
-    __shared__ int pre_len[BEAM_IMAGES][BEAM_MAX];
-    const int n = a.n, L = a.Lmax;
-    const bool pre = n * a.k <= BEAM_PRE;
-    {
-        const int li = threadIdx.x >> 3, sub = threadIdx.x & 7, b = blockIdx.x * BEAM_IMAGES + li;
-        if (b < a.B) {
-            if (pre)
-                for (int q = sub; q < n * a.k; q += 8) {
-                    pre_p[li][q] = a.tv[(long)b * n * a.k + q];
-                    pre_i[li][q] = a.ti[(long)b * n * a.k + q];
-                }
-            for (int q = sub; q < n; q += 8) {
-                pre_lp[li][q] = a.p_logprob[(long)b * n + q];
-                pre_len[li][q] = a.p_len[(long)b * n + q];
+// One wave per image.  Per round:
+//   1. in parallel, lane q prepares candidate q (beam q / k, its j-th word): float32 log of the word's probability added to the beam's
+//      float64 running sum, the length-normalised score if the word is <EOS> -- the transcendental work of the whole round at once;
+//   2. the walk over the candidates in the reference's order (beams in heap-array order, words by descending probability), heaps in
+//      registers (WaveHeap): a kept beam's sentence and a finished caption are only RECORDED (parent + last word; per pool slot);
+//   3. the token copies by the 64 lanes: each kept beam's sentence into the next round's buffer, each recorded caption into its pool
+//      slot (a slot freed and taken again within the round keeps its last writer's record, which is the caption the sequential
+//      code left there).
+__global__ __launch_bounds__(64) void beam_update_kernel(BeamArgs a) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int n = a.n, k = a.k, L = a.Lmax;
+    const int np = __builtin_amdgcn_readfirstlane(a.pcount[b]);
+    if (lane < n) {   // defaults for slots that stay empty: continue row b*n with token 0 (ignored)
+        a.parent[b * n + lane] = b * n;
+        a.tok[b * n + lane] = 0;
+    }
+    if (np == 0) return;   // every beam of this image has ended
+    WaveHeap part{0.0, 0.0, 0, 0, 0, -1}, comp{0.0, 0.0, 0, 0, 0, -1};
+    int hn = 0, cn = __builtin_amdgcn_readfirstlane(a.ccount[b]);
+    if (lane < cn) {
+        comp.sc = a.c_score[b * n + lane];
+        comp.lp = a.c_logprob[b * n + lane];
+        comp.len = a.c_len[b * n + lane];
+        comp.slot = a.c_slot[b * n + lane];
+    }
+    int freemask = __builtin_amdgcn_readfirstlane(a.c_free[b]);
+    int rec_src = 0, rec_len0 = -1, rec_tok = 0;   // lane s: the caption recorded for pool slot s this round (len0 < 0: none)
+    const int total = np * k;
+    for (int base = 0; base < total; base += 64) {
+        // ---- 1. candidate base + lane
+        const int q = base + lane;
+        const bool have = q < total;
+        const int i_q = have ? q / k : 0;
+        const long row = (long)b * n + i_q;
+        const float pw = have ? a.tv[(long)b * n * k + q] : 0.f;
+        const int tok_q = have ? a.ti[(long)b * n * k + q] : 0;
+        const int len0_q = a.p_len[row];
+        const double lp_q = a.p_logprob[row] + (double)logf(pw);   // decoder.py:282: np.log of a float32 is a float32; the SUM is a float64
+        double sc_q = lp_q;
+        if (tok_q == a.eos && a.len_norm_f > 0) sc_q = lp_q / pow((double)(len0_q + 1), a.len_norm_f);
+        const int skip_q = (!have || (double)pw < 1e-12) ? 1 : 0;   // decoder.py:279: float32 p against the Python float 1e-12
+        // ---- 2. the walk
+        const int cnt = total - base < 64 ? total - base : 64;
+        for (int c = 0; c < cnt; ++c) {
+            if (lane_get(skip_q, c)) continue;
+            BeamItem it;
+            it.tok = lane_get(tok_q, c);
+            it.parent = (base + c) / k;
+            const int len0 = lane_get(len0_q, c);
+            it.len = len0 + 1;
+            it.logprob = lane_get(lp_q, c);
+            it.score = lane_get(sc_q, c);
+            it.slot = -1;
+            if (it.tok == a.eos) {
+                // take a free pool slot, record the caption for it, give the slot back if the heap does not keep it
+                const int s = __builtin_ctz(freemask);
+                freemask &= ~(1 << s);
+                it.slot = s;
+                rec_src = lane_set(rec_src, s, it.parent); rec_len0 = lane_set(rec_len0, s, len0); rec_tok = lane_set(rec_tok, s, it.tok);
+                const int freed = topn_push(comp, cn, n, it);
+                if (freed >= 0) freemask |= 1 << freed;
+            } else {
+                topn_push(part, hn, n, it);
             }
         }
     }
-    __syncthreads();
-    if (threadIdx.x < BEAM_IMAGES) {   // ---- the walk: one thread per image
-        const int li = threadIdx.x, b = blockIdx.x * BEAM_IMAGES + li;
-        part_n[li] = 0;
-        for (int q = 0; q < BEAM_SLOTS; ++q) crec_len0[li][q] = -1;
-        if (b < a.B) {
-            const int np = a.pcount[b];
-            for (int j = 0; j < n; ++j) {  // defaults for slots that stay empty: continue row b*n with token 0 (ignored)
-                a.parent[b * n + j] = b * n;
-                a.tok[b * n + j] = 0;
-            }
-            if (np != 0) {  // (0: every beam of this image has ended)
-                const HeapRef part{&h_sc[0][0][li], &h_lp[0][0][li], &h_meta[0][0][li]};
-                const HeapRef comp{&h_sc[1][0][li], &h_lp[1][0][li], &h_meta[1][0][li]};
-                int hn = 0, cn = a.ccount[b];
-                for (int j = 0; j < cn; ++j) {
-                    BeamItem it;
-                    it.score = a.c_score[b * n + j];
-                    it.logprob = a.c_logprob[b * n + j];
-                    it.len = a.c_len[b * n + j];
-                    it.slot = a.c_slot[b * n + j];
-                    it.parent = it.tok = 0;
-                    comp.put(j, it);
-                }
-                int freemask = a.c_free[b];
-                for (int i = 0; i < np; ++i) {
-                    const long row = (long)b * n + i;
-                    const double lp0 = pre_lp[li][i];
-                    const int len0 = pre_len[li][i];
-                    for (int j = 0; j < a.k; ++j) {
-                        const float pw = pre ? pre_p[li][i * a.k + j] : a.tv[row * a.k + j];
-                        if ((double)pw < 1e-12) continue;  // decoder.py:279: float32 p against the Python float 1e-12
-                        BeamItem it;
-                        it.tok = pre ? pre_i[li][i * a.k + j] : a.ti[row * a.k + j];
-                        it.parent = i;
-                        it.len = len0 + 1;
-                        it.logprob = lp0 + (double)logf(pw);  // decoder.py:282: np.log of a float32 is a float32; the SUM is a float64
-                        it.score = it.logprob;
-                        it.slot = -1;
-                        if (it.tok == a.eos) {
-                            if (a.len_norm_f > 0) it.score = it.logprob / pow((double)it.len, a.len_norm_f);
-                            // take a free pool slot, record the caption for it, give the slot back if the heap does not keep it
-                            int s = 0;
-                            while (!((freemask >> s) & 1)) ++s;
-                            freemask &= ~(1 << s);
-                            it.slot = s;
-                            crec_src[li][s] = (short)i; crec_len0[li][s] = (short)len0; crec_tok[li][s] = it.tok;
-                            const int freed = topn_push(comp, cn, n, it);
-                            if (freed >= 0) freemask |= 1 << freed;
-                        } else {
-                            topn_push(part, hn, n, it);
-                        }
-                    }
-                }
-                for (int j = 0; j < hn; ++j) {
-                    const long o = (long)b * n + j;
-                    const BeamItem it = part.get(j);
-                    a.p_score[o] = it.score;
-                    a.p_logprob[o] = it.logprob;
-                    a.p_len[o] = it.len;
-                    a.parent[o] = b * n + it.parent;
-                    a.tok[o] = it.tok;
-                }
-                a.pcount[b] = hn;
-                for (int j = 0; j < cn; ++j) {
-                    const long o = (long)b * n + j;
-                    const BeamItem it = comp.get(j);
-                    a.c_score[o] = it.score;
-                    a.c_logprob[o] = it.logprob;
-                    a.c_len[o] = it.len;
-                    a.c_slot[o] = it.slot;
-                }
-                a.ccount[b] = cn;
-                a.c_free[b] = freemask;
-                part_n[li] = hn;
-            }
-        }
+    if (lane < hn) {
+        const long o = (long)b * n + lane;
+        a.p_score[o] = part.sc;
+        a.p_logprob[o] = part.lp;
+        a.p_len[o] = part.len;
+        a.parent[o] = b * n + part.par;
+        a.tok[o] = part.tok;
     }
-    __syncthreads();
-    // ---- the copies: eight threads per image
-    const int li = threadIdx.x >> 3, sub = threadIdx.x & 7, b = blockIdx.x * BEAM_IMAGES + li;
-    if (b >= a.B) return;
+    if (lane < cn) {
+        const long o = (long)b * n + lane;
+        a.c_score[o] = comp.sc;
+        a.c_logprob[o] = comp.lp;
+        a.c_len[o] = comp.len;
+        a.c_slot[o] = comp.slot;
+    }
+    if (lane == 0) {
+        a.pcount[b] = hn;
+        a.ccount[b] = cn;
+        a.c_free[b] = freemask;
+    }
+    // ---- 3. the copies
     const int32_t* cur = a.sent_cur + (long)b * n * L;
-    for (int q = 0; q <= n; ++q) {   // finished captions, per pool slot
-        const int len0 = crec_len0[li][q], i = crec_src[li][q];
+    for (int s = 0; s <= n; ++s) {   // finished captions, per pool slot
+        const int len0 = lane_get(rec_len0, s);
         if (len0 < 0) continue;
-        int32_t* dst = a.c_sent + ((long)b * (n + 1) + q) * L;
-        for (int t = sub; t <= len0; t += 8) dst[t] = t < len0 ? cur[i * L + t] : crec_tok[li][q];
+        const int i = lane_get(rec_src, s), tk = lane_get(rec_tok, s);
+        int32_t* dst = a.c_sent + ((long)b * (n + 1) + s) * L;
+        for (int t = lane; t <= len0; t += 64) dst[t] = t < len0 ? cur[i * L + t] : tk;
     }
-    const int hn = part_n[li];
     int32_t* nxt = a.sent_next + (long)b * n * L;
     for (int j = 0; j < hn; ++j) {
-        const int4 m = h_meta[0][j][li];   // (parent, tok, len, slot) of the kept beam in heap-array position j
-        const int len = m.z, src = m.x;
-        for (int t = sub; t < len; t += 8) nxt[j * L + t] = t < len - 1 ? cur[src * L + t] : m.y;
+        const int len = lane_get(part.len, j), src = lane_get(part.par, j), tk = lane_get(part.tok, j);
+        for (int t = lane; t < len; t += 64) nxt[j * L + t] = t < len - 1 ? cur[src * L + t] : tk;
+    }
+}
+
+// vae_model/decoder.py:238-247 for every image at once: the state the first round's vc_beam_update reads (twenty fills, two state
+// gathers and two index ramps as torch / library launches before: ~0.2 ms of a 5 ms call at 128 images)
+__global__ __launch_bounds__(256) void beam_init_kernel(BeamArgs a, int bos, int H, const float* __restrict__ c_in, const float* __restrict__ h_in,
+                                                        float* __restrict__ c_out, float* __restrict__ h_out, int32_t* __restrict__ sent_cur) {
+    const long M = (long)a.B * a.n, stride = (long)gridDim.x * 256, t0 = (long)blockIdx.x * 256 + threadIdx.x;
+    for (long i = t0; i < M * H; i += stride) {
+        const long src = (i / H) / a.n * H + i % H;
+        c_out[i] = c_in[src];
+        h_out[i] = h_in[src];
+    }
+    for (long i = t0; i < M * a.Lmax; i += stride) {
+        sent_cur[i] = bos;
+        a.sent_next[i] = 0;
+    }
+    for (long i = t0; i < (long)a.B * (a.n + 1) * a.Lmax; i += stride) a.c_sent[i] = 0;
+    for (long i = t0; i < M; i += stride) {
+        a.p_score[i] = 0.0; a.p_logprob[i] = 0.0; a.p_len[i] = 1;
+        a.c_score[i] = 0.0; a.c_logprob[i] = 0.0; a.c_len[i] = 0; a.c_slot[i] = 0;
+        a.parent[i] = (int)i; a.tok[i] = bos;
+    }
+    for (long i = t0; i < a.B; i += stride) {
+        a.pcount[i] = 1; a.ccount[i] = 0; a.c_free[i] = (1 << (a.n + 1)) - 1;
     }
 }
 
@@ -272,6 +263,26 @@ extern "C" int vc_eos_track_i32(void* stream, const int32_t* tok, int B, int eos
     return 0;
 }
 
+extern "C" int vc_beam_init(void* stream, int B, int beam, int Lmax, int bos, int H, const float* c_in, const float* h_in, float* c_out,
+                            float* h_out, int32_t* pcount, int32_t* ccount, double* p_score, double* p_logprob, int32_t* p_len,
+                            int32_t* sent_cur, int32_t* sent_next, double* c_score, double* c_logprob, int32_t* c_len, int32_t* c_slot,
+                            int32_t* c_free, int32_t* c_sent, int32_t* parent, int32_t* tok) {
+    using namespace vc;
+    VC_CHECK_ARG(B > 0 && beam > 0 && beam <= BEAM_MAX && Lmax > 1 && H > 0, "beam size must be 1..16");
+    VC_CHECK_ARG(c_in && h_in && c_out && h_out && pcount && ccount && p_score && p_logprob && p_len && sent_cur && sent_next && c_score &&
+                 c_logprob && c_len && c_slot && c_free && c_sent && parent && tok, "null pointer");
+    BeamArgs a;
+    a.B = B; a.n = beam; a.k = beam; a.Lmax = Lmax; a.eos = 0; a.len_norm_f = 0; a.tv = nullptr; a.ti = nullptr;
+    a.pcount = pcount; a.ccount = ccount; a.p_len = p_len; a.c_len = c_len; a.c_slot = c_slot;
+    a.c_free = c_free; a.p_score = p_score; a.p_logprob = p_logprob; a.c_score = c_score; a.c_logprob = c_logprob;
+    a.sent_cur = sent_cur; a.sent_next = sent_next; a.c_sent = c_sent; a.parent = parent; a.tok = tok;
+    const long work = (long)B * beam * (H > Lmax ? H : Lmax);
+    hipLaunchKernelGGL(beam_init_kernel, dim3((unsigned)(cdiv(work, 256L) < 1024 ? cdiv(work, 256L) : 1024)), dim3(256), 0, (hipStream_t)stream,
+                       a, bos, H, c_in, h_in, c_out, h_out, sent_cur);
+    VC_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int vc_beam_update(void* stream, int B, int beam, int Lmax, int eos, double len_norm_f, const float* top_p,
                               const int32_t* top_i, int32_t* pcount, int32_t* ccount, double* p_score, double* p_logprob,
                               int32_t* p_len, const int32_t* sent_cur, int32_t* sent_next, double* c_score, double* c_logprob,
@@ -285,7 +296,7 @@ extern "C" int vc_beam_update(void* stream, int B, int beam, int Lmax, int eos, 
     a.tv = top_p; a.ti = top_i; a.pcount = pcount; a.ccount = ccount; a.p_len = p_len; a.c_len = c_len; a.c_slot = c_slot;
     a.c_free = c_free; a.p_score = p_score; a.p_logprob = p_logprob; a.c_score = c_score; a.c_logprob = c_logprob;
     a.sent_cur = sent_cur; a.sent_next = sent_next; a.c_sent = c_sent; a.parent = parent; a.tok = tok;
-    hipLaunchKernelGGL(beam_update_kernel, dim3(cdiv(B, BEAM_IMAGES)), dim3(BEAM_THREADS), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(beam_update_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, a);
     VC_LAUNCH_CHECK();
     return 0;
 }

@@ -214,6 +214,7 @@ class CaptionEngine(object):
         self.inject = False
         self.seed = seed
         self.timer = None
+        self.param_updates = 0   # optimiser steps taken by apply_gradients (its kernels write the parameters without torch noticing)
         # arithmetic of this engine's dense products and LSTM sequence calls: "f32" (the reference's tf.float32) or "bf16x3" (split-bf16
         # operands, f32 accumulate: an opt-in mode).  Carried by EVERY call (VC_GEMM_BF16X3 / VC_LSTM_BF16X3, ABI 4): engines of different
         # precision coexist in one process, and nothing another engine or caller does can change this one's arithmetic.
@@ -947,9 +948,17 @@ class CaptionEngine(object):
             tail[1:2].copy_(self.red[0:1])
             tail[2:3].copy_(self.red[2:3])
 
+    @property
+    def param_version(self):
+        """Changes whenever the parameter values may have: torch counts in-place writes through the flat buffer or a view of it
+        (load_params, checkpoint restore, p.copy_), apply_gradients counts its own optimiser kernels.  Derived operands (the
+        generator's packed Wh, its vocabulary projection table) are rebuilt when this differs from the version they were built at."""
+        return (self.store.p._version, self.param_updates, self.store.p.data_ptr(), self.gemm_flags)
+
     def apply_gradients(self):
         """non_cnn_optimizer (ops/optimizers.py:3-47): global-norm clip 5.0 + Adam / SGD / Momentum."""
         p, lib, st, S, nb = self.p, self.lib, _stream(), self.store, self.nb
+        self.param_updates += 1
         if getattr(self, "_losses_deferred", False):  # the tail has been summed over the ranks: finalise the reported losses
             self._losses_deferred = False
             self.red[0:1].copy_(S.g[S.n + 1:S.n + 2])

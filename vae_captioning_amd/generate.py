@@ -12,6 +12,7 @@ Per-image semantics of the z input are those of batch 1: row b of the z_rnn inpu
 samples of image b (the Q1 reshape is the identity at N = 1).
 """
 import os
+import types
 
 import numpy as np
 import torch
@@ -24,6 +25,18 @@ from .utils.top_n import Beam
 # vae_model/decoder.py:56 -- category ids absent from MSCOCO (obj_vectors/category_index.pickle)
 UN_CLUSTERS = {0, 66, 68, 69, 71, 12, 45, 83, 26, 29, 30}
 
+PHASE_TIMES = None   # diagnostics (tools/experiments/prof_beam.py): a dict here makes beam_search synchronise at its phase boundaries and add up seconds
+
+
+def _phase(name, t0):
+    if PHASE_TIMES is None:
+        return t0
+    import time
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    PHASE_TIMES[name] = PHASE_TIMES.get(name, 0.0) + (t - t0)
+    return t
+
 
 class CaptionGenerator(object):
     def __init__(self, engine):
@@ -33,10 +46,13 @@ class CaptionGenerator(object):
         self.buf = {}
         self._ones = {}
         self._whp = None        # decoder Wh in the recurrence kernel's operand order
-        self._whp_fresh = False  # re-packed at the start of every init_state (the weights may have been trained in between)
+        self._whp_version = None  # engine.param_version the pack was made at (the weights may have been trained in between)
         self._graphs = {}        # captured decode rounds (hipGraphs), keyed by shapes + the addresses they bake
         self._xproj = None       # [V, 4H] input projection of every word (beam search with many rows x rounds)
-        self._xproj_fresh = False
+        self._xproj_version = None
+        self._side = []          # extra streams of a sliced beam search
+        self._bos = 1
+        self.slices, self.slice_rows = 2, 256   # beam search: images decoded as `slices` independent slices when each has >= slice_rows rows
 
     def _b(self, name, shape, dtype=torch.float32):
         t = self.buf.get(name)
@@ -73,8 +89,6 @@ class CaptionGenerator(object):
         """State after image -> (c_v) -> z (decoder.py:96-114), batched over B images.
         eps: [S, B, L] N(0,1) draws (generated on device when None)."""
         e, p, lib, st, S = self.e, self.p, self.lib, _stream(), self.e.store
-        self._whp_fresh = False  # a new generation call: re-pack Wh on the first step (5 us)
-        self._xproj_fresh = False
         feats = self._dev(features, np.float32)
         B = feats.shape[0]
         E, Hd, L, Sm, F = p.embed_size, p.decoder_hidden, p.latent_size, p.gen_z_samples, p.cnn_feature_size
@@ -125,28 +139,28 @@ class CaptionGenerator(object):
         return t
 
     def _pack_wh(self, M):
-        """decoder Wh in the recurrence step kernel's operand order, once per generation call (init_state clears _whp_fresh)"""
+        """decoder Wh in the recurrence step kernel's operand order, once per parameter version (engine.param_version)"""
         e, p, lib = self.e, self.p, self.lib
         E, Hd = p.embed_size, p.decoder_hidden
-        if self._whp_fresh or not lib.vc_lstm_step_packed_supported(M, Hd):
+        if self._whp_version == e.param_version or not lib.vc_lstm_step_packed_supported(M, Hd):
             return
         if self._whp is None or self._whp.numel() != 2 * Hd * 4 * Hd:
             self._whp = torch.empty(2 * Hd * 4 * Hd, dtype=torch.float32, device=e.dev)
         lib.vc_lstm_pack_wh_f32(_stream(), Hd, e.store.param(spec.DEC_CELL + "kernel").data_ptr() + E * 4 * Hd * 4, P(self._whp))
-        self._whp_fresh = True
+        self._whp_version = e.param_version
 
     def _project_vocab(self):
-        """xproj [V, 4H] = dec_embeddings . Wx + b: the LSTM input projection of EVERY word, once per generation call (the weights may
-        have been trained since the last one).  A round then looks its rows up (vc_beam_gather_f32) instead of gathering embeddings and
+        """xproj [V, 4H] = dec_embeddings . Wx + b: the LSTM input projection of EVERY word, once per parameter version
+        (engine.param_version: the weights may have been trained or reloaded since the last call).  A round then looks its rows up (vc_beam_gather_f32) instead of gathering embeddings and
         multiplying: one product of V rows (0.1 ms at V = 10 000) against rows x rounds of them -- callers use it when rows x rounds >= V."""
         e, p, S = self.e, self.p, self.e.store
         E, Hd, V = p.embed_size, p.decoder_hidden, e.V
-        if not self._xproj_fresh:
+        if self._xproj_version != e.param_version:
             if self._xproj is None or tuple(self._xproj.shape) != (V, 4 * Hd):
                 self._xproj = torch.empty((V, 4 * Hd), dtype=torch.float32, device=e.dev)
             e.gemm(0, 0, V, 4 * Hd, E, S.param("decoder/net/dec_embeddings"), E, S.param(spec.DEC_CELL + "kernel"), 4 * Hd, self._xproj, 4 * Hd,
                    S.param(spec.DEC_CELL + "bias"))
-            self._xproj_fresh = True
+            self._xproj_version = e.param_version
         return self._xproj
 
     def step(self, tokens, c, h, want="probs", bufs=None, timed=True, projected=False):
@@ -170,6 +184,8 @@ class CaptionGenerator(object):
             lib.vc_lstm_step_fwd_packed_f32(st, M, Hd, 0, P(h), P(c), P(self._whp), P(gact), P(ones), P(c2), P(h2))
         else:
             lib.vc_lstm_step_fwd_f32(st, M, Hd, 0, P(h), P(c), W.data_ptr() + E * 4 * Hd * 4, P(gact), P(ones), P(c2), P(h2))
+        if want == "state":   # (beam search's first step: decoder.py:230-236 runs it for the state only)
+            return None, c2, h2
         logits = new("logits", (M, V))
         e.gemm(0, 0, M, V, Hd, h2, Hd, S.param("decoder/rnn_logits/kernel"), e.Vp, logits, V, S.param("decoder/rnn_logits/bias"),
                tag="logits_gemm" if timed else None)   # (None inside a hipGraph capture: no timer events)
@@ -180,6 +196,12 @@ class CaptionGenerator(object):
         return probs, c2, h2
 
     # ------------------------------------------------------------------ captured rounds
+    def _pinned(self, name, n, dtype):
+        t = self.buf.get(name)
+        if t is None or t.numel() != n or t.dtype != dtype:
+            t = self.buf[name] = torch.zeros(int(n), dtype=dtype).pin_memory()
+        return t
+
     def _pinned_alive(self, n):
         t = self.buf.get("bm_host_alive")
         if t is None or t.numel() < n:
@@ -300,60 +322,44 @@ class CaptionGenerator(object):
         return self._trim(ids[:steps], eos)
 
     # ------------------------------------------------------------------ beam search
-    def beam_search(self, features, c_v=None, eps=None, bos=1, eos=2, beam_size=2, max_len=None, len_norm_f=0.7, check_every=4):
-        """decoder.py:203-320 for a batch of images.  Returns per image the list of
-        (sentence, score) of the kept beams in descending score order.
-
-        Rows are [B, beam_size] throughout; every round is gather-state -> LSTM step -> logits -> softmax ->
-        top-k -> vc_beam_update (the TopN bookkeeping, on device), with no host synchronisation except a
-        4-byte "is any beam alive" read every `check_every` rounds."""
-        lib, e, st = self.lib, self.e, _stream()
-        max_len = max_len or self.p.gen_max_len
-        c, h = self.init_state(features, c_v, eps)
-        B, Hd, V, n = c.shape[0], self.p.decoder_hidden, e.V, int(beam_size)
-        dev = e.dev
-        tok0 = self._b("bm_tok0", (B,), torch.int32)
-        tok0.fill_(bos)
-        _, c, h = self.step(tok0, c, h, want="logits", bufs=self._round_bufs("bm0_", B))  # :230-236 -- probabilities discarded, state kept
-        M, L = B * n, max_len + 2
+    def _beam_part(self, k, nparts, c, h, n, L, rounds, K, eos, len_norm_f, xproj, fused):
+        """The persistent device state of one slice of images (vae_model/decoder.py:238-247) and its round function.  A call decodes its
+        images as `nparts` independent slices on `nparts` streams (beam_search): buffers are per (slice, beam width, length) and a
+        captured chunk of rounds bakes their addresses."""
+        lib, e = self.lib, self.e
+        B, Hd, V = int(c.shape[0]), self.p.decoder_hidden, e.V
+        M, dev = B * n, e.dev
         i32, f64 = torch.int32, torch.float64
-        # the bookkeeping of vae_model/decoder.py:238-247 as PERSISTENT device buffers (a captured chunk of rounds bakes their addresses
-        # and is replayed by later calls of the same shape), re-initialised per call: partial = [Beam([bos], state b, 0.0, 0.0)]
-        tag = "bm%d_%d_" % (n, L)
-        pcount, ccount = self._b(tag + "pcount", (B,), i32), self._b(tag + "ccount", (B,), i32)
-        p_score, p_logprob, p_len = self._b(tag + "p_score", (M,), f64), self._b(tag + "p_logprob", (M,), f64), self._b(tag + "p_len", (M,), i32)
-        sent = [self._b(tag + "sent0", (M, L), i32), self._b(tag + "sent1", (M, L), i32)]
-        c_score, c_logprob = self._b(tag + "c_score", (M,), f64), self._b(tag + "c_logprob", (M,), f64)
-        c_len, c_slot = self._b(tag + "c_len", (M,), i32), self._b(tag + "c_slot", (M,), i32)
-        c_free, c_sent = self._b(tag + "c_free", (B,), i32), self._b(tag + "c_sent", (B * (n + 1), L), i32)
+        tag = "bm%d_%d_%dof%d_" % (n, L, k, nparts)
+        pt = types.SimpleNamespace(B=B, M=M, k=k)
+        # everything the host reads at the end lives in TWO flat buffers (int32 fields, float64 scores): two copies into pinned memory
+        # bring a slice's results back, with no gathering launches in between
+        sizes = [("pcount", B), ("ccount", B), ("p_len", M), ("c_len", M), ("c_slot", M), ("sent0", M * L), ("sent1", M * L), ("c_sent", B * (n + 1) * L)]
+        ibuf, dbuf = self._b(tag + "ibuf", (sum(sz for _, sz in sizes),), i32), self._b(tag + "dbuf", (4 * M,), f64)
+        iv, o = {}, 0
+        for name, sz in sizes:
+            iv[name] = (o, ibuf[o:o + sz])
+            o += sz
+        pcount, ccount, p_len, c_len, c_slot = (iv[k_][1] for k_ in ("pcount", "ccount", "p_len", "c_len", "c_slot"))
+        sent, c_sent = [iv["sent0"][1].view(M, L), iv["sent1"][1].view(M, L)], iv["c_sent"][1].view(B * (n + 1), L)
+        p_score, c_score, p_logprob, c_logprob = dbuf[0:M], dbuf[M:2 * M], dbuf[2 * M:3 * M], dbuf[3 * M:4 * M]
+        c_free = self._b(tag + "c_free", (B,), i32)
         parent, tok = self._b(tag + "parent", (M,), i32), self._b(tag + "tok", (M,), i32)
         tv, ti = self._b(tag + "tv", (M, n)), self._b(tag + "ti", (M, n), i32)
-        first = self._b(tag + "first", (M,), i32)
-        pcount.fill_(1); ccount.zero_(); p_score.zero_(); p_logprob.zero_(); p_len.fill_(1)
-        sent[0].fill_(bos); sent[1].zero_()
-        c_score.zero_(); c_logprob.zero_(); c_len.zero_(); c_slot.zero_(); c_sent.zero_()
-        c_free.fill_((1 << (n + 1)) - 1)
-        tok.fill_(bos)
-        # every row starts from its image's state: the [B, Hd] state expanded to the M rows once, then parent = identity (what
-        # parent = arange(B).repeat_interleave(n) on the B-row state selects)
-        bufs = self._round_bufs("bm_", M)
-        torch.div(torch.arange(M, dtype=i32, device=dev), n, rounding_mode="floor", out=first)
-        lib.vc_embedding_gather_f32(st, P(c), P(first), M, Hd, B, P(bufs["c2"]))
-        lib.vc_embedding_gather_f32(st, P(h), P(first), M, Hd, B, P(bufs["h2"]))
-        torch.arange(M, dtype=i32, device=dev, out=parent)
-        cg, hg = self._b("bm_cg", (M, Hd)), self._b("bm_hg", (M, Hd))
-        alive = self._b("bm_alive", (1,))
-        fused = n <= 8   # softmax + top-k in one read of the logits (vc_softmax_topk_rows_f32: bit-identical to the two calls)
-
-        rounds = max_len - 1
-        # the words' input projections from a table (rows x rounds of lookups against ONE product over the vocabulary)
-        xproj = self._project_vocab() if (M * rounds >= V and Hd % 4 == 0 and os.environ.get("VC_DECODE_XPROJ", "1") != "0") else None
+        bufs = self._round_bufs(tag, M)
+        # re-initialised per call: partial = [Beam([bos], state b, 0.0, 0.0)], and every row starts from its image's state (the [B, Hd]
+        # state expanded to the M rows, parent = identity) -- one launch
+        lib.vc_beam_init(_stream(), B, n, L, int(self._bos), Hd, P(c), P(h), P(bufs["c2"]), P(bufs["h2"]), P(pcount), P(ccount), P(p_score),
+                         P(p_logprob), P(p_len), P(sent[0]), P(sent[1]), P(c_score), P(c_logprob), P(c_len), P(c_slot), P(c_free), P(c_sent),
+                         P(parent), P(tok))
+        cg, hg = self._b(tag + "cg", (M, Hd)), self._b(tag + "hg", (M, Hd))
+        alive = self._b(tag + "alive", (1,))
 
         def one(it, timed):
             s_ = _stream()
             # every new beam continues its parent's state and feeds its last word: three row moves, one launch
             lib.vc_beam_gather_f32(s_, P(bufs["c2"]), P(bufs["h2"]), P(parent), M, Hd, P(cg), P(hg), P(xproj), P(tok), V, 4 * Hd, P(bufs["gact"]))
-            if fused:
+            if fused:   # softmax + top-k in one read of the logits (vc_softmax_topk_rows_f32: bit-identical to the two calls)
                 logits, _, _ = self.step(tok, cg, hg, want="logits", bufs=bufs, timed=timed, projected=xproj is not None)
                 lib.vc_softmax_topk_rows_f32(s_, P(logits), M, V, V, n, P(tv), P(ti))
             else:
@@ -363,68 +369,130 @@ class CaptionGenerator(object):
                                P(p_len), P(sent[it & 1]), P(sent[1 - (it & 1)]), P(c_score), P(c_logprob), P(c_len), P(c_slot),
                                P(c_free), P(c_sent), P(parent), P(tok))
 
-        # Rounds run as hipGraph replays of K rounds each (nine launches per round otherwise): every buffer above is persistent and the
-        # sentence buffers alternate with the round's parity, so a chunk that starts at an even round is the same graph every time.
-        # The FIRST call of a shape runs eagerly and captures the chunk at its end (a capture executes nothing); later calls replay
-        # it.  VC_DECODE_GRAPH=0 keeps the eager loop -- same kernels, same beams.
-        K = int(check_every) if check_every and check_every % 2 == 0 else 4
-
         def chunk_fn():
             for r in range(K):
                 one(r, False)
             lib.vc_count_nonzero_i32(_stream(), P(pcount), B, P(alive))
-        key = self._graph_key("beam", B, n, L, K, int(eos), float(len_norm_f),
-                              tensors=[pcount, ccount, p_score, p_logprob, p_len, sent[0], sent[1], c_score, c_logprob, c_len, c_slot, c_free, c_sent,
-                                       parent, tok, tv, ti, cg, hg, alive, xproj, self._ones_for(M)] + list(bufs.values()))
-        graph = self._graphs.get(key) if fused else None
+
+        pt.one, pt.chunk_fn, pt.alive, pt.pcount = one, chunk_fn, alive, pcount
+        pt.key = self._graph_key("beam", B, n, L, K, int(eos), float(len_norm_f),
+                                 tensors=[pcount, ccount, p_score, p_logprob, p_len, sent[0], sent[1], c_score, c_logprob, c_len, c_slot, c_free, c_sent,
+                                          parent, tok, tv, ti, cg, hg, alive, xproj, self._ones_for(M)] + list(bufs.values()))
+        pt.graph = self._graphs.get(pt.key) if fused else None
+        pt.ibuf, pt.dbuf, pt.ioff = ibuf, dbuf, {k_: v[0] for k_, v in iv.items()}
+        pt.ihost, pt.dhost = self._pinned(tag + "ihost", ibuf.numel(), i32), self._pinned(tag + "dhost", 2 * M, f64)
+        pt.it, pt.last, pt.done, pt.pending = 0, 0, rounds <= 0, []
+        return pt
+
+    def beam_search(self, features, c_v=None, eps=None, bos=1, eos=2, beam_size=2, max_len=None, len_norm_f=0.7, check_every=4):
+        """decoder.py:203-320 for a batch of images.  Returns per image the list of
+        (sentence, score) of the kept beams in descending score order.
+
+        Rows are [B, beam_size] throughout; every round is gather-state -> LSTM step -> logits -> softmax ->
+        top-k -> vc_beam_update (the TopN bookkeeping, on device), with no host synchronisation except a
+        4-byte "is any beam alive" read every `check_every` rounds.
+
+        Images are independent, and a round is a chain of one throughput-bound kernel (the logits product) and four latency-bound
+        ones (state gather, LSTM step, top-k, the heap bookkeeping: together half the round's time at 640 rows, on a fraction of
+        the CUs).  A batch of >= 512 rows is therefore decoded as TWO slices of images on two streams: while one slice is in its
+        latency-bound kernels the other's logits product has the CUs.  VC_DECODE_SLICES=1 keeps one slice -- same beams."""
+        lib, e, st = self.lib, self.e, _stream()
+        max_len = max_len or self.p.gen_max_len
+        t_ph = _phase("", 0.0)
+        c, h = self.init_state(features, c_v, eps)
+        t_ph = _phase("init_state", t_ph)
+        B, Hd, V, n = c.shape[0], self.p.decoder_hidden, e.V, int(beam_size)
+        self._bos = int(bos)
+        tok0 = self._b("bm_tok0", (B,), torch.int32)
+        tok0.fill_(bos)
+        _, c, h = self.step(tok0, c, h, want="state", bufs=self._round_bufs("bm0_", B))  # :230-236 -- probabilities discarded, state kept
+        L, rounds = max_len + 2, max_len - 1
+        fused = n <= 8
+        # the words' input projections from a table (rows x rounds of lookups against ONE product over the vocabulary)
+        xproj = self._project_vocab() if (B * n * rounds >= V and Hd % 4 == 0 and os.environ.get("VC_DECODE_XPROJ", "1") != "0") else None
+        # Rounds run as hipGraph replays of K rounds each (nine launches per round otherwise): every buffer of a slice is persistent and
+        # the sentence buffers alternate with the round's parity, so a chunk that starts at an even round is the same graph every time.
+        # The FIRST call of a shape runs eagerly and captures the chunks at its end (a capture executes nothing); later calls replay
+        # them.  VC_DECODE_GRAPH=0 keeps the eager loop -- same kernels, same beams.
+        K = int(check_every) if check_every and check_every % 2 == 0 else 4
+        want = int(os.environ.get("VC_DECODE_SLICES", self.slices))
+        nparts = want if (want > 1 and B % want == 0 and B * n >= self.slice_rows * want and xproj is not None) else 1
+        nb = B // nparts
+        if nparts > 1 and lib.vc_gemm_workspace_bytes(nb * n, V, Hd) != 0:
+            nparts, nb = 1, B    # (a K-split logits product writes the engine's ONE workspace: slices on two streams would share it)
+        parts = [self._beam_part(k, nparts, c[k * nb:(k + 1) * nb], h[k * nb:(k + 1) * nb], n, L, rounds, K, eos, len_norm_f, xproj, fused)
+                 for k in range(nparts)]
+        main = torch.cuda.current_stream()
+        while len(self._side) < nparts - 1:
+            self._side.append(torch.cuda.Stream())
+        streams = [main] + self._side[:nparts - 1]
+        for s in streams[1:]:
+            s.wait_stream(main)
         # "is any beam alive" without idling the GPU: after every replayed chunk the 4-byte count is copied to pinned memory behind an
         # event; the host looks at the count of the PREVIOUS chunk before it launches the next (rounds of an image whose beams have all
         # ended are no-ops of vc_beam_update, so a chunk too many changes nothing)
-        host_alive = self._pinned_alive(rounds // K + 2)
-        pending = []
-        last, it = 0, 0
-        while it < rounds:
-            if graph is not None and it % 2 == 0 and it + K <= rounds:
-                if check_every and len(pending) >= 2 and pending[-2][1].query() and float(host_alive[pending[-2][0]]) == 0.0:
-                    break
-                graph.replay()
-                it += K
-                last = 0
+        per = rounds // K + 2
+        host_alive = self._pinned_alive(nparts * per)
+
+        t_ph = _phase("bos step, vocabulary projection, slice set-up", t_ph)
+
+        def advance(pt):
+            if pt.graph is not None and pt.it % 2 == 0 and pt.it + K <= rounds:
+                pend = pt.pending
+                if check_every and len(pend) >= 2 and pend[-2][1].query() and float(host_alive[pend[-2][0]]) == 0.0:
+                    pt.done = True
+                    return
+                pt.graph.replay()
+                pt.it += K
+                pt.last = 0
                 if check_every:
-                    slot = len(pending)
-                    host_alive[slot:slot + 1].copy_(alive, non_blocking=True)
+                    slot = pt.k * per + len(pend)
+                    host_alive[slot:slot + 1].copy_(pt.alive, non_blocking=True)
                     ev = torch.cuda.Event()
                     ev.record()
-                    pending.append((slot, ev))
+                    pend.append((slot, ev))
             else:
-                one(it, True)
-                last = 1 - (it & 1)
-                it += 1
-                if check_every and it % check_every == 0:
-                    lib.vc_count_nonzero_i32(st, P(pcount), B, P(alive))
-                    if alive.item() == 0:
-                        break
-        # results: TWO device-to-host copies (every int32 field in one buffer, the two float64 score arrays in another)
-        ints = torch.cat([pcount, ccount, p_len, c_len, c_slot, sent[last].reshape(-1), c_sent.reshape(-1)]).cpu().numpy()
-        dbls = torch.cat([p_score, c_score]).cpu().numpy()
-        o = 0
-        def take(cnt, shape):
-            nonlocal o
-            a = ints[o:o + cnt].reshape(shape)
-            o += cnt
-            return a
-        pc, cc = take(B, (B,)).tolist(), take(B, (B,)).tolist()
-        pl, cl, csl = take(M, (B, n)).tolist(), take(M, (B, n)).tolist(), take(M, (B, n)).tolist()
-        psent, csent = take(M * L, (B, n, L)), take(B * (n + 1) * L, (B, n + 1, L))
-        ps, cs = dbls[:M].reshape(B, n).tolist(), dbls[M:].reshape(B, n).tolist()
+                pt.one(pt.it, True)
+                pt.last = 1 - (pt.it & 1)
+                pt.it += 1
+                if check_every and pt.it % check_every == 0:
+                    lib.vc_count_nonzero_i32(_stream(), P(pt.pcount), pt.B, P(pt.alive))
+                    if pt.alive.item() == 0:
+                        pt.done = True
+            if pt.it >= rounds:
+                pt.done = True
+
+        while not all(pt.done for pt in parts):
+            for pt, s in zip(parts, streams):
+                if not pt.done:
+                    with torch.cuda.stream(s):
+                        advance(pt)
+        for s in streams[1:]:
+            main.wait_stream(s)
+        t_ph = _phase("rounds", t_ph)
+        # results: two asynchronous copies per slice into pinned memory, one wait
+        for pt in parts:
+            pt.ihost.copy_(pt.ibuf, non_blocking=True)
+            pt.dhost.copy_(pt.dbuf[:2 * pt.M], non_blocking=True)
+        torch.cuda.current_stream().synchronize()
         res = []
-        for b in range(B):
-            if cc[b]:  # never mix complete and partial (:295-299)
-                beams = [Beam(csent[b, csl[b][j], :cl[b][j]].tolist(), None, None, cs[b][j]) for j in range(cc[b])]
-            else:
-                beams = [Beam(psent[b, j, :pl[b][j]].tolist(), None, None, ps[b][j]) for j in range(pc[b])]
-            beams.sort(reverse=True)  # TopN.extract(sort=True) on the heap array
-            res.append([(bm.sentence, float(bm.score)) for bm in beams])
-        if graph is None and fused and rounds > K:
-            self._capture(key, chunk_fn)   # (the results are on the host: the capture touches no state)
+        for pt in parts:
+            Bp, Mp, ints, dbls, io = pt.B, pt.M, pt.ihost.numpy(), pt.dhost.numpy(), pt.ioff
+            take = lambda name, cnt, shape: ints[io[name]:io[name] + cnt].reshape(shape)
+            pc, cc = take("pcount", Bp, (Bp,)).tolist(), take("ccount", Bp, (Bp,)).tolist()
+            pl, cl, csl = take("p_len", Mp, (Bp, n)).tolist(), take("c_len", Mp, (Bp, n)).tolist(), take("c_slot", Mp, (Bp, n)).tolist()
+            psent, csent = take("sent%d" % pt.last, Mp * L, (Bp, n, L)), take("c_sent", Bp * (n + 1) * L, (Bp, n + 1, L))
+            ps, cs = dbls[:Mp].reshape(Bp, n).tolist(), dbls[Mp:2 * Mp].reshape(Bp, n).tolist()
+            for b in range(Bp):
+                if cc[b]:  # never mix complete and partial (:295-299)
+                    beams = [Beam(csent[b, csl[b][j], :cl[b][j]].tolist(), None, None, cs[b][j]) for j in range(cc[b])]
+                else:
+                    beams = [Beam(psent[b, j, :pl[b][j]].tolist(), None, None, ps[b][j]) for j in range(pc[b])]
+                beams.sort(reverse=True)  # TopN.extract(sort=True) on the heap array
+                res.append([(bm.sentence, float(bm.score)) for bm in beams])
+        t_ph = _phase("results to host lists", t_ph)
+        if fused and rounds > K:
+            for pt in parts:
+                if pt.graph is None:
+                    self._capture(pt.key, pt.chunk_fn)   # (the results are on the host: the capture touches no state)
         return res
