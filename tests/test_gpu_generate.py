@@ -100,6 +100,10 @@ def test_fused_softmax_topk_equals_softmax_then_topk_bit_for_bit(lib, k, V, ld):
     x[2, :V] = 0.25                          # constant row
     x[3, :V] = -200.0
     x[3, V // 2] = 100.0                     # one word takes everything
+    if V >= 1000:   # two-level rows: 300 / 200 words share the top probability (more / fewer than the selection's candidate list holds)
+        for r, cnt in ((6, 300), (7, 200)):
+            x[r, :V] = 0.0
+            x[r, rng.choice(V, size=cnt, replace=False)] = 1.0
     dx = dev(x)
     probs = torch.empty((R, ld), dtype=torch.float32, device="cuda")
     tv, ti = [torch.empty((R, k), dtype=torch.float32, device="cuda") for _ in range(2)], [torch.empty((R, k), dtype=torch.int32, device="cuda") for _ in range(2)]
@@ -115,6 +119,9 @@ def test_fused_softmax_topk_equals_softmax_then_topk_bit_for_bit(lib, k, V, ld):
         assert host(ti[1])[r].tolist() == order
         np.testing.assert_allclose(host(tv[1])[r], ref[r, order], rtol=2e-6)
     assert host(ti[1])[2].tolist() == list(range(k)) and host(ti[1])[3, 0] == V // 2 and host(tv[1])[3, 0] == 1.0
+    if V >= 1000:
+        for r in (6, 7):
+            assert host(ti[1])[r].tolist() == np.nonzero(x[r, :V] == 1.0)[0][:k].tolist()
 
 
 @pytest.mark.parametrize("kw", [dict(prior="GMM"), dict(no_encoder=True)], ids=["gmm", "no-encoder"])

@@ -53,9 +53,9 @@ struct WaveHeap {
     __device__ __forceinline__ double score(int pos) const { return lane_get(sc, pos); }
 };
 
-// CPython Lib/heapq.py _siftdown / _siftup, move for move (comparisons by score only)
-__device__ __forceinline__ void sift_down(WaveHeap& heap, int startpos, int pos) {
-    const BeamItem newitem = heap.get(pos);
+// CPython Lib/heapq.py _siftdown / _siftup, move for move (comparisons by score only).  `newitem` is the item heapq has just stored at
+// `pos` (heappush: appended at the end; heappushpop: written over the root): it is carried in scalars and stored once, where it settles.
+__device__ __forceinline__ void sift_down(WaveHeap& heap, int startpos, int pos, const BeamItem& newitem) {
     while (pos > startpos) {
         const int parentpos = (pos - 1) >> 1;
         if (newitem.score < heap.score(parentpos)) {
@@ -68,9 +68,8 @@ __device__ __forceinline__ void sift_down(WaveHeap& heap, int startpos, int pos)
     heap.put(pos, newitem);
 }
 
-__device__ __forceinline__ void sift_up(WaveHeap& heap, int n, int pos) {
+__device__ __forceinline__ void sift_up(WaveHeap& heap, int n, int pos, const BeamItem& newitem) {
     const int startpos = pos;
-    const BeamItem newitem = heap.get(pos);
     int childpos = 2 * pos + 1;
     while (childpos < n) {
         const int rightpos = childpos + 1;
@@ -79,22 +78,19 @@ __device__ __forceinline__ void sift_up(WaveHeap& heap, int n, int pos) {
         pos = childpos;
         childpos = 2 * pos + 1;
     }
-    heap.put(pos, newitem);
-    sift_down(heap, startpos, pos);
+    sift_down(heap, startpos, pos, newitem);
 }
 
 // TopN.push: returns the slot field of the item that left the heap (the popped root, or the rejected newcomer), -1 if none
 __device__ __forceinline__ int topn_push(WaveHeap& heap, int& count, int cap, const BeamItem& item) {
     if (count < cap) {
-        heap.put(count, item);
         ++count;
-        sift_down(heap, 0, count - 1);
+        sift_down(heap, 0, count - 1, item);
         return -1;
     }
     if (count > 0 && heap.score(0) < item.score) {
         const int freed = lane_get(heap.slot, 0);
-        heap.put(0, item);
-        sift_up(heap, count, 0);
+        sift_up(heap, count, 0, item);
         return freed;
     }
     return item.slot;

@@ -495,6 +495,13 @@ __global__ __launch_bounds__(256) void beam_gather_kernel(const float4* __restri
 // softmax_rows_reg_kernel / softmax_rows_kernel (loss.hip: same maximum, same summation order, p = exp(l - max) * (1 / sum)) and offered
 // to the per-thread lists of topk_rows_small_kernel in the same column order, so (p, index) out equal vc_softmax_rows_f32 followed by
 // vc_topk_rows_f32 bit for bit -- without writing the [rows, V] probabilities (25.6 MB per round at 640 rows) and reading them back.
+//
+// The register form's selection: instead of every thread keeping a sorted list of its best eight of 40 -- an insertion path the wave
+// takes whenever ANY of its lanes inserts, i.e. for nearly every element -- the workgroup first agrees on a threshold that at least k
+// probabilities reach (the k-th largest of one wave's 64 thread maxima, the largest such value of the four waves), collects the few
+// elements that reach it into an LDS list, and ONE wave picks the k best of those (value descending, index ascending: the order of the
+// stable sort).  A row with more than TOPK_CAND elements at the threshold (many equal probabilities) takes the list path below.
+constexpr int TOPK_CAND = 256;
 template <bool REG>
 __global__ __launch_bounds__(256) void softmax_topk_rows_kernel(const float* __restrict__ x, int V, long ld, int k,
                                                                 float* __restrict__ out_val, int32_t* __restrict__ out_idx) {
@@ -503,6 +510,7 @@ __global__ __launch_bounds__(256) void softmax_topk_rows_kernel(const float* __r
     __shared__ int li[8][256];
     __shared__ float wv[4];
     __shared__ int wi[4], wt[4];
+    __shared__ int ncand;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float tv[8];
     int ti[8];
@@ -544,10 +552,77 @@ __global__ __launch_bounds__(256) void softmax_topk_rows_kernel(const float* __r
         }
         s = block_sum<256>(s, sh);
         const float inv = 1.f / s;
+        {
+            if (tid == 0) ncand = 0;
+            float tm = -INFINITY;
 #pragma unroll
-        for (int i = 0; i < 12; ++i) {
-            const int c = tid + 256 * i;
-            if (c < Q) { offer(r[i].x * inv, 4 * c); offer(r[i].y * inv, 4 * c + 1); offer(r[i].z * inv, 4 * c + 2); offer(r[i].w * inv, 4 * c + 3); }
+            for (int i = 0; i < 12; ++i) {
+                const int c = tid + 256 * i;
+                if (c < Q) {
+                    r[i].x *= inv; r[i].y *= inv; r[i].z *= inv; r[i].w *= inv;
+                    tm = fmaxf(fmaxf(tm, fmaxf(r[i].x, r[i].y)), fmaxf(r[i].z, r[i].w));
+                }
+            }
+            float kth = -INFINITY;
+            for (int j = 0; j < k; ++j) {   // the k-th largest thread maximum of this wave: k maxima, each knocked out of ONE lane
+                kth = wave_max(tm);
+                const unsigned long long holders = __ballot(tm == kth);
+                if (lane == __builtin_ctzll(holders)) tm = -INFINITY;
+            }
+            if (lane == 0) wv[wave] = kth;
+            __syncthreads();
+            const float thr = fmaxf(fmaxf(wv[0], wv[1]), fmaxf(wv[2], wv[3]));
+            auto cand = [&](float v, int c) {
+                if (v >= thr) {
+                    const int slot = atomicAdd(&ncand, 1);
+                    if (slot < TOPK_CAND) { lv[0][slot] = v; li[0][slot] = c; }
+                }
+            };
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                const int c = tid + 256 * i;
+                if (c < Q) { cand(r[i].x, 4 * c); cand(r[i].y, 4 * c + 1); cand(r[i].z, 4 * c + 2); cand(r[i].w, 4 * c + 3); }
+            }
+            __syncthreads();
+            const int nc = ncand;
+            if (nc <= TOPK_CAND) {
+                if (wave != 0) return;
+                float cv[TOPK_CAND / 64];
+                int ci[TOPK_CAND / 64];
+#pragma unroll
+                for (int q = 0; q < TOPK_CAND / 64; ++q) {
+                    const int sidx = lane + 64 * q;
+                    cv[q] = sidx < nc ? lv[0][sidx] : -INFINITY;
+                    ci[q] = sidx < nc ? li[0][sidx] : 0x7fffffff;
+                }
+                for (int j = 0; j < k; ++j) {
+                    float bv = cv[0];
+                    int bi = ci[0];
+#pragma unroll
+                    for (int q = 1; q < TOPK_CAND / 64; ++q)
+                        if (cv[q] > bv || (cv[q] == bv && ci[q] < bi)) { bv = cv[q]; bi = ci[q]; }
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) {
+                        const float v2 = __shfl_xor(bv, o, 64);
+                        const int i2 = __shfl_xor(bi, o, 64);
+                        if (v2 > bv || (v2 == bv && i2 < bi)) { bv = v2; bi = i2; }
+                    }
+#pragma unroll
+                    for (int q = 0; q < TOPK_CAND / 64; ++q)
+                        if (ci[q] == bi) { cv[q] = -INFINITY; ci[q] = 0x7fffffff; }   // (indices are unique: exactly one lane holds the winner)
+                    if (lane == 0) {
+                        out_val[(long)blockIdx.x * k + j] = bv;
+                        out_idx[(long)blockIdx.x * k + j] = bi;
+                    }
+                }
+                return;
+            }
+            __syncthreads();   // (the list path reuses lv / li)
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                const int c = tid + 256 * i;
+                if (c < Q) { offer(r[i].x, 4 * c); offer(r[i].y, 4 * c + 1); offer(r[i].z, 4 * c + 2); offer(r[i].w, 4 * c + 3); }
+            }
         }
     } else {
         const float* p = x + (long)blockIdx.x * ld;
