@@ -481,6 +481,10 @@ def bench_generation(args, torch, dist, lib, w, p, world, rank):
         dt = float(t.item())
     roof = roofline_from_timer(eng.timer, False)
     roof["instrumented_pass"] = False
+    roof["note"] += ("; cfg5: decoder rounds replayed from hipGraphs carry no events -- the bracketed launches are each call's LAST round (run eagerly: "
+                     "29 rounds = 7 replayed chunks of 4 + 1) of both image slices, whose logits products [320, 512] x [512, V] share the CUs with the "
+                     "other slice's kernels (two streams), and the small products outside the rounds; every kernel's in-graph duration is in "
+                     "profiles/r06_cfg5_kernel_stats.md")
     out = {"metric": "captions/sec generated (beam search)", "value": round(B * world * args.steps / dt, 2), "unit": "captions/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * dt / args.steps, 3),
            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",

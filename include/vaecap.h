@@ -30,7 +30,7 @@ extern "C" {
  *      choice of their own (the product path never calls them: two trainers of different precision coexist in one process).  Gone: the
  *      direct split-bf16 forward / data-gradient convolutions (vc_conv3x3_bx_* except the weight gradient, vc_conv3x3_bx2_*), which no
  *      product path called.  New: the F(4x4,3x3) convolution with a pre-transformed input (vc_conv3x3_wino4v_*), the decode-round
- *      entries vc_softmax_topk_rows_f32 / vc_beam_gather_f32 / vc_eos_track_i32.
+ *      entries vc_softmax_topk_rows_f32 / vc_beam_gather_f32 / vc_eos_track_i32 / vc_beam_init.
  *   3  the 3x3-convolution family (vc_conv3x3_wino_*, vc_conv3x3_wino4_*, vc_conv3x3_wino_wgrad_*, vc_conv1_fwd* / vc_conv1_wgrad*,
  *      vc_maxpool2x2_bwd_bits_f32) takes and returns activations in the C4 layout [B][C/4][H][W][4] (v2: NHWC) and the pool routing
  *      codes / ReLU mask bits follow it; the vc_conv3x3_patch_*, vc_conv3x3_pack_f32, *_packed_f32 and wgrad_patch_* entries of v2 are
