@@ -209,6 +209,163 @@ __global__ __launch_bounds__(64) void beam_update_kernel(BeamArgs a) {
     }
 }
 
+// ---- beam x beam <= 64 (beam <= 8): every candidate of the round has a lane of its own for the whole kernel, so the heaps hold
+// (score, id) PAIRS -- three registers per move instead of eight -- and an item's other fields are read where they already are: id < 64
+// is candidate id (lane id of the registers step 1 filled), id >= 64 a complete caption carried in from earlier rounds (lane id - 64 of
+// the registers loaded from c_*).  Same pushes, same sift moves, same order; what leaves the kernel is gathered by id at the end.
+struct SlimHeap {
+    double sc;
+    int id;
+    __device__ __forceinline__ double score(int pos) const { return lane_get(sc, pos); }
+    __device__ __forceinline__ void move(int dst, int src) {   // heap[dst] = heap[src]
+        const double s = lane_get(sc, src);
+        const int i = lane_get(id, src);
+        sc = lane_set(sc, dst, s); id = lane_set(id, dst, i);
+    }
+    __device__ __forceinline__ void put(int pos, double s, int i) { sc = lane_set(sc, pos, s); id = lane_set(id, pos, i); }
+    // CPython Lib/heapq.py _siftdown / _siftup, move for move, the new item (s, i) carried in scalars
+    __device__ __forceinline__ void sift_down(int startpos, int pos, double s, int i) {
+        while (pos > startpos) {
+            const int parentpos = (pos - 1) >> 1;
+            if (s < score(parentpos)) {
+                move(pos, parentpos);
+                pos = parentpos;
+                continue;
+            }
+            break;
+        }
+        put(pos, s, i);
+    }
+    __device__ __forceinline__ void sift_up(int n, int pos, double s, int i) {
+        const int startpos = pos;
+        int childpos = 2 * pos + 1;
+        while (childpos < n) {
+            const int rightpos = childpos + 1;
+            if (rightpos < n && !(score(childpos) < score(rightpos))) childpos = rightpos;
+            move(pos, childpos);
+            pos = childpos;
+            childpos = 2 * pos + 1;
+        }
+        sift_down(startpos, pos, s, i);
+    }
+    // TopN.push: the id that left the heap (the popped root, or the rejected newcomer), -1 if none
+    __device__ __forceinline__ int push(int& count, int cap, double s, int i) {
+        if (count < cap) {
+            ++count;
+            sift_down(0, count - 1, s, i);
+            return -1;
+        }
+        if (count > 0 && score(0) < s) {
+            const int out = lane_get(id, 0);
+            sift_up(count, 0, s, i);
+            return out;
+        }
+        return i;
+    }
+};
+
+__global__ __launch_bounds__(64) void beam_update_slim_kernel(BeamArgs a) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int n = a.n, k = a.k, L = a.Lmax;
+    const int np = __builtin_amdgcn_readfirstlane(a.pcount[b]);
+    if (lane < n) {   // defaults for slots that stay empty: continue row b*n with token 0 (ignored)
+        a.parent[b * n + lane] = b * n;
+        a.tok[b * n + lane] = 0;
+    }
+    if (np == 0) return;   // every beam of this image has ended
+    int hn = 0, cn = __builtin_amdgcn_readfirstlane(a.ccount[b]);
+    // complete captions carried in (lane j < cn): they start as the complete heap, ids 64 + j
+    double cc_lp = 0.0;
+    int cc_len = 0, cc_slot = -1;
+    SlimHeap part{0.0, 0}, comp{0.0, 0};
+    if (lane < cn) {
+        comp.sc = a.c_score[b * n + lane];
+        comp.id = 64 + lane;
+        cc_lp = a.c_logprob[b * n + lane];
+        cc_len = a.c_len[b * n + lane];
+        cc_slot = a.c_slot[b * n + lane];
+    }
+    int freemask = __builtin_amdgcn_readfirstlane(a.c_free[b]);
+    // ---- 1. candidate `lane`: beam lane / k, its (lane % k)-th word
+    const int total = np * k;
+    const bool have = lane < total;
+    const int i_q = have ? lane / k : 0;
+    const long row = (long)b * n + i_q;
+    const float pw = have ? a.tv[(long)b * n * k + lane] : 0.f;
+    const int tok_q = have ? a.ti[(long)b * n * k + lane] : 0;
+    const int len0_q = a.p_len[row];
+    const double lp_q = a.p_logprob[row] + (double)logf(pw);   // decoder.py:282: np.log of a float32 is a float32; the SUM is a float64
+    double sc_q = lp_q;
+    if (tok_q == a.eos && a.len_norm_f > 0) sc_q = lp_q / pow((double)(len0_q + 1), a.len_norm_f);
+    const int skip_q = (!have || (double)pw < 1e-12) ? 1 : 0;   // decoder.py:279: float32 p against the Python float 1e-12
+    int slot_q = -1;     // pool slot of candidate `lane`, if it is a finished caption the walk gave one
+    int rec_cand = -1;   // lane s: the candidate whose caption pool slot s receives this round (-1: none)
+    // ---- 2. the walk
+    for (int c = 0; c < total; ++c) {
+        if (lane_get(skip_q, c)) continue;
+        const double s = lane_get(sc_q, c);
+        if (lane_get(tok_q, c) == a.eos) {
+            // take a free pool slot, record the caption for it, give the slot back if the heap does not keep it
+            const int sl = __builtin_ctz(freemask);
+            freemask &= ~(1 << sl);
+            slot_q = lane_set(slot_q, c, sl);
+            rec_cand = lane_set(rec_cand, sl, c);
+            const int out = comp.push(cn, n, s, c);
+            if (out >= 0) freemask |= 1 << (out < 64 ? lane_get(slot_q, out) : lane_get(cc_slot, out - 64));
+        } else {
+            part.push(hn, n, s, c);
+        }
+    }
+    // ---- what the heaps hold, gathered by id (lane j: heap position j)
+    {   // (the exchanges run with every lane active; the stores are per heap position)
+        const int id = lane < hn ? part.id : 0;
+        const double lp = __shfl(lp_q, id, 64);
+        const int len0 = __shfl(len0_q, id, 64), tk = __shfl(tok_q, id, 64);
+        if (lane < hn) {
+            const long o = (long)b * n + lane;
+            a.p_score[o] = part.sc;
+            a.p_logprob[o] = lp;
+            a.p_len[o] = len0 + 1;
+            a.parent[o] = b * n + id / k;
+            a.tok[o] = tk;
+        }
+    }
+    {
+        const int id = lane < cn ? comp.id : 0;
+        const int cq = id < 64 ? id : 0, cj = id < 64 ? 0 : id - 64;
+        const double lp_new = __shfl(lp_q, cq, 64), lp_old = __shfl(cc_lp, cj, 64);
+        const int len_new = __shfl(len0_q, cq, 64) + 1, len_old = __shfl(cc_len, cj, 64);
+        const int slot_new = __shfl(slot_q, cq, 64), slot_old = __shfl(cc_slot, cj, 64);
+        if (lane < cn) {
+            const long o = (long)b * n + lane;
+            a.c_score[o] = comp.sc;
+            a.c_logprob[o] = id < 64 ? lp_new : lp_old;
+            a.c_len[o] = id < 64 ? len_new : len_old;
+            a.c_slot[o] = id < 64 ? slot_new : slot_old;
+        }
+    }
+    if (lane == 0) {
+        a.pcount[b] = hn;
+        a.ccount[b] = cn;
+        a.c_free[b] = freemask;
+    }
+    // ---- 3. the copies
+    const int32_t* cur = a.sent_cur + (long)b * n * L;
+    for (int sl = 0; sl <= n; ++sl) {   // finished captions, per pool slot
+        const int c = lane_get(rec_cand, sl);
+        if (c < 0) continue;
+        const int len0 = lane_get(len0_q, c), i = c / k;
+        int32_t* dst = a.c_sent + ((long)b * (n + 1) + sl) * L;
+        for (int t = lane; t <= len0; t += 64) dst[t] = t < len0 ? cur[i * L + t] : a.eos;
+    }
+    int32_t* nxt = a.sent_next + (long)b * n * L;
+    for (int j = 0; j < hn; ++j) {
+        const int id = lane_get(part.id, j);
+        const int len = lane_get(len0_q, id) + 1, src = id / k, tk = lane_get(tok_q, id);
+        for (int t = lane; t < len; t += 64) nxt[j * L + t] = t < len - 1 ? cur[src * L + t] : tk;
+    }
+}
+
 // vae_model/decoder.py:238-247 for every image at once: the state the first round's vc_beam_update reads (twenty fills, two state
 // gathers and two index ramps as torch / library launches before: ~0.2 ms of a 5 ms call at 128 images)
 __global__ __launch_bounds__(256) void beam_init_kernel(BeamArgs a, int bos, int H, const float* __restrict__ c_in, const float* __restrict__ h_in,
@@ -292,7 +449,8 @@ extern "C" int vc_beam_update(void* stream, int B, int beam, int Lmax, int eos, 
     a.tv = top_p; a.ti = top_i; a.pcount = pcount; a.ccount = ccount; a.p_len = p_len; a.c_len = c_len; a.c_slot = c_slot;
     a.c_free = c_free; a.p_score = p_score; a.p_logprob = p_logprob; a.c_score = c_score; a.c_logprob = c_logprob;
     a.sent_cur = sent_cur; a.sent_next = sent_next; a.c_sent = c_sent; a.parent = parent; a.tok = tok;
-    hipLaunchKernelGGL(beam_update_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, a);
+    if (beam * beam <= 64) hipLaunchKernelGGL(beam_update_slim_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(beam_update_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, a);
     VC_LAUNCH_CHECK();
     return 0;
 }
