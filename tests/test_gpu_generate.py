@@ -124,6 +124,28 @@ def test_fused_softmax_topk_equals_softmax_then_topk_bit_for_bit(lib, k, V, ld):
             assert host(ti[1])[r].tolist() == np.nonzero(x[r, :V] == 1.0)[0][:k].tolist()
 
 
+@pytest.mark.parametrize("kw", CASES, ids=lambda k: "-".join("%s=%s" % i for i in k.items()))
+def test_replayed_calls_decode_the_inputs_of_the_call_not_of_the_capture(lib, kw):
+    """From the second call of a shape on, `init_state` and the rounds replay hipGraphs over persistent input buffers (features, cluster
+    vectors, the AG prior means computed on the host, injected noise).  A generator that has captured its graphs on one batch must
+    decode ANOTHER batch of the same shape exactly as a fresh generator does -- greedy and beam search, every prior."""
+    p, eng, gen, P64, feats, cv, eps, cm = setup(lib, 21, **kw)
+    rng = np.random.default_rng(99)
+    c = cv if spec.uses_ci(p) else None
+    run = lambda g, f, c_, e_: (g.greedy(f, c_, e_, BOS, EOS, max_len=11), g.beam_search(f, c_, e_, BOS, EOS, beam_size=3, max_len=11))
+    first = run(gen, feats, c, eps)
+    assert run(gen, feats, c, eps) == first                      # (replay on the same inputs)
+    feats2 = np.maximum(rng.standard_normal(feats.shape), 0).astype(np.float32)
+    eps2 = rng.standard_normal(eps.shape).astype(np.float32)
+    cv2 = np.zeros_like(cv)
+    for b in range(cv.shape[0]):
+        cv2[b, rng.choice(90, size=3, replace=False)] = 0.3
+    c2 = cv2 if spec.uses_ci(p) else None
+    second = run(gen, feats2, c2, eps2)                           # replayed graphs, new inputs
+    assert second == run(CaptionGenerator(eng), feats2, c2, eps2) and second != first
+    assert run(gen, feats, c, eps) == first
+
+
 @pytest.mark.parametrize("kw", [dict(prior="GMM"), dict(no_encoder=True)], ids=["gmm", "no-encoder"])
 def test_captured_rounds_generate_what_the_eager_loop_generates(lib, kw, monkeypatch):
     """greedy and beam search replay hipGraphs of four decoder rounds; VC_DECODE_GRAPH=0 runs the same launches one by one.  Same
