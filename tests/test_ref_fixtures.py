@@ -2,8 +2,8 @@
 (tests/golden/make_ref_fixtures.py imports /root/reference/utils/{captions,caption_utils,top_n,parameters}.py in the build
 container and stores inputs + outputs as json).  These pin, against the reference itself rather than hand-worked answers:
 tokenisation and vocabulary order (utils/captions.py:38-126), preprocess_captions (utils/caption_utils.py:4-25),
-TopN / Beam heap behaviour under exact score ties (utils/top_n.py:4-72) and every Parameters flag cast
-(utils/parameters.py:75-164)."""
+TopN / Beam heap behaviour under exact score ties (utils/top_n.py:4-72), every Parameters flag cast
+(utils/parameters.py:75-164) and the inference driver's calls into the decoders (ops/inference.py:4-56)."""
 import json
 import os
 
@@ -150,3 +150,20 @@ def test_parse_args_casts_match_reference_for_every_flag():
             os.environ.update(env)
         seen.update(a for a in case["argv"] if a.startswith("--"))
     assert len(seen) == 26, sorted(seen)  # every flag of utils/parameters.py:75-132 is exercised
+
+
+# ------------------------------------------------------------------ the caller of the decode path
+@pytest.mark.parametrize("k", range(5))
+def test_inference_driver_makes_the_reference_drivers_calls(k, tmp_path):
+    """ops/inference.py:4-56 run BY THE REFERENCE on recording stand-ins for its arguments (tests/inference_fakes.py) against this
+    build's `vae_captioning_amd.ops.inference.inference` on the same objects: checkpoint path, generator keywords, decoder method
+    per image set (beam search only for the validation set), the cluster-vector columns that reach the decoder (column 0 is cut
+    for c_v / GMM / AG models on the validation set, for c_v models only on the test set -- ops/inference.py:17-19,43-44), and both
+    result files (a stale one is replaced)."""
+    from tests import inference_fakes as F
+    from vae_captioning_amd.ops.inference import inference
+    fx = load("ref_inference.json")[k]
+    assert fx["case"] == F.CASES[k]
+    got = F.run(inference, fx["case"], str(tmp_path))
+    assert got["trace"] == fx["result"]["trace"]
+    assert got["val"] == fx["result"]["val"] and got["test"] == fx["result"]["test"]
