@@ -4,7 +4,7 @@
 The reference decodes ONE image and ONE beam per `sess.run` (batch 1, one Python<->runtime
 crossing per token per beam).  Here every round advances all images x all live beams in one
 batched LSTM step + logits GEMM + softmax + top-k on the GPU, and the O(beam) bookkeeping (TopN
-heaps, sentence lists, length-normalised scores) runs in `vc_beam_update`, one thread per image,
+heaps, sentence lists, length-normalised scores) runs in `vc_beam_update`, one wave per image,
 with the reference's exact semantics: stable top-`beam_size` expansion, p < 1e-12 skipped, heapq
 tie order, score = logprob / len**0.7 for completed captions, `<BOS>` consumed twice
 (decoder.py:230-262).  The host is not involved between decoder steps.
@@ -50,7 +50,6 @@ class CaptionGenerator(object):
         self._xproj = None       # [V, 4H] input projection of every word (beam search with many rows x rounds)
         self._xproj_version = None
         self._side = []          # extra streams of a sliced beam search
-        self._bos = 1
         self.slices, self.slice_rows = 2, 256   # beam search: images decoded as `slices` independent slices when each has >= slice_rows rows
 
     def _b(self, name, shape, dtype=torch.float32):
@@ -356,7 +355,7 @@ class CaptionGenerator(object):
         return self._trim(ids[:steps], eos)
 
     # ------------------------------------------------------------------ beam search
-    def _beam_part(self, k, nparts, c, h, n, L, rounds, K, eos, len_norm_f, xproj, fused):
+    def _beam_part(self, k, nparts, c, h, n, L, rounds, K, bos, eos, len_norm_f, xproj, fused):
         """The persistent device state of one slice of images (vae_model/decoder.py:238-247) and its round function.  A call decodes its
         images as `nparts` independent slices on `nparts` streams (beam_search): buffers are per (slice, beam width, length) and a
         captured chunk of rounds bakes their addresses."""
@@ -383,7 +382,7 @@ class CaptionGenerator(object):
         bufs = self._round_bufs(tag, M)
         # re-initialised per call: partial = [Beam([bos], state b, 0.0, 0.0)], and every row starts from its image's state (the [B, Hd]
         # state expanded to the M rows, parent = identity) -- one launch
-        lib.vc_beam_init(_stream(), B, n, L, int(self._bos), Hd, P(c), P(h), P(bufs["c2"]), P(bufs["h2"]), P(pcount), P(ccount), P(p_score),
+        lib.vc_beam_init(_stream(), B, n, L, int(bos), Hd, P(c), P(h), P(bufs["c2"]), P(bufs["h2"]), P(pcount), P(ccount), P(p_score),
                          P(p_logprob), P(p_len), P(sent[0]), P(sent[1]), P(c_score), P(c_logprob), P(c_len), P(c_slot), P(c_free), P(c_sent),
                          P(parent), P(tok))
         cg, hg = self._b(tag + "cg", (M, Hd)), self._b(tag + "hg", (M, Hd))
@@ -430,13 +429,12 @@ class CaptionGenerator(object):
         ones (state gather, LSTM step, top-k, the heap bookkeeping: together half the round's time at 640 rows, on a fraction of
         the CUs).  A batch of >= 512 rows is therefore decoded as TWO slices of images on two streams: while one slice is in its
         latency-bound kernels the other's logits product has the CUs.  VC_DECODE_SLICES=1 keeps one slice -- same beams."""
-        lib, e, st = self.lib, self.e, _stream()
+        lib, e = self.lib, self.e
         max_len = max_len or self.p.gen_max_len
         t_ph = _phase("", 0.0)
         c, h = self.init_state(features, c_v, eps)
         t_ph = _phase("init_state", t_ph)
         B, Hd, V, n = c.shape[0], self.p.decoder_hidden, e.V, int(beam_size)
-        self._bos = int(bos)
         tok0 = self._b("bm_tok0", (B,), torch.int32)
         tok0.fill_(bos)
         _, c, h = self.step(tok0, c, h, want="state", bufs=self._round_bufs("bm0_", B))  # :230-236 -- probabilities discarded, state kept
@@ -454,7 +452,7 @@ class CaptionGenerator(object):
         nb = B // nparts
         if nparts > 1 and lib.vc_gemm_workspace_bytes(nb * n, V, Hd) != 0:
             nparts, nb = 1, B    # (a K-split logits product writes the engine's ONE workspace: slices on two streams would share it)
-        parts = [self._beam_part(k, nparts, c[k * nb:(k + 1) * nb], h[k * nb:(k + 1) * nb], n, L, rounds, K, eos, len_norm_f, xproj, fused)
+        parts = [self._beam_part(k, nparts, c[k * nb:(k + 1) * nb], h[k * nb:(k + 1) * nb], n, L, rounds, K, bos, eos, len_norm_f, xproj, fused)
                  for k in range(nparts)]
         main = torch.cuda.current_stream()
         while len(self._side) < nparts - 1:
