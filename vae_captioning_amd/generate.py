@@ -37,6 +37,37 @@ def _phase(name, t0):
     return t
 
 
+def beams_from_host(ints, dbls, io, B, n, L, last):
+    """The kept beams of B images from a slice's result buffers (host copies): per image the list of (sentence, score), descending.
+    ints: the int32 fields at the offsets `io` (pcount / ccount [B], p_len / c_len / c_slot [B, n], sent0 / sent1 [B, n, L],
+    c_sent [B, n + 1, L]); dbls: p_score [B, n] then c_score [B, n]; last: which of sent0 / sent1 the last round wrote.
+    vae_model/decoder.py:295-320: the complete captions if an image has any, else its live beams -- never mixed -- sorted by
+    TopN.extract(sort=True), i.e. list.sort(reverse=True) on the heap array: descending score, equal scores in array order.
+    Python lists come from whole buffers (one tolist each; slicing lists is ~5x cheaper than a numpy view + tolist per beam), and of
+    the two sentence stores only what the slice needs: the pool of complete captions, the live beams, or both."""
+    M = B * n
+    small, sc = ints[:io["sent0"]].tolist(), dbls.tolist()
+    pc, cc = small[io["pcount"]:io["pcount"] + B], small[io["ccount"]:io["ccount"] + B]
+    pl, cl, csl = small[io["p_len"]:io["p_len"] + M], small[io["c_len"]:io["c_len"] + M], small[io["c_slot"]:io["c_slot"] + M]
+    o = io["sent%d" % last]
+    pf = None if all(cc) else ints[o:o + M * L].tolist()
+    cf = ints[io["c_sent"]:io["c_sent"] + B * (n + 1) * L].tolist() if any(cc) else None
+    res = []
+    for b in range(B):
+        r0 = b * n
+        if cc[b]:
+            k_, s_ = cc[b], sc[M + r0:M + r0 + cc[b]]
+            rows = [(b * (n + 1) + csl[r0 + j]) * L for j in range(k_)]
+            ln, src = cl[r0:r0 + k_], cf
+        else:
+            k_, s_ = pc[b], sc[r0:r0 + pc[b]]
+            rows = [(r0 + j) * L for j in range(k_)]
+            ln, src = pl[r0:r0 + k_], pf
+        order = sorted(range(k_), key=s_.__getitem__, reverse=True) if k_ > 1 else range(k_)
+        res.append([(src[rows[j]:rows[j] + ln[j]], s_[j]) for j in order])
+    return res
+
+
 class CaptionGenerator(object):
     def __init__(self, engine):
         self.e = engine
@@ -510,30 +541,7 @@ class CaptionGenerator(object):
         t_ph = _phase("results: copies to pinned memory", t_ph)
         res = []
         for pt in parts:
-            Bp, Mp, ints, io = pt.B, pt.M, pt.ihost.numpy(), pt.ioff
-            # Python lists from whole buffers (one tolist each; slicing lists is ~5x cheaper than a numpy view + tolist per beam), and of the
-            # two sentence stores only what this slice needs: the pool of complete captions, the live beams, or both
-            small, sc = ints[:io["sent0"]].tolist(), pt.dhost.numpy().tolist()
-            pc, cc = small[io["pcount"]:io["pcount"] + Bp], small[io["ccount"]:io["ccount"] + Bp]
-            pl, cl, csl = small[io["p_len"]:io["p_len"] + Mp], small[io["c_len"]:io["c_len"] + Mp], small[io["c_slot"]:io["c_slot"] + Mp]
-            o = io["sent%d" % pt.last]
-            pf = None if all(cc) else ints[o:o + Mp * L].tolist()
-            cf = ints[io["c_sent"]:io["c_sent"] + Bp * (n + 1) * L].tolist() if any(cc) else None
-            for b in range(Bp):
-                r0 = b * n
-                # TopN.extract(sort=True) is list.sort(reverse=True) on the heap array: descending score, equal scores in array order
-                if cc[b]:  # never mix complete and partial (:295-299)
-                    k_, s_ = cc[b], sc[Mp + r0:Mp + r0 + cc[b]]
-                    rows = [(b * (n + 1) + csl[r0 + j]) * L for j in range(k_)]
-                    ln = cl[r0:r0 + k_]
-                    src = cf
-                else:
-                    k_, s_ = pc[b], sc[r0:r0 + pc[b]]
-                    rows = [(r0 + j) * L for j in range(k_)]
-                    ln = pl[r0:r0 + k_]
-                    src = pf
-                order = sorted(range(k_), key=s_.__getitem__, reverse=True) if k_ > 1 else range(k_)
-                res.append([(src[rows[j]:rows[j] + ln[j]], s_[j]) for j in order])
+            res += beams_from_host(pt.ihost.numpy(), pt.dhost.numpy(), pt.ioff, pt.B, n, L, pt.last)
         t_ph = _phase("results to host lists", t_ph)
         if fused and rounds > K:
             for pt in parts:
